@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X modal sound engine.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[3], at N=1 on ONE GPU): 1024 objects x 512
+modes, a random impulse stream per object (Poisson, ~20 PointForce hits/s,
+vertex hits projected onto the mode shapes on the device), 86 buffers x 513
+samples (~1 s of audio) per step.  Weak scaling: every rank owns 1024 objects
+(objects are independent -- no data-path collective); with --gather the
+finished audio buffers of all ranks are all-gathered over RCCL inside the
+timed region, as a consumer of the whole mix would need.
+
+One "step" = one pbso_step(86): host bookkeeping of ModalSolver::step for every
+(object, buffer), upload of the plan, projection, force combination, and the
+oscillator-bank kernel.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B = 513
+SAMPLE_RATE = 44100
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak (= fp32 MFMA dense peak), same guide
+FLOP_PER_MODE_SAMPLE = 10      # reference arithmetic incl. qnorm
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--objects", type=int, default=1024, help="objects per GPU")
+    ap.add_argument("--modes", type=int, default=512)
+    ap.add_argument("--buffers", type=int, default=86, help="audio buffers per step")
+    ap.add_argument("--form", choices=["velocity", "direct"], default="velocity")
+    ap.add_argument("--no-qnorm", action="store_true", help="skip getQBufferNorm (not the headline)")
+    ap.add_argument("--modes-per-lane", type=int, default=0)
+    ap.add_argument("--gather", action="store_true", help="all-gather audio over RCCL inside the timed region")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-objects", type=int, default=0, help="objects in the CPU baseline sample (0 = auto)")
+    return ap.parse_args()
+
+
+def build_inputs(args, rank):
+    """Deterministic per-rank inputs: eigenvalues, mode shapes, hit script."""
+    from openpbso_amd import synth
+    n_obj, M = args.objects, args.modes
+    total_buffers = (args.steps + args.warmup) * args.buffers
+    lam = np.empty((n_obj, M))
+    shapes = []
+    scripts = []
+    for i in range(n_obj):
+        seed = synth.seed_for(4, rank * n_obj + i)
+        lam[i] = synth.eigenvalues(M, seed)
+        shapes.append(synth.mode_shapes(M, seed))
+        hits = synth.poisson_hits(total_buffers, seed)
+        vns = synth.unit_normals(total_buffers, seed)
+        scripts.append((hits, vns))
+    return lam, shapes, scripts
+
+
+def cpu_baseline(args, lam, shapes, scripts):
+    """The fp64 oracle (a port: the reference itself cannot be built here) timed on
+    this box's host cores on a bounded sample of the same workload."""
+    from oracle import oracle_py as orc
+    from openpbso_amd import synth
+    ncores = os.cpu_count() or 1
+    try:
+        lib = orc.lib(native=True)
+    except Exception:
+        lib = orc.lib()
+    n_obj = args.cpu_objects or min(args.objects, max(ncores, 8) * 2)
+    nb, M = args.buffers, args.modes
+    om = np.ascontiguousarray(lam[:n_obj])
+    hit_data = np.zeros((n_obj, M))
+    mask = np.zeros((n_obj, nb), dtype=np.uint8)
+    for i in range(n_obj):
+        hits, vns = scripts[i]
+        mask[i] = (hits[:nb] >= 0).astype(np.uint8)
+        first = int(np.argmax(hits[:nb] >= 0)) if mask[i].any() else 0
+        # one spatial vector per object (the CPU leg times stepping, not projection)
+        hit_data[i] = orc.modal_force_vertex(shapes[i], max(int(hits[first]), 0), vns[first])
+    dp = orc._dp
+    secs = lib.or_bench_run(n_obj, M, nb, ncores, dp(om), synth.RHO, synth.ALPHA, synth.BETA,
+                            dp(hit_data), mask.tobytes(), None, 0)
+    samples = n_obj * nb * B
+    return {
+        "value": samples / secs, "unit": "audio samples/s", "cores": ncores, "kind": "port",
+        "realtime_x": (nb * B / SAMPLE_RATE) / secs,
+        "sample": f"{n_obj} objects x {M} modes x {nb} buffers (same generator/seeds as the GPU run), "
+                  f"fp64 oracle with qnorm, OpenMP over objects, default FP env (denormals kept), {secs:.2f} s",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from openpbso_amd import Engine, ForceMessage, capi, synth
+
+    lam, shapes, scripts = build_inputs(args, rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    eng = Engine(device=local_rank,
+                 form=capi.FORM_VELOCITY if args.form == "velocity" else capi.FORM_DIRECT,
+                 qnorm=capi.QNORM_OFF if args.no_qnorm else capi.QNORM_ALL,
+                 modes_per_lane=args.modes_per_lane, stream=stream)
+    for i in range(args.objects):
+        eng.add_object(lam[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
+    eng.finalize()
+    n_hits = 0
+    for i in range(args.objects):
+        eng.set_use_transfer(i, False)                 # no FFAT maps in this config: unit transfer
+        hits, vns = scripts[i]
+        for b in np.nonzero(hits >= 0)[0]:
+            ok = eng.enqueue_force(i, ForceMessage(vid=int(hits[b]), vn=vns[b]), int(b))
+            assert ok
+            n_hits += 1
+
+    nb = args.buffers
+    audio = torch.empty((args.objects, nb * B), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world * args.objects, nb * B), dtype=torch.float32, device=dev) if (args.gather and world > 1) else None
+
+    def one_step():
+        eng.step(nb, into=audio.data_ptr())
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, audio)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    info0 = eng.info()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    info1 = eng.info()
+    assert torch.isfinite(audio).all()
+
+    if rank == 0:
+        total_obj = world * args.objects
+        samples = total_obj * nb * B * args.steps
+        value = samples / elapsed
+        rt = (nb * B * args.steps / SAMPLE_RATE) / elapsed
+        # roofline of the dominant kernel (iir_bank): HIP events on the launch stream, this rank
+        k_ms = (info1["total_kernel_ms"] - info0["total_kernel_ms"]) / args.steps
+        d_ms = (info1["total_device_ms"] - info0["total_device_ms"]) / args.steps
+        plan_ms = (info1["total_host_plan_ms"] - info0["total_host_plan_ms"]) / args.steps
+        M = args.modes
+        mode_samples = args.objects * M * nb * B
+        flops = FLOP_PER_MODE_SAMPLE * mode_samples
+        # algorithmic bytes of one launch (SURVEY 8(d) formula with NB_l = nb; M = modes per object)
+        bytes_alg = args.objects * (M * (12 + 8 + 8 + (4 + 4 + 4) * nb) + nb * B * (4 + 4))
+        tf = flops / (k_ms * 1e-3) * 1e-12
+        gbs = bytes_alg / (k_ms * 1e-3) * 1e-9
+        out = {
+            "metric": "audio samples/s & real-time x at N_obj x N_modes",
+            "value": value, "unit": "audio samples/s", "realtime_x": rt,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{args.objects} objects x {M} modes per GPU, Poisson impulse stream (~20 PointForce hits/s/object, "
+                            f"on-device vertex projection), {nb} buffers x 513 samples per step, unit transfer, "
+                            f"qnorm {'off' if args.no_qnorm else 'on'}, {args.form} recurrence form",
+                "objects_per_gpu": args.objects, "modes": M, "buffers_per_step": nb, "frames_per_buffer": B,
+                "hits": n_hits, "modes_per_lane": info1["modes_per_lane"], "waves_per_object": info1["waves_per_object"],
+                "kernel_build": "packed" if os.environ.get("PBSO_IIR_PACKED", "0") != "0" else "scalar",
+                "gather": bool(gathered is not None), "parallelism": f"object-sharded x{world}",
+            },
+            "roofline": {
+                "bound": "valu", "kernel": "iir_bank_kernel",
+                "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS,
+                "flop_per_mode_sample": FLOP_PER_MODE_SAMPLE, "kernel_ms": k_ms,
+                "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": bytes_alg},
+                "traffic": None,
+            },
+            "timing": {"device_pipeline_ms": d_ms, "host_plan_ms": plan_ms},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, lam, shapes, scripts)
+            except Exception as ex:   # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,230 @@
+/*
+ * openpbso_amd.h -- C ABI of the MI355X-native modal sound engine.
+ *
+ * Drop-in boundary for the per-audio-sample hot path of jhwang7628/openpbso.
+ * The reference has no FFI of its own: the boundary it sits behind is the
+ * public interface of the header-only template ModalSolver<double,513>
+ * (modal_solver.h:100-179) plus its message structs.  Every entry point below
+ * names the reference interface it replaces (file:line, relative to the
+ * reference root).  One engine batches MANY independent ModalSolver instances
+ * ("objects") on one GPU; object i behaves like its own ModalSolver<double>.
+ *
+ * Conventions
+ *  - every function returns an int status (PBSO_OK == 0, errors < 0); the
+ *    bool-returning queue operations of the reference return 1 (true) /
+ *    0 (false) / <0 (error).  No exceptions cross this boundary.
+ *  - plain pointers and sizes only; `void *` device pointers are HIP device
+ *    addresses, `void *stream` is a hipStream_t.
+ *  - one caller thread per engine (the facade keeps the reference's
+ *    single-producer/single-consumer discipline).
+ *  - time is counted in audio buffers of `frames_per_buffer` samples; buffer 0
+ *    is the first buffer the first pbso_step() produces.  `not_before` stamps
+ *    let a batch caller say at which buffer a message becomes visible to the
+ *    simulation thread's try_dequeue (the GUI thread's wall-clock in the
+ *    reference).  not_before = 0 means "already there".
+ *  - the HIP path is the only path: there is no CPU fallback.
+ */
+#ifndef OPENPBSO_AMD_H
+#define OPENPBSO_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBSO_ABI_VERSION 1
+#define PBSO_SAMPLE_RATE 44100          /* config.h:13 */
+#define PBSO_FRAMES_PER_BUFFER 513      /* config.h:14 */
+
+enum pbso_status {
+    PBSO_OK = 0,
+    PBSO_ERR_INVALID = -1,      /* bad argument (the reference would assert) */
+    PBSO_ERR_HIP = -2,          /* a HIP runtime call failed; see pbso_last_error */
+    PBSO_ERR_STATE = -3,        /* call not valid in the engine's current state */
+    PBSO_ERR_IO = -4,           /* file missing / unreadable / malformed */
+    PBSO_ERR_MISSING_MAP = -5,  /* std::map::at would throw (modal_solver.h:296,312) */
+    PBSO_ERR_ASSERT = -6,       /* a live reference assert would fire (e.g. modal_solver.h:223) */
+    PBSO_ERR_NOMEM = -7
+};
+
+/* forces.h:12-16 */
+enum pbso_force_type {
+    PBSO_POINT_FORCE = 0,
+    PBSO_GAUSSIAN_FORCE = 1,
+    PBSO_AUTOREGRESSIVE_FORCE = 2
+};
+
+/* how the spatial (modal) part of a force message is given */
+enum pbso_force_data_kind {
+    PBSO_DATA_EXPLICIT = 0,   /* data[n_data] doubles: ForceMessage::data as the GUI built it */
+    PBSO_DATA_VERTEX = 1,     /* GetModalForceVertex on the device (tools/real_time_modal_sound.cpp:268-280) */
+    PBSO_DATA_FACE = 2,       /* GetModalForceFace on the device   (tools/real_time_modal_sound.cpp:236-252) */
+    PBSO_DATA_ZERO = 3        /* setZero(N): the dummy start/stop messages (tools/...:754-776) */
+};
+
+enum pbso_recurrence_form {
+    PBSO_FORM_VELOCITY = 0,   /* default: state (q, q-q_prev), coefficients (eps^2, 1-c1-c2): fp32-safe */
+    PBSO_FORM_DIRECT = 1      /* the reference's literal q = c1 q1 + c2 q2 + c3 Q in fp32 */
+};
+
+enum pbso_qnorm_mode {
+    PBSO_QNORM_OFF = 0,       /* getQBufferNorm never consumed: skip the 5th FMA */
+    PBSO_QNORM_ALL = 1        /* per-sample accumulation, one row per (object, buffer): modal_solver.h:262-273 */
+};
+
+typedef struct pbso_engine pbso_engine;
+
+typedef struct pbso_engine_desc {
+    int abi_version;          /* PBSO_ABI_VERSION */
+    int device;               /* HIP device ordinal */
+    int frames_per_buffer;    /* 0 -> 513 (ModalSolver's BUF_SIZE template argument) */
+    int sample_rate;          /* 0 -> 44100 */
+    int recurrence_form;      /* enum pbso_recurrence_form */
+    int qnorm_mode;           /* enum pbso_qnorm_mode */
+    int modes_per_lane;       /* 0 = auto; 1, 2, 4 or 8 oscillators per lane */
+    void *stream;             /* hipStream_t to launch on; NULL -> engine-owned stream */
+} pbso_engine_desc;
+
+/* --- lifetime ------------------------------------------------------------- */
+int pbso_engine_create(const pbso_engine_desc *desc, pbso_engine **out);
+void pbso_engine_destroy(pbso_engine *e);
+const char *pbso_last_error(const pbso_engine *e);
+const char *pbso_status_string(int status);
+int pbso_abi_version(void);
+
+/* --- BuildSolver (tools/real_time_modal_sound.cpp:309-345) ------------------
+ * new ModalSolver<double>(n_modes) + ModalIntegrator<double>::Build(density,
+ * omega_squared, alpha, beta, 1/44100, n_modes) (modal_integrator.h:47-101).
+ * mode_shapes (optional) is ModeData::_modes, mode-major [>=n_modes][n_dof]
+ * doubles (ModeData.h:24), needed only for PBSO_DATA_VERTEX/FACE messages.   */
+typedef struct pbso_object_desc {
+    int n_modes;                    /* N_modesAudible */
+    int n_omega;                    /* entries in omega_squared (>= n_modes; the reference asserts) */
+    const double *omega_squared;    /* ModeData::_omegaSquared */
+    double density, alpha, beta;    /* ModalMaterial */
+    int n_dof;                      /* 3 * |V|, 0 if no mode shapes */
+    const double *mode_shapes;      /* [n_modes][n_dof] or NULL */
+} pbso_object_desc;
+int pbso_add_object(pbso_engine *e, const pbso_object_desc *d, int *object_id);
+
+/* the reference's file conventions (tools/...:480-501, 316-329): reads
+ * <modes_path> (ModeData.h:61-83), <material_path> (ModalMaterial.h:35-55),
+ * optional <ffat_dir>/freq_threshold.txt and <ffat_dir>/ *.fatcube
+ * (ffat_map_serialize.h:166-279).  ffat_dir may be NULL.                      */
+int pbso_add_object_from_files(pbso_engine *e, const char *modes_path,
+                               const char *material_path, const char *ffat_dir,
+                               int *object_id, int *n_modes_audible);
+
+/* FFAT_Map<double,3> runtime fields (ffat_solver.h:171-180, 281-293) as the
+ * .fatcube loader fills them (ffat_map_serialize.h:166-254).                  */
+typedef struct pbso_ffat_map {
+    int mode_id;
+    double k;
+    double center3[3];
+    double cell_size;
+    double low_corners[6][3];
+    int n_elements[6][2];
+    int strides[6];
+    double center[3];
+    double bbox_low[3];
+    double bbox_top[3];
+    int n_psi;
+    const double *psi;
+} pbso_ffat_map;
+/* ModalSolver::readFFATMaps (modal_solver.h:278-284), maps already parsed */
+int pbso_object_set_ffat_maps(pbso_engine *e, int object_id, const pbso_ffat_map *maps, int n_maps);
+/* ModalSolver::readFFATMaps from a directory of .fatcube files */
+int pbso_object_read_ffat_maps(pbso_engine *e, int object_id, const char *dir);
+/* parse one .fatcube byte string (ffat_map.proto:8-51). psi is malloc'ed:
+ * release with pbso_ffat_map_free.                                            */
+int pbso_fatcube_parse(const unsigned char *bytes, size_t n, pbso_ffat_map *out);
+void pbso_ffat_map_free(pbso_ffat_map *m);
+
+/* uploads all objects to HBM; no pbso_add_object afterwards */
+int pbso_finalize(pbso_engine *e);
+
+/* --- messages (modal_solver.h:27-98, forces.h:50-55) ---------------------- */
+typedef struct pbso_force_msg {
+    int force_type;                 /* ForceMessage::forceType; selects the Force subclass */
+    double gaussian_width_us;       /* GaussianForce(width), forces.h:42-46 */
+    int sustained_force_start;      /* ForceMessage::sustainedForceStart */
+    int sustained_force_end;        /* ForceMessage::sustainedForceEnd */
+    int clear_all_forces;           /* ForceMessage::clearAllForces */
+    int data_kind;                  /* enum pbso_force_data_kind */
+    const double *data;             /* PBSO_DATA_EXPLICIT: ForceMessage::data */
+    int n_data;
+    int vids[3];                    /* VERTEX: vids[0]; FACE: the three vertex ids */
+    double coords[3];               /* FACE: barycentric coordinates */
+    double vn[3];                   /* hit normal (ONE normal for all three vertices, tools/...:241) */
+} pbso_force_msg;
+
+/* ModalSolver::enqueueForceMessage (modal_solver.h:329-333): 1 = enqueued,
+ * 0 = the 1023-slot queue is full.                                            */
+int pbso_enqueue_force(pbso_engine *e, int object_id, const pbso_force_msg *m, int64_t not_before);
+/* ModalSolver::enqueueArprmMessageNoFail (modal_solver.h:382-393); 1-slot queue */
+int pbso_enqueue_arprm(pbso_engine *e, int object_id, const double a[2], double sigma,
+                       double mu, int64_t not_before);
+/* ModalSolver::computeTransfer(pos) (modal_solver.h:286-300): FFAT lookup for
+ * every mode on the device, result offered to the 1-slot transfer queue.
+ * 1 = enqueued, 0 = no maps / queue still full.                               */
+int pbso_compute_transfer(pbso_engine *e, int object_id, const double pos[3], int64_t not_before);
+/* ModalSolver::computeTransfer(pos, T *trans) (modal_solver.h:302-315),
+ * batched over n_pos listener positions: out[n_pos][n_maps] doubles.          */
+int pbso_compute_transfer_batch(pbso_engine *e, int object_id, const double *pos, int n_pos, double *out);
+/* ModalSolver::setUseTransfer (modal_solver.h:148-152) */
+int pbso_set_use_transfer(pbso_engine *e, int object_id, int use, int64_t not_before);
+/* ModalSolver::getLatestTransfer (modal_solver.h:145-147): n_modes doubles */
+int pbso_get_latest_transfer(pbso_engine *e, int object_id, double *out);
+
+/* --- ModalSolver::step (modal_solver.h:181-276) for every object, n_buffers
+ * times, one launch.  Asynchronous on the engine's stream.                    */
+int pbso_step(pbso_engine *e, int n_buffers);
+/* same, audio written to a caller-owned device buffer [n_objects][n_buffers*B] fp32 */
+int pbso_step_into(pbso_engine *e, int n_buffers, void *d_audio);
+int pbso_sync(pbso_engine *e);
+
+/* results of the LAST step.  audio is the reference's SoundMessage::data
+ * (pressure units; PaModalCallback divides by 1e10, tools/...:207-210), fp32,
+ * [n_objects][n_buffers * frames_per_buffer].  emitted[obj][buf] is 0 where
+ * the reference's step() returned early without a buffer (clearAllForces,
+ * modal_solver.h:186-189); those samples are 0.                               */
+int pbso_read_audio(pbso_engine *e, float *host_out, size_t n_floats);
+int pbso_read_emitted(pbso_engine *e, unsigned char *host_out, size_t n);
+/* getQBufferNorm (modal_solver.h:153-159) for (object, buffer) of the last step */
+int pbso_read_qnorm(pbso_engine *e, int object_id, int buffer, float *host_out, int n);
+/* integrator state after the last step: q_{k-1}, q_{k-2} (modal_integrator.h:24) */
+int pbso_read_state(pbso_engine *e, int object_id, double *q1, double *q2, int n);
+void *pbso_audio_device_ptr(pbso_engine *e);
+
+/* PaModalCallback body (tools/real_time_modal_sound.cpp:207-210): mono sound
+ * -> interleaved stereo float32 scaled by 1e-10.                              */
+void pbso_pa_convert(const float *sound, unsigned long frames, float *out_stereo);
+
+/* --- introspection -------------------------------------------------------- */
+typedef struct pbso_engine_info {
+    int n_objects;
+    int frames_per_buffer;
+    int modes_padded;         /* oscillators per object after padding */
+    int modes_per_lane;
+    int waves_per_object;
+    int lds_bytes_per_workgroup;
+    int64_t buffers_done;
+    double last_step_kernel_ms;       /* HIP-event time of the oscillator-bank kernel, last step */
+    double last_step_device_ms;       /* HIP-event time of the whole device pipeline, last step */
+    double last_step_host_plan_ms;    /* host bookkeeping (modal_solver.h:184-256) */
+    int64_t last_step_forced_rows;
+    int64_t last_step_transfer_rows;
+    /* running totals since engine creation (HIP events on the engine's stream,
+     * one pair per pbso_step around the oscillator-bank kernel / the pipeline) */
+    double total_kernel_ms;
+    double total_device_ms;
+    double total_host_plan_ms;
+    int64_t total_steps;
+} pbso_engine_info;
+int pbso_get_info(pbso_engine *e, pbso_engine_info *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

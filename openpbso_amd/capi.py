@@ -1,0 +1,119 @@
+"""ctypes binding of include/openpbso_amd.h (libopenpbso_amd.so).
+
+Fails loudly when the library is missing -- the HIP path is the only path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libopenpbso_amd.so")
+
+ABI_VERSION = 1
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_STATE, ERR_IO, ERR_MISSING_MAP, ERR_ASSERT, ERR_NOMEM = -1, -2, -3, -4, -5, -6, -7
+POINT_FORCE, GAUSSIAN_FORCE, AUTOREGRESSIVE_FORCE = 0, 1, 2
+DATA_EXPLICIT, DATA_VERTEX, DATA_FACE, DATA_ZERO = 0, 1, 2, 3
+FORM_VELOCITY, FORM_DIRECT = 0, 1
+QNORM_OFF, QNORM_ALL = 0, 1
+
+# every symbol include/openpbso_amd.h declares
+EXPORTS = [
+    "pbso_abi_version", "pbso_status_string", "pbso_engine_create", "pbso_engine_destroy",
+    "pbso_last_error", "pbso_add_object", "pbso_add_object_from_files", "pbso_object_set_ffat_maps",
+    "pbso_object_read_ffat_maps", "pbso_fatcube_parse", "pbso_ffat_map_free", "pbso_finalize",
+    "pbso_enqueue_force", "pbso_enqueue_arprm", "pbso_compute_transfer", "pbso_compute_transfer_batch",
+    "pbso_set_use_transfer", "pbso_get_latest_transfer", "pbso_step", "pbso_step_into", "pbso_sync",
+    "pbso_read_audio", "pbso_read_emitted", "pbso_read_qnorm", "pbso_read_state",
+    "pbso_audio_device_ptr", "pbso_pa_convert", "pbso_get_info",
+]
+
+
+class EngineDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_int), ("device", C.c_int), ("frames_per_buffer", C.c_int),
+                ("sample_rate", C.c_int), ("recurrence_form", C.c_int), ("qnorm_mode", C.c_int),
+                ("modes_per_lane", C.c_int), ("stream", C.c_void_p)]
+
+
+class ObjectDesc(C.Structure):
+    _fields_ = [("n_modes", C.c_int), ("n_omega", C.c_int), ("omega_squared", C.POINTER(C.c_double)),
+                ("density", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
+                ("n_dof", C.c_int), ("mode_shapes", C.POINTER(C.c_double))]
+
+
+class FfatMap(C.Structure):
+    _fields_ = [("mode_id", C.c_int), ("k", C.c_double), ("center3", C.c_double * 3),
+                ("cell_size", C.c_double), ("low_corners", (C.c_double * 3) * 6),
+                ("n_elements", (C.c_int * 2) * 6), ("strides", C.c_int * 6),
+                ("center", C.c_double * 3), ("bbox_low", C.c_double * 3), ("bbox_top", C.c_double * 3),
+                ("n_psi", C.c_int), ("psi", C.POINTER(C.c_double))]
+
+
+class ForceMsg(C.Structure):
+    _fields_ = [("force_type", C.c_int), ("gaussian_width_us", C.c_double),
+                ("sustained_force_start", C.c_int), ("sustained_force_end", C.c_int),
+                ("clear_all_forces", C.c_int), ("data_kind", C.c_int),
+                ("data", C.POINTER(C.c_double)), ("n_data", C.c_int), ("vids", C.c_int * 3),
+                ("coords", C.c_double * 3), ("vn", C.c_double * 3)]
+
+
+class EngineInfo(C.Structure):
+    _fields_ = [("n_objects", C.c_int), ("frames_per_buffer", C.c_int), ("modes_padded", C.c_int),
+                ("modes_per_lane", C.c_int), ("waves_per_object", C.c_int),
+                ("lds_bytes_per_workgroup", C.c_int), ("buffers_done", C.c_int64),
+                ("last_step_kernel_ms", C.c_double), ("last_step_device_ms", C.c_double),
+                ("last_step_host_plan_ms", C.c_double), ("last_step_forced_rows", C.c_int64),
+                ("last_step_transfer_rows", C.c_int64),
+                ("total_kernel_ms", C.c_double), ("total_device_ms", C.c_double),
+                ("total_host_plan_ms", C.c_double), ("total_steps", C.c_int64)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libopenpbso_amd.so (raises if it is not built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP engine first "
+            "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    l = C.CDLL(LIB_PATH)
+    vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)
+    l.pbso_abi_version.restype = C.c_int
+    l.pbso_status_string.restype = C.c_char_p
+    l.pbso_status_string.argtypes = [C.c_int]
+    l.pbso_engine_create.argtypes = [C.POINTER(EngineDesc), C.POINTER(vp)]
+    l.pbso_engine_destroy.argtypes = [vp]
+    l.pbso_engine_destroy.restype = None
+    l.pbso_last_error.restype = C.c_char_p
+    l.pbso_last_error.argtypes = [vp]
+    l.pbso_add_object.argtypes = [vp, C.POINTER(ObjectDesc), ip]
+    l.pbso_add_object_from_files.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, ip, ip]
+    l.pbso_object_set_ffat_maps.argtypes = [vp, C.c_int, C.POINTER(FfatMap), C.c_int]
+    l.pbso_object_read_ffat_maps.argtypes = [vp, C.c_int, C.c_char_p]
+    l.pbso_fatcube_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(FfatMap)]
+    l.pbso_ffat_map_free.argtypes = [C.POINTER(FfatMap)]
+    l.pbso_ffat_map_free.restype = None
+    l.pbso_finalize.argtypes = [vp]
+    l.pbso_enqueue_force.argtypes = [vp, C.c_int, C.POINTER(ForceMsg), C.c_int64]
+    l.pbso_enqueue_arprm.argtypes = [vp, C.c_int, dp, C.c_double, C.c_double, C.c_int64]
+    l.pbso_compute_transfer.argtypes = [vp, C.c_int, dp, C.c_int64]
+    l.pbso_compute_transfer_batch.argtypes = [vp, C.c_int, dp, C.c_int, dp]
+    l.pbso_set_use_transfer.argtypes = [vp, C.c_int, C.c_int, C.c_int64]
+    l.pbso_get_latest_transfer.argtypes = [vp, C.c_int, dp]
+    l.pbso_step.argtypes = [vp, C.c_int]
+    l.pbso_step_into.argtypes = [vp, C.c_int, vp]
+    l.pbso_sync.argtypes = [vp]
+    l.pbso_read_audio.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t]
+    l.pbso_read_emitted.argtypes = [vp, C.POINTER(C.c_ubyte), C.c_size_t]
+    l.pbso_read_qnorm.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]
+    l.pbso_read_state.argtypes = [vp, C.c_int, dp, dp, C.c_int]
+    l.pbso_audio_device_ptr.restype = vp
+    l.pbso_audio_device_ptr.argtypes = [vp]
+    l.pbso_pa_convert.argtypes = [C.POINTER(C.c_float), C.c_ulong, C.POINTER(C.c_float)]
+    l.pbso_pa_convert.restype = None
+    l.pbso_get_info.argtypes = [vp, C.POINTER(EngineInfo)]
+    _lib = l
+    return l

@@ -1,0 +1,959 @@
+// Host engine: see engine.h.  Compiled by hipcc for the HIP runtime API only;
+// there is no CPU compute path here -- every sample is produced by the HIP
+// kernels in kernels_iir.hip / kernels_exact.hip.
+#include "engine.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace pbso {
+
+// ---------------------------------------------------------------------------
+template <class T>
+hipError_t DevBuf<T>::ensure(size_t n, bool keep, hipStream_t s) {
+    if (n <= cap) return hipSuccess;
+    size_t ncap = std::max(n, cap + cap / 2);
+    T *np = nullptr;
+    hipError_t e = hipMalloc((void **)&np, ncap * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (keep && p && cap) {
+        e = hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { (void)hipFree(np); return e; }
+    }
+    if (p) {
+        // in-flight kernels may still read the old block: drain the stream first
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(p);
+    }
+    p = np;
+    cap = ncap;
+    return hipSuccess;
+}
+template <class T>
+void DevBuf<T>::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+template <class T>
+hipError_t PinBuf<T>::ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    size_t ncap = std::max(n, cap + cap / 2);
+    T *np = nullptr;
+    hipError_t e = hipHostMalloc((void **)&np, ncap * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    if (p) (void)hipHostFree(p);
+    p = np;
+    cap = ncap;
+    return hipSuccess;
+}
+template <class T>
+void PinBuf<T>::release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+void Engine::PlanSet::release() {
+    h_desc.release(); d_desc.release(); h_row_ptr.release(); d_row_ptr.release();
+    h_slot_idx.release(); d_slot_idx.release(); h_row_obj.release(); d_row_obj.release();
+    h_tprof.release(); d_tprof.release(); h_stage.release(); d_stage.release();
+    h_stage_slot.release(); d_stage_slot.release(); h_proj.release(); d_proj.release();
+    h_ffat.release(); d_ffat.release(); h_copy.release(); d_copy.release();
+    h_xfer_init.release(); d_xfer_init.release();
+}
+
+// ---------------------------------------------------------------------------
+// forces.h
+ForceProfile ForceProfile::make(int type, double gaussian_width_us, int sample_rate) {
+    ForceProfile f;
+    f.type = type;
+    if (type == PBSO_GAUSSIAN_FORCE) {                       // forces.h:42-46
+        f.width = gaussian_width_us;
+        f.width_samples = std::max(1, (int)(f.width / 1000000. * sample_rate));
+        f.center = (int)((f.cutoff - 0.5) * f.width_samples);
+    }
+    return f;
+}
+
+bool ForceProfile::add(double *t, int frames) {
+    switch (type) {
+    case PBSO_POINT_FORCE:                                   // forces.h:81-90
+        if (used) return false;
+        t[0] += 1.;
+        used = true;
+        return true;
+    case PBSO_GAUSSIAN_FORCE:                                // forces.h:92-105
+        if (width == 0 || count >= cutoff * 2 * width_samples) return false;
+        for (int ii = 0; ii < frames; ++ii) {
+            const double p = -0.5 * std::pow((double)(count + ii - center) / (double)width_samples, 2);
+            t[ii] += std::exp(p);
+        }
+        count += frames;
+        return true;
+    case PBSO_AUTOREGRESSIVE_FORCE:                          // forces.h:107-128
+        for (int ii = 0; ii < frames; ++ii) {
+            double mu_tilde = 0.0;
+            for (int jj = 0; jj < 2; ++jj) mu_tilde += a[jj] * buf[(buf_idx + 3 - jj - 1) % 3];
+            mu_tilde += sigma * distribution(generator);
+            buf[buf_idx] = mu_tilde;
+            buf_idx = (buf_idx + 1) % 3;
+            t[ii] += mu + mu_tilde;
+        }
+        return true;
+    }
+    return false;
+}
+
+void ForceProfile::set_param(const double a_[2], double sigma_, double mu_) {   // forces.h:130-137
+    buf[0] = buf[1] = buf[2] = 0;
+    a[0] = a_[0];
+    a[1] = a_[1];
+    sigma = sigma_;
+    mu = mu_;
+}
+
+// ---------------------------------------------------------------------------
+Engine::Engine(const pbso_engine_desc &d) : desc_(d) {}
+
+Engine::~Engine() {
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    d_ca_.release(); d_cb_.release(); d_sq_.release(); d_sd_.release(); d_c3_.release();
+    d_shapes_.release(); d_shape_off_.release(); d_n_modes_.release(); d_geom_.release();
+    d_geom_off_.release(); d_psi_.release(); d_slots_.release(); d_xfer_.release();
+    d_audio_.release(); d_qnorm_.release(); d_grows_.release();
+    set_[0].release();
+    set_[1].release();
+    for (hipEvent_t ev : {ev_set_[0], ev_set_[1]})
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto *v : {&ev_free_, &ev_pending_})
+        for (EvQuad &q : *v)
+            for (hipEvent_t ev : {q.k0, q.k1, q.p0, q.p1}) (void)hipEventDestroy(ev);
+    if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+}
+
+int Engine::fail(int code, const std::string &msg) {
+    err_ = msg;
+    return code;
+}
+int Engine::hip_fail(hipError_t e, const char *what) {
+    err_ = std::string(what) + ": " + hipGetErrorString(e);
+    return PBSO_ERR_HIP;
+}
+#define HIPTRY(expr)                                                   \
+    do {                                                               \
+        hipError_t _e = (expr);                                        \
+        if (_e != hipSuccess) return hip_fail(_e, #expr);              \
+    } while (0)
+#define LAUNCHTRY(expr)                                                \
+    do {                                                               \
+        int _e = (expr);                                               \
+        if (_e != 0) return hip_fail((hipError_t)_e, #expr);           \
+    } while (0)
+
+int Engine::init() {
+    if (desc_.abi_version != PBSO_ABI_VERSION) return fail(PBSO_ERR_INVALID, "abi_version mismatch");
+    if (desc_.frames_per_buffer > 0) B_ = desc_.frames_per_buffer;
+    if (desc_.sample_rate > 0) rate_ = desc_.sample_rate;
+    if (B_ % TILE != 0 || B_ / TILE > MAX_TILES)
+        return fail(PBSO_ERR_INVALID, "frames_per_buffer must be a multiple of 57 (<= 1824); the reference uses 513");
+    n_tiles_ = B_ / TILE;
+    b_pad_ = (B_ + 15) / 16 * 16;
+    if (desc_.recurrence_form != PBSO_FORM_VELOCITY && desc_.recurrence_form != PBSO_FORM_DIRECT)
+        return fail(PBSO_ERR_INVALID, "recurrence_form");
+    if (desc_.qnorm_mode != PBSO_QNORM_OFF && desc_.qnorm_mode != PBSO_QNORM_ALL)
+        return fail(PBSO_ERR_INVALID, "qnorm_mode");
+    int ndev = 0;
+    HIPTRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(PBSO_ERR_HIP, "no HIP device: this engine has no CPU fallback");
+    if (desc_.device < 0 || desc_.device >= ndev) return fail(PBSO_ERR_INVALID, "device ordinal out of range");
+    HIPTRY(hipSetDevice(desc_.device));
+    if (desc_.stream) {
+        stream_ = (hipStream_t)desc_.stream;
+    } else {
+        HIPTRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        own_stream_ = true;
+    }
+    HIPTRY(hipEventCreateWithFlags(&ev_set_[0], hipEventDisableTiming));
+    HIPTRY(hipEventCreateWithFlags(&ev_set_[1], hipEventDisableTiming));
+    tbuf_.assign(B_, 0.0);
+    // which build of the oscillator bank to launch (see kernels_iir.hip)
+    if (const char *v = std::getenv("PBSO_IIR_PACKED")) packed_ = std::atoi(v) != 0;
+    return PBSO_OK;
+}
+
+// BuildSolver -> ModalIntegrator<double>::Build + ctor, modal_integrator.h:47-101
+int Engine::add_object(const pbso_object_desc &d, int *id) {
+    if (finalized_) return fail(PBSO_ERR_STATE, "add_object after finalize");
+    if (d.n_modes < 0 || d.n_omega < d.n_modes || (d.n_modes > 0 && !d.omega_squared))
+        return fail(PBSO_ERR_INVALID, "N for modal integrator invalid");         // assert :56
+    Object o;
+    o.n_modes = d.n_modes;
+    o.c1.resize(d.n_modes);
+    o.c2.resize(d.n_modes);
+    o.c3.resize(d.n_modes);
+    const double h = 1.0 / (double)rate_;
+    for (int ii = 0; ii < d.n_modes; ++ii) {
+        const double omega0 = std::sqrt(d.omega_squared[ii] / d.density);         // :63
+        const double xi = 0.5 * (d.alpha / omega0 + d.beta * omega0);             // :64
+        const double a = 2.0 * xi * omega0;                                       // :65
+        const double b = std::pow(omega0, 2);                                     // :66
+        const double epsilon = std::exp(-a / 2 * h);                              // :89
+        const double theta = h * std::sqrt(b - a * a / 4.0);                      // :90
+        const double gamma = std::asin(a / (2.0 * std::sqrt(b)));                 // :91
+        const double omega = std::sqrt(b);                                        // :92
+        const double omega_d = std::sqrt(b - std::pow(a, 2) / 4.0);               // :93
+        o.c1[ii] = 2.0 * epsilon * std::cos(theta);                               // :95
+        o.c2[ii] = -std::pow(epsilon, 2);                                         // :96
+        double c3 = 2.0 * (epsilon * std::cos(theta + gamma)
+                           - std::pow(epsilon, 2) * std::cos(2.0 * theta + gamma));  // :97
+        c3 /= (3.0 * omega * omega_d);                                            // :98
+        c3 *= 1E9;                                                                // :99
+        o.c3[ii] = c3;
+    }
+    if (d.mode_shapes && d.n_dof > 0) {
+        o.n_dof = d.n_dof;
+        o.shapes.assign(d.mode_shapes, d.mode_shapes + (size_t)d.n_modes * d.n_dof);
+    }
+    objs_.push_back(std::move(o));
+    if (id) *id = (int)objs_.size() - 1;
+    return PBSO_OK;
+}
+
+// ModalSolver::readFFATMaps, modal_solver.h:278-284 (std::map keyed by modeId)
+int Engine::set_ffat_maps(int obj, const pbso_ffat_map *maps, int n) {
+    if (finalized_) return fail(PBSO_ERR_STATE, "set_ffat_maps after finalize");
+    if (!valid_obj(obj) || n < 0 || (n > 0 && !maps)) return fail(PBSO_ERR_INVALID, "set_ffat_maps arguments");
+    Object &o = objs_[obj];
+    o.have_maps = true;               // LoadAll returns a non-null (possibly empty) map, SURVEY Q12
+    o.geom.clear();
+    o.psi.clear();
+    o.n_maps = 0;
+    for (int i = 0; i < n; ++i) {
+        const pbso_ffat_map &m = maps[i];
+        if (m.mode_id < 0) return fail(PBSO_ERR_INVALID, "negative modeId");
+        if ((int)o.geom.size() <= m.mode_id) {
+            FfatGeom z;
+            std::memset(&z, 0, sizeof(z));
+            o.geom.resize(m.mode_id + 1, z);
+        }
+        FfatGeom &g = o.geom[m.mode_id];
+        if (!g.valid) o.n_maps++;
+        // every index GetMapVal can form must be inside psi
+        for (int f = 0; f < 6; ++f) {
+            if (m.n_elements[f][0] < 1 || m.n_elements[f][1] < 1 || m.strides[f] < 0 ||
+                (long long)m.strides[f] + (long long)m.n_elements[f][0] * m.n_elements[f][1] > m.n_psi)
+                return fail(PBSO_ERR_INVALID, "FFAT map strides/n_elements exceed psi");
+        }
+        g.k = m.k;
+        g.cell_size = m.cell_size;
+        for (int j = 0; j < 3; ++j) {
+            g.center3[j] = m.center3[j];
+            g.center[j] = m.center[j];
+            g.bbox_low[j] = m.bbox_low[j];
+            g.bbox_top[j] = m.bbox_top[j];
+        }
+        for (int f = 0; f < 6; ++f) {
+            for (int j = 0; j < 3; ++j) g.low_corners[f][j] = m.low_corners[f][j];
+            g.n_elements[f][0] = m.n_elements[f][0];
+            g.n_elements[f][1] = m.n_elements[f][1];
+            g.strides[f] = m.strides[f];
+        }
+        g.n_psi = m.n_psi;
+        g.valid = 1;
+        g.psi_off = (long long)o.psi.size();       // a replaced map leaves its old psi unused
+        o.psi.insert(o.psi.end(), m.psi, m.psi + m.n_psi);
+    }
+    return PBSO_OK;
+}
+
+int Engine::finalize() {
+    if (finalized_) return fail(PBSO_ERR_STATE, "finalize called twice");
+    if (objs_.empty()) return fail(PBSO_ERR_STATE, "no objects");
+    const int N = (int)objs_.size();
+    int mmax = 1;
+    for (const Object &o : objs_) mmax = std::max(mmax, o.n_modes);
+    // team shape: R oscillators per lane, W waves per object.  >= 2 waves per
+    // SIMD (2048 on the chip) are needed for the 2-cycle VALU issue rate; LDS
+    // (one transpose tile per wave) allows W <= 10.
+    const int maxW = 10;
+    int R = desc_.modes_per_lane;
+    if (R != 0 && R != 1 && R != 2 && R != 4 && R != 8) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,4,8");
+    auto waves_for = [&](int r) { return (mmax + 64 * r - 1) / (64 * r); };
+    if (R == 0) {
+        R = 1;
+        for (int r : {4, 2, 1}) {
+            if ((long long)N * waves_for(r) >= 2048 || r == 1) { R = r; break; }
+        }
+        while (waves_for(R) > maxW && R < 8) R *= 2;
+    }
+    int W = waves_for(R);
+    if (W > maxW) return fail(PBSO_ERR_INVALID, "object too large: more than 5120 modes per object not supported yet");
+    R_ = R;
+    W_ = W;
+    m_pad_ = 64 * R * W;
+
+    const size_t nm = (size_t)N * m_pad_;
+    std::vector<float> ca(nm, 0.f), cb(nm, 0.f);
+    std::vector<double> c3(nm, 0.0);
+    std::vector<int> nmodes(N);
+    for (int i = 0; i < N; ++i) {
+        const Object &o = objs_[i];
+        nmodes[i] = o.n_modes;
+        for (int m = 0; m < o.n_modes; ++m) {
+            const size_t k = (size_t)i * m_pad_ + m;
+            if (desc_.recurrence_form == PBSO_FORM_VELOCITY) {
+                ca[k] = (float)(-o.c2[m]);                     // eps^2
+                cb[k] = (float)((1.0 - o.c1[m]) - o.c2[m]);    // |1 - z|^2 = 1 - c1 - c2
+            } else {
+                ca[k] = (float)o.c1[m];
+                cb[k] = (float)o.c2[m];
+            }
+            c3[k] = o.c3[m];
+        }
+    }
+    HIPTRY(d_ca_.ensure(nm));
+    HIPTRY(d_cb_.ensure(nm));
+    HIPTRY(d_sq_.ensure(nm));
+    HIPTRY(d_sd_.ensure(nm));
+    HIPTRY(d_c3_.ensure(nm));
+    HIPTRY(d_n_modes_.ensure(N));
+    HIPTRY(hipMemcpy(d_ca_.p, ca.data(), nm * sizeof(float), hipMemcpyHostToDevice));
+    HIPTRY(hipMemcpy(d_cb_.p, cb.data(), nm * sizeof(float), hipMemcpyHostToDevice));
+    HIPTRY(hipMemset(d_sq_.p, 0, nm * sizeof(float)));
+    HIPTRY(hipMemset(d_sd_.p, 0, nm * sizeof(float)));
+    HIPTRY(hipMemcpy(d_c3_.p, c3.data(), nm * sizeof(double), hipMemcpyHostToDevice));
+
+    // mode shapes: mode-major (ModeData.h:24) -> vertex-major [dof][m_pad]
+    {
+        std::vector<long long> off(N, 0);
+        size_t total = 0;
+        for (int i = 0; i < N; ++i) {
+            off[i] = (long long)total;
+            total += (size_t)objs_[i].n_dof * m_pad_;
+        }
+        HIPTRY(d_shape_off_.ensure(N));
+        HIPTRY(hipMemcpy(d_shape_off_.p, off.data(), N * sizeof(long long), hipMemcpyHostToDevice));
+        if (total) {
+            HIPTRY(d_shapes_.ensure(total));
+            std::vector<double> vm;
+            for (int i = 0; i < N; ++i) {
+                Object &o = objs_[i];
+                if (!o.n_dof) continue;
+                vm.assign((size_t)o.n_dof * m_pad_, 0.0);
+                for (int m = 0; m < o.n_modes; ++m)
+                    for (int dof = 0; dof < o.n_dof; ++dof)
+                        vm[(size_t)dof * m_pad_ + m] = o.shapes[(size_t)m * o.n_dof + dof];
+                HIPTRY(hipMemcpy(d_shapes_.p + off[i], vm.data(), vm.size() * sizeof(double), hipMemcpyHostToDevice));
+                std::vector<double>().swap(o.shapes);
+            }
+        }
+    }
+    // FFAT maps
+    {
+        std::vector<long long> goff(N, 0);
+        std::vector<FfatGeom> geom;
+        std::vector<double> psi;
+        for (int i = 0; i < N; ++i) {
+            Object &o = objs_[i];
+            goff[i] = (long long)geom.size();
+            const int ng = std::min((int)o.geom.size(), m_pad_);
+            nmodes[i] = o.n_modes;
+            for (int m = 0; m < ng; ++m) {
+                FfatGeom g = o.geom[m];
+                g.psi_off += (long long)psi.size();
+                geom.push_back(g);
+            }
+            // pad so that every mode < n_modes has an entry
+            for (int m = ng; m < o.n_modes; ++m) {
+                FfatGeom z;
+                std::memset(&z, 0, sizeof(z));
+                geom.push_back(z);
+            }
+            psi.insert(psi.end(), o.psi.begin(), o.psi.end());
+            std::vector<double>().swap(o.psi);
+        }
+        HIPTRY(d_geom_off_.ensure(N));
+        HIPTRY(hipMemcpy(d_geom_off_.p, goff.data(), N * sizeof(long long), hipMemcpyHostToDevice));
+        if (!geom.empty()) {
+            HIPTRY(d_geom_.ensure(geom.size()));
+            HIPTRY(hipMemcpy(d_geom_.p, geom.data(), geom.size() * sizeof(FfatGeom), hipMemcpyHostToDevice));
+        }
+        if (!psi.empty()) {
+            HIPTRY(d_psi_.ensure(psi.size()));
+            HIPTRY(hipMemcpy(d_psi_.p, psi.data(), psi.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
+    HIPTRY(hipMemcpy(d_n_modes_.p, nmodes.data(), N * sizeof(int), hipMemcpyHostToDevice));
+    // transfer rows: [0,N) _latest_transfer, [N,2N) the 1-slot transfer queue, then per-launch scratch
+    HIPTRY(d_xfer_.ensure((size_t)2 * N * m_pad_));
+    HIPTRY(hipMemset(d_xfer_.p, 0, (size_t)2 * N * m_pad_ * sizeof(double)));
+    finalized_ = true;
+    return PBSO_OK;
+}
+
+// ---------------------------------------------------------------------------
+// ModalSolver::enqueueForceMessage, modal_solver.h:329-333
+int Engine::enqueue_force(int obj, const pbso_force_msg &m, int64_t not_before) {
+    if (!finalized_) return fail(PBSO_ERR_STATE, "enqueue_force before finalize");
+    if (!valid_obj(obj)) return fail(PBSO_ERR_INVALID, "object id");
+    Object &o = objs_[obj];
+    if (m.force_type < PBSO_POINT_FORCE || m.force_type > PBSO_AUTOREGRESSIVE_FORCE)
+        return fail(PBSO_ERR_INVALID, "unrecognized force type");             // assert modal_solver.h:73
+    HostForceMsg h;
+    h.force_type = m.force_type;
+    h.sustained_start = m.sustained_force_start != 0;
+    h.sustained_end = m.sustained_force_end != 0;
+    h.clear_all = m.clear_all_forces != 0;
+    h.data_kind = m.data_kind;
+    h.not_before = not_before;
+    h.force = ForceProfile::make(m.force_type, m.gaussian_width_us, rate_);
+    switch (m.data_kind) {
+    case PBSO_DATA_EXPLICIT:
+        if (!m.data || m.n_data != o.n_modes)
+            return fail(PBSO_ERR_INVALID, "dimension of force message incorrect");   // assert :258
+        h.data.assign(m.data, m.data + m.n_data);
+        break;
+    case PBSO_DATA_VERTEX:
+    case PBSO_DATA_FACE: {
+        if (!o.n_dof) return fail(PBSO_ERR_INVALID, "object has no mode shapes for on-device projection");
+        const int nv = o.n_dof / 3;
+        const int cnt = m.data_kind == PBSO_DATA_VERTEX ? 1 : 3;
+        for (int j = 0; j < cnt; ++j)
+            if (m.vids[j] < 0 || m.vids[j] >= nv) return fail(PBSO_ERR_INVALID, "vertex id out of range");
+        for (int j = 0; j < 3; ++j) {
+            h.vids[j] = m.vids[j];
+            h.coords[j] = m.coords[j];
+            h.vn[j] = m.vn[j];
+        }
+        break;
+    }
+    case PBSO_DATA_ZERO:
+        break;
+    default:
+        return fail(PBSO_ERR_INVALID, "data_kind");
+    }
+    if (o.force_q.size() >= 1023) return 0;      // ReaderWriterQueue(512): ceilToPow2(513)-1 usable slots
+    // keep arrival order monotone: a message cannot overtake an earlier one (FIFO)
+    if (!o.force_q.empty()) h.not_before = std::max(h.not_before, o.force_q.back().not_before);
+    o.force_q.push_back(std::move(h));
+    return 1;
+}
+
+static void push_timed(std::deque<TimedEvent> &q, const TimedEvent &ev) {
+    auto it = q.end();
+    while (it != q.begin() && (it - 1)->not_before > ev.not_before) --it;
+    q.insert(it, ev);
+}
+
+// ModalSolver::enqueueArprmMessageNoFail, modal_solver.h:382-393
+int Engine::enqueue_arprm(int obj, const double a[2], double sigma, double mu, int64_t not_before) {
+    if (!finalized_) return fail(PBSO_ERR_STATE, "enqueue_arprm before finalize");
+    if (!valid_obj(obj)) return fail(PBSO_ERR_INVALID, "object id");
+    TimedEvent ev;
+    ev.kind = TimedEvent::ARPRM;
+    ev.not_before = not_before;
+    ev.v[0] = a[0]; ev.v[1] = a[1]; ev.v[2] = sigma; ev.v[3] = mu;
+    ev.flag = 0;
+    push_timed(objs_[obj].pending, ev);
+    return 1;
+}
+
+// ModalSolver::computeTransfer(pos), modal_solver.h:286-300
+int Engine::compute_transfer(int obj, const double pos[3], int64_t not_before) {
+    if (!finalized_) return fail(PBSO_ERR_STATE, "compute_transfer before finalize");
+    if (!valid_obj(obj)) return fail(PBSO_ERR_INVALID, "object id");
+    Object &o = objs_[obj];
+    if (!o.have_maps) return 0;                                   // :290-291
+    for (int m = 0; m < o.n_modes; ++m)
+        if (m >= (int)o.geom.size() || !o.geom[m].valid)
+            return fail(PBSO_ERR_MISSING_MAP, "FFAT map for a modeId in 0..N_modes-1 is missing (std::map::at throws)");
+    if (not_before <= buffers_done_ && o.pending.empty() && o.trans_full) return 0;   // try_enqueue on a full 1-slot queue
+    TimedEvent ev;
+    ev.kind = TimedEvent::TRANSFER;
+    ev.not_before = not_before;
+    ev.v[0] = pos[0]; ev.v[1] = pos[1]; ev.v[2] = pos[2]; ev.v[3] = 0;
+    ev.flag = 0;
+    push_timed(o.pending, ev);
+    return 1;
+}
+
+// ModalSolver::setUseTransfer, modal_solver.h:148-152
+int Engine::set_use_transfer(int obj, int use, int64_t not_before) {
+    if (!finalized_) return fail(PBSO_ERR_STATE, "set_use_transfer before finalize");
+    if (!valid_obj(obj)) return fail(PBSO_ERR_INVALID, "object id");
+    TimedEvent ev;
+    ev.kind = TimedEvent::USE_TRANSFER;
+    ev.not_before = not_before;
+    ev.v[0] = ev.v[1] = ev.v[2] = ev.v[3] = 0;
+    ev.flag = use ? 1 : 0;
+    push_timed(objs_[obj].pending, ev);
+    return PBSO_OK;
+}
+
+int Engine::alloc_slot() {
+    if (!free_slots_.empty()) {
+        int s = free_slots_.back();
+        free_slots_.pop_back();
+        return s;
+    }
+    return (int)n_slots_++;
+}
+
+// ---------------------------------------------------------------------------
+// One object, one buffer: ModalSolver::step lines 184-256.
+int Engine::plan_object(int oi, int b, int nb, int64_t t) {
+    Object &o = objs_[oi];
+    const int N = (int)objs_.size();
+    BufDesc &d = set_[cur_set_].h_desc.p[(size_t)oi * nb + b];
+
+    // GUI-thread calls stamped for this buffer or earlier
+    while (!o.pending.empty() && o.pending.front().not_before <= t) {
+        const TimedEvent ev = o.pending.front();
+        if (ev.kind == TimedEvent::ARPRM) {
+            if (o.arprm_full) break;              // NoFail: the caller spins until the 1-slot queue drains
+            o.arprm_full = true;
+            std::memcpy(o.arprm, ev.v, sizeof(o.arprm));
+        } else if (ev.kind == TimedEvent::TRANSFER) {
+            if (!o.trans_full) {                  // try_enqueue; a full queue drops the update
+                FfatEvent fe;
+                fe.obj = oi;
+                fe.row = 2 * N + n_xfer_scratch_++;
+                fe.pos[0] = ev.v[0]; fe.pos[1] = ev.v[1]; fe.pos[2] = ev.v[2];
+                ffat_.push_back(fe);
+                o.trans_full = true;
+                o.trans_row = fe.row;
+            }
+        } else {
+            o.use_transfer = ev.flag != 0;
+        }
+        o.pending.pop_front();
+    }
+
+    // :184 dequeue at most one force message
+    if (!o.force_q.empty() && o.force_q.front().not_before <= t) {
+        HostForceMsg mess = std::move(o.force_q.front());
+        o.force_q.pop_front();
+        if (mess.clear_all) {                                           // :186-189
+            for (ActiveForce &af : o.active) freed_this_plan_.push_back(af.slot);
+            o.active.clear();
+            d.flags |= DESC_SKIP;
+            emitted_[(size_t)oi * nb + b] = 0;
+            return PBSO_OK;
+        }
+        // the message's modal data becomes one immutable row of the slot pool
+        const int slot = alloc_slot();
+        if (mess.data_kind == PBSO_DATA_EXPLICIT || mess.data_kind == PBSO_DATA_ZERO) {
+            const size_t off = stage_.size();
+            stage_.resize(off + m_pad_, 0.0);
+            if (mess.data_kind == PBSO_DATA_EXPLICIT)
+                std::copy(mess.data.begin(), mess.data.end(), stage_.begin() + off);
+            stage_slot_.push_back(slot);
+        } else {
+            ProjectEvent pe;
+            pe.obj = oi;
+            pe.kind = mess.data_kind;
+            pe.slot = slot;
+            for (int j = 0; j < 3; ++j) {
+                pe.vids[j] = mess.vids[j];
+                pe.coords[j] = mess.coords[j];
+                pe.vn[j] = mess.vn[j];
+            }
+            proj_.push_back(pe);
+        }
+        ActiveForce af;
+        af.slot = slot;
+        af.force_type = mess.force_type;
+        af.force = mess.force;
+        bool slot_used = false;
+        if (mess.sustained_start) {                                     // :190-194
+            for (ActiveForce &x : o.active) freed_this_plan_.push_back(x.slot);
+            o.active.clear();
+            o.sustained = true;
+            o.active.push_back(af);
+            slot_used = true;
+        }
+        if (!o.sustained) {                                             // :195-196
+            o.active.push_back(af);
+            slot_used = true;
+        } else {                                                        // :197-200 data only
+            if (o.active.empty())
+                return fail(PBSO_ERR_ASSERT, "sustained force list is empty (reference dereferences begin() of an empty list)");
+            if (o.active.front().slot != slot) {
+                freed_this_plan_.push_back(o.active.front().slot);
+                o.active.front().slot = slot;
+                slot_used = true;
+            }
+        }
+        if (mess.sustained_end) {                                       // :201-204
+            for (ActiveForce &x : o.active) freed_this_plan_.push_back(x.slot);
+            o.active.clear();
+            o.sustained = false;
+            slot_used = true;   // freed through the list (or below)
+        }
+        if (!slot_used) freed_this_plan_.push_back(slot);
+    }
+
+    // :206-240 time profile and spatial sum
+    double *T = tbuf_.data();
+    std::fill(T, T + B_, 0.0);
+    const int row_begin = (int)slot_idx_.size();
+    if (!o.sustained) {
+        size_t w = 0;
+        for (size_t r = 0; r < o.active.size(); ++r) {
+            ActiveForce &af = o.active[r];
+            const bool added = af.force.add(T, B_);
+            if (!added) {
+                freed_this_plan_.push_back(af.slot);                    // erase
+            } else {
+                slot_idx_.push_back(af.slot);
+                if (w != r) o.active[w] = std::move(af);
+                ++w;
+            }
+        }
+        o.active.resize(w);
+    } else {
+        if (o.active.size() != 1)
+            return fail(PBSO_ERR_ASSERT, "Should only have 1 concurrent sustained force");   // assert :223
+        ActiveForce &af = o.active.front();
+        if (af.force_type == PBSO_AUTOREGRESSIVE_FORCE && o.arprm_full) {   // :226-236
+            o.arprm_full = false;
+            af.force.set_param(o.arprm, o.arprm[2], o.arprm[3]);
+        }
+        af.force.add(T, B_);
+        slot_idx_.push_back(af.slot);
+    }
+    uint32_t mask = 0;
+    for (int i = 0; i < B_; ++i)
+        if (T[i] != 0.0) mask |= 1u << (i / TILE);
+    if ((int)slot_idx_.size() > row_begin && mask) {
+        d.frow = (int)row_obj_.size();
+        d.tile_mask = mask;
+        row_obj_.push_back(oi);
+        row_ptr_.push_back((int)slot_idx_.size());
+        const size_t off = tprof_.size();
+        tprof_.resize(off + b_pad_, 0.f);
+        for (int i = 0; i < B_; ++i) tprof_[off + i] = (float)T[i];
+    } else {
+        slot_idx_.resize(row_begin);          // S * 0 == 0: a force-free buffer
+    }
+
+    // :242-256 transfer selection (single caller thread: try_lock always succeeds)
+    if (o.use_transfer) {
+        if (o.trans_full) {
+            o.latest_row = o.trans_row;
+            d.trow = o.trans_row;
+            o.trans_full = false;
+        }
+    } else if (o.latest_row != XFER_UNIT) {
+        o.latest_row = XFER_UNIT;
+        d.trow = XFER_UNIT;
+    }
+    return PBSO_OK;
+}
+
+int Engine::plan(int nb) {
+    const int N = (int)objs_.size();
+    PlanSet &ps = set_[cur_set_];
+    HIPTRY(ps.h_desc.ensure((size_t)N * nb));
+    HIPTRY(ps.h_xfer_init.ensure(N));
+    const BufDesc dflt = {-1, 0u, XFER_KEEP, 0u};
+    std::fill(ps.h_desc.p, ps.h_desc.p + (size_t)N * nb, dflt);
+    emitted_.assign((size_t)N * nb, 1);
+    row_ptr_.assign(1, 0);
+    slot_idx_.clear(); row_obj_.clear(); tprof_.clear(); stage_.clear(); stage_slot_.clear();
+    proj_.clear(); ffat_.clear(); freed_this_plan_.clear();
+    n_xfer_scratch_ = 0;
+    busy_.clear();
+    for (int i = 0; i < N; ++i) {
+        const Object &o = objs_[i];
+        ps.h_xfer_init.p[i] = o.latest_row;
+        if (!o.force_q.empty() || !o.active.empty() || !o.pending.empty() || o.trans_full ||
+            o.sustained || (!o.use_transfer && o.latest_row != XFER_UNIT))
+            busy_.push_back(i);
+    }
+    for (int b = 0; b < nb; ++b) {
+        const int64_t t = buffers_done_ + b;
+        for (int i : busy_) {
+            int rc = plan_object(i, b, nb, t);
+            if (rc != PBSO_OK) return rc;
+        }
+    }
+    return PBSO_OK;
+}
+
+// ---------------------------------------------------------------------------
+template <class T>
+static hipError_t upload(PinBuf<T> &h, DevBuf<T> &d, const T *src, size_t n, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipError_t e = h.ensure(n);
+    if (e != hipSuccess) return e;
+    e = d.ensure(n, false, s);
+    if (e != hipSuccess) return e;
+    std::memcpy(h.p, src, n * sizeof(T));
+    return hipMemcpyAsync(d.p, h.p, n * sizeof(T), hipMemcpyHostToDevice, s);
+}
+
+int Engine::step(int nb, void *d_audio_user) {
+    if (!finalized_) return fail(PBSO_ERR_STATE, "step before finalize");
+    if (nb <= 0) return fail(PBSO_ERR_INVALID, "n_buffers must be > 0");
+    const int N = (int)objs_.size();
+    PlanSet &ps = set_[cur_set_];
+    HIPTRY(hipEventSynchronize(ev_set_[cur_set_]));      // this set's previous uploads are done
+
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = plan(nb);
+    if (rc != PBSO_OK) return rc;
+    // keep _latest_transfer / the transfer queue in their persistent rows after the launch
+    std::vector<int> copy_latest, copy_queued;
+    for (int i : busy_) {
+        Object &o = objs_[i];
+        if (o.latest_row >= 0 && o.latest_row != i) {
+            copy_latest.push_back(o.latest_row);
+            copy_latest.push_back(i);
+            o.latest_row = i;
+        }
+        if (o.trans_full && o.trans_row != N + i) {
+            copy_queued.push_back(o.trans_row);
+            copy_queued.push_back(N + i);
+            o.trans_row = N + i;
+        }
+    }
+    for (int s : freed_this_plan_) free_slots_.push_back(s);
+    last_plan_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+
+    const int n_frows = (int)row_obj_.size();
+    last_frows_ = n_frows;
+    last_trows_ = (int64_t)ffat_.size();
+    // device arenas
+    HIPTRY(d_slots_.ensure(std::max<size_t>(1, n_slots_) * m_pad_, true, stream_));
+    HIPTRY(d_xfer_.ensure((size_t)(2 * N + n_xfer_scratch_) * m_pad_, true, stream_));
+    HIPTRY(d_grows_.ensure(std::max<size_t>(1, (size_t)n_frows) * m_pad_, false, stream_));
+    float *audio = (float *)d_audio_user;
+    if (!audio) {
+        HIPTRY(d_audio_.ensure((size_t)N * nb * B_, false, stream_));
+        audio = d_audio_.p;
+    }
+    const bool qn = desc_.qnorm_mode == PBSO_QNORM_ALL;
+    if (qn) HIPTRY(d_qnorm_.ensure((size_t)N * nb * m_pad_, false, stream_));
+
+    if (ev_pending_.size() >= 256) {          // bound the number of live events
+        int hrc = harvest_timing();
+        if (hrc != PBSO_OK) return hrc;
+    }
+    EvQuad evq;
+    if (!ev_free_.empty()) {
+        evq = ev_free_.back();
+        ev_free_.pop_back();
+    } else {
+        HIPTRY(hipEventCreate(&evq.k0));
+        HIPTRY(hipEventCreate(&evq.k1));
+        HIPTRY(hipEventCreate(&evq.p0));
+        HIPTRY(hipEventCreate(&evq.p1));
+    }
+    HIPTRY(hipEventRecord(evq.p0, stream_));
+    HIPTRY(ps.d_desc.ensure((size_t)N * nb, false, stream_));
+    HIPTRY(hipMemcpyAsync(ps.d_desc.p, ps.h_desc.p, (size_t)N * nb * sizeof(BufDesc), hipMemcpyHostToDevice, stream_));
+    HIPTRY(ps.d_xfer_init.ensure(N, false, stream_));
+    HIPTRY(hipMemcpyAsync(ps.d_xfer_init.p, ps.h_xfer_init.p, (size_t)N * sizeof(int), hipMemcpyHostToDevice, stream_));
+    HIPTRY(upload(ps.h_row_ptr, ps.d_row_ptr, row_ptr_.data(), row_ptr_.size(), stream_));
+    HIPTRY(upload(ps.h_slot_idx, ps.d_slot_idx, slot_idx_.data(), slot_idx_.size(), stream_));
+    HIPTRY(upload(ps.h_row_obj, ps.d_row_obj, row_obj_.data(), row_obj_.size(), stream_));
+    HIPTRY(upload(ps.h_tprof, ps.d_tprof, tprof_.data(), tprof_.size(), stream_));
+    HIPTRY(upload(ps.h_stage, ps.d_stage, stage_.data(), stage_.size(), stream_));
+    HIPTRY(upload(ps.h_stage_slot, ps.d_stage_slot, stage_slot_.data(), stage_slot_.size(), stream_));
+    HIPTRY(upload(ps.h_proj, ps.d_proj, proj_.data(), proj_.size(), stream_));
+    HIPTRY(upload(ps.h_ffat, ps.d_ffat, ffat_.data(), ffat_.size(), stream_));
+    std::vector<int> copies(copy_latest);
+    copies.insert(copies.end(), copy_queued.begin(), copy_queued.end());
+    // layout: [src,dst] pairs -> split into src[] and dst[] arrays
+    std::vector<int> cp(copies.size());
+    const int n_cl = (int)copy_latest.size() / 2, n_cq = (int)copy_queued.size() / 2;
+    for (int i = 0; i < n_cl + n_cq; ++i) {
+        cp[i] = copies[2 * i];
+        cp[n_cl + n_cq + i] = copies[2 * i + 1];
+    }
+    HIPTRY(upload(ps.h_copy, ps.d_copy, cp.data(), cp.size(), stream_));
+
+    // K3 / scatter -> data slots ; K4 -> transfer rows ; combine -> g rows
+    LAUNCHTRY(launch_scatter_rows(ps.d_stage.p, ps.d_stage_slot.p, (int)stage_slot_.size(), d_slots_.p, m_pad_, stream_));
+    LAUNCHTRY(launch_modal_project(ps.d_proj.p, (int)proj_.size(), d_shapes_.p, d_shape_off_.p, d_n_modes_.p,
+                                   d_slots_.p, m_pad_, stream_));
+    LAUNCHTRY(launch_ffat_lookup(ps.d_ffat.p, (int)ffat_.size(), d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p,
+                                 d_xfer_.p, m_pad_, stream_));
+    LAUNCHTRY(launch_force_combine(ps.d_row_ptr.p, ps.d_slot_idx.p, ps.d_row_obj.p, n_frows, d_slots_.p, d_c3_.p,
+                                   d_grows_.p, m_pad_, stream_));
+    // K1
+    IirParams kp;
+    kp.ca = d_ca_.p; kp.cb = d_cb_.p; kp.sq = d_sq_.p; kp.sd = d_sd_.p;
+    kp.desc = ps.d_desc.p;
+    kp.grows = d_grows_.p;
+    kp.tprof = ps.d_tprof.p;
+    kp.xfer_rows = d_xfer_.p;
+    kp.xfer_init = ps.d_xfer_init.p;
+    kp.audio = audio;
+    kp.qnorm = qn ? d_qnorm_.p : nullptr;
+    kp.nb = nb; kp.n_tiles = n_tiles_; kp.m_pad = m_pad_; kp.b_pad = b_pad_;
+    kp.audio_stride = (long long)nb * B_;
+    HIPTRY(hipEventRecord(evq.k0, stream_));
+    if (packed_)
+        LAUNCHTRY(iir_slp::launch_iir_bank(kp, N, R_, W_, desc_.recurrence_form, qn, stream_));
+    else
+        LAUNCHTRY(iir_noslp::launch_iir_bank(kp, N, R_, W_, desc_.recurrence_form, qn, stream_));
+    HIPTRY(hipEventRecord(evq.k1, stream_));
+    // _latest_transfer = trans (modal_solver.h:251), then re-park a still-queued transfer
+    LAUNCHTRY(launch_copy_rows(ps.d_copy.p, ps.d_copy.p + (n_cl + n_cq), n_cl, d_xfer_.p, m_pad_, stream_));
+    LAUNCHTRY(launch_copy_rows(ps.d_copy.p + n_cl, ps.d_copy.p + (n_cl + n_cq) + n_cl, n_cq, d_xfer_.p, m_pad_, stream_));
+    HIPTRY(hipEventRecord(evq.p1, stream_));
+    HIPTRY(hipEventRecord(ev_set_[cur_set_], stream_));
+    ev_pending_.push_back(evq);
+    tot_plan_ms_ += last_plan_ms_;
+    tot_steps_ += 1;
+    last_audio_ = audio;
+    last_nb_ = nb;
+    buffers_done_ += nb;
+    cur_set_ ^= 1;
+    return PBSO_OK;
+}
+
+int Engine::sync() {
+    if (stream_) HIPTRY(hipStreamSynchronize(stream_));
+    return PBSO_OK;
+}
+
+int Engine::read_audio(float *out, size_t n) {
+    if (!last_audio_) return fail(PBSO_ERR_STATE, "no step yet");
+    const size_t total = (size_t)objs_.size() * last_nb_ * B_;
+    if (n != total) return fail(PBSO_ERR_INVALID, "read_audio size mismatch");
+    HIPTRY(hipMemcpyAsync(out, last_audio_, total * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    return sync();
+}
+
+int Engine::read_emitted(unsigned char *out, size_t n) {
+    if (n != emitted_.size()) return fail(PBSO_ERR_INVALID, "read_emitted size mismatch");
+    std::memcpy(out, emitted_.data(), n);
+    return PBSO_OK;
+}
+
+int Engine::read_qnorm(int obj, int buffer, float *out, int n) {
+    if (desc_.qnorm_mode != PBSO_QNORM_ALL) return fail(PBSO_ERR_STATE, "qnorm_mode is OFF");
+    if (!valid_obj(obj) || buffer < 0 || buffer >= last_nb_ || n < 0 || n > m_pad_)
+        return fail(PBSO_ERR_INVALID, "read_qnorm arguments");
+    HIPTRY(hipMemcpyAsync(out, d_qnorm_.p + ((size_t)obj * last_nb_ + buffer) * m_pad_, (size_t)n * sizeof(float),
+                          hipMemcpyDeviceToHost, stream_));
+    return sync();
+}
+
+int Engine::read_state(int obj, double *q1, double *q2, int n) {
+    if (!finalized_) return fail(PBSO_ERR_STATE, "read_state before finalize");
+    if (!valid_obj(obj) || n < 0 || n > m_pad_) return fail(PBSO_ERR_INVALID, "read_state arguments");
+    std::vector<float> a(n), b(n);
+    HIPTRY(hipMemcpyAsync(a.data(), d_sq_.p + (size_t)obj * m_pad_, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    HIPTRY(hipMemcpyAsync(b.data(), d_sd_.p + (size_t)obj * m_pad_, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    int rc = sync();
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        q1[i] = a[i];
+        q2[i] = desc_.recurrence_form == PBSO_FORM_VELOCITY ? (double)a[i] - (double)b[i] : (double)b[i];
+    }
+    return PBSO_OK;
+}
+
+// ModalSolver::getLatestTransfer, modal_solver.h:145-147
+int Engine::get_latest_transfer(int obj, double *out) {
+    if (!finalized_) return fail(PBSO_ERR_STATE, "get_latest_transfer before finalize");
+    if (!valid_obj(obj)) return fail(PBSO_ERR_INVALID, "object id");
+    const Object &o = objs_[obj];
+    if (o.latest_row == XFER_UNIT) {
+        for (int i = 0; i < o.n_modes; ++i) { out[i] = 1.0; out[i] *= 1E7; }     // setToUnit :89-92
+        return PBSO_OK;
+    }
+    HIPTRY(hipMemcpyAsync(out, d_xfer_.p + (size_t)o.latest_row * m_pad_, (size_t)o.n_modes * sizeof(double),
+                          hipMemcpyDeviceToHost, stream_));
+    return sync();
+}
+
+// ModalSolver::computeTransfer(pos, T *trans), modal_solver.h:302-315, batched
+int Engine::compute_transfer_batch(int obj, const double *pos, int n_pos, double *out) {
+    if (!finalized_) return fail(PBSO_ERR_STATE, "compute_transfer_batch before finalize");
+    if (!valid_obj(obj) || n_pos < 0 || (n_pos && (!pos || !out))) return fail(PBSO_ERR_INVALID, "arguments");
+    Object &o = objs_[obj];
+    if (!o.have_maps) return 0;
+    const int nmap = o.n_maps;
+    if (nmap > o.n_modes) return fail(PBSO_ERR_INVALID, "more FFAT maps than audible modes is not supported");
+    for (int m = 0; m < nmap; ++m)
+        if (m >= (int)o.geom.size() || !o.geom[m].valid)
+            return fail(PBSO_ERR_MISSING_MAP, "FFAT map ids are not 0..size-1 (std::map::at throws)");
+    if (!n_pos) return 1;
+    DevBuf<double> rows;
+    DevBuf<FfatEvent> dev;
+    std::vector<FfatEvent> evs(n_pos);
+    for (int i = 0; i < n_pos; ++i) {
+        evs[i].obj = obj;
+        evs[i].row = i;
+        for (int j = 0; j < 3; ++j) evs[i].pos[j] = pos[3 * i + j];
+    }
+    int rc = PBSO_OK;
+    hipError_t e = rows.ensure((size_t)n_pos * m_pad_, false, stream_);
+    if (e == hipSuccess) e = dev.ensure(n_pos, false, stream_);
+    if (e == hipSuccess) e = hipMemcpyAsync(dev.p, evs.data(), n_pos * sizeof(FfatEvent), hipMemcpyHostToDevice, stream_);
+    if (e == hipSuccess) {
+        int le = launch_ffat_lookup(dev.p, n_pos, d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p, rows.p, m_pad_, stream_);
+        if (le) e = (hipError_t)le;
+    }
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(out, (size_t)nmap * sizeof(double), rows.p, (size_t)m_pad_ * sizeof(double),
+                             (size_t)nmap * sizeof(double), n_pos, hipMemcpyDeviceToHost, stream_);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+    if (e != hipSuccess) rc = hip_fail(e, "compute_transfer_batch");
+    rows.release();
+    dev.release();
+    return rc == PBSO_OK ? 1 : rc;
+}
+
+int Engine::info(pbso_engine_info *out) {
+    std::memset(out, 0, sizeof(*out));
+    out->n_objects = (int)objs_.size();
+    out->frames_per_buffer = B_;
+    out->modes_padded = m_pad_;
+    out->modes_per_lane = R_;
+    out->waves_per_object = W_;
+    out->lds_bytes_per_workgroup = finalized_ ? (int)iir_lds_bytes(W_) : 0;
+    out->buffers_done = buffers_done_;
+    out->last_step_host_plan_ms = last_plan_ms_;
+    out->last_step_forced_rows = last_frows_;
+    out->last_step_transfer_rows = last_trows_;
+    int rc = harvest_timing();
+    if (rc) return rc;
+    out->last_step_kernel_ms = last_kernel_ms_;
+    out->last_step_device_ms = last_device_ms_;
+    out->total_kernel_ms = tot_kernel_ms_;
+    out->total_device_ms = tot_device_ms_;
+    out->total_host_plan_ms = tot_plan_ms_;
+    out->total_steps = tot_steps_;
+    return PBSO_OK;
+}
+
+int Engine::harvest_timing() {
+    if (ev_pending_.empty()) return PBSO_OK;
+    int rc = sync();
+    if (rc) return rc;
+    for (EvQuad &q : ev_pending_) {
+        float ms = 0;
+        HIPTRY(hipEventElapsedTime(&ms, q.k0, q.k1));
+        last_kernel_ms_ = ms;
+        tot_kernel_ms_ += ms;
+        HIPTRY(hipEventElapsedTime(&ms, q.p0, q.p1));
+        last_device_ms_ = ms;
+        tot_device_ms_ += ms;
+        ev_free_.push_back(q);
+    }
+    ev_pending_.clear();
+    return PBSO_OK;
+}
+
+}  // namespace pbso

@@ -1,0 +1,208 @@
+// Host side of the MI355X modal sound engine: one Engine = a batch of
+// independent ModalSolver<double> instances ("objects") on one GPU.
+//
+// The host does what ModalSolver::step does before its hot loop
+// (modal_solver.h:184-256: dequeue <=1 force message, active-force list,
+// sustained forces, AR parameter updates, transfer selection) for every
+// (object, buffer) of a batch and compiles the outcome into a table of
+// BufDesc plus small work lists; the device then runs projection, force
+// combination, FFAT lookups and the oscillator bank for the whole batch.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <deque>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/openpbso_amd.h"
+#include "kernels.h"
+
+namespace pbso {
+
+// ---- growable device / pinned-host buffers ---------------------------------
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n, bool keep = false, hipStream_t s = nullptr);
+    void release();
+};
+template <class T>
+struct PinBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n);
+    void release();
+};
+
+// ---- forces.h: time profile of one force (Point / Gaussian / AR(2)) ---------
+struct ForceProfile {
+    int type = PBSO_POINT_FORCE;
+    bool used = false;                                   // PointForce, forces.h:28
+    double width = 0;                                    // GaussianForce, forces.h:35-40
+    int width_samples = 1, count = 0, center = 0, cutoff = 5;
+    double buf[3] = {0, 0, 0};                           // AutoregressiveForce, forces.h:62-72
+    int buf_idx = 0;
+    double a[2] = {0.783, 0.116}, sigma = 0.00148, mu = 0.142;
+    std::default_random_engine generator;                // default seed, copied with the message
+    std::normal_distribution<double> distribution;
+    static ForceProfile make(int type, double gaussian_width_us, int sample_rate);
+    bool add(double *t, int frames);                     // Force::Add, forces.h:81-128
+    void set_param(const double a_[2], double sigma_, double mu_);   // forces.h:130-137
+};
+
+struct HostForceMsg {                                    // ForceMessage, modal_solver.h:27-77
+    int force_type = PBSO_POINT_FORCE;
+    bool sustained_start = false, sustained_end = false, clear_all = false;
+    int data_kind = PBSO_DATA_ZERO;
+    std::vector<double> data;
+    int vids[3] = {0, 0, 0};
+    double coords[3] = {0, 0, 0}, vn[3] = {0, 0, 0};
+    ForceProfile force;
+    int64_t not_before = 0;
+};
+
+struct ActiveForce {                                     // one entry of _activeForces
+    int slot = -1;                                       // row of the device data-slot pool
+    int force_type = PBSO_POINT_FORCE;
+    ForceProfile force;
+};
+
+struct TimedEvent {
+    enum Kind { ARPRM, TRANSFER, USE_TRANSFER } kind;
+    int64_t not_before;
+    double v[4];                                         // arprm: a0,a1,sigma,mu; transfer: pos
+    int flag;
+};
+
+struct Object {
+    int n_modes = 0;
+    std::vector<double> c1, c2, c3;                      // modal_integrator.h:95-99 (fp64)
+    int n_dof = 0;
+    std::vector<double> shapes;                          // mode-major until finalize
+    bool have_maps = false;                              // _ffat_maps non-null
+    int n_maps = 0;
+    std::vector<FfatGeom> geom;                          // index = modeId
+    std::vector<double> psi;
+    // run-time state of the ModalSolver this object stands for
+    std::deque<HostForceMsg> force_q;                    // _queue_force (1023 usable slots)
+    std::vector<ActiveForce> active;                     // _activeForces
+    bool sustained = false;                              // _sustainedForces
+    bool arprm_full = false;                             // _queue_arprm (1 slot)
+    double arprm[4] = {0, 0, 0, 0};
+    bool trans_full = false;                             // _queue_trans (1 slot)
+    int trans_row = XFER_UNIT;
+    bool use_transfer = true;                            // _useTransfer
+    int latest_row = XFER_UNIT;                          // where _latest_transfer lives (XFER_UNIT or own row)
+    std::deque<TimedEvent> pending;                      // stamped arprm / transfer / use-transfer calls
+};
+
+class Engine {
+public:
+    explicit Engine(const pbso_engine_desc &d);
+    ~Engine();
+    int init();
+    int add_object(const pbso_object_desc &d, int *id);
+    int set_ffat_maps(int obj, const pbso_ffat_map *maps, int n);
+    int finalize();
+    int enqueue_force(int obj, const pbso_force_msg &m, int64_t not_before);
+    int enqueue_arprm(int obj, const double a[2], double sigma, double mu, int64_t not_before);
+    int compute_transfer(int obj, const double pos[3], int64_t not_before);
+    int compute_transfer_batch(int obj, const double *pos, int n_pos, double *out);
+    int set_use_transfer(int obj, int use, int64_t not_before);
+    int get_latest_transfer(int obj, double *out);
+    int step(int n_buffers, void *d_audio);
+    int sync();
+    int read_audio(float *out, size_t n);
+    int read_emitted(unsigned char *out, size_t n);
+    int read_qnorm(int obj, int buffer, float *out, int n);
+    int read_state(int obj, double *q1, double *q2, int n);
+    void *audio_ptr() { return last_audio_; }
+    int info(pbso_engine_info *out);
+    const char *last_error() const { return err_.c_str(); }
+    int n_objects() const { return (int)objs_.size(); }
+    int object_modes(int obj) const { return objs_[obj].n_modes; }
+
+private:
+    int fail(int code, const std::string &msg);
+    int hip_fail(hipError_t e, const char *what);
+    bool valid_obj(int obj) const { return obj >= 0 && obj < (int)objs_.size(); }
+    int alloc_slot();
+    int plan(int nb);                                    // host bookkeeping for one batch
+    int plan_object(int o, int b, int nb, int64_t t);
+
+    pbso_engine_desc desc_;
+    int B_ = PBSO_FRAMES_PER_BUFFER, rate_ = PBSO_SAMPLE_RATE, n_tiles_ = 9, b_pad_ = 528;
+    int R_ = 0, W_ = 0, m_pad_ = 0;
+    bool finalized_ = false, own_stream_ = false;
+    bool packed_ = false;                                // PBSO_IIR_PACKED: v_pk_*_f32 build of K1
+    hipStream_t stream_ = nullptr;
+    hipEvent_t ev_set_[2] = {nullptr, nullptr};
+    struct EvQuad { hipEvent_t k0, k1, p0, p1; };
+    std::vector<EvQuad> ev_free_, ev_pending_;           // one quad per step, harvested in info()
+    int harvest_timing();
+    double tot_kernel_ms_ = 0, tot_device_ms_ = 0, tot_plan_ms_ = 0, last_kernel_ms_ = 0, last_device_ms_ = 0;
+    int64_t tot_steps_ = 0;
+    std::string err_;
+    std::vector<Object> objs_;
+    int64_t buffers_done_ = 0;
+    int cur_set_ = 0;
+
+    // persistent device state
+    DevBuf<float> d_ca_, d_cb_, d_sq_, d_sd_;
+    DevBuf<double> d_c3_;
+    DevBuf<double> d_shapes_;
+    DevBuf<long long> d_shape_off_;
+    DevBuf<int> d_n_modes_;
+    DevBuf<FfatGeom> d_geom_;
+    DevBuf<long long> d_geom_off_;
+    DevBuf<double> d_psi_;
+    DevBuf<double> d_slots_;                             // [n_slots][m_pad] ForceMessage::data rows
+    DevBuf<double> d_xfer_;                              // [n_obj + scratch][m_pad]
+    DevBuf<float> d_audio_, d_qnorm_;
+    float *last_audio_ = nullptr;
+    int last_nb_ = 0;
+    size_t n_slots_ = 0;
+    std::vector<int> free_slots_, freed_this_plan_;
+
+    // per-launch plan, double-buffered (host pinned + device copies)
+    struct PlanSet {
+        PinBuf<BufDesc> h_desc;     DevBuf<BufDesc> d_desc;
+        PinBuf<int> h_row_ptr;      DevBuf<int> d_row_ptr;
+        PinBuf<int> h_slot_idx;     DevBuf<int> d_slot_idx;
+        PinBuf<int> h_row_obj;      DevBuf<int> d_row_obj;
+        PinBuf<float> h_tprof;      DevBuf<float> d_tprof;
+        PinBuf<double> h_stage;     DevBuf<double> d_stage;
+        PinBuf<int> h_stage_slot;   DevBuf<int> d_stage_slot;
+        PinBuf<ProjectEvent> h_proj; DevBuf<ProjectEvent> d_proj;
+        PinBuf<FfatEvent> h_ffat;   DevBuf<FfatEvent> d_ffat;
+        PinBuf<int> h_copy;         DevBuf<int> d_copy;
+        PinBuf<int> h_xfer_init;    DevBuf<int> d_xfer_init;
+        void release();
+    } set_[2];
+    DevBuf<float> d_grows_;
+    // plan scratch (host)
+    std::vector<int> row_ptr_, slot_idx_, row_obj_, stage_slot_, busy_;
+    std::vector<float> tprof_;
+    std::vector<double> stage_;
+    std::vector<ProjectEvent> proj_;
+    std::vector<FfatEvent> ffat_;
+    std::vector<unsigned char> emitted_;
+    std::vector<double> tbuf_;
+    int n_xfer_scratch_ = 0;
+    double last_plan_ms_ = 0;
+    int64_t last_frows_ = 0, last_trows_ = 0;
+};
+
+// loaders (loaders.cpp)
+int load_modes_file(const char *path, int *n_dof, int *n_modes, std::vector<double> &omega2,
+                    std::vector<double> &modes);
+int num_modes_audible(const std::vector<double> &omega2, double density, double audible_freq);
+int load_material_file(const char *path, double out[5]);
+int parse_fatcube(const unsigned char *bytes, size_t n, pbso_ffat_map *out);
+int list_dir_files(const char *dir, const char *contains, std::vector<std::string> &names);
+int read_file_bytes(const char *path, std::vector<unsigned char> &out);
+
+}  // namespace pbso

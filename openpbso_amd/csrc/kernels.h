@@ -1,0 +1,102 @@
+// Shared host/device declarations of the HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pbso {
+
+// one audio buffer is processed as tiles of TILE samples; 513 = 9 * 57
+constexpr int TILE = 57;
+// LDS row stride (floats) of the per-wave [TILE][64] transpose tile: 68 keeps
+// 16-B alignment for ds_read_b128 and puts the 16 lanes of every b128 lane
+// group on 16 distinct 4-bank slots (68 mod 64 = 4).
+constexpr int LDS_ROW = 68;
+constexpr int MAX_TILES = 32;          // tile mask is 32 bits
+
+// transfer-row codes in BufDesc::trow
+constexpr int XFER_KEEP = -1;          // keep _latest_transfer
+constexpr int XFER_UNIT = -2;          // TransMessage::setToUnit, 1e7 (modal_solver.h:89-92)
+
+constexpr uint32_t DESC_SKIP = 1u;     // step() returned early (modal_solver.h:186-189)
+
+// what ModalSolver::step's bookkeeping (modal_solver.h:184-256) decided for one
+// (object, buffer); written by the host planner, read with scalar loads.
+struct BufDesc {
+    int32_t frow;        // row of g = c3 * S and of the time profile; -1: force-free buffer
+    uint32_t tile_mask;  // bit t set: profile has a non-zero sample in tile t
+    int32_t trow;        // transfer row to switch to before this buffer, or XFER_*
+    uint32_t flags;
+};
+
+struct IirParams {
+    const float *ca, *cb;        // [n_obj][m_pad] coefficients (form dependent)
+    float *sq, *sd;              // [n_obj][m_pad] state (form dependent)
+    const BufDesc *desc;         // [n_obj][nb]
+    const float *grows;          // [n_frows][m_pad]  g = (float)(c3 * S)
+    const float *tprof;          // [n_frows][b_pad]  force time profiles
+    const double *xfer_rows;     // [n_rows][m_pad]   FFAT transfer rows (fp64)
+    const int *xfer_init;        // [n_obj] row (or XFER_UNIT) in effect when the launch starts
+    float *audio;                // [n_obj][audio_stride]
+    float *qnorm;                // [n_obj][nb][m_pad] or nullptr
+    int nb, n_tiles, m_pad, b_pad;
+    long long audio_stride;
+};
+
+// launches the oscillator bank; returns hipError_t as int.  Two builds of the
+// same source: packed (v_pk_*_f32 pairs from the SLP vectoriser) and scalar.
+namespace iir_slp {
+int launch_iir_bank(const IirParams &p, int n_obj, int modes_per_lane, int waves_per_object,
+                    int form, bool qnorm, hipStream_t stream);
+}
+namespace iir_noslp {
+int launch_iir_bank(const IirParams &p, int n_obj, int modes_per_lane, int waves_per_object,
+                    int form, bool qnorm, hipStream_t stream);
+}
+inline size_t iir_lds_bytes(int W) {
+    return sizeof(float) * ((size_t)W * TILE * LDS_ROW + (W > 1 ? 2 * (size_t)(W - 1) * 64 : 0));
+}
+
+// ---- exact fp64 helper kernels (kernels_exact.hip, built with -ffp-contract=off)
+struct ProjectEvent {
+    int obj;
+    int kind;            // PBSO_DATA_VERTEX / PBSO_DATA_FACE
+    int vids[3];
+    int slot;            // destination row of the data-slot pool
+    double coords[3];
+    double vn[3];
+};
+int launch_modal_project(const ProjectEvent *events, int n_events, const double *shapes,
+                         const long long *shape_off, const int *n_modes, double *slots,
+                         int m_pad, hipStream_t stream);
+int launch_scatter_rows(const double *src, const int *dst_slot, int n_rows, double *slots,
+                        int m_pad, hipStream_t stream);
+int launch_force_combine(const int *row_ptr, const int *slot_idx, const int *row_obj, int n_rows,
+                         const double *slots, const double *c3, float *grows, int m_pad,
+                         hipStream_t stream);
+
+struct FfatGeom {        // FFAT_Map<double,3> runtime fields, one per (object, mode)
+    double k;
+    double center3[3];
+    double cell_size;
+    double low_corners[6][3];
+    double center[3];
+    double bbox_low[3];
+    double bbox_top[3];
+    int n_elements[6][2];
+    int strides[6];
+    int n_psi;
+    int valid;
+    long long psi_off;   // offset into the psi pool (doubles)
+};
+struct FfatEvent {
+    int obj;
+    int row;             // destination transfer row
+    double pos[3];
+};
+int launch_ffat_lookup(const FfatEvent *events, int n_events, const FfatGeom *geom,
+                       const long long *geom_off, const int *n_modes, const double *psi,
+                       double *rows, int m_pad, hipStream_t stream);
+int launch_copy_rows(const int *src_row, const int *dst_row, int n, double *rows, int m_pad,
+                     hipStream_t stream);
+
+}  // namespace pbso

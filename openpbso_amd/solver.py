@@ -1,0 +1,323 @@
+"""Host-side mirror of the reference's ModalSolver interface over the C ABI.
+
+`Engine` batches many objects (one reference ModalSolver<double> each) on one
+GPU; `ModalSolver` is the one-object facade with the reference's method names
+(modal_solver.h:100-179) so that tests read like code written against the
+reference.  All numerics happen in libopenpbso_amd.so (HIP); nothing here
+computes audio.
+"""
+import collections
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+POINT_FORCE = capi.POINT_FORCE
+GAUSSIAN_FORCE = capi.GAUSSIAN_FORCE
+AUTOREGRESSIVE_FORCE = capi.AUTOREGRESSIVE_FORCE
+
+
+class PbsoError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__(f"[{status}] {text}")
+        self.status = status
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class ForceMessage:
+    """ForceMessage<double> (modal_solver.h:27-77).
+
+    The modal `data` is either given explicitly (as the GUI thread built it), or
+    as a vertex / face hit to be projected onto the mode shapes on the device
+    (GetModalForceVertex / GetModalForceFace, tools/real_time_modal_sound.cpp:236-295).
+    """
+
+    def __init__(self, data=None, forceType=POINT_FORCE, gaussianWidth=0.0, sustainedForceStart=False,
+                 sustainedForceEnd=False, clearAllForces=False, vid=None, vids=None, coords=None, vn=None):
+        self.data = None if data is None else np.ascontiguousarray(data, dtype=np.float64)
+        self.forceType = forceType
+        self.gaussianWidth = float(gaussianWidth)
+        self.sustainedForceStart = sustainedForceStart
+        self.sustainedForceEnd = sustainedForceEnd
+        self.clearAllForces = clearAllForces
+        self.vid, self.vids, self.coords, self.vn = vid, vids, coords, vn
+
+    def to_c(self):
+        m = capi.ForceMsg()
+        m.force_type = int(self.forceType)
+        m.gaussian_width_us = self.gaussianWidth
+        m.sustained_force_start = int(bool(self.sustainedForceStart))
+        m.sustained_force_end = int(bool(self.sustainedForceEnd))
+        m.clear_all_forces = int(bool(self.clearAllForces))
+        if self.data is not None:
+            m.data_kind = capi.DATA_EXPLICIT
+            m.data = _dp(self.data)
+            m.n_data = self.data.size
+        elif self.vid is not None:
+            m.data_kind = capi.DATA_VERTEX
+            m.vids[0] = int(self.vid)
+            for j in range(3):
+                m.vn[j] = float(self.vn[j])
+        elif self.vids is not None:
+            m.data_kind = capi.DATA_FACE
+            for j in range(3):
+                m.vids[j] = int(self.vids[j])
+                m.coords[j] = float(self.coords[j])
+                m.vn[j] = float(self.vn[j])
+        else:
+            m.data_kind = capi.DATA_ZERO
+        return m
+
+
+class Engine:
+    def __init__(self, device=0, form=capi.FORM_VELOCITY, qnorm=capi.QNORM_ALL, modes_per_lane=0,
+                 stream=None, frames_per_buffer=0):
+        self._l = capi.lib()
+        d = capi.EngineDesc()
+        d.abi_version = capi.ABI_VERSION
+        d.device = device
+        d.frames_per_buffer = frames_per_buffer
+        d.recurrence_form = form
+        d.qnorm_mode = qnorm
+        d.modes_per_lane = modes_per_lane
+        d.stream = stream
+        h = C.c_void_p()
+        rc = self._l.pbso_engine_create(C.byref(d), C.byref(h))
+        self._h = h
+        if rc != capi.OK:
+            text = self._l.pbso_last_error(h).decode() if h else "engine_create failed"
+            if h:
+                self._l.pbso_engine_destroy(h)
+            self._h = None
+            raise PbsoError(rc, text)
+        self.n_modes = []
+        self.B = frames_per_buffer or 513
+        self.qnorm_mode = qnorm
+        self._last_nb = 0
+
+    # -- plumbing -----------------------------------------------------------
+    def _chk(self, rc):
+        if rc < 0:
+            raise PbsoError(rc, self._l.pbso_last_error(self._h).decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.pbso_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- BuildSolver ----------------------------------------------------------
+    def add_object(self, omega_squared, density, alpha, beta, n_modes=None, mode_shapes=None):
+        om = np.ascontiguousarray(omega_squared, dtype=np.float64)
+        d = capi.ObjectDesc()
+        d.n_modes = om.size if n_modes is None else int(n_modes)
+        d.n_omega = om.size
+        d.omega_squared = _dp(om)
+        d.density, d.alpha, d.beta = float(density), float(alpha), float(beta)
+        if mode_shapes is not None:
+            ms = np.ascontiguousarray(mode_shapes, dtype=np.float64)
+            assert ms.ndim == 2 and ms.shape[0] >= d.n_modes
+            ms = np.ascontiguousarray(ms[: d.n_modes])
+            d.n_dof = ms.shape[1]
+            d.mode_shapes = _dp(ms)
+        oid = C.c_int(-1)
+        self._chk(self._l.pbso_add_object(self._h, C.byref(d), C.byref(oid)))
+        self.n_modes.append(d.n_modes)
+        return oid.value
+
+    def add_object_from_files(self, modes_path, material_path, ffat_dir=None):
+        oid, naud = C.c_int(-1), C.c_int(0)
+        self._chk(self._l.pbso_add_object_from_files(
+            self._h, modes_path.encode(), material_path.encode(),
+            None if ffat_dir is None else ffat_dir.encode(), C.byref(oid), C.byref(naud)))
+        self.n_modes.append(naud.value)
+        return oid.value, naud.value
+
+    def set_ffat_maps(self, obj, maps):
+        """maps: list of dicts with the FFAT_Map<double,3> runtime fields."""
+        arr = (capi.FfatMap * len(maps))()
+        keep = []
+        for i, m in enumerate(maps):
+            a = arr[i]
+            a.mode_id = int(m["mode_id"])
+            a.k = float(m["k"])
+            a.cell_size = float(m["cell_size"])
+            for j in range(3):
+                a.center3[j] = float(m["center3"][j])
+                a.center[j] = float(m["center"][j])
+                a.bbox_low[j] = float(m["bbox_low"][j])
+                a.bbox_top[j] = float(m["bbox_top"][j])
+            for f in range(6):
+                for j in range(3):
+                    a.low_corners[f][j] = float(m["low_corners"][f][j])
+                a.n_elements[f][0] = int(m["n_elements"][f][0])
+                a.n_elements[f][1] = int(m["n_elements"][f][1])
+                a.strides[f] = int(m["strides"][f])
+            psi = np.ascontiguousarray(m["psi"], dtype=np.float64)
+            keep.append(psi)
+            a.n_psi = psi.size
+            a.psi = _dp(psi)
+        self._chk(self._l.pbso_object_set_ffat_maps(self._h, obj, arr, len(maps)))
+
+    def read_ffat_maps(self, obj, directory):
+        self._chk(self._l.pbso_object_read_ffat_maps(self._h, obj, directory.encode()))
+
+    def finalize(self):
+        self._chk(self._l.pbso_finalize(self._h))
+
+    # -- messages -------------------------------------------------------------
+    def enqueue_force(self, obj, msg, not_before=0):
+        return bool(self._chk(self._l.pbso_enqueue_force(self._h, obj, C.byref(msg.to_c()), not_before)))
+
+    def enqueue_arprm(self, obj, a, sigma, mu, not_before=0):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        return bool(self._chk(self._l.pbso_enqueue_arprm(self._h, obj, _dp(a), sigma, mu, not_before)))
+
+    def compute_transfer(self, obj, pos, not_before=0):
+        p = np.ascontiguousarray(pos, dtype=np.float64)
+        return bool(self._chk(self._l.pbso_compute_transfer(self._h, obj, _dp(p), not_before)))
+
+    def compute_transfer_batch(self, obj, pos, n_maps):
+        p = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+        out = np.empty((p.shape[0], n_maps))
+        rc = self._chk(self._l.pbso_compute_transfer_batch(self._h, obj, _dp(p), p.shape[0], _dp(out)))
+        return bool(rc), out
+
+    def set_use_transfer(self, obj, use, not_before=0):
+        self._chk(self._l.pbso_set_use_transfer(self._h, obj, int(use), not_before))
+
+    def latest_transfer(self, obj):
+        out = np.empty(max(self.n_modes[obj], 1))
+        self._chk(self._l.pbso_get_latest_transfer(self._h, obj, _dp(out)))
+        return out[: self.n_modes[obj]]
+
+    # -- stepping -------------------------------------------------------------
+    def step(self, n_buffers=1, into=None):
+        if into is None:
+            self._chk(self._l.pbso_step(self._h, n_buffers))
+        else:
+            self._chk(self._l.pbso_step_into(self._h, n_buffers, C.c_void_p(into)))
+        self._last_nb = n_buffers
+
+    def sync(self):
+        self._chk(self._l.pbso_sync(self._h))
+
+    def audio(self):
+        n = len(self.n_modes) * self._last_nb * self.B
+        out = np.empty(n, dtype=np.float32)
+        self._chk(self._l.pbso_read_audio(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), n))
+        return out.reshape(len(self.n_modes), self._last_nb * self.B)
+
+    def emitted(self):
+        n = len(self.n_modes) * self._last_nb
+        out = np.empty(n, dtype=np.uint8)
+        self._chk(self._l.pbso_read_emitted(self._h, out.ctypes.data_as(C.POINTER(C.c_ubyte)), n))
+        return out.reshape(len(self.n_modes), self._last_nb).astype(bool)
+
+    def qnorm(self, obj, buffer):
+        n = self.n_modes[obj]
+        out = np.empty(max(n, 1), dtype=np.float32)
+        self._chk(self._l.pbso_read_qnorm(self._h, obj, buffer, out.ctypes.data_as(C.POINTER(C.c_float)), n))
+        return out[:n]
+
+    def state(self, obj):
+        n = self.n_modes[obj]
+        q1, q2 = np.empty(max(n, 1)), np.empty(max(n, 1))
+        self._chk(self._l.pbso_read_state(self._h, obj, _dp(q1), _dp(q2), n))
+        return q1[:n], q2[:n]
+
+    def audio_device_ptr(self):
+        return self._l.pbso_audio_device_ptr(self._h)
+
+    def info(self):
+        i = capi.EngineInfo()
+        self._chk(self._l.pbso_get_info(self._h, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in capi.EngineInfo._fields_}
+
+
+class ModalSolver:
+    """One-object facade with the reference's ModalSolver<double> method names
+    (modal_solver.h:100-179).  step() produces one 513-sample buffer."""
+
+    def __init__(self, omega_squared, density, alpha, beta, N_modes=None, mode_shapes=None, **engine_kw):
+        self.engine = Engine(**engine_kw)
+        self.obj = self.engine.add_object(omega_squared, density, alpha, beta, N_modes, mode_shapes)
+        self._N_modes = self.engine.n_modes[self.obj]
+        self._queue_sound = collections.deque()       # ReaderWriterQueue(2): 3 usable slots
+        self._queue_qnorm = collections.deque()
+        self._pending_maps = None
+        self._final = False
+
+    def readFFATMaps(self, maps_or_dir):
+        if isinstance(maps_or_dir, str):
+            self.engine.read_ffat_maps(self.obj, maps_or_dir)
+        else:
+            self.engine.set_ffat_maps(self.obj, maps_or_dir)
+
+    def _ensure(self):
+        if not self._final:
+            self.engine.finalize()
+            self._final = True
+
+    def enqueueForceMessage(self, mess):
+        self._ensure()
+        return self.engine.enqueue_force(self.obj, mess)
+
+    def enqueueForceMessageNoFail(self, mess, maxIte=-1):
+        return self.enqueueForceMessage(mess)
+
+    def enqueueArprmMessageNoFail(self, a, sigma, mu, maxIte=-1):
+        self._ensure()
+        return self.engine.enqueue_arprm(self.obj, a, sigma, mu)
+
+    def computeTransfer(self, pos, out=None):
+        self._ensure()
+        if out is None:
+            return self.engine.compute_transfer(self.obj, pos)
+        ok, vals = self.engine.compute_transfer_batch(self.obj, pos, out.size)
+        if ok:
+            out[:] = vals[0]
+        return ok
+
+    def setUseTransfer(self, s):
+        self._ensure()
+        self.engine.set_use_transfer(self.obj, s)
+
+    def getLatestTransfer(self):
+        self._ensure()
+        return self.engine.latest_transfer(self.obj)
+
+    def step(self):
+        self._ensure()
+        self.engine.step(1)
+        if not self.engine.emitted()[0, 0]:
+            return                                   # clearAllForces: no SoundMessage (modal_solver.h:186-189)
+        if self.engine.qnorm_mode == capi.QNORM_ALL and len(self._queue_qnorm) < 3:
+            self._queue_qnorm.append(self.engine.qnorm(0, 0))     # try_enqueue, may drop (:273)
+        self._queue_sound.append(self.engine.audio()[0].copy())   # enqueueSoundMessageNoFail (:275)
+
+    def dequeueSoundMessage(self):
+        if not self._queue_sound:
+            return None
+        return self._queue_sound.popleft()
+
+    def getQBufferNorm(self):
+        if self._queue_qnorm:
+            return self._queue_qnorm.popleft()
+        return np.zeros(self._N_modes, dtype=np.float32)
