@@ -141,6 +141,17 @@ int pbso_object_read_ffat_maps(pbso_engine *e, int object_id, const char *dir);
 int pbso_fatcube_parse(const unsigned char *bytes, size_t n, pbso_ffat_map *out);
 void pbso_ffat_map_free(pbso_ffat_map *m);
 
+/* --- loaders, usable without an engine -------------- */
+/* ModeData<double>::read (ModeData.h:61-83).  *omega_squared [n_modes] and
+ * *modes [n_modes][n_dof] are malloc'ed: release with pbso_free.              */
+int pbso_modes_read(const char *path, int *n_dof, int *n_modes, double **omega_squared, double **modes);
+/* ModeData<double>::numModesAudible (ModeData.h:120-148) */
+int pbso_num_modes_audible(const double *omega_squared, int n_modes, double density, double audible_freq);
+/* ModalMaterial<double>::Read (ModalMaterial.h:35-55): out = density,
+ * youngsModulus, poissonRatio, alpha, beta                                    */
+int pbso_material_read(const char *path, double out[5]);
+void pbso_free(void *p);
+
 /* uploads all objects to HBM; no pbso_add_object afterwards */
 int pbso_finalize(pbso_engine *e);
 

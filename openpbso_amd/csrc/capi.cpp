@@ -1,5 +1,6 @@
 // extern "C" surface declared in include/openpbso_amd.h.  No exception leaves
 // this file.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -190,6 +191,46 @@ int pbso_add_object_from_files(pbso_engine *e, const char *modes_path, const cha
     return rc;
     GUARD_END(e)
 }
+
+int pbso_modes_read(const char *path, int *n_dof, int *n_modes, double **omega_squared, double **modes) {
+    if (!path || !n_dof || !n_modes || !omega_squared || !modes) return PBSO_ERR_INVALID;
+    try {
+        std::vector<double> om, md;
+        int rc = pbso::load_modes_file(path, n_dof, n_modes, om, md);
+        if (rc != PBSO_OK) return rc;
+        double *a = (double *)std::malloc(sizeof(double) * std::max<size_t>(om.size(), 1));
+        double *b = (double *)std::malloc(sizeof(double) * std::max<size_t>(md.size(), 1));
+        if (!a || !b) { std::free(a); std::free(b); return PBSO_ERR_NOMEM; }
+        if (!om.empty()) std::memcpy(a, om.data(), sizeof(double) * om.size());
+        if (!md.empty()) std::memcpy(b, md.data(), sizeof(double) * md.size());
+        *omega_squared = a;
+        *modes = b;
+        return PBSO_OK;
+    } catch (...) {
+        return PBSO_ERR_NOMEM;
+    }
+}
+
+int pbso_num_modes_audible(const double *omega_squared, int n_modes, double density, double audible_freq) {
+    if (n_modes < 0 || (n_modes > 0 && !omega_squared)) return PBSO_ERR_INVALID;
+    try {
+        std::vector<double> om(omega_squared, omega_squared + n_modes);
+        return pbso::num_modes_audible(om, density, audible_freq);
+    } catch (...) {
+        return PBSO_ERR_NOMEM;
+    }
+}
+
+int pbso_material_read(const char *path, double out[5]) {
+    if (!path || !out) return PBSO_ERR_INVALID;
+    try {
+        return pbso::load_material_file(path, out);
+    } catch (...) {
+        return PBSO_ERR_IO;
+    }
+}
+
+void pbso_free(void *p) { std::free(p); }
 
 int pbso_finalize(pbso_engine *e) {
     NEED(e);

@@ -80,15 +80,17 @@ ForceProfile ForceProfile::make(int type, double gaussian_width_us, int sample_r
     return f;
 }
 
-bool ForceProfile::add(double *t, int frames) {
+bool ForceProfile::add(double *t, int frames, int *extent) {
     switch (type) {
     case PBSO_POINT_FORCE:                                   // forces.h:81-90
         if (used) return false;
         t[0] += 1.;
         used = true;
+        *extent = std::max(*extent, 1);
         return true;
     case PBSO_GAUSSIAN_FORCE:                                // forces.h:92-105
         if (width == 0 || count >= cutoff * 2 * width_samples) return false;
+        *extent = frames;
         for (int ii = 0; ii < frames; ++ii) {
             const double p = -0.5 * std::pow((double)(count + ii - center) / (double)width_samples, 2);
             t[ii] += std::exp(p);
@@ -96,6 +98,7 @@ bool ForceProfile::add(double *t, int frames) {
         count += frames;
         return true;
     case PBSO_AUTOREGRESSIVE_FORCE:                          // forces.h:107-128
+        *extent = frames;
         for (int ii = 0; ii < frames; ++ii) {
             double mu_tilde = 0.0;
             for (int jj = 0; jj < 2; ++jj) mu_tilde += a[jj] * buf[(buf_idx + 3 - jj - 1) % 3];
@@ -183,6 +186,7 @@ int Engine::init() {
     tbuf_.assign(B_, 0.0);
     // which build of the oscillator bank to launch (see kernels_iir.hip)
     if (const char *v = std::getenv("PBSO_IIR_PACKED")) packed_ = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PBSO_LDS_ADDTID")) addtid_ = std::atoi(v) != 0;
     return PBSO_OK;
 }
 
@@ -277,22 +281,31 @@ int Engine::finalize() {
     const int N = (int)objs_.size();
     int mmax = 1;
     for (const Object &o : objs_) mmax = std::max(mmax, o.n_modes);
-    // team shape: R oscillators per lane, W waves per object.  >= 2 waves per
-    // SIMD (2048 on the chip) are needed for the 2-cycle VALU issue rate; LDS
-    // (one transpose tile per wave) allows W <= 10.
-    const int maxW = 10;
+    // team shape: R oscillators per lane, W waves per object.  The VALU issue
+    // rate needs ~4 waves per SIMD (4096 on the chip, profiles/r01_microbench.txt):
+    // take the largest R that still gives that many waves, else the most waves.
+    const int maxW = MAX_WAVES_PER_OBJECT;
     int R = desc_.modes_per_lane;
     if (R != 0 && R != 1 && R != 2 && R != 4 && R != 8) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,4,8");
     auto waves_for = [&](int r) { return (mmax + 64 * r - 1) / (64 * r); };
+    // kernel builds exist for W <= 4 with R in {1,2,4} and 4 < W <= 16 with R in {4,8}
+    auto shape_ok = [&](int r) {
+        const int w = waves_for(r);
+        return w <= 4 ? (r <= 4) : (w <= maxW && r >= 4);
+    };
     if (R == 0) {
-        R = 1;
         for (int r : {4, 2, 1}) {
-            if ((long long)N * waves_for(r) >= 2048 || r == 1) { R = r; break; }
+            if (shape_ok(r) && ((long long)N * waves_for(r) >= 4096)) { R = r; break; }
         }
-        while (waves_for(R) > maxW && R < 8) R *= 2;
+        if (R == 0)
+            for (int r : {1, 2, 4, 8})      // else: the most waves a supported shape gives
+                if (shape_ok(r)) { R = r; break; }
+        if (R == 0) return fail(PBSO_ERR_INVALID, "object too large: more than 8192 modes per object not supported yet");
+    } else if (!shape_ok(R)) {
+        return fail(PBSO_ERR_INVALID, "modes_per_lane not supported for this object size (W<=4: 1,2,4; W<=16: 4,8)");
     }
     int W = waves_for(R);
-    if (W > maxW) return fail(PBSO_ERR_INVALID, "object too large: more than 5120 modes per object not supported yet");
+    if (W > maxW) return fail(PBSO_ERR_INVALID, "object too large: more than 8192 modes per object not supported yet");
     R_ = R;
     W_ = W;
     m_pad_ = 64 * R * W;
@@ -599,47 +612,57 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
     }
 
     // :206-240 time profile and spatial sum
-    double *T = tbuf_.data();
-    std::fill(T, T + B_, 0.0);
-    const int row_begin = (int)slot_idx_.size();
-    if (!o.sustained) {
-        size_t w = 0;
-        for (size_t r = 0; r < o.active.size(); ++r) {
-            ActiveForce &af = o.active[r];
-            const bool added = af.force.add(T, B_);
-            if (!added) {
-                freed_this_plan_.push_back(af.slot);                    // erase
-            } else {
-                slot_idx_.push_back(af.slot);
-                if (w != r) o.active[w] = std::move(af);
-                ++w;
+    if (!o.active.empty() || o.sustained) {
+        double *T = tbuf_.data();
+        std::fill(T, T + t_extent_, 0.0);
+        t_extent_ = 0;
+        const int row_begin = (int)slot_idx_.size();
+        if (!o.sustained) {
+            size_t w = 0;
+            for (size_t r = 0; r < o.active.size(); ++r) {
+                ActiveForce &af = o.active[r];
+                const bool added = af.force.add(T, B_, &t_extent_);
+                if (!added) {
+                    freed_this_plan_.push_back(af.slot);                    // erase
+                } else {
+                    slot_idx_.push_back(af.slot);
+                    if (w != r) o.active[w] = std::move(af);
+                    ++w;
+                }
             }
+            o.active.resize(w);
+        } else {
+            if (o.active.size() != 1)
+                return fail(PBSO_ERR_ASSERT, "Should only have 1 concurrent sustained force");   // assert :223
+            ActiveForce &af = o.active.front();
+            if (af.force_type == PBSO_AUTOREGRESSIVE_FORCE && o.arprm_full) {   // :226-236
+                o.arprm_full = false;
+                af.force.set_param(o.arprm, o.arprm[2], o.arprm[3]);
+            }
+            af.force.add(T, B_, &t_extent_);
+            slot_idx_.push_back(af.slot);
         }
-        o.active.resize(w);
-    } else {
-        if (o.active.size() != 1)
-            return fail(PBSO_ERR_ASSERT, "Should only have 1 concurrent sustained force");   // assert :223
-        ActiveForce &af = o.active.front();
-        if (af.force_type == PBSO_AUTOREGRESSIVE_FORCE && o.arprm_full) {   // :226-236
-            o.arprm_full = false;
-            af.force.set_param(o.arprm, o.arprm[2], o.arprm[3]);
+        uint32_t mask = 0;
+        int last_nz = -1;
+        for (int i = 0; i < t_extent_; ++i)
+            if (T[i] != 0.0) { mask |= 1u << (i / TILE); last_nz = i; }
+        if ((int)slot_idx_.size() > row_begin && mask) {
+            d.frow = n_frows_++;
+            d.tile_mask = mask;
+            row_obj_.push_back(oi);
+            row_ptr_.push_back((int)slot_idx_.size());
+            if (last_nz == 0) {
+                d.flags |= DESC_IMPULSE;                  // PointForce(s): amp * delta[0], no profile row
+                d.amp = (float)T[0];
+            } else {
+                d.prow = (int)(tprof_.size() / b_pad_);
+                const size_t off = tprof_.size();
+                tprof_.resize(off + b_pad_, 0.f);
+                for (int i = 0; i <= last_nz; ++i) tprof_[off + i] = (float)T[i];
+            }
+        } else {
+            slot_idx_.resize(row_begin);          // S * 0 == 0: a force-free buffer
         }
-        af.force.add(T, B_);
-        slot_idx_.push_back(af.slot);
-    }
-    uint32_t mask = 0;
-    for (int i = 0; i < B_; ++i)
-        if (T[i] != 0.0) mask |= 1u << (i / TILE);
-    if ((int)slot_idx_.size() > row_begin && mask) {
-        d.frow = (int)row_obj_.size();
-        d.tile_mask = mask;
-        row_obj_.push_back(oi);
-        row_ptr_.push_back((int)slot_idx_.size());
-        const size_t off = tprof_.size();
-        tprof_.resize(off + b_pad_, 0.f);
-        for (int i = 0; i < B_; ++i) tprof_[off + i] = (float)T[i];
-    } else {
-        slot_idx_.resize(row_begin);          // S * 0 == 0: a force-free buffer
     }
 
     // :242-256 transfer selection (single caller thread: try_lock always succeeds)
@@ -656,18 +679,45 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
     return PBSO_OK;
 }
 
+// All buffers of one object.  Objects are independent, and between stamped
+// messages an idle object needs no bookkeeping at all: jump to the next stamp.
+int Engine::plan_object_span(int oi, int nb) {
+    Object &o = objs_[oi];
+    int b = 0;
+    while (b < nb) {
+        const int64_t t = buffers_done_ + b;
+        const bool due = (!o.pending.empty() && o.pending.front().not_before <= t) ||
+                         (!o.force_q.empty() && o.force_q.front().not_before <= t);
+        const bool live = !o.active.empty() || o.sustained || (o.trans_full && o.use_transfer) ||
+                          (!o.use_transfer && o.latest_row != XFER_UNIT);
+        if (!due && !live) {
+            int64_t next = INT64_MAX;
+            if (!o.pending.empty()) next = std::min(next, o.pending.front().not_before);
+            if (!o.force_q.empty()) next = std::min(next, o.force_q.front().not_before);
+            if (next >= buffers_done_ + nb) break;
+            b = (int)(next - buffers_done_);
+            continue;
+        }
+        int rc = plan_object(oi, b, nb, t);
+        if (rc != PBSO_OK) return rc;
+        ++b;
+    }
+    return PBSO_OK;
+}
+
 int Engine::plan(int nb) {
     const int N = (int)objs_.size();
     PlanSet &ps = set_[cur_set_];
     HIPTRY(ps.h_desc.ensure((size_t)N * nb));
     HIPTRY(ps.h_xfer_init.ensure(N));
-    const BufDesc dflt = {-1, 0u, XFER_KEEP, 0u};
+    const BufDesc dflt = {-1, -1, 0u, 0.f, XFER_KEEP, 0u, {0, 0}};
     std::fill(ps.h_desc.p, ps.h_desc.p + (size_t)N * nb, dflt);
     emitted_.assign((size_t)N * nb, 1);
     row_ptr_.assign(1, 0);
     slot_idx_.clear(); row_obj_.clear(); tprof_.clear(); stage_.clear(); stage_slot_.clear();
     proj_.clear(); ffat_.clear(); freed_this_plan_.clear();
     n_xfer_scratch_ = 0;
+    n_frows_ = 0;
     busy_.clear();
     for (int i = 0; i < N; ++i) {
         const Object &o = objs_[i];
@@ -676,12 +726,9 @@ int Engine::plan(int nb) {
             o.sustained || (!o.use_transfer && o.latest_row != XFER_UNIT))
             busy_.push_back(i);
     }
-    for (int b = 0; b < nb; ++b) {
-        const int64_t t = buffers_done_ + b;
-        for (int i : busy_) {
-            int rc = plan_object(i, b, nb, t);
-            if (rc != PBSO_OK) return rc;
-        }
+    for (int i : busy_) {
+        int rc = plan_object_span(i, nb);
+        if (rc != PBSO_OK) return rc;
     }
     return PBSO_OK;
 }
@@ -726,7 +773,7 @@ int Engine::step(int nb, void *d_audio_user) {
     for (int s : freed_this_plan_) free_slots_.push_back(s);
     last_plan_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
-    const int n_frows = (int)row_obj_.size();
+    const int n_frows = n_frows_;
     last_frows_ = n_frows;
     last_trows_ = (int64_t)ffat_.size();
     // device arenas
@@ -800,10 +847,10 @@ int Engine::step(int nb, void *d_audio_user) {
     kp.nb = nb; kp.n_tiles = n_tiles_; kp.m_pad = m_pad_; kp.b_pad = b_pad_;
     kp.audio_stride = (long long)nb * B_;
     HIPTRY(hipEventRecord(evq.k0, stream_));
-    if (packed_)
-        LAUNCHTRY(iir_slp::launch_iir_bank(kp, N, R_, W_, desc_.recurrence_form, qn, stream_));
+    if (packed_ && R_ >= 2)
+        LAUNCHTRY(iir_packed::launch_iir_bank(kp, N, R_, W_, desc_.recurrence_form, qn, addtid_, stream_));
     else
-        LAUNCHTRY(iir_noslp::launch_iir_bank(kp, N, R_, W_, desc_.recurrence_form, qn, stream_));
+        LAUNCHTRY(iir_scalar::launch_iir_bank(kp, N, R_, W_, desc_.recurrence_form, qn, addtid_, stream_));
     HIPTRY(hipEventRecord(evq.k1, stream_));
     // _latest_transfer = trans (modal_solver.h:251), then re-park a still-queued transfer
     LAUNCHTRY(launch_copy_rows(ps.d_copy.p, ps.d_copy.p + (n_cl + n_cq), n_cl, d_xfer_.p, m_pad_, stream_));

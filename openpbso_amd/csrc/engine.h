@@ -49,7 +49,8 @@ struct ForceProfile {
     std::default_random_engine generator;                // default seed, copied with the message
     std::normal_distribution<double> distribution;
     static ForceProfile make(int type, double gaussian_width_us, int sample_rate);
-    bool add(double *t, int frames);                     // Force::Add, forces.h:81-128
+    // Force::Add, forces.h:81-128.  *extent grows to the number of leading samples it touched.
+    bool add(double *t, int frames, int *extent);
     void set_param(const double a_[2], double sigma_, double mu_);   // forces.h:130-137
 };
 
@@ -132,12 +133,15 @@ private:
     int alloc_slot();
     int plan(int nb);                                    // host bookkeeping for one batch
     int plan_object(int o, int b, int nb, int64_t t);
+    int plan_object_span(int o, int nb);
 
     pbso_engine_desc desc_;
     int B_ = PBSO_FRAMES_PER_BUFFER, rate_ = PBSO_SAMPLE_RATE, n_tiles_ = 9, b_pad_ = 528;
     int R_ = 0, W_ = 0, m_pad_ = 0;
     bool finalized_ = false, own_stream_ = false;
-    bool packed_ = false;                                // PBSO_IIR_PACKED: v_pk_*_f32 build of K1
+    bool packed_ = true;                                 // PBSO_IIR_PACKED: v_pk_*_f32 build of K1
+    bool addtid_ = true;                                 // PBSO_LDS_ADDTID: ds_write_addtid_b32 tile writes
+    int t_extent_ = 0;                                   // leading samples of tbuf_ that may be non-zero
     hipStream_t stream_ = nullptr;
     hipEvent_t ev_set_[2] = {nullptr, nullptr};
     struct EvQuad { hipEvent_t k0, k1, p0, p1; };
@@ -186,6 +190,7 @@ private:
     // plan scratch (host)
     std::vector<int> row_ptr_, slot_idx_, row_obj_, stage_slot_, busy_;
     std::vector<float> tprof_;
+    int n_frows_ = 0;
     std::vector<double> stage_;
     std::vector<ProjectEvent> proj_;
     std::vector<FfatEvent> ffat_;

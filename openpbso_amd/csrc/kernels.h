@@ -5,8 +5,11 @@
 
 namespace pbso {
 
-// one audio buffer is processed as tiles of TILE samples; 513 = 9 * 57
-constexpr int TILE = 57;
+// one audio buffer is processed as tiles of TILE samples; 513 = 19 * 27.
+// 27 rows x 68 floats = 7.3 KB of LDS per wave: 16+ waves per CU fit, which the
+// VALU issue rate needs (one wave alone issues a v_fma_f32 every ~5.5 cycles,
+// four per SIMD every ~2.4-2.8: profiles/r01_microbench.txt).
+constexpr int TILE = 27;
 // LDS row stride (floats) of the per-wave [TILE][64] transpose tile: 68 keeps
 // 16-B alignment for ds_read_b128 and puts the 16 lanes of every b128 lane
 // group on 16 distinct 4-bank slots (68 mod 64 = 4).
@@ -18,22 +21,27 @@ constexpr int XFER_KEEP = -1;          // keep _latest_transfer
 constexpr int XFER_UNIT = -2;          // TransMessage::setToUnit, 1e7 (modal_solver.h:89-92)
 
 constexpr uint32_t DESC_SKIP = 1u;     // step() returned early (modal_solver.h:186-189)
+constexpr uint32_t DESC_IMPULSE = 2u;  // time profile is amp * delta[0] (PointForce): no profile row
 
 // what ModalSolver::step's bookkeeping (modal_solver.h:184-256) decided for one
 // (object, buffer); written by the host planner, read with scalar loads.
 struct BufDesc {
-    int32_t frow;        // row of g = c3 * S and of the time profile; -1: force-free buffer
+    int32_t frow;        // row of g = c3 * S; -1: force-free buffer
+    int32_t prow;        // row of the dense time profile (unused with DESC_IMPULSE)
     uint32_t tile_mask;  // bit t set: profile has a non-zero sample in tile t
+    float amp;           // DESC_IMPULSE: profile value at sample 0
     int32_t trow;        // transfer row to switch to before this buffer, or XFER_*
     uint32_t flags;
+    int32_t pad[2];
 };
+static_assert(sizeof(BufDesc) == 32, "BufDesc is read with one s_load_dwordx8");
 
 struct IirParams {
     const float *ca, *cb;        // [n_obj][m_pad] coefficients (form dependent)
     float *sq, *sd;              // [n_obj][m_pad] state (form dependent)
     const BufDesc *desc;         // [n_obj][nb]
     const float *grows;          // [n_frows][m_pad]  g = (float)(c3 * S)
-    const float *tprof;          // [n_frows][b_pad]  force time profiles
+    const float *tprof;          // [n_prows][b_pad]  dense force time profiles
     const double *xfer_rows;     // [n_rows][m_pad]   FFAT transfer rows (fp64)
     const int *xfer_init;        // [n_obj] row (or XFER_UNIT) in effect when the launch starts
     float *audio;                // [n_obj][audio_stride]
@@ -43,18 +51,20 @@ struct IirParams {
 };
 
 // launches the oscillator bank; returns hipError_t as int.  Two builds of the
-// same source: packed (v_pk_*_f32 pairs from the SLP vectoriser) and scalar.
-namespace iir_slp {
+// same source: packed (float2 mode pairs, v_pk_*_f32; R >= 2) and scalar.
+// Supported shapes: W <= 4 with R in {1,2,4}; 4 < W <= 16 with R in {4,8}.
+namespace iir_packed {
 int launch_iir_bank(const IirParams &p, int n_obj, int modes_per_lane, int waves_per_object,
-                    int form, bool qnorm, hipStream_t stream);
+                    int form, bool qnorm, bool addtid, hipStream_t stream);
 }
-namespace iir_noslp {
+namespace iir_scalar {
 int launch_iir_bank(const IirParams &p, int n_obj, int modes_per_lane, int waves_per_object,
-                    int form, bool qnorm, hipStream_t stream);
+                    int form, bool qnorm, bool addtid, hipStream_t stream);
 }
 inline size_t iir_lds_bytes(int W) {
-    return sizeof(float) * ((size_t)W * TILE * LDS_ROW + (W > 1 ? 2 * (size_t)(W - 1) * 64 : 0));
+    return sizeof(float) * ((size_t)W * TILE * LDS_ROW + (W > 1 ? 2 * (size_t)(W - 1) * 32 : 0));
 }
+constexpr int MAX_WAVES_PER_OBJECT = 16;
 
 // ---- exact fp64 helper kernels (kernels_exact.hip, built with -ffp-contract=off)
 struct ProjectEvent {

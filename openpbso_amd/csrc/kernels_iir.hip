@@ -8,74 +8,122 @@
 // oscillators: mode m = r * (64 W) + tid, so every r-slice of the SoA arrays
 // is one contiguous, coalesced row.  Coefficients, state, g = c3*S, the
 // transfer weights and the qnorm accumulators live in VGPRs for the whole
-// launch; the force time profile of the current tile is read with scalar
-// loads (it is uniform over the team).  This loop is bound by the fp32 vector
-// ALU issue rate, not HBM: per oscillator-sample it issues
+// launch; descriptors and force time profiles are uniform over the team and
+// are read with scalar loads.  The loop is bound by the fp32 vector ALU issue
+// rate, not by HBM: per oscillator-sample it issues
 //   velocity form:  v_mul, v_fma [, v_fma force], v_add, v_fma out [, v_fma qnorm]
 //   direct form:    v_mul [, v_fma force], v_fma, v_fma out [, v_fma qnorm]
+// (pairs of modes fuse into v_pk_* in the "packed" build of this file).
 //
 // Per-sample reduction over modes.  Each lane first sums its own R modes
-// (p = sum_r t_r q_r), then the 64 lane partials of TILE consecutive samples
-// are transposed through a per-wave LDS tile P[TILE][LDS_ROW]: lane l writes
-// P[k][l] while stepping sample k (conflict-free), then lane k reads row k with
-// 16 ds_read_b128 and adds the 64 values in a fixed order.  That costs one
-// v_add per wave-sample instead of a 6-step cross-lane reduction, and the
-// result is deterministic.  Teams of W > 1 waves add their row sums through a
-// small double-buffered LDS array, one workgroup barrier per tile.
+// (p = sum_r t_r q_r), then the 64 lane partials of TILE = 27 consecutive
+// samples are transposed through a per-wave LDS tile P[27][68]: lane l writes
+// P[k][l] while stepping sample k (ds_write_addtid_b32: no address VGPR, half
+// the issue cost of ds_write_b32), then lanes 2k and 2k+1 read the two halves
+// of row k with 8 ds_read_b128 each (bank-conflict free with the 68-float
+// stride), add their 32 values in a fixed order and combine with one DPP add.
+// That is ~1.2 VALU instructions per wave-sample instead of a 6-step
+// cross-lane reduction, and the result is deterministic.  Teams of W > 1
+// waves add their row sums through a small double-buffered LDS array, one
+// workgroup barrier per tile.
+#include <type_traits>
+
 #include "kernels.h"
 
-// built twice (Makefile): PBSO_IIR_NS = iir_slp (SLP vectoriser on: mode pairs
-// become v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) and iir_noslp
-// (-fno-slp-vectorize: plain v_fma_f32).  The engine picks one at run time.
-#ifndef PBSO_IIR_NS
-#define PBSO_IIR_NS iir_slp
+// built twice (Makefile), both with -fno-slp-vectorize so that the instruction
+// selection is the one written here:
+//   PBSO_IIR_PACKED=1 -> namespace iir_packed: a lane's modes are held as float2
+//     pairs and stepped with v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 (2 FMAs
+//     per lane per instruction; faster than v_fma_f32 from ~3 waves per SIMD on,
+//     profiles/r01_microbench.txt);
+//   PBSO_IIR_PACKED=0 -> namespace iir_scalar: plain v_fma_f32.
+// The engine picks one at run time.
+#ifndef PBSO_IIR_PACKED
+#define PBSO_IIR_PACKED 1
+#endif
+#if PBSO_IIR_PACKED
+#define PBSO_IIR_NS iir_packed
+#else
+#define PBSO_IIR_NS iir_scalar
 #endif
 
 namespace pbso {
 namespace PBSO_IIR_NS {
 
-template <int R, int FORM, bool QN, bool FORCED>
-__device__ __forceinline__ void step_tile(float (&q)[R], float (&d)[R], const float (&ca)[R],
-                                          const float (&cb)[R], const float (&g)[R],
-                                          const float (&t)[R], float (&qn)[R],
-                                          const float *__restrict__ tp, float *__restrict__ col) {
-#pragma unroll
-    for (int k = 0; k < TILE; ++k) {
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int K0, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (N > 0) {
+        f(std::integral_constant<int, K0>{});
+        static_for<K0 + 1, N - 1>(f);
+    }
+}
+
+// lane-local vector of oscillators: float (1 mode) or float2 (2 modes, v_pk_*)
+__device__ __forceinline__ float vfma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float vsplat(float, float x) { return x; }
+__device__ __forceinline__ v2f vsplat(v2f, float x) { return (v2f){x, x}; }
+template <int E> __device__ __forceinline__ float vget(float v) { return v; }
+template <int E> __device__ __forceinline__ float vget(v2f v) { return E == 0 ? v.x : v.y; }
+__device__ __forceinline__ void vset(float &v, int, float x) { v = x; }
+__device__ __forceinline__ void vset(v2f &v, int e, float x) { if (e == 0) v.x = x; else v.y = x; }
+template <class V> struct lanes_of { static constexpr int n = 1; };
+template <> struct lanes_of<v2f> { static constexpr int n = 2; };
+
+// FMODE: 0 force-free, 1 dense time profile tp[0..TILE), 2 impulse (amp at sample 0 only)
+template <class V, int NV, int FORM, bool QN, int FMODE, bool ADDTID>
+__device__ __forceinline__ void step_tile(V (&q)[NV], V (&d)[NV], const V (&ca)[NV], const V (&cb)[NV],
+                                          const V (&g)[NV], const V (&t)[NV], V (&qn)[NV],
+                                          const float *__restrict__ tp, float amp,
+                                          float *__restrict__ col) {
+    static_for<0, TILE>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr bool forced = FMODE == 1 || (FMODE == 2 && k == 0);
         float tk = 0.f;
-        if (FORCED) tk = tp[k];
+        if (FMODE == 1) tk = tp[k];
+        if (FMODE == 2 && k == 0) tk = amp;
         float p = 0.f;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
+        for (int v = 0; v < NV; ++v) {
             if (FORM == 0) {
                 // d_k = eps^2 d_{k-1} - e q_{k-1} + g T_k ;  q_k = q_{k-1} + d_k
-                float a = ca[r] * d[r];
-                a = fmaf(-cb[r], q[r], a);
-                if (FORCED) a = fmaf(g[r], tk, a);
-                d[r] = a;
-                q[r] = q[r] + a;
+                V a = ca[v] * d[v];
+                a = vfma(-cb[v], q[v], a);
+                if (forced) a = vfma(g[v], vsplat(a, tk), a);
+                d[v] = a;
+                q[v] = q[v] + a;
             } else {
                 // q_k = c1 q_{k-1} + c2 q_{k-2} + g T_k   (d holds q_{k-2})
-                float a = cb[r] * d[r];
-                if (FORCED) a = fmaf(g[r], tk, a);
-                const float qk = fmaf(ca[r], q[r], a);
-                d[r] = q[r];
-                q[r] = qk;
+                V a = cb[v] * d[v];
+                if (forced) a = vfma(g[v], vsplat(a, tk), a);
+                const V qk = vfma(ca[v], q[v], a);
+                d[v] = q[v];
+                q[v] = qk;
             }
-            p = (r == 0) ? t[r] * q[r] : fmaf(t[r], q[r], p);
-            if (QN) qn[r] = fmaf(q[r], q[r], qn[r]);
+            // the lane's own modes are summed with scalar FMAs: a packed product
+            // would need an extra add to fold its two halves
+            p = (v == 0) ? vget<0>(t[v]) * vget<0>(q[v]) : fmaf(vget<0>(t[v]), vget<0>(q[v]), p);
+            if (lanes_of<V>::n == 2) p = fmaf(vget<1>(t[v]), vget<1>(q[v]), p);
+            if (QN) qn[v] = vfma(q[v], q[v], qn[v]);
         }
-        col[k * LDS_ROW] = p;
+        if (ADDTID) {
+            // LDS address = M0 (this wave's tile, set by the caller) + offset + 4 * lane
+            asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(p), "n"(k * LDS_ROW * 4) : "memory");
+        } else {
+            col[k * LDS_ROW] = p;
+        }
         if (QN) {
             // pin the qnorm accumulators here: without it the q^2 FMAs of a whole
-            // tile are sunk to the tile's end and 57*R q values stay live.
+            // tile are sunk to the tile's end and TILE*R q values stay live.
 #pragma unroll
-            for (int r = 0; r < R; ++r) asm volatile("" : "+v"(qn[r]));
+            for (int v = 0; v < NV; ++v) asm volatile("" : "+v"(qn[v]));
         }
-        // keep the scheduler from interleaving whole samples (it otherwise keeps
-        // hundreds of q values live to batch the qnorm chain): one wave issues a
-        // VALU every 4 cycles anyway, the R modes of one sample are ILP enough.
+        // keep the scheduler from interleaving whole samples: the other waves of
+        // the SIMD fill the issue slots, and register pressure stays bounded.
         __builtin_amdgcn_sched_barrier(0);
-    }
+    });
 }
 
 // Pointers are separate __restrict__ kernel arguments (not struct members) so
@@ -86,8 +134,8 @@ struct IirDims {
     long long audio_stride;
 };
 
-template <int R, int FORM, bool QN>
-__global__ __launch_bounds__(256) void iir_bank_kernel(
+template <class V, int NV, int FORM, bool QN, bool ADDTID, int MAXT>
+__global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     const float *__restrict__ p_ca, const float *__restrict__ p_cb, float *__restrict__ p_sq,
     float *__restrict__ p_sd, const BufDesc *__restrict__ p_desc, const float *__restrict__ p_grows,
     const float *__restrict__ p_tprof, const double *__restrict__ p_xfer_rows,
@@ -101,37 +149,46 @@ __global__ __launch_bounds__(256) void iir_bank_kernel(
     const int W = blockDim.x >> 6;
     const int rowlen = blockDim.x;
     float *tile = lds + wave * (TILE * LDS_ROW);
-    float *xw = lds + W * (TILE * LDS_ROW);          // [2][W-1][64] cross-wave partials
+    float *xw = lds + W * (TILE * LDS_ROW);          // [2][W-1][32] cross-wave partials
     float *col = tile + lane;
+    const unsigned tile_m0 = (unsigned)wave * (unsigned)(TILE * LDS_ROW * sizeof(float));
     const size_t mbase = (size_t)obj * p.m_pad + tid;
 
-    float ca[R], cb[R], q[R], d[R], g[R], t[R], qn[R];
+    constexpr int VW = lanes_of<V>::n;
+    constexpr int R = NV * VW;                       // oscillators per lane; slice r = v * VW + e
+    V ca[NV], cb[NV], q[NV], d[NV], g[NV], t[NV], qn[NV];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        ca[r] = p_ca[mbase + r * rowlen];
-        cb[r] = p_cb[mbase + r * rowlen];
-        q[r] = p_sq[mbase + r * rowlen];
-        d[r] = p_sd[mbase + r * rowlen];
-        g[r] = 0.f;
-        qn[r] = 0.f;
+        vset(ca[r / VW], r % VW, p_ca[mbase + r * rowlen]);
+        vset(cb[r / VW], r % VW, p_cb[mbase + r * rowlen]);
+        vset(q[r / VW], r % VW, p_sq[mbase + r * rowlen]);
+        vset(d[r / VW], r % VW, p_sd[mbase + r * rowlen]);
+        vset(g[r / VW], r % VW, 0.f);
+        vset(qn[r / VW], r % VW, 0.f);
     }
     {
         const int row0 = p_xfer_init[obj];
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            t[r] = row0 >= 0 ? (float)p_xfer_rows[(size_t)row0 * p.m_pad + tid + r * rowlen] : 1e7f;
+            vset(t[r / VW], r % VW,
+                 row0 >= 0 ? (float)p_xfer_rows[(size_t)row0 * p.m_pad + tid + r * rowlen] : 1e7f);
     }
 
     const BufDesc *__restrict__ dsc = p_desc + (size_t)obj * p.nb;
     float *__restrict__ aout = p_audio + (size_t)obj * p.audio_stride;
     const int B = p.n_tiles * TILE;
     int par = 0;
+    // row-sum phase: lanes 2k, 2k+1 own the two 32-float halves of row k
+    const int rrow = lane >> 1;
+    const float4 *rsrc = reinterpret_cast<const float4 *>(tile + rrow * LDS_ROW + (lane & 1) * 32);
 
     for (int b = 0; b < p.nb; ++b) {
-        const int frow = __builtin_amdgcn_readfirstlane(dsc[b].frow);
-        const uint32_t mask = __builtin_amdgcn_readfirstlane(dsc[b].tile_mask);
-        const int trow = __builtin_amdgcn_readfirstlane(dsc[b].trow);
-        const uint32_t flags = __builtin_amdgcn_readfirstlane(dsc[b].flags);
+        const int frow = dsc[b].frow;
+        const int prow = dsc[b].prow;
+        const uint32_t mask = dsc[b].tile_mask;
+        const float amp = dsc[b].amp;
+        const int trow = dsc[b].trow;
+        const uint32_t flags = dsc[b].flags;
 
         if (flags & DESC_SKIP) {
             // the reference's step() returned before stepping: no samples, state untouched
@@ -146,75 +203,93 @@ __global__ __launch_bounds__(256) void iir_bank_kernel(
         if (trow != XFER_KEEP) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                t[r] = trow >= 0 ? (float)p_xfer_rows[(size_t)trow * p.m_pad + tid + r * rowlen] : 1e7f;
+                vset(t[r / VW], r % VW,
+                     trow >= 0 ? (float)p_xfer_rows[(size_t)trow * p.m_pad + tid + r * rowlen] : 1e7f);
         }
         if (frow >= 0) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) g[r] = p_grows[(size_t)frow * p.m_pad + tid + r * rowlen];
+            for (int r = 0; r < R; ++r)
+                vset(g[r / VW], r % VW, p_grows[(size_t)frow * p.m_pad + tid + r * rowlen]);
         }
-        const float *__restrict__ tprow = p_tprof + (size_t)(frow >= 0 ? frow : 0) * p.b_pad;
+        const bool impulse = (flags & DESC_IMPULSE) != 0;
+        const float *__restrict__ tprow = p_tprof + (size_t)(prow >= 0 ? prow : 0) * p.b_pad;
         if (QN) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) qn[r] = 0.f;
+            for (int r = 0; r < R; ++r) vset(qn[r / VW], r % VW, 0.f);
         }
 
         for (int tl = 0; tl < p.n_tiles; ++tl) {
-            if (frow >= 0 && ((mask >> tl) & 1u))
-                step_tile<R, FORM, QN, true>(q, d, ca, cb, g, t, qn, tprow + tl * TILE, col);
+            if (ADDTID) asm volatile("s_mov_b32 m0, %0" ::"s"(tile_m0) : "memory");
+            const bool hit = frow >= 0 && ((mask >> tl) & 1u);
+            if (hit && impulse)
+                step_tile<V, NV, FORM, QN, 2, ADDTID>(q, d, ca, cb, g, t, qn, nullptr, amp, col);
+            else if (hit)
+                step_tile<V, NV, FORM, QN, 1, ADDTID>(q, d, ca, cb, g, t, qn, tprow + tl * TILE, 0.f, col);
             else
-                step_tile<R, FORM, QN, false>(q, d, ca, cb, g, t, qn, nullptr, col);
+                step_tile<V, NV, FORM, QN, 0, ADDTID>(q, d, ca, cb, g, t, qn, nullptr, 0.f, col);
 
-            // wave-local hand-off: LDS ops of one wave execute in order; the fence
-            // only stops the compiler from moving the row reads above the writes.
+            // wave-local hand-off: LDS ops of one wave execute in order; the fences
+            // only stop the compiler from moving the row reads above the writes.
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             float s = 0.f;
-            if (lane < TILE) {
-                const float4 *row = reinterpret_cast<const float4 *>(tile + lane * LDS_ROW);
+            if (lane < 2 * TILE) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const float4 v = row[j];
+                for (int j = 0; j < 8; ++j) {
+                    const float4 v = rsrc[j];
                     s += v.x;
                     s += v.y;
                     s += v.z;
                     s += v.w;
                 }
             }
+            // row k = (lane 2k: first half) + (lane 2k+1: second half), same order in every launch
+            // quad_perm [1,0,3,2]: the partner lane's half (a + b == b + a bitwise)
+            s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, false));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 
+            const bool owner = (lane & 1) == 0 && lane < 2 * TILE;
             if (W > 1) {
-                float *x = xw + par * ((W - 1) * 64);
-                if (wave > 0 && lane < TILE) x[(wave - 1) * 64 + lane] = s;
+                float *x = xw + par * ((W - 1) * 32);
+                if (wave > 0 && owner) x[(wave - 1) * 32 + rrow] = s;
                 __syncthreads();
-                if (wave == 0 && lane < TILE) {
-                    for (int w = 1; w < W; ++w) s += x[(w - 1) * 64 + lane];
+                if (wave == 0 && owner) {
+                    for (int w = 1; w < W; ++w) s += x[(w - 1) * 32 + rrow];
                 }
                 par ^= 1;
             }
-            if (wave == 0 && lane < TILE) aout[(size_t)b * B + tl * TILE + lane] = s;
+            if (wave == 0 && owner) aout[(size_t)b * B + tl * TILE + rrow] = s;
         }
 
         if (QN) {
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                p_qnorm[((size_t)obj * p.nb + b) * p.m_pad + tid + r * rowlen] = sqrtf(qn[r]);
+            for (int r = 0; r < R; ++r) {
+                const float e0 = vget<0>(qn[r / VW]), e1 = vget<1>(qn[r / VW]);
+                p_qnorm[((size_t)obj * p.nb + b) * p.m_pad + tid + r * rowlen] = sqrtf(r % VW ? e1 : e0);
+            }
         }
     }
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        p_sq[mbase + r * rowlen] = q[r];
-        p_sd[mbase + r * rowlen] = d[r];
+        p_sq[mbase + r * rowlen] = r % VW ? vget<1>(q[r / VW]) : vget<0>(q[r / VW]);
+        p_sd[mbase + r * rowlen] = r % VW ? vget<1>(d[r / VW]) : vget<0>(d[r / VW]);
     }
 }
 
-template <int R, int FORM, bool QN>
+template <int R, int FORM, bool QN, bool ADDTID, int MAXT>
 static int launch_one(const IirParams &p, int n_obj, int W, hipStream_t stream) {
     const size_t lds = iir_lds_bytes(W);
-    auto kern = iir_bank_kernel<R, FORM, QN>;
+#if PBSO_IIR_PACKED
+    auto kern = R >= 2 ? iir_bank_kernel<v2f, (R >= 2 ? R / 2 : 1), FORM, QN, ADDTID, MAXT>
+                       : nullptr;
+    if (R < 2) return (int)hipErrorInvalidValue;      // one mode per lane has nothing to pack
+#else
+    auto kern = iir_bank_kernel<float, R, FORM, QN, ADDTID, MAXT>;
+#endif
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -226,19 +301,41 @@ static int launch_one(const IirParams &p, int n_obj, int W, hipStream_t stream) 
     return (int)hipGetLastError();
 }
 
-template <int R>
-static int launch_r(const IirParams &p, int n_obj, int W, int form, bool qn, hipStream_t s) {
-    if (form == 0) return qn ? launch_one<R, 0, true>(p, n_obj, W, s) : launch_one<R, 0, false>(p, n_obj, W, s);
-    return qn ? launch_one<R, 1, true>(p, n_obj, W, s) : launch_one<R, 1, false>(p, n_obj, W, s);
+template <int R, int MAXT>
+static int launch_r(const IirParams &p, int n_obj, int W, int form, bool qn, bool at, hipStream_t s) {
+    const int sel = (form ? 4 : 0) | (qn ? 2 : 0) | (at ? 1 : 0);
+    switch (sel) {
+    case 0: return launch_one<R, 0, false, false, MAXT>(p, n_obj, W, s);
+    case 1: return launch_one<R, 0, false, true, MAXT>(p, n_obj, W, s);
+    case 2: return launch_one<R, 0, true, false, MAXT>(p, n_obj, W, s);
+    case 3: return launch_one<R, 0, true, true, MAXT>(p, n_obj, W, s);
+    case 4: return launch_one<R, 1, false, false, MAXT>(p, n_obj, W, s);
+    case 5: return launch_one<R, 1, false, true, MAXT>(p, n_obj, W, s);
+    case 6: return launch_one<R, 1, true, false, MAXT>(p, n_obj, W, s);
+    default: return launch_one<R, 1, true, true, MAXT>(p, n_obj, W, s);
+    }
 }
 
-int launch_iir_bank(const IirParams &p, int n_obj, int R, int W, int form, bool qn, hipStream_t s) {
+// teams of up to 4 waves use the 256-thread build (no VGPR cap in practice);
+// larger teams (objects with more than 256 R modes) the 1024-thread build.
+// Instantiated shapes: R in {1,2,4} for small teams, {4,8} for large ones.
+int launch_iir_bank(const IirParams &p, int n_obj, int R, int W, int form, bool qn, bool addtid,
+                    hipStream_t s) {
     if (n_obj <= 0) return 0;
-    switch (R) {
-    case 1: return launch_r<1>(p, n_obj, W, form, qn, s);
-    case 2: return launch_r<2>(p, n_obj, W, form, qn, s);
-    case 4: return launch_r<4>(p, n_obj, W, form, qn, s);
-    case 8: return launch_r<8>(p, n_obj, W, form, qn, s);
+    if (W < 1 || W > MAX_WAVES_PER_OBJECT) return (int)hipErrorInvalidValue;
+    if (W <= 4) {
+        switch (R) {
+#if !PBSO_IIR_PACKED
+        case 1: return launch_r<1, 256>(p, n_obj, W, form, qn, addtid, s);
+#endif
+        case 2: return launch_r<2, 256>(p, n_obj, W, form, qn, addtid, s);
+        case 4: return launch_r<4, 256>(p, n_obj, W, form, qn, addtid, s);
+        }
+    } else {
+        switch (R) {
+        case 4: return launch_r<4, 1024>(p, n_obj, W, form, qn, addtid, s);
+        case 8: return launch_r<8, 1024>(p, n_obj, W, form, qn, addtid, s);
+        }
     }
     return (int)hipErrorInvalidValue;
 }

@@ -53,12 +53,15 @@ def test_config1_wine_glass_one_impulse():
         assert np.abs(a - w).max() <= 2e-3 * max(np.abs(want["state"][0][0]).max(), 1e-300)
 
 
-@pytest.mark.parametrize("mpl", [1, 2, 4, 8])
+@pytest.mark.parametrize("mpl", [1, 2, 4])
 @pytest.mark.parametrize("packed", ["0", "1"])
-def test_config2_512_modes_poisson_train(mpl, packed, monkeypatch):
+@pytest.mark.parametrize("addtid", ["0", "1"])
+def test_config2_512_modes_poisson_train(mpl, packed, addtid, monkeypatch):
     """configs[1]: single object, 512 modes, Poisson impulse train; every team
-    shape (R oscillators per lane) and both builds of the kernel."""
+    shape (R oscillators per lane), both builds of the kernel (v_pk_* / scalar)
+    and both LDS tile-write forms (ds_write_addtid_b32 / ds_write_b32)."""
     monkeypatch.setenv("PBSO_IIR_PACKED", packed)
+    monkeypatch.setenv("PBSO_LDS_ADDTID", addtid)
     seed = synth.seed_for(2, 0)
     lam = synth.eigenvalues(512, seed)
     shapes = synth.mode_shapes(512, seed)
@@ -72,7 +75,28 @@ def test_config2_512_modes_poisson_train(mpl, packed, monkeypatch):
     want = run_oracle(objs, evs, NB)
     mx, l2 = _check(got, want)
     assert got["info"]["modes_per_lane"] == mpl
-    print(f"C2 R={mpl} packed={packed} max/peak={mx:.2e} relL2={l2:.2e}")
+    print(f"C2 R={mpl} packed={packed} addtid={addtid} max/peak={mx:.2e} relL2={l2:.2e}")
+
+
+@pytest.mark.parametrize("mpl", [4, 8])
+@pytest.mark.parametrize("packed", ["0", "1"])
+def test_config5_shape_large_objects(mpl, packed, monkeypatch):
+    """configs[4] object size: 4096 modes per object -> teams of 16 / 8 waves
+    (the 1024-thread build of the kernel), Gaussian + point forces."""
+    monkeypatch.setenv("PBSO_IIR_PACKED", packed)
+    n_modes, nb = 4096, 10
+    objs, evs = [], []
+    rng = np.random.default_rng(55)
+    for i in range(2):
+        lam = synth.eigenvalues(n_modes, synth.seed_for(5, i))
+        objs.append(ObjSpec(lam))
+        evs.append(force_ev(0, i, data=rng.standard_normal(n_modes) * 1e-3, force_type=1, width=1500.0))
+        evs.append(force_ev(3, i, data=rng.standard_normal(n_modes) * 1e-3))
+        evs.append(dict(t=0, obj=i, kind="use_transfer", use=False))
+    got = run_engine(objs, evs, nb, modes_per_lane=mpl)
+    want = run_oracle(objs, evs, nb)
+    _check(got, want)
+    assert got["info"]["waves_per_object"] == 4096 // (64 * mpl)
 
 
 def test_direct_form_reference_literal_arithmetic():
