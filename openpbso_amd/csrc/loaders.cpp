@@ -188,9 +188,11 @@ bool take3(Rd s, double out[3]) {
 // ffat_map_t_1 -> FFAT_Map<double,1>, ffat_map_serialize.h:176-222
 bool read_shell(Rd s, pbso_ffat_map *m) {
     bool ok = true;
+    unsigned seen = 0;
     while (s.p < s.end && !s.err && ok) {
         const uint64_t key = s.varint();
         const int fn = (int)(key >> 3), wt = (int)(key & 7);
+        if (fn >= 1 && fn <= 7) seen |= 1u << fn;
         if (fn == 1 && wt == 1) m->cell_size = s.f64();
         else if (fn == 2 && wt == 2) {
             std::vector<std::vector<double>> rows;
@@ -215,15 +217,19 @@ bool read_shell(Rd s, pbso_ffat_map *m) {
         else if (fn == 7 && wt == 2) ok = take3(s.sub(), m->bbox_top);
         else s.skip(wt);
     }
-    return ok && !s.err;
+    // the reference's loader asserts the fixed-size vectors (DESERIALIZE_VEC(.., false))
+    // and GetMapVal indexes all six faces: a shell without them is unusable
+    return ok && !s.err && (seen & 0xFC) == 0xFC;
 }
 
 // ffat_map_t_3 -> FFAT_Map<double,3>, ffat_map_serialize.h:223-253
 bool read_map3(Rd s, pbso_ffat_map *m, bool *compressed) {
     bool ok = true;
+    unsigned seen = 0;
     while (s.p < s.end && !s.err && ok) {
         const uint64_t key = s.varint();
         const int fn = (int)(key >> 3), wt = (int)(key & 7);
+        if (fn >= 1 && fn <= 6) seen |= 1u << fn;
         if (fn == 1 && wt == 1) m->k = s.f64();
         else if (fn == 2 && wt == 2) ok = take3(s.sub(), m->center3);
         else if (fn == 3 && wt == 2) ok = read_shell(s.sub(), m);
@@ -243,7 +249,7 @@ bool read_map3(Rd s, pbso_ffat_map *m, bool *compressed) {
         } else if (fn == 6 && wt == 0) m->mode_id = (int)(int64_t)s.varint();
         else s.skip(wt);
     }
-    return ok && !s.err;
+    return ok && !s.err && (seen & 0x2C) == 0x2C;      // center, shells and psi must be there
 }
 }  // namespace
 
