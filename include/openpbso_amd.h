@@ -234,6 +234,11 @@ typedef struct pbso_engine_info {
     int64_t total_steps;
 } pbso_engine_info;
 int pbso_get_info(pbso_engine *e, pbso_engine_info *out);
+/* diagnostics (engine created with env PBSO_CENSUS=1): for every object's
+ * workgroup of the last oscillator-bank launch: start, end (100 MHz ticks),
+ * HW_REG_HW_ID, HW_REG_XCC_ID, shader-clock count at start and end.
+ * out[n_objects][6].                                                          */
+int pbso_read_census(pbso_engine *e, unsigned long long *out, size_t n);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,7 @@ EXPORTS = [
     "pbso_set_use_transfer", "pbso_get_latest_transfer", "pbso_step", "pbso_step_into", "pbso_sync",
     "pbso_read_audio", "pbso_read_emitted", "pbso_read_qnorm", "pbso_read_state",
     "pbso_audio_device_ptr", "pbso_pa_convert", "pbso_get_info",
-    "pbso_modes_read", "pbso_num_modes_audible", "pbso_material_read", "pbso_free",
+    "pbso_modes_read", "pbso_num_modes_audible", "pbso_material_read", "pbso_free", "pbso_read_census",
 ]
 
 
@@ -119,6 +119,7 @@ def lib():
     l.pbso_modes_read.argtypes = [C.c_char_p, ip, ip, C.POINTER(dp), C.POINTER(dp)]
     l.pbso_num_modes_audible.argtypes = [dp, C.c_int, C.c_double, C.c_double]
     l.pbso_material_read.argtypes = [C.c_char_p, dp]
+    l.pbso_read_census.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t]
     l.pbso_free.argtypes = [vp]
     l.pbso_free.restype = None
     _lib = l

@@ -353,6 +353,14 @@ void pbso_pa_convert(const float *sound, unsigned long frames, float *out) {
     }
 }
 
+int pbso_read_census(pbso_engine *e, unsigned long long *out, size_t n) {
+    NEED(e);
+    if (!out) return PBSO_ERR_INVALID;
+    GUARD_BEGIN
+    return e->impl->read_census(out, n);
+    GUARD_END(e)
+}
+
 int pbso_get_info(pbso_engine *e, pbso_engine_info *out) {
     NEED(e);
     if (!out) return PBSO_ERR_INVALID;

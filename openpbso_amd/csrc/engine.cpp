@@ -128,7 +128,7 @@ Engine::~Engine() {
     d_ca_.release(); d_cb_.release(); d_sq_.release(); d_sd_.release(); d_c3_.release();
     d_shapes_.release(); d_shape_off_.release(); d_n_modes_.release(); d_geom_.release();
     d_geom_off_.release(); d_psi_.release(); d_slots_.release(); d_xfer_.release();
-    d_audio_.release(); d_qnorm_.release(); d_grows_.release();
+    d_audio_.release(); d_qnorm_.release(); d_grows_.release(); d_census_.release();
     set_[0].release();
     set_[1].release();
     for (hipEvent_t ev : {ev_set_[0], ev_set_[1]})
@@ -187,6 +187,8 @@ int Engine::init() {
     // which build of the oscillator bank to launch (see kernels_iir.hip)
     if (const char *v = std::getenv("PBSO_IIR_PACKED")) packed_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_LDS_ADDTID")) addtid_ = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PBSO_CENSUS")) census_ = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PBSO_ROTATE_PRIO")) rotate_prio_ = std::atoi(v) != 0;
     return PBSO_OK;
 }
 
@@ -288,11 +290,7 @@ int Engine::finalize() {
     int R = desc_.modes_per_lane;
     if (R != 0 && R != 1 && R != 2 && R != 4 && R != 8) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,4,8");
     auto waves_for = [&](int r) { return (mmax + 64 * r - 1) / (64 * r); };
-    // kernel builds exist for W <= 4 with R in {1,2,4} and 4 < W <= 16 with R in {4,8}
-    auto shape_ok = [&](int r) {
-        const int w = waves_for(r);
-        return w <= 4 ? (r <= 4) : (w <= maxW && r >= 4);
-    };
+    auto shape_ok = [&](int r) { return waves_for(r) <= maxW; };
     if (R == 0) {
         for (int r : {4, 2, 1}) {
             if (shape_ok(r) && ((long long)N * waves_for(r) >= 4096)) { R = r; break; }
@@ -302,7 +300,7 @@ int Engine::finalize() {
                 if (shape_ok(r)) { R = r; break; }
         if (R == 0) return fail(PBSO_ERR_INVALID, "object too large: more than 8192 modes per object not supported yet");
     } else if (!shape_ok(R)) {
-        return fail(PBSO_ERR_INVALID, "modes_per_lane not supported for this object size (W<=4: 1,2,4; W<=16: 4,8)");
+        return fail(PBSO_ERR_INVALID, "modes_per_lane too small for this object size (at most 16 waves per object)");
     }
     int W = waves_for(R);
     if (W > maxW) return fail(PBSO_ERR_INVALID, "object too large: more than 8192 modes per object not supported yet");
@@ -844,8 +842,14 @@ int Engine::step(int nb, void *d_audio_user) {
     kp.xfer_init = ps.d_xfer_init.p;
     kp.audio = audio;
     kp.qnorm = qn ? d_qnorm_.p : nullptr;
+    kp.census = nullptr;
+    if (census_) {
+        HIPTRY(d_census_.ensure((size_t)N * 6, false, stream_));
+        kp.census = d_census_.p;
+    }
     kp.nb = nb; kp.n_tiles = n_tiles_; kp.m_pad = m_pad_; kp.b_pad = b_pad_;
     kp.audio_stride = (long long)nb * B_;
+    kp.rotate_prio = rotate_prio_ ? 1 : 0;
     HIPTRY(hipEventRecord(evq.k0, stream_));
     if (packed_ && R_ >= 2)
         LAUNCHTRY(iir_packed::launch_iir_bank(kp, N, R_, W_, desc_.recurrence_form, qn, addtid_, stream_));
@@ -877,6 +881,13 @@ int Engine::read_audio(float *out, size_t n) {
     const size_t total = (size_t)objs_.size() * last_nb_ * B_;
     if (n != total) return fail(PBSO_ERR_INVALID, "read_audio size mismatch");
     HIPTRY(hipMemcpyAsync(out, last_audio_, total * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    return sync();
+}
+
+int Engine::read_census(unsigned long long *out, size_t n) {
+    if (!census_ || !d_census_.p) return fail(PBSO_ERR_STATE, "census not enabled (PBSO_CENSUS=1) or no step yet");
+    if (n != (size_t)objs_.size() * 6) return fail(PBSO_ERR_INVALID, "read_census size mismatch");
+    HIPTRY(hipMemcpyAsync(out, d_census_.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
     return sync();
 }
 
@@ -969,7 +980,7 @@ int Engine::info(pbso_engine_info *out) {
     out->modes_padded = m_pad_;
     out->modes_per_lane = R_;
     out->waves_per_object = W_;
-    out->lds_bytes_per_workgroup = finalized_ ? (int)iir_lds_bytes(W_) : 0;
+    out->lds_bytes_per_workgroup = finalized_ ? (int)iir_lds_bytes(W_, n_tiles_) : 0;
     out->buffers_done = buffers_done_;
     out->last_step_host_plan_ms = last_plan_ms_;
     out->last_step_forced_rows = last_frows_;

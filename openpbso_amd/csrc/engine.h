@@ -121,6 +121,7 @@ public:
     int read_qnorm(int obj, int buffer, float *out, int n);
     int read_state(int obj, double *q1, double *q2, int n);
     void *audio_ptr() { return last_audio_; }
+    int read_census(unsigned long long *out, size_t n);
     int info(pbso_engine_info *out);
     const char *last_error() const { return err_.c_str(); }
     int n_objects() const { return (int)objs_.size(); }
@@ -166,6 +167,9 @@ private:
     DevBuf<double> d_slots_;                             // [n_slots][m_pad] ForceMessage::data rows
     DevBuf<double> d_xfer_;                              // [n_obj + scratch][m_pad]
     DevBuf<float> d_audio_, d_qnorm_;
+    DevBuf<unsigned long long> d_census_;                // PBSO_CENSUS=1: per-workgroup placement/timing
+    bool census_ = false;
+    bool rotate_prio_ = true;                            // PBSO_ROTATE_PRIO: see kernels_iir.hip
     float *last_audio_ = nullptr;
     int last_nb_ = 0;
     size_t n_slots_ = 0;

@@ -46,13 +46,15 @@ struct IirParams {
     const int *xfer_init;        // [n_obj] row (or XFER_UNIT) in effect when the launch starts
     float *audio;                // [n_obj][audio_stride]
     float *qnorm;                // [n_obj][nb][m_pad] or nullptr
+    unsigned long long *census;  // diagnostics: [n_obj][6] = start, end (100 MHz), HW_ID, XCC_ID, clk0, clk1; or nullptr
     int nb, n_tiles, m_pad, b_pad;
     long long audio_stride;
+    int rotate_prio;             // rotate s_setprio per tile (fair progress of resident teams)
 };
 
 // launches the oscillator bank; returns hipError_t as int.  Two builds of the
 // same source: packed (float2 mode pairs, v_pk_*_f32; R >= 2) and scalar.
-// Supported shapes: W <= 4 with R in {1,2,4}; 4 < W <= 16 with R in {4,8}.
+// Supported shapes: W <= 16 waves per object, R in {1,2,4,8}.
 namespace iir_packed {
 int launch_iir_bank(const IirParams &p, int n_obj, int modes_per_lane, int waves_per_object,
                     int form, bool qnorm, bool addtid, hipStream_t stream);
@@ -61,8 +63,9 @@ namespace iir_scalar {
 int launch_iir_bank(const IirParams &p, int n_obj, int modes_per_lane, int waves_per_object,
                     int form, bool qnorm, bool addtid, hipStream_t stream);
 }
-inline size_t iir_lds_bytes(int W) {
-    return sizeof(float) * ((size_t)W * TILE * LDS_ROW + (W > 1 ? 2 * (size_t)(W - 1) * 32 : 0));
+// per wave: one [TILE][LDS_ROW] transpose tile + a ring of (n_tiles + 1) tiles of row sums
+inline size_t iir_lds_bytes(int W, int n_tiles) {
+    return sizeof(float) * (size_t)W * (TILE * LDS_ROW + (size_t)(n_tiles + 1) * TILE);
 }
 constexpr int MAX_WAVES_PER_OBJECT = 16;
 

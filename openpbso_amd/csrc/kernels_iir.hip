@@ -19,13 +19,16 @@
 // (p = sum_r t_r q_r), then the 64 lane partials of TILE = 27 consecutive
 // samples are transposed through a per-wave LDS tile P[27][68]: lane l writes
 // P[k][l] while stepping sample k (ds_write_addtid_b32: no address VGPR, half
-// the issue cost of ds_write_b32), then lanes 2k and 2k+1 read the two halves
-// of row k with 8 ds_read_b128 each (bank-conflict free with the 68-float
-// stride), add their 32 values in a fixed order and combine with one DPP add.
-// That is ~1.2 VALU instructions per wave-sample instead of a 6-step
-// cross-lane reduction, and the result is deterministic.  Teams of W > 1
-// waves add their row sums through a small double-buffered LDS array, one
-// workgroup barrier per tile.
+// the issue cost of ds_write_b32).  The row sums are taken ONE TILE LATER:
+// at the start of the next tile lanes 2k and 2k+1 issue 8 ds_read_b128 each
+// for the two halves of row k (bank-conflict free with the 68-float stride;
+// LDS ops of a wave execute in order, so the reads see the old tile although
+// the new tile's writes follow), and the 32 adds are spread over the next
+// tile's sample bodies where they fill dependency stalls; one DPP add joins
+// the halves.  ~1.2 VALU instructions per wave-sample, fixed order, no LDS
+// latency exposed.  Row sums go to a small per-wave LDS ring; a team of W
+// waves meets at a workgroup barrier only once per audio buffer, when all
+// waves add their rings and store the buffer's 513 samples coalesced.
 #include <type_traits>
 
 #include "kernels.h"
@@ -51,6 +54,7 @@ namespace pbso {
 namespace PBSO_IIR_NS {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 template <int K0, int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {
@@ -77,12 +81,18 @@ template <class V, int NV, int FORM, bool QN, int FMODE, bool ADDTID>
 __device__ __forceinline__ void step_tile(V (&q)[NV], V (&d)[NV], const V (&ca)[NV], const V (&cb)[NV],
                                           const V (&g)[NV], const V (&t)[NV], V (&qn)[NV],
                                           const float *__restrict__ tp, float amp,
-                                          float *__restrict__ col) {
+                                          float *__restrict__ col, f4 (&rv)[8], float &rsum) {
+    // dense profile: fetch the tile's 27 values into SGPRs up front (one wait)
+    float tt[TILE];
+    if (FMODE == 1) {
+#pragma unroll
+        for (int k = 0; k < TILE; ++k) tt[k] = tp[k];
+    }
     static_for<0, TILE>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         constexpr bool forced = FMODE == 1 || (FMODE == 2 && k == 0);
         float tk = 0.f;
-        if (FMODE == 1) tk = tp[k];
+        if (FMODE == 1) tk = tt[k];
         if (FMODE == 2 && k == 0) tk = amp;
         float p = 0.f;
 #pragma unroll
@@ -120,6 +130,15 @@ __device__ __forceinline__ void step_tile(V (&q)[NV], V (&d)[NV], const V (&ca)[
 #pragma unroll
             for (int v = 0; v < NV; ++v) asm volatile("" : "+v"(qn[v]));
         }
+        // two adds of the previous tile's row sum per sample (samples 1..16): they
+        // are independent of the recurrence and fill its dependency stalls
+        if constexpr (k >= 1 && k <= 16) {
+            constexpr int i0 = 2 * (k - 1), i1 = i0 + 1;
+            const f4 va = rv[i0 / 4], vb = rv[i1 / 4];
+            rsum += (i0 % 4 == 0) ? va.x : va.z;
+            rsum += (i1 % 4 == 1) ? vb.y : vb.w;
+            asm volatile("" : "+v"(rsum));           // keep the adds here (they would be sunk past the tile)
+        }
         // keep the scheduler from interleaving whole samples: the other waves of
         // the SIMD fill the issue slots, and register pressure stays bounded.
         __builtin_amdgcn_sched_barrier(0);
@@ -132,6 +151,7 @@ __device__ __forceinline__ void step_tile(V (&q)[NV], V (&d)[NV], const V (&ca)[
 struct IirDims {
     int nb, n_tiles, m_pad, b_pad;
     long long audio_stride;
+    int rotate_prio;
 };
 
 template <class V, int NV, int FORM, bool QN, bool ADDTID, int MAXT>
@@ -140,30 +160,34 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     float *__restrict__ p_sd, const BufDesc *__restrict__ p_desc, const float *__restrict__ p_grows,
     const float *__restrict__ p_tprof, const double *__restrict__ p_xfer_rows,
     const int *__restrict__ p_xfer_init, float *__restrict__ p_audio, float *__restrict__ p_qnorm,
-    const IirDims p) {
+    unsigned long long *__restrict__ p_census, const IirDims p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int obj = blockIdx.x;
+    unsigned long long census_t0 = 0, census_c0 = 0;
+    if (p_census) {
+        census_t0 = __builtin_amdgcn_s_memrealtime();
+        census_c0 = __builtin_amdgcn_s_memtime();
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W = blockDim.x >> 6;
     const int rowlen = blockDim.x;
     float *tile = lds + wave * (TILE * LDS_ROW);
-    float *xw = lds + W * (TILE * LDS_ROW);          // [2][W-1][32] cross-wave partials
     float *col = tile + lane;
     const unsigned tile_m0 = (unsigned)wave * (unsigned)(TILE * LDS_ROW * sizeof(float));
     const size_t mbase = (size_t)obj * p.m_pad + tid;
 
     constexpr int VW = lanes_of<V>::n;
     constexpr int R = NV * VW;                       // oscillators per lane; slice r = v * VW + e
-    V ca[NV], cb[NV], q[NV], d[NV], g[NV], t[NV], qn[NV];
+    V ca[NV], cb[NV], q[NV], d[NV], g_[NV], t[NV], qn[NV];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         vset(ca[r / VW], r % VW, p_ca[mbase + r * rowlen]);
         vset(cb[r / VW], r % VW, p_cb[mbase + r * rowlen]);
         vset(q[r / VW], r % VW, p_sq[mbase + r * rowlen]);
         vset(d[r / VW], r % VW, p_sd[mbase + r * rowlen]);
-        vset(g[r / VW], r % VW, 0.f);
+        vset(g_[r / VW], r % VW, 0.f);
         vset(qn[r / VW], r % VW, 0.f);
     }
     {
@@ -176,22 +200,98 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
 
     const BufDesc *__restrict__ dsc = p_desc + (size_t)obj * p.nb;
     float *__restrict__ aout = p_audio + (size_t)obj * p.audio_stride;
-    const int B = p.n_tiles * TILE;
-    int par = 0;
+    const int NT = p.n_tiles;
+    const int B = NT * TILE;
+    const int ring = NT + 1;                         // tile slots in the row-sum ring
+    float *pbuf = lds + W * (TILE * LDS_ROW);        // [W][ring * TILE] row sums per wave
+    float *mybuf = pbuf + wave * (ring * TILE);
     // row-sum phase: lanes 2k, 2k+1 own the two 32-float halves of row k
     const int rrow = lane >> 1;
-    const float4 *rsrc = reinterpret_cast<const float4 *>(tile + rrow * LDS_ROW + (lane & 1) * 32);
+    const bool owner = (lane & 1) == 0 && lane < 2 * TILE;
+    const f4 *rsrc = reinterpret_cast<const f4 *>(tile + (lane < 2 * TILE ? rrow : 0) * LDS_ROW + (lane & 1) * 32);
 
+    // The SIMD arbiter serves equal-priority waves oldest first: left alone, the
+    // four teams resident on a CU finish at ~57/66/83/100 % of the kernel and the
+    // youngest runs the tail at one-wave issue efficiency (scripts/census.py).
+    // Rotating s_setprio by (wave slot + tile counter) gives every resident wave
+    // each priority level equally often, so all teams progress at the same pace.
+    // Performance hint only: results do not depend on it.
+    const int wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 0xF;   // HW_REG_HW_ID.WAVE_ID
+    const bool ROTATE = p.rotate_prio != 0;
+
+    // state of the one-tile lag (all wave-uniform)
+    bool have_prev = false, prev_last = false, settle = false;
+    int g = 0, prev_slot = 0, prev_b = 0, prev_g0 = 0;
+
+    // all waves add their ring entries of buffer bb (tiles g0 .. g0 + NT - 1) and store it
+    auto combine = [&](int bb, int g0) {
+        for (int sidx = tid; sidx < B; sidx += blockDim.x) {
+            const int tl = sidx / TILE, row = sidx - tl * TILE;
+            const int off = ((g0 + tl) % ring) * TILE + row;
+            float acc = pbuf[off];
+            for (int w = 1; w < W; ++w) acc += pbuf[w * (ring * TILE) + off];
+            aout[(size_t)bb * B + sidx] = acc;
+        }
+    };
+    // finish the row sum held in rsum (lane halves -> row), park it in the ring, and
+    // when it completes a buffer, combine that buffer
+    auto retire = [&](float rsum) {
+        // quad_perm [1,0,3,2]: the partner lane's half (a + b == b + a bitwise)
+        rsum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rsum), 0xB1, 0xF, 0xF, false));
+        if (owner) mybuf[prev_slot * TILE + rrow] = rsum;
+        if (prev_last) {
+            __syncthreads();                         // every wave's ring holds buffer prev_b
+            combine(prev_b, prev_g0);
+            settle = true;
+        } else if (settle) {
+            __syncthreads();                         // combine done everywhere: slots may be reused
+            settle = false;
+        }
+    };
+    // plain (compiler-visible) LDS loads: its s_waitcnt placement cannot see the
+    // inline-asm tile writes and is therefore conservative, never wrong.  (Hand-placed
+    // asm reads + counted waits measured no faster and break if rv is ever spilled.)
+    auto load_rows = [&](f4 (&rv)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rv[j] = rsrc[j];
+    };
+    // the pending tile has no successor to hide behind: sum it now
+    auto flush = [&]() {
+        if (!have_prev) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f4 rv[8];
+        load_rows(rv);
+        float rsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            rsum += rv[j].x;
+            rsum += rv[j].y;
+            rsum += rv[j].z;
+            rsum += rv[j].w;
+        }
+        retire(rsum);
+        __syncthreads();
+        settle = false;
+        have_prev = false;
+    };
+
+    // descriptors are fetched one buffer ahead (scalar loads, ~1-2 us from HBM)
+    BufDesc next = dsc[0];
     for (int b = 0; b < p.nb; ++b) {
-        const int frow = dsc[b].frow;
-        const int prow = dsc[b].prow;
-        const uint32_t mask = dsc[b].tile_mask;
-        const float amp = dsc[b].amp;
-        const int trow = dsc[b].trow;
-        const uint32_t flags = dsc[b].flags;
+        const BufDesc cur = next;
+        next = dsc[b + 1 < p.nb ? b + 1 : b];
+        const int frow = cur.frow;
+        const int prow = cur.prow;
+        const uint32_t mask = cur.tile_mask;
+        const float amp = cur.amp;
+        const int trow = cur.trow;
+        const uint32_t flags = cur.flags;
 
         if (flags & DESC_SKIP) {
             // the reference's step() returned before stepping: no samples, state untouched
+            flush();
             for (int i = tid; i < B; i += blockDim.x) aout[(size_t)b * B + i] = 0.f;
             if (QN) {
 #pragma unroll
@@ -209,7 +309,7 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
         if (frow >= 0) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                vset(g[r / VW], r % VW, p_grows[(size_t)frow * p.m_pad + tid + r * rowlen]);
+                vset(g_[r / VW], r % VW, p_grows[(size_t)frow * p.m_pad + tid + r * rowlen]);
         }
         const bool impulse = (flags & DESC_IMPULSE) != 0;
         const float *__restrict__ tprow = p_tprof + (size_t)(prow >= 0 ? prow : 0) * p.b_pad;
@@ -217,51 +317,40 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
 #pragma unroll
             for (int r = 0; r < R; ++r) vset(qn[r / VW], r % VW, 0.f);
         }
+        const int g0 = g;
 
-        for (int tl = 0; tl < p.n_tiles; ++tl) {
-            if (ADDTID) asm volatile("s_mov_b32 m0, %0" ::"s"(tile_m0) : "memory");
-            const bool hit = frow >= 0 && ((mask >> tl) & 1u);
-            if (hit && impulse)
-                step_tile<V, NV, FORM, QN, 2, ADDTID>(q, d, ca, cb, g, t, qn, nullptr, amp, col);
-            else if (hit)
-                step_tile<V, NV, FORM, QN, 1, ADDTID>(q, d, ca, cb, g, t, qn, tprow + tl * TILE, 0.f, col);
-            else
-                step_tile<V, NV, FORM, QN, 0, ADDTID>(q, d, ca, cb, g, t, qn, nullptr, 0.f, col);
-
-            // wave-local hand-off: LDS ops of one wave execute in order; the fences
-            // only stop the compiler from moving the row reads above the writes.
+        for (int tl = 0; tl < NT; ++tl) {
+            // previous tile's rows: issued before this tile's writes (in-order LDS), used during it
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-            float s = 0.f;
-            if (lane < 2 * TILE) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float4 v = rsrc[j];
-                    s += v.x;
-                    s += v.y;
-                    s += v.z;
-                    s += v.w;
+            f4 rv[8];
+            load_rows(rv);
+            float rsum = 0.f;
+            if (ROTATE) {
+                switch ((wave_slot + g) & 3) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
                 }
             }
-            // row k = (lane 2k: first half) + (lane 2k+1: second half), same order in every launch
-            // quad_perm [1,0,3,2]: the partner lane's half (a + b == b + a bitwise)
-            s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, false));
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            if (ADDTID) asm volatile("s_mov_b32 m0, %0" ::"s"(tile_m0) : "memory");
+            const bool hit = frow >= 0 && ((mask >> tl) & 1u);
+            if (hit && impulse)
+                step_tile<V, NV, FORM, QN, 2, ADDTID>(q, d, ca, cb, g_, t, qn, nullptr, amp, col, rv, rsum);
+            else if (hit)
+                step_tile<V, NV, FORM, QN, 1, ADDTID>(q, d, ca, cb, g_, t, qn, tprow + tl * TILE, 0.f, col, rv, rsum);
+            else
+                step_tile<V, NV, FORM, QN, 0, ADDTID>(q, d, ca, cb, g_, t, qn, nullptr, 0.f, col, rv, rsum);
 
-            const bool owner = (lane & 1) == 0 && lane < 2 * TILE;
-            if (W > 1) {
-                float *x = xw + par * ((W - 1) * 32);
-                if (wave > 0 && owner) x[(wave - 1) * 32 + rrow] = s;
-                __syncthreads();
-                if (wave == 0 && owner) {
-                    for (int w = 1; w < W; ++w) s += x[(w - 1) * 32 + rrow];
-                }
-                par ^= 1;
-            }
-            if (wave == 0 && owner) aout[(size_t)b * B + tl * TILE + rrow] = s;
+            if (have_prev) retire(rsum);
+            have_prev = true;
+            prev_slot = g % ring;
+            prev_b = b;
+            prev_g0 = g0;
+            prev_last = tl == NT - 1;
+            ++g;
         }
 
         if (QN) {
@@ -271,6 +360,16 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
                 p_qnorm[((size_t)obj * p.nb + b) * p.m_pad + tid + r * rowlen] = sqrtf(r % VW ? e1 : e0);
             }
         }
+    }
+    flush();
+    if (p_census && tid == 0) {
+        // where and when this workgroup ran (placement / residency diagnostics)
+        p_census[(size_t)obj * 6 + 0] = census_t0;
+        p_census[(size_t)obj * 6 + 1] = __builtin_amdgcn_s_memrealtime();
+        p_census[(size_t)obj * 6 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        p_census[(size_t)obj * 6 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+        p_census[(size_t)obj * 6 + 4] = census_c0;                                    // shader clock at start
+        p_census[(size_t)obj * 6 + 5] = __builtin_amdgcn_s_memtime();                 // ... and at the end
     }
 
 #pragma unroll
@@ -282,7 +381,7 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
 
 template <int R, int FORM, bool QN, bool ADDTID, int MAXT>
 static int launch_one(const IirParams &p, int n_obj, int W, hipStream_t stream) {
-    const size_t lds = iir_lds_bytes(W);
+    const size_t lds = iir_lds_bytes(W, p.n_tiles);
 #if PBSO_IIR_PACKED
     auto kern = R >= 2 ? iir_bank_kernel<v2f, (R >= 2 ? R / 2 : 1), FORM, QN, ADDTID, MAXT>
                        : nullptr;
@@ -295,9 +394,9 @@ static int launch_one(const IirParams &p, int n_obj, int W, hipStream_t stream) 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    const IirDims dims = {p.nb, p.n_tiles, p.m_pad, p.b_pad, p.audio_stride};
+    const IirDims dims = {p.nb, p.n_tiles, p.m_pad, p.b_pad, p.audio_stride, p.rotate_prio};
     hipLaunchKernelGGL(kern, dim3(n_obj), dim3(64 * W), lds, stream, p.ca, p.cb, p.sq, p.sd, p.desc,
-                       p.grows, p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, dims);
+                       p.grows, p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.census, dims);
     return (int)hipGetLastError();
 }
 
@@ -318,7 +417,7 @@ static int launch_r(const IirParams &p, int n_obj, int W, int form, bool qn, boo
 
 // teams of up to 4 waves use the 256-thread build (no VGPR cap in practice);
 // larger teams (objects with more than 256 R modes) the 1024-thread build.
-// Instantiated shapes: R in {1,2,4} for small teams, {4,8} for large ones.
+// R in {1,2,4,8} for both (R = 1 only in the scalar build).
 int launch_iir_bank(const IirParams &p, int n_obj, int R, int W, int form, bool qn, bool addtid,
                     hipStream_t s) {
     if (n_obj <= 0) return 0;
@@ -330,9 +429,14 @@ int launch_iir_bank(const IirParams &p, int n_obj, int R, int W, int form, bool 
 #endif
         case 2: return launch_r<2, 256>(p, n_obj, W, form, qn, addtid, s);
         case 4: return launch_r<4, 256>(p, n_obj, W, form, qn, addtid, s);
+        case 8: return launch_r<8, 256>(p, n_obj, W, form, qn, addtid, s);
         }
     } else {
         switch (R) {
+#if !PBSO_IIR_PACKED
+        case 1: return launch_r<1, 1024>(p, n_obj, W, form, qn, addtid, s);
+#endif
+        case 2: return launch_r<2, 1024>(p, n_obj, W, form, qn, addtid, s);
         case 4: return launch_r<4, 1024>(p, n_obj, W, form, qn, addtid, s);
         case 8: return launch_r<8, 1024>(p, n_obj, W, form, qn, addtid, s);
         }
