@@ -1,0 +1,103 @@
+// Uses include/openpbso_amd_facade.h the way tools/real_time_modal_sound.cpp
+// uses modal_solver.h: BuildSolver (:309-345), a Shift+click hit
+// (GetModalForceVertex :268-295 + enqueueForceMessage :610), the simulation
+// thread's step() loop (:527-536) and PaModalCallback (:192-212).  Writes the
+// mono float32 stream the callback would play to argv[1].
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <vector>
+
+#include "openpbso_amd_facade.h"
+
+template <typename T>
+struct ModeDataLite {                       // ModeData<T> accessors used by the tool
+    std::vector<T> _omegaSquared;
+    std::vector<std::vector<T>> _modes;
+    const std::vector<T> &mode(int i) const { return _modes.at(i); }
+    int numModes() const { return (int)_omegaSquared.size(); }
+};
+
+// tools/real_time_modal_sound.cpp:268-295, verbatim control flow with the facade types
+template <typename T>
+void GetModalForceVertex(const int forceDim, const ModeDataLite<T> &modes, const int vid, const double vn[3],
+                         ForceMessage<double> &force, ForceType type, float gaussWidth) {
+    force.data.setZero(forceDim);
+    for (int mm = 0; mm < forceDim; ++mm)
+        force.data(mm) = vn[0] * modes.mode(mm).at(vid * 3 + 0) + vn[1] * modes.mode(mm).at(vid * 3 + 1) +
+                         vn[2] * modes.mode(mm).at(vid * 3 + 2);
+    force.forceType = type;
+    if (type == ForceType::PointForce) force.force.reset(new PointForce<T>());
+    else if (type == ForceType::GaussianForce) force.force.reset(new GaussianForce<T>(gaussWidth));
+    else force.force.reset(new AutoregressiveForce<T>());
+}
+
+struct PaModalData {
+    std::unique_ptr<ModalSolver<double>> *solver;
+    SoundMessage<double> soundMessage;
+};
+// tools/real_time_modal_sound.cpp:192-212
+static int PaModalCallback(void *outputBuffer, unsigned long framesPerBuffer, void *userData) {
+    PaModalData *data = (PaModalData *)userData;
+    float *out = (float *)outputBuffer;
+    (*(data->solver))->dequeueSoundMessage(data->soundMessage);
+    for (unsigned i = 0; i < framesPerBuffer; i++) {
+        *out++ = (float)(data->soundMessage.data(i) / 1E10);
+        *out++ = (float)(data->soundMessage.data(i) / 1E10);
+    }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    const char *out_path = argc > 1 ? argv[1] : "facade_out.f32";
+    const int n_modes = 96, n_verts = 8, n_buffers = 6;
+    // deterministic "model": eigenvalues 200 Hz .. 9 kHz, mode shapes from a LCG
+    ModeDataLite<double> modes;
+    unsigned lcg = 12345u;
+    auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return ((lcg >> 8) & 0xFFFF) / 65536.0 - 0.5; };
+    for (int m = 0; m < n_modes; ++m) {
+        const double f = 200.0 * std::pow(45.0, (double)m / (n_modes - 1));
+        modes._omegaSquared.push_back(2500.0 * std::pow(2 * M_PI * f, 2));
+        std::vector<double> u(3 * n_verts);
+        for (auto &x : u) x = rnd() * 2e-3;
+        modes._modes.push_back(u);
+    }
+    // BuildSolver
+    std::unique_ptr<ModalSolver<double>> solver(new ModalSolver<double>(n_modes));
+    std::shared_ptr<ModalIntegrator<double>> integrator(ModalIntegrator<double>::Build(
+        2500.0, modes._omegaSquared, 6.0, 1e-7, 1. / (double)SAMPLE_RATE, n_modes));
+    solver->setIntegrator(integrator);
+    solver->setUseTransfer(false);                   // no FFAT maps in this smoke model
+    // a Shift+click on vertex 3, a Gaussian-force hit two buffers later
+    const double vn[3] = {0.6, 0.0, 0.8};
+    ForceMessage<double> force;
+    GetModalForceVertex(n_modes, modes, 3, vn, force, ForceType::PointForce, 0.f);
+    if (!solver->enqueueForceMessage(force)) return 2;
+    PaModalData pa;
+    pa.solver = &solver;
+    std::vector<float> stereo(2 * FRAMES_PER_BUFFER), mono;
+    for (int b = 0; b < n_buffers; ++b) {
+        if (b == 2) {
+            GetModalForceVertex(n_modes, modes, 5, vn, force, ForceType::GaussianForce, 300.f);
+            solver->enqueueForceMessageNoFail(force);
+        }
+        solver->step();                              // simulation thread
+        PaModalCallback(stereo.data(), FRAMES_PER_BUFFER, &pa);   // audio thread
+        for (int i = 0; i < FRAMES_PER_BUFFER; ++i) mono.push_back(stereo[2 * i]);
+    }
+    pbso_facade::VecX<double> qn = solver->getQBufferNorm();
+    const TransMessage<double> &tr = solver->getLatestTransfer();
+    std::printf("qnorm[0]=%g transfer[0]=%g n=%d\n", qn(0), tr.data(0), tr.data.size());
+    FILE *f = std::fopen(out_path, "wb");
+    if (!f) return 3;
+    std::fwrite(mono.data(), sizeof(float), mono.size(), f);
+    std::fclose(f);
+    // also dump the model so the test can rebuild it for the oracle
+    std::string mp = std::string(out_path) + ".model";
+    f = std::fopen(mp.c_str(), "wb");
+    std::fwrite(modes._omegaSquared.data(), sizeof(double), n_modes, f);
+    for (int m = 0; m < n_modes; ++m) std::fwrite(modes._modes[m].data(), sizeof(double), 3 * n_verts, f);
+    std::fclose(f);
+    return 0;
+}
