@@ -15,18 +15,21 @@ namespace pbso {
 template <class T>
 hipError_t DevBuf<T>::ensure(size_t n, bool keep, hipStream_t s) {
     if (n <= cap) return hipSuccess;
-    size_t ncap = std::max(n, cap + cap / 2);
+    // 25 % headroom: per-step demand (forced rows, slots) fluctuates by a few percent, and a
+    // regrowth drains the device
+    size_t ncap = std::max(n + n / 4, cap + cap / 2);
     T *np = nullptr;
     hipError_t e = hipMalloc((void **)&np, ncap * sizeof(T));
     if (e != hipSuccess) return e;
-    if (keep && p && cap) {
-        e = hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) { (void)hipFree(np); return e; }
-    }
     if (p) {
-        // in-flight kernels may still read the old block: drain the stream first
-        (void)hipStreamSynchronize(s);
+        // in-flight work on either engine stream may still use the old block: drain the device
+        // (growth is rare: capacities only ever increase)
+        e = hipDeviceSynchronize();
+        if (e == hipSuccess && keep && cap) {
+            e = hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+        }
+        if (e != hipSuccess) { (void)hipFree(np); return e; }
         (void)hipFree(p);
     }
     p = np;
@@ -42,7 +45,7 @@ void DevBuf<T>::release() {
 template <class T>
 hipError_t PinBuf<T>::ensure(size_t n) {
     if (n <= cap) return hipSuccess;
-    size_t ncap = std::max(n, cap + cap / 2);
+    size_t ncap = std::max(n + n / 4, cap + cap / 2);
     T *np = nullptr;
     hipError_t e = hipHostMalloc((void **)&np, ncap * sizeof(T), hipHostMallocDefault);
     if (e != hipSuccess) return e;
@@ -125,10 +128,14 @@ Engine::Engine(const pbso_engine_desc &d) : desc_(d) {}
 
 Engine::~Engine() {
     if (stream_) (void)hipStreamSynchronize(stream_);
+    if (prep_stream_) (void)hipStreamSynchronize(prep_stream_);
     d_ca_.release(); d_cb_.release(); d_sq_.release(); d_sd_.release(); d_c3_.release();
     d_shapes_.release(); d_shape_off_.release(); d_n_modes_.release(); d_geom_.release();
     d_geom_off_.release(); d_psi_.release(); d_slots_.release(); d_xfer_.release();
-    d_audio_.release(); d_qnorm_.release(); d_grows_.release(); d_census_.release();
+    d_audio_.release(); d_qnorm_.release(); d_grows_[0].release(); d_grows_[1].release(); d_census_.release();
+    for (hipEvent_t ev : {ev_prep_done_[0], ev_prep_done_[1], ev_k1_done_[0], ev_k1_done_[1]})
+        if (ev) (void)hipEventDestroy(ev);
+    if (prep_stream_) (void)hipStreamDestroy(prep_stream_);
     set_[0].release();
     set_[1].release();
     for (hipEvent_t ev : {ev_set_[0], ev_set_[1]})
@@ -183,6 +190,13 @@ int Engine::init() {
     }
     HIPTRY(hipEventCreateWithFlags(&ev_set_[0], hipEventDisableTiming));
     HIPTRY(hipEventCreateWithFlags(&ev_set_[1], hipEventDisableTiming));
+    // preparation of step k+1 (plan upload, projection, FFAT lookup, force combination)
+    // runs on its own stream beside the oscillator bank of step k
+    HIPTRY(hipStreamCreateWithFlags(&prep_stream_, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIPTRY(hipEventCreateWithFlags(&ev_prep_done_[i], hipEventDisableTiming));
+        HIPTRY(hipEventCreateWithFlags(&ev_k1_done_[i], hipEventDisableTiming));
+    }
     tbuf_.assign(B_, 0.0);
     // which build of the oscillator bank to launch (see kernels_iir.hip)
     if (const char *v = std::getenv("PBSO_IIR_PACKED")) packed_ = std::atoi(v) != 0;
@@ -533,7 +547,7 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
             if (!o.trans_full) {                  // try_enqueue; a full queue drops the update
                 FfatEvent fe;
                 fe.obj = oi;
-                fe.row = 2 * N + n_xfer_scratch_++;
+                fe.row = 2 * N + cur_set_ * xfer_cap_ + n_xfer_scratch_++;
                 fe.pos[0] = ev.v[0]; fe.pos[1] = ev.v[1]; fe.pos[2] = ev.v[2];
                 ffat_.push_back(fe);
                 o.trans_full = true;
@@ -724,6 +738,18 @@ int Engine::plan(int nb) {
             o.sustained || (!o.use_transfer && o.latest_row != XFER_UNIT))
             busy_.push_back(i);
     }
+    // every stamped computeTransfer that can fire in this batch may need one scratch row
+    size_t need = 0;
+    for (int i : busy_)
+        for (const TimedEvent &ev : objs_[i].pending)
+            if (ev.kind == TimedEvent::TRANSFER && ev.not_before < buffers_done_ + nb) ++need;
+    if ((int)need > xfer_cap_) {
+        const int ncap = std::max<int>((int)need, 2 * xfer_cap_ + 16);
+        // rows [2N + s*cap, ...) change meaning with cap: nothing may be in flight (ensure() drains)
+        HIPTRY(d_xfer_.ensure((size_t)(2 * N + 2 * ncap) * m_pad_, true, stream_));
+        HIPTRY(hipDeviceSynchronize());
+        xfer_cap_ = ncap;
+    }
     for (int i : busy_) {
         int rc = plan_object_span(i, nb);
         if (rc != PBSO_OK) return rc;
@@ -774,17 +800,18 @@ int Engine::step(int nb, void *d_audio_user) {
     const int n_frows = n_frows_;
     last_frows_ = n_frows;
     last_trows_ = (int64_t)ffat_.size();
-    // device arenas
-    HIPTRY(d_slots_.ensure(std::max<size_t>(1, n_slots_) * m_pad_, true, stream_));
-    HIPTRY(d_xfer_.ensure((size_t)(2 * N + n_xfer_scratch_) * m_pad_, true, stream_));
-    HIPTRY(d_grows_.ensure(std::max<size_t>(1, (size_t)n_frows) * m_pad_, false, stream_));
+    hipStream_t sp = prep_stream_, sk = stream_;
+    DevBuf<float> &grows = d_grows_[cur_set_];
+    // device arenas (growth drains the device first, see DevBuf::ensure)
+    HIPTRY(d_slots_.ensure(std::max<size_t>(1, n_slots_) * m_pad_, true, sp));
+    HIPTRY(grows.ensure(std::max<size_t>(1, (size_t)n_frows) * m_pad_, false, sp));
     float *audio = (float *)d_audio_user;
     if (!audio) {
-        HIPTRY(d_audio_.ensure((size_t)N * nb * B_, false, stream_));
+        HIPTRY(d_audio_.ensure((size_t)N * nb * B_, false, sk));
         audio = d_audio_.p;
     }
     const bool qn = desc_.qnorm_mode == PBSO_QNORM_ALL;
-    if (qn) HIPTRY(d_qnorm_.ensure((size_t)N * nb * m_pad_, false, stream_));
+    if (qn) HIPTRY(d_qnorm_.ensure((size_t)N * nb * m_pad_, false, sk));
 
     if (ev_pending_.size() >= 256) {          // bound the number of live events
         int hrc = harvest_timing();
@@ -800,19 +827,22 @@ int Engine::step(int nb, void *d_audio_user) {
         HIPTRY(hipEventCreate(&evq.p0));
         HIPTRY(hipEventCreate(&evq.p1));
     }
-    HIPTRY(hipEventRecord(evq.p0, stream_));
-    HIPTRY(ps.d_desc.ensure((size_t)N * nb, false, stream_));
-    HIPTRY(hipMemcpyAsync(ps.d_desc.p, ps.h_desc.p, (size_t)N * nb * sizeof(BufDesc), hipMemcpyHostToDevice, stream_));
-    HIPTRY(ps.d_xfer_init.ensure(N, false, stream_));
-    HIPTRY(hipMemcpyAsync(ps.d_xfer_init.p, ps.h_xfer_init.p, (size_t)N * sizeof(int), hipMemcpyHostToDevice, stream_));
-    HIPTRY(upload(ps.h_row_ptr, ps.d_row_ptr, row_ptr_.data(), row_ptr_.size(), stream_));
-    HIPTRY(upload(ps.h_slot_idx, ps.d_slot_idx, slot_idx_.data(), slot_idx_.size(), stream_));
-    HIPTRY(upload(ps.h_row_obj, ps.d_row_obj, row_obj_.data(), row_obj_.size(), stream_));
-    HIPTRY(upload(ps.h_tprof, ps.d_tprof, tprof_.data(), tprof_.size(), stream_));
-    HIPTRY(upload(ps.h_stage, ps.d_stage, stage_.data(), stage_.size(), stream_));
-    HIPTRY(upload(ps.h_stage_slot, ps.d_stage_slot, stage_slot_.data(), stage_slot_.size(), stream_));
-    HIPTRY(upload(ps.h_proj, ps.d_proj, proj_.data(), proj_.size(), stream_));
-    HIPTRY(upload(ps.h_ffat, ps.d_ffat, ffat_.data(), ffat_.size(), stream_));
+    // ---- preparation stream: this set's device buffers are free once the oscillator
+    //      bank that last read them (two steps ago) has finished
+    HIPTRY(hipStreamWaitEvent(sp, ev_k1_done_[cur_set_], 0));
+    HIPTRY(hipEventRecord(evq.p0, sp));
+    HIPTRY(ps.d_desc.ensure((size_t)N * nb, false, sp));
+    HIPTRY(hipMemcpyAsync(ps.d_desc.p, ps.h_desc.p, (size_t)N * nb * sizeof(BufDesc), hipMemcpyHostToDevice, sp));
+    HIPTRY(ps.d_xfer_init.ensure(N, false, sp));
+    HIPTRY(hipMemcpyAsync(ps.d_xfer_init.p, ps.h_xfer_init.p, (size_t)N * sizeof(int), hipMemcpyHostToDevice, sp));
+    HIPTRY(upload(ps.h_row_ptr, ps.d_row_ptr, row_ptr_.data(), row_ptr_.size(), sp));
+    HIPTRY(upload(ps.h_slot_idx, ps.d_slot_idx, slot_idx_.data(), slot_idx_.size(), sp));
+    HIPTRY(upload(ps.h_row_obj, ps.d_row_obj, row_obj_.data(), row_obj_.size(), sp));
+    HIPTRY(upload(ps.h_tprof, ps.d_tprof, tprof_.data(), tprof_.size(), sp));
+    HIPTRY(upload(ps.h_stage, ps.d_stage, stage_.data(), stage_.size(), sp));
+    HIPTRY(upload(ps.h_stage_slot, ps.d_stage_slot, stage_slot_.data(), stage_slot_.size(), sp));
+    HIPTRY(upload(ps.h_proj, ps.d_proj, proj_.data(), proj_.size(), sp));
+    HIPTRY(upload(ps.h_ffat, ps.d_ffat, ffat_.data(), ffat_.size(), sp));
     std::vector<int> copies(copy_latest);
     copies.insert(copies.end(), copy_queued.begin(), copy_queued.end());
     // layout: [src,dst] pairs -> split into src[] and dst[] arrays
@@ -822,21 +852,25 @@ int Engine::step(int nb, void *d_audio_user) {
         cp[i] = copies[2 * i];
         cp[n_cl + n_cq + i] = copies[2 * i + 1];
     }
-    HIPTRY(upload(ps.h_copy, ps.d_copy, cp.data(), cp.size(), stream_));
+    HIPTRY(upload(ps.h_copy, ps.d_copy, cp.data(), cp.size(), sp));
+    HIPTRY(hipEventRecord(ev_set_[cur_set_], sp));          // this set's pinned buffers are reusable
 
     // K3 / scatter -> data slots ; K4 -> transfer rows ; combine -> g rows
-    LAUNCHTRY(launch_scatter_rows(ps.d_stage.p, ps.d_stage_slot.p, (int)stage_slot_.size(), d_slots_.p, m_pad_, stream_));
+    LAUNCHTRY(launch_scatter_rows(ps.d_stage.p, ps.d_stage_slot.p, (int)stage_slot_.size(), d_slots_.p, m_pad_, sp));
     LAUNCHTRY(launch_modal_project(ps.d_proj.p, (int)proj_.size(), d_shapes_.p, d_shape_off_.p, d_n_modes_.p,
-                                   d_slots_.p, m_pad_, stream_));
+                                   d_slots_.p, m_pad_, sp));
     LAUNCHTRY(launch_ffat_lookup(ps.d_ffat.p, (int)ffat_.size(), d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p,
-                                 d_xfer_.p, m_pad_, stream_));
+                                 d_xfer_.p, m_pad_, sp));
     LAUNCHTRY(launch_force_combine(ps.d_row_ptr.p, ps.d_slot_idx.p, ps.d_row_obj.p, n_frows, d_slots_.p, d_c3_.p,
-                                   d_grows_.p, m_pad_, stream_));
-    // K1
+                                   grows.p, m_pad_, sp));
+    HIPTRY(hipEventRecord(ev_prep_done_[cur_set_], sp));
+
+    // ---- compute stream: K1 after its preparation (and, stream order, after the previous K1)
+    HIPTRY(hipStreamWaitEvent(sk, ev_prep_done_[cur_set_], 0));
     IirParams kp;
     kp.ca = d_ca_.p; kp.cb = d_cb_.p; kp.sq = d_sq_.p; kp.sd = d_sd_.p;
     kp.desc = ps.d_desc.p;
-    kp.grows = d_grows_.p;
+    kp.grows = grows.p;
     kp.tprof = ps.d_tprof.p;
     kp.xfer_rows = d_xfer_.p;
     kp.xfer_init = ps.d_xfer_init.p;
@@ -844,23 +878,23 @@ int Engine::step(int nb, void *d_audio_user) {
     kp.qnorm = qn ? d_qnorm_.p : nullptr;
     kp.census = nullptr;
     if (census_) {
-        HIPTRY(d_census_.ensure((size_t)N * 6, false, stream_));
+        HIPTRY(d_census_.ensure((size_t)N * 6, false, sk));
         kp.census = d_census_.p;
     }
     kp.nb = nb; kp.n_tiles = n_tiles_; kp.m_pad = m_pad_; kp.b_pad = b_pad_;
     kp.audio_stride = (long long)nb * B_;
     kp.rotate_prio = rotate_prio_ ? 1 : 0;
-    HIPTRY(hipEventRecord(evq.k0, stream_));
+    HIPTRY(hipEventRecord(evq.k0, sk));
     if (packed_ && R_ >= 2)
-        LAUNCHTRY(iir_packed::launch_iir_bank(kp, N, R_, W_, desc_.recurrence_form, qn, addtid_, stream_));
+        LAUNCHTRY(iir_packed::launch_iir_bank(kp, N, R_, W_, desc_.recurrence_form, qn, addtid_, sk));
     else
-        LAUNCHTRY(iir_scalar::launch_iir_bank(kp, N, R_, W_, desc_.recurrence_form, qn, addtid_, stream_));
-    HIPTRY(hipEventRecord(evq.k1, stream_));
+        LAUNCHTRY(iir_scalar::launch_iir_bank(kp, N, R_, W_, desc_.recurrence_form, qn, addtid_, sk));
+    HIPTRY(hipEventRecord(evq.k1, sk));
     // _latest_transfer = trans (modal_solver.h:251), then re-park a still-queued transfer
-    LAUNCHTRY(launch_copy_rows(ps.d_copy.p, ps.d_copy.p + (n_cl + n_cq), n_cl, d_xfer_.p, m_pad_, stream_));
-    LAUNCHTRY(launch_copy_rows(ps.d_copy.p + n_cl, ps.d_copy.p + (n_cl + n_cq) + n_cl, n_cq, d_xfer_.p, m_pad_, stream_));
-    HIPTRY(hipEventRecord(evq.p1, stream_));
-    HIPTRY(hipEventRecord(ev_set_[cur_set_], stream_));
+    LAUNCHTRY(launch_copy_rows(ps.d_copy.p, ps.d_copy.p + (n_cl + n_cq), n_cl, d_xfer_.p, m_pad_, sk));
+    LAUNCHTRY(launch_copy_rows(ps.d_copy.p + n_cl, ps.d_copy.p + (n_cl + n_cq) + n_cl, n_cq, d_xfer_.p, m_pad_, sk));
+    HIPTRY(hipEventRecord(evq.p1, sk));
+    HIPTRY(hipEventRecord(ev_k1_done_[cur_set_], sk));
     ev_pending_.push_back(evq);
     tot_plan_ms_ += last_plan_ms_;
     tot_steps_ += 1;
@@ -872,6 +906,7 @@ int Engine::step(int nb, void *d_audio_user) {
 }
 
 int Engine::sync() {
+    if (prep_stream_) HIPTRY(hipStreamSynchronize(prep_stream_));
     if (stream_) HIPTRY(hipStreamSynchronize(stream_));
     return PBSO_OK;
 }
@@ -930,6 +965,8 @@ int Engine::get_latest_transfer(int obj, double *out) {
         for (int i = 0; i < o.n_modes; ++i) { out[i] = 1.0; out[i] *= 1E7; }     // setToUnit :89-92
         return PBSO_OK;
     }
+    int src = sync();
+    if (src) return src;
     HIPTRY(hipMemcpyAsync(out, d_xfer_.p + (size_t)o.latest_row * m_pad_, (size_t)o.n_modes * sizeof(double),
                           hipMemcpyDeviceToHost, stream_));
     return sync();

@@ -143,7 +143,10 @@ private:
     bool packed_ = true;                                 // PBSO_IIR_PACKED: v_pk_*_f32 build of K1
     bool addtid_ = true;                                 // PBSO_LDS_ADDTID: ds_write_addtid_b32 tile writes
     int t_extent_ = 0;                                   // leading samples of tbuf_ that may be non-zero
-    hipStream_t stream_ = nullptr;
+    hipStream_t stream_ = nullptr;                       // oscillator bank (caller's stream if given)
+    hipStream_t prep_stream_ = nullptr;                  // plan upload + projection + FFAT + combine
+    hipEvent_t ev_prep_done_[2] = {nullptr, nullptr}, ev_k1_done_[2] = {nullptr, nullptr};
+    int xfer_cap_ = 0;                                   // scratch transfer rows per plan set
     hipEvent_t ev_set_[2] = {nullptr, nullptr};
     struct EvQuad { hipEvent_t k0, k1, p0, p1; };
     std::vector<EvQuad> ev_free_, ev_pending_;           // one quad per step, harvested in info()
@@ -190,7 +193,7 @@ private:
         PinBuf<int> h_xfer_init;    DevBuf<int> d_xfer_init;
         void release();
     } set_[2];
-    DevBuf<float> d_grows_;
+    DevBuf<float> d_grows_[2];                           // g rows, one arena per plan set
     // plan scratch (host)
     std::vector<int> row_ptr_, slot_idx_, row_obj_, stage_slot_, busy_;
     std::vector<float> tprof_;
