@@ -43,7 +43,9 @@ def parse():
     ap.add_argument("--modes", type=int, default=512)
     ap.add_argument("--buffers", type=int, default=86, help="audio buffers per step")
     ap.add_argument("--form", choices=["velocity", "direct"], default="velocity")
-    ap.add_argument("--no-qnorm", action="store_true", help="skip getQBufferNorm (not the headline)")
+    ap.add_argument("--qnorm", choices=["sample", "closed", "off"], default="sample",
+                    help="getQBufferNorm: per-sample accumulation (reference loop), closed form, or off")
+    ap.add_argument("--no-qnorm", action="store_true", help="same as --qnorm off")
     ap.add_argument("--modes-per-lane", type=int, default=0)
     ap.add_argument("--gather", action="store_true", help="all-gather audio over RCCL inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -126,7 +128,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     eng = Engine(device=local_rank,
                  form=capi.FORM_VELOCITY if args.form == "velocity" else capi.FORM_DIRECT,
-                 qnorm=capi.QNORM_OFF if args.no_qnorm else capi.QNORM_ALL,
+                 qnorm={"sample": capi.QNORM_ALL, "closed": capi.QNORM_CLOSED, "off": capi.QNORM_OFF}[
+                     "off" if args.no_qnorm else args.qnorm],
                  modes_per_lane=args.modes_per_lane, stream=stream)
     for i in range(args.objects):
         eng.add_object(lam[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
@@ -197,11 +200,10 @@ def main():
             "config": {
                 "workload": f"{args.objects} objects x {M} modes per GPU, Poisson impulse stream (~20 PointForce hits/s/object, "
                             f"on-device vertex projection), {nb} buffers x 513 samples per step, unit transfer, "
-                            f"qnorm {'off' if args.no_qnorm else 'on'}, {args.form} recurrence form",
+                            f"qnorm {'off' if args.no_qnorm else args.qnorm}, {args.form} recurrence form",
                 "objects_per_gpu": args.objects, "modes": M, "buffers_per_step": nb, "frames_per_buffer": B,
                 "hits": n_hits, "modes_per_lane": info1["modes_per_lane"], "waves_per_object": info1["waves_per_object"],
                 "kernel_build": "packed" if os.environ.get("PBSO_IIR_PACKED", "1") != "0" else "scalar",
-                "lds_write": "addtid" if os.environ.get("PBSO_LDS_ADDTID", "1") != "0" else "b32",
                 "gather": bool(gathered is not None), "parallelism": f"object-sharded x{world}",
             },
             "roofline": {

@@ -70,7 +70,10 @@ enum pbso_recurrence_form {
 
 enum pbso_qnorm_mode {
     PBSO_QNORM_OFF = 0,       /* getQBufferNorm never consumed: skip the 5th FMA */
-    PBSO_QNORM_ALL = 1        /* per-sample accumulation, one row per (object, buffer): modal_solver.h:262-273 */
+    PBSO_QNORM_ALL = 1,       /* per-sample accumulation, one row per (object, buffer): modal_solver.h:262-273 */
+    PBSO_QNORM_CLOSED = 2     /* same rows; in buffers that are force-free after their first sample the sum
+                                 of q^2 is the quadratic form x0' G x0 of the state after sample 0 (G per mode,
+                                 fp64 on the host) -- exact in exact arithmetic; other buffers as mode 1 */
 };
 
 typedef struct pbso_engine pbso_engine;

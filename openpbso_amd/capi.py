@@ -14,7 +14,7 @@ ERR_INVALID, ERR_HIP, ERR_STATE, ERR_IO, ERR_MISSING_MAP, ERR_ASSERT, ERR_NOMEM 
 POINT_FORCE, GAUSSIAN_FORCE, AUTOREGRESSIVE_FORCE = 0, 1, 2
 DATA_EXPLICIT, DATA_VERTEX, DATA_FACE, DATA_ZERO = 0, 1, 2, 3
 FORM_VELOCITY, FORM_DIRECT = 0, 1
-QNORM_OFF, QNORM_ALL = 0, 1
+QNORM_OFF, QNORM_ALL, QNORM_CLOSED = 0, 1, 2
 
 # every symbol include/openpbso_amd.h declares
 EXPORTS = [

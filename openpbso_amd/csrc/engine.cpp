@@ -129,7 +129,7 @@ Engine::Engine(const pbso_engine_desc &d) : desc_(d) {}
 Engine::~Engine() {
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (prep_stream_) (void)hipStreamSynchronize(prep_stream_);
-    d_ca_.release(); d_cb_.release(); d_sq_.release(); d_sd_.release(); d_c3_.release();
+    d_ca_.release(); d_cb_.release(); d_sq_.release(); d_sd_.release(); d_c3_.release(); d_gq_.release();
     d_shapes_.release(); d_shape_off_.release(); d_n_modes_.release(); d_geom_.release();
     d_geom_off_.release(); d_psi_.release(); d_slots_.release(); d_xfer_.release();
     d_audio_.release(); d_qnorm_.release(); d_grows_[0].release(); d_grows_[1].release(); d_census_.release();
@@ -175,7 +175,7 @@ int Engine::init() {
     b_pad_ = (B_ + 15) / 16 * 16;
     if (desc_.recurrence_form != PBSO_FORM_VELOCITY && desc_.recurrence_form != PBSO_FORM_DIRECT)
         return fail(PBSO_ERR_INVALID, "recurrence_form");
-    if (desc_.qnorm_mode != PBSO_QNORM_OFF && desc_.qnorm_mode != PBSO_QNORM_ALL)
+    if (desc_.qnorm_mode < PBSO_QNORM_OFF || desc_.qnorm_mode > PBSO_QNORM_CLOSED)
         return fail(PBSO_ERR_INVALID, "qnorm_mode");
     int ndev = 0;
     HIPTRY(hipGetDeviceCount(&ndev));
@@ -200,7 +200,6 @@ int Engine::init() {
     tbuf_.assign(B_, 0.0);
     // which build of the oscillator bank to launch (see kernels_iir.hip)
     if (const char *v = std::getenv("PBSO_IIR_PACKED")) packed_ = std::atoi(v) != 0;
-    if (const char *v = std::getenv("PBSO_LDS_ADDTID")) addtid_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_CENSUS")) census_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_ROTATE_PRIO")) rotate_prio_ = std::atoi(v) != 0;
     return PBSO_OK;
@@ -352,6 +351,31 @@ int Engine::finalize() {
     HIPTRY(hipMemset(d_sq_.p, 0, nm * sizeof(float)));
     HIPTRY(hipMemset(d_sd_.p, 0, nm * sizeof(float)));
     HIPTRY(hipMemcpy(d_c3_.p, c3.data(), nm * sizeof(double), hipMemcpyHostToDevice));
+    if (desc_.qnorm_mode == PBSO_QNORM_CLOSED) {
+        // G = sum_{k=0}^{B-1} (A^k)' e1 e1' A^k per mode, in fp64, in the basis x = (q_k, q_k - q_{k-1})
+        // (well conditioned at low frequency; the direct-form kernel forms the difference itself):
+        // A = [[1-e, eps^2], [-e, eps^2]], e = 1 - c1 - c2, eps^2 = -c2.  Row r_k = e1' A^k: r_{k+1} = r_k A.
+        std::vector<float> gq(3 * nm, 0.f);
+        for (int i = 0; i < N; ++i) {
+            const Object &o = objs_[i];
+            for (int m = 0; m < o.n_modes; ++m) {
+                const double eps2 = -o.c2[m], e = (1.0 - o.c1[m]) - o.c2[m];
+                const double a00 = 1.0 - e, a01 = eps2, a10 = -e, a11 = eps2;
+                double r0 = 1.0, r1 = 0.0, s11 = 0.0, s12 = 0.0, s22 = 0.0;
+                for (int k = 0; k < B_; ++k) {
+                    s11 += r0 * r0; s12 += r0 * r1; s22 += r1 * r1;
+                    const double n0 = r0 * a00 + r1 * a10, n1 = r0 * a01 + r1 * a11;
+                    r0 = n0; r1 = n1;
+                }
+                const size_t k = (size_t)i * m_pad_ + m;
+                gq[k] = (float)s11;
+                gq[nm + k] = (float)(2.0 * s12);
+                gq[2 * nm + k] = (float)s22;
+            }
+        }
+        HIPTRY(d_gq_.ensure(3 * nm));
+        HIPTRY(hipMemcpy(d_gq_.p, gq.data(), 3 * nm * sizeof(float), hipMemcpyHostToDevice));
+    }
 
     // mode shapes: mode-major (ModeData.h:24) -> vertex-major [dof][m_pad]
     {
@@ -810,7 +834,7 @@ int Engine::step(int nb, void *d_audio_user) {
         HIPTRY(d_audio_.ensure((size_t)N * nb * B_, false, sk));
         audio = d_audio_.p;
     }
-    const bool qn = desc_.qnorm_mode == PBSO_QNORM_ALL;
+    const bool qn = desc_.qnorm_mode != PBSO_QNORM_OFF;
     if (qn) HIPTRY(d_qnorm_.ensure((size_t)N * nb * m_pad_, false, sk));
 
     if (ev_pending_.size() >= 256) {          // bound the number of live events
@@ -876,6 +900,8 @@ int Engine::step(int nb, void *d_audio_user) {
     kp.xfer_init = ps.d_xfer_init.p;
     kp.audio = audio;
     kp.qnorm = qn ? d_qnorm_.p : nullptr;
+    kp.gq = d_gq_.p;
+    kp.gq_plane = (long long)N * m_pad_;
     kp.census = nullptr;
     if (census_) {
         HIPTRY(d_census_.ensure((size_t)N * 6, false, sk));
@@ -886,9 +912,9 @@ int Engine::step(int nb, void *d_audio_user) {
     kp.rotate_prio = rotate_prio_ ? 1 : 0;
     HIPTRY(hipEventRecord(evq.k0, sk));
     if (packed_ && R_ >= 2)
-        LAUNCHTRY(iir_packed::launch_iir_bank(kp, N, R_, W_, desc_.recurrence_form, qn, addtid_, sk));
+        LAUNCHTRY(iir_packed::launch_iir_bank(kp, N, R_, W_, desc_.recurrence_form, desc_.qnorm_mode, sk));
     else
-        LAUNCHTRY(iir_scalar::launch_iir_bank(kp, N, R_, W_, desc_.recurrence_form, qn, addtid_, sk));
+        LAUNCHTRY(iir_scalar::launch_iir_bank(kp, N, R_, W_, desc_.recurrence_form, desc_.qnorm_mode, sk));
     HIPTRY(hipEventRecord(evq.k1, sk));
     // _latest_transfer = trans (modal_solver.h:251), then re-park a still-queued transfer
     LAUNCHTRY(launch_copy_rows(ps.d_copy.p, ps.d_copy.p + (n_cl + n_cq), n_cl, d_xfer_.p, m_pad_, sk));
@@ -933,7 +959,7 @@ int Engine::read_emitted(unsigned char *out, size_t n) {
 }
 
 int Engine::read_qnorm(int obj, int buffer, float *out, int n) {
-    if (desc_.qnorm_mode != PBSO_QNORM_ALL) return fail(PBSO_ERR_STATE, "qnorm_mode is OFF");
+    if (desc_.qnorm_mode == PBSO_QNORM_OFF) return fail(PBSO_ERR_STATE, "qnorm_mode is OFF");
     if (!valid_obj(obj) || buffer < 0 || buffer >= last_nb_ || n < 0 || n > m_pad_)
         return fail(PBSO_ERR_INVALID, "read_qnorm arguments");
     HIPTRY(hipMemcpyAsync(out, d_qnorm_.p + ((size_t)obj * last_nb_ + buffer) * m_pad_, (size_t)n * sizeof(float),

@@ -141,7 +141,6 @@ private:
     int R_ = 0, W_ = 0, m_pad_ = 0;
     bool finalized_ = false, own_stream_ = false;
     bool packed_ = true;                                 // PBSO_IIR_PACKED: v_pk_*_f32 build of K1
-    bool addtid_ = true;                                 // PBSO_LDS_ADDTID: ds_write_addtid_b32 tile writes
     int t_extent_ = 0;                                   // leading samples of tbuf_ that may be non-zero
     hipStream_t stream_ = nullptr;                       // oscillator bank (caller's stream if given)
     hipStream_t prep_stream_ = nullptr;                  // plan upload + projection + FFAT + combine
@@ -161,6 +160,7 @@ private:
     // persistent device state
     DevBuf<float> d_ca_, d_cb_, d_sq_, d_sd_;
     DevBuf<double> d_c3_;
+    DevBuf<float> d_gq_;                                 // closed-form qnorm: G11, 2 G12, G22 planes
     DevBuf<double> d_shapes_;
     DevBuf<long long> d_shape_off_;
     DevBuf<int> d_n_modes_;

@@ -46,6 +46,8 @@ struct IirParams {
     const int *xfer_init;        // [n_obj] row (or XFER_UNIT) in effect when the launch starts
     float *audio;                // [n_obj][audio_stride]
     float *qnorm;                // [n_obj][nb][m_pad] or nullptr
+    const float *gq;             // closed-form qnorm: planes G11, 2*G12, G22, each [n_obj][m_pad]; or nullptr
+    long long gq_plane;          // elements per plane
     unsigned long long *census;  // diagnostics: [n_obj][6] = start, end (100 MHz), HW_ID, XCC_ID, clk0, clk1; or nullptr
     int nb, n_tiles, m_pad, b_pad;
     long long audio_stride;
@@ -56,12 +58,13 @@ struct IirParams {
 // same source: packed (float2 mode pairs, v_pk_*_f32; R >= 2) and scalar.
 // Supported shapes: W <= 16 waves per object, R in {1,2,4,8}.
 namespace iir_packed {
+// qnorm_mode: 0 off, 1 per-sample, 2 closed form (needs IirParams::gq).
 int launch_iir_bank(const IirParams &p, int n_obj, int modes_per_lane, int waves_per_object,
-                    int form, bool qnorm, bool addtid, hipStream_t stream);
+                    int form, int qnorm_mode, hipStream_t stream);
 }
 namespace iir_scalar {
 int launch_iir_bank(const IirParams &p, int n_obj, int modes_per_lane, int waves_per_object,
-                    int form, bool qnorm, bool addtid, hipStream_t stream);
+                    int form, int qnorm_mode, hipStream_t stream);
 }
 // per wave: one [TILE][LDS_ROW] transpose tile + a ring of (n_tiles + 1) tiles of row sums
 inline size_t iir_lds_bytes(int W, int n_tiles) {

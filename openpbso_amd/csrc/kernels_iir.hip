@@ -77,11 +77,11 @@ template <class V> struct lanes_of { static constexpr int n = 1; };
 template <> struct lanes_of<v2f> { static constexpr int n = 2; };
 
 // FMODE: 0 force-free, 1 dense time profile tp[0..TILE), 2 impulse (amp at sample 0 only)
-template <class V, int NV, int FORM, bool QN, int FMODE, bool ADDTID>
+template <class V, int NV, int FORM, bool QN, int FMODE>
 __device__ __forceinline__ void step_tile(V (&q)[NV], V (&d)[NV], const V (&ca)[NV], const V (&cb)[NV],
                                           const V (&g)[NV], const V (&t)[NV], V (&qn)[NV],
-                                          const float *__restrict__ tp, float amp,
-                                          float *__restrict__ col, f4 (&rv)[8], float &rsum) {
+                                          const float *__restrict__ tp, float amp, f4 (&rv)[8],
+                                          float &rsum) {
     // dense profile: fetch the tile's 27 values into SGPRs up front (one wait)
     float tt[TILE];
     if (FMODE == 1) {
@@ -118,12 +118,8 @@ __device__ __forceinline__ void step_tile(V (&q)[NV], V (&d)[NV], const V (&ca)[
             if (lanes_of<V>::n == 2) p = fmaf(vget<1>(t[v]), vget<1>(q[v]), p);
             if (QN) qn[v] = vfma(q[v], q[v], qn[v]);
         }
-        if (ADDTID) {
-            // LDS address = M0 (this wave's tile, set by the caller) + offset + 4 * lane
-            asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(p), "n"(k * LDS_ROW * 4) : "memory");
-        } else {
-            col[k * LDS_ROW] = p;
-        }
+        // LDS address = M0 (this wave's tile, set by the caller) + offset + 4 * lane
+        asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(p), "n"(k * LDS_ROW * 4) : "memory");
         if (QN) {
             // pin the qnorm accumulators here: without it the q^2 FMAs of a whole
             // tile are sunk to the tile's end and TILE*R q values stay live.
@@ -152,15 +148,21 @@ struct IirDims {
     int nb, n_tiles, m_pad, b_pad;
     long long audio_stride;
     int rotate_prio;
+    long long gq_plane;          // elements between the G11 / 2 G12 / G22 planes
 };
 
-template <class V, int NV, int FORM, bool QN, bool ADDTID, int MAXT>
+// QNM: 0 no qnorm; 1 per-sample accumulation (the reference's loop, modal_solver.h:270);
+//      2 closed form: in a buffer that is force-free after its first sample,
+//        sum_k q_k^2 = x0' G x0 with x0 = (q_0, q_0 - q_-1) after sample 0 and G = sum_k (A^k)' e1 e1' A^k
+//        precomputed per mode in fp64; buffers with a dense profile accumulate per sample.
+template <class V, int NV, int FORM, int QNM, int MAXT>
 __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     const float *__restrict__ p_ca, const float *__restrict__ p_cb, float *__restrict__ p_sq,
     float *__restrict__ p_sd, const BufDesc *__restrict__ p_desc, const float *__restrict__ p_grows,
     const float *__restrict__ p_tprof, const double *__restrict__ p_xfer_rows,
     const int *__restrict__ p_xfer_init, float *__restrict__ p_audio, float *__restrict__ p_qnorm,
-    unsigned long long *__restrict__ p_census, const IirDims p) {
+    const float *__restrict__ p_gq, unsigned long long *__restrict__ p_census, const IirDims p) {
+    constexpr bool QN = QNM != 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int obj = blockIdx.x;
     unsigned long long census_t0 = 0, census_c0 = 0;
@@ -174,7 +176,6 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     const int W = blockDim.x >> 6;
     const int rowlen = blockDim.x;
     float *tile = lds + wave * (TILE * LDS_ROW);
-    float *col = tile + lane;
     const unsigned tile_m0 = (unsigned)wave * (unsigned)(TILE * LDS_ROW * sizeof(float));
     const size_t mbase = (size_t)obj * p.m_pad + tid;
 
@@ -196,6 +197,16 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
         for (int r = 0; r < R; ++r)
             vset(t[r / VW], r % VW,
                  row0 >= 0 ? (float)p_xfer_rows[(size_t)row0 * p.m_pad + tid + r * rowlen] : 1e7f);
+    }
+
+    V g11[NV], g12[NV], g22[NV];                     // QNM == 2: G11, 2 G12, G22 of every mode
+    if (QNM == 2) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            vset(g11[r / VW], r % VW, p_gq[mbase + r * rowlen]);
+            vset(g12[r / VW], r % VW, p_gq[p.gq_plane + mbase + r * rowlen]);
+            vset(g22[r / VW], r % VW, p_gq[2 * p.gq_plane + mbase + r * rowlen]);
+        }
     }
 
     const BufDesc *__restrict__ dsc = p_desc + (size_t)obj * p.nb;
@@ -312,10 +323,35 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
                 vset(g_[r / VW], r % VW, p_grows[(size_t)frow * p.m_pad + tid + r * rowlen]);
         }
         const bool impulse = (flags & DESC_IMPULSE) != 0;
+        const bool dense = frow >= 0 && !impulse;
+        const bool accum = QNM == 1 || (QNM == 2 && dense);     // per-sample q^2 in this buffer?
         const float *__restrict__ tprow = p_tprof + (size_t)(prow >= 0 ? prow : 0) * p.b_pad;
         if (QN) {
 #pragma unroll
             for (int r = 0; r < R; ++r) vset(qn[r / VW], r % VW, 0.f);
+        }
+        if (QNM == 2 && !dense) {
+            // x0 = state after sample 0, with exactly the arithmetic sample 0 will use
+            const float f0 = (frow >= 0 && (mask & 1u)) ? amp : 0.f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                V q0, s0;
+                if (FORM == 0) {
+                    V a = ca[v] * d[v];
+                    a = vfma(-cb[v], q[v], a);
+                    if (f0 != 0.f) a = vfma(g_[v], vsplat(a, f0), a);
+                    s0 = a;
+                    q0 = q[v] + a;
+                } else {
+                    V a = cb[v] * d[v];
+                    if (f0 != 0.f) a = vfma(g_[v], vsplat(a, f0), a);
+                    q0 = vfma(ca[v], q[v], a);
+                    s0 = q0 - q[v];             // G is kept in the (q, q - q_prev) basis for both forms
+                }
+                V e = g22[v] * s0 * s0;
+                e = vfma(g12[v] * q0, s0, e);
+                qn[v] = vfma(g11[v] * q0, q0, e);
+            }
         }
         const int g0 = g;
 
@@ -335,14 +371,18 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
                 default: __builtin_amdgcn_s_setprio(3); break;
                 }
             }
-            if (ADDTID) asm volatile("s_mov_b32 m0, %0" ::"s"(tile_m0) : "memory");
+            asm volatile("s_mov_b32 m0, %0" ::"s"(tile_m0) : "memory");
             const bool hit = frow >= 0 && ((mask >> tl) & 1u);
-            if (hit && impulse)
-                step_tile<V, NV, FORM, QN, 2, ADDTID>(q, d, ca, cb, g_, t, qn, nullptr, amp, col, rv, rsum);
-            else if (hit)
-                step_tile<V, NV, FORM, QN, 1, ADDTID>(q, d, ca, cb, g_, t, qn, tprow + tl * TILE, 0.f, col, rv, rsum);
-            else
-                step_tile<V, NV, FORM, QN, 0, ADDTID>(q, d, ca, cb, g_, t, qn, nullptr, 0.f, col, rv, rsum);
+            if (hit && impulse) {
+                step_tile<V, NV, FORM, QNM == 1, 2>(q, d, ca, cb, g_, t, qn, nullptr, amp, rv, rsum);
+            } else if (hit) {
+                step_tile<V, NV, FORM, QN, 1>(q, d, ca, cb, g_, t, qn, tprow + tl * TILE, 0.f, rv, rsum);
+            } else if (QNM == 2) {
+                if (accum) step_tile<V, NV, FORM, true, 0>(q, d, ca, cb, g_, t, qn, nullptr, 0.f, rv, rsum);
+                else step_tile<V, NV, FORM, false, 0>(q, d, ca, cb, g_, t, qn, nullptr, 0.f, rv, rsum);
+            } else {
+                step_tile<V, NV, FORM, QN, 0>(q, d, ca, cb, g_, t, qn, nullptr, 0.f, rv, rsum);
+            }
 
             if (have_prev) retire(rsum);
             have_prev = true;
@@ -357,7 +397,8 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float e0 = vget<0>(qn[r / VW]), e1 = vget<1>(qn[r / VW]);
-                p_qnorm[((size_t)obj * p.nb + b) * p.m_pad + tid + r * rowlen] = sqrtf(r % VW ? e1 : e0);
+                // (the closed form can round a tiny sum below zero)
+                p_qnorm[((size_t)obj * p.nb + b) * p.m_pad + tid + r * rowlen] = sqrtf(fmaxf(r % VW ? e1 : e0, 0.f));
             }
         }
     }
@@ -379,66 +420,62 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     }
 }
 
-template <int R, int FORM, bool QN, bool ADDTID, int MAXT>
+template <int R, int FORM, int QNM, int MAXT>
 static int launch_one(const IirParams &p, int n_obj, int W, hipStream_t stream) {
     const size_t lds = iir_lds_bytes(W, p.n_tiles);
 #if PBSO_IIR_PACKED
-    auto kern = R >= 2 ? iir_bank_kernel<v2f, (R >= 2 ? R / 2 : 1), FORM, QN, ADDTID, MAXT>
-                       : nullptr;
+    auto kern = R >= 2 ? iir_bank_kernel<v2f, (R >= 2 ? R / 2 : 1), FORM, QNM, MAXT> : nullptr;
     if (R < 2) return (int)hipErrorInvalidValue;      // one mode per lane has nothing to pack
 #else
-    auto kern = iir_bank_kernel<float, R, FORM, QN, ADDTID, MAXT>;
+    auto kern = iir_bank_kernel<float, R, FORM, QNM, MAXT>;
 #endif
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    const IirDims dims = {p.nb, p.n_tiles, p.m_pad, p.b_pad, p.audio_stride, p.rotate_prio};
+    const IirDims dims = {p.nb, p.n_tiles, p.m_pad, p.b_pad, p.audio_stride, p.rotate_prio, p.gq_plane};
     hipLaunchKernelGGL(kern, dim3(n_obj), dim3(64 * W), lds, stream, p.ca, p.cb, p.sq, p.sd, p.desc,
-                       p.grows, p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.census, dims);
+                       p.grows, p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.census, dims);
     return (int)hipGetLastError();
 }
 
 template <int R, int MAXT>
-static int launch_r(const IirParams &p, int n_obj, int W, int form, bool qn, bool at, hipStream_t s) {
-    const int sel = (form ? 4 : 0) | (qn ? 2 : 0) | (at ? 1 : 0);
-    switch (sel) {
-    case 0: return launch_one<R, 0, false, false, MAXT>(p, n_obj, W, s);
-    case 1: return launch_one<R, 0, false, true, MAXT>(p, n_obj, W, s);
-    case 2: return launch_one<R, 0, true, false, MAXT>(p, n_obj, W, s);
-    case 3: return launch_one<R, 0, true, true, MAXT>(p, n_obj, W, s);
-    case 4: return launch_one<R, 1, false, false, MAXT>(p, n_obj, W, s);
-    case 5: return launch_one<R, 1, false, true, MAXT>(p, n_obj, W, s);
-    case 6: return launch_one<R, 1, true, false, MAXT>(p, n_obj, W, s);
-    default: return launch_one<R, 1, true, true, MAXT>(p, n_obj, W, s);
+static int launch_r(const IirParams &p, int n_obj, int W, int form, int qnm, hipStream_t s) {
+    switch ((form ? 3 : 0) + qnm) {
+    case 0: return launch_one<R, 0, 0, MAXT>(p, n_obj, W, s);
+    case 1: return launch_one<R, 0, 1, MAXT>(p, n_obj, W, s);
+    case 2: return launch_one<R, 0, 2, MAXT>(p, n_obj, W, s);
+    case 3: return launch_one<R, 1, 0, MAXT>(p, n_obj, W, s);
+    case 4: return launch_one<R, 1, 1, MAXT>(p, n_obj, W, s);
+    default: return launch_one<R, 1, 2, MAXT>(p, n_obj, W, s);
     }
 }
 
 // teams of up to 4 waves use the 256-thread build (no VGPR cap in practice);
 // larger teams (objects with more than 256 R modes) the 1024-thread build.
 // R in {1,2,4,8} for both (R = 1 only in the scalar build).
-int launch_iir_bank(const IirParams &p, int n_obj, int R, int W, int form, bool qn, bool addtid,
-                    hipStream_t s) {
+int launch_iir_bank(const IirParams &p, int n_obj, int R, int W, int form, int qnm, hipStream_t s) {
     if (n_obj <= 0) return 0;
+    if (qnm < 0 || qnm > 2) return (int)hipErrorInvalidValue;
     if (W < 1 || W > MAX_WAVES_PER_OBJECT) return (int)hipErrorInvalidValue;
     if (W <= 4) {
         switch (R) {
 #if !PBSO_IIR_PACKED
-        case 1: return launch_r<1, 256>(p, n_obj, W, form, qn, addtid, s);
+        case 1: return launch_r<1, 256>(p, n_obj, W, form, qnm, s);
 #endif
-        case 2: return launch_r<2, 256>(p, n_obj, W, form, qn, addtid, s);
-        case 4: return launch_r<4, 256>(p, n_obj, W, form, qn, addtid, s);
-        case 8: return launch_r<8, 256>(p, n_obj, W, form, qn, addtid, s);
+        case 2: return launch_r<2, 256>(p, n_obj, W, form, qnm, s);
+        case 4: return launch_r<4, 256>(p, n_obj, W, form, qnm, s);
+        case 8: return launch_r<8, 256>(p, n_obj, W, form, qnm, s);
         }
     } else {
         switch (R) {
 #if !PBSO_IIR_PACKED
-        case 1: return launch_r<1, 1024>(p, n_obj, W, form, qn, addtid, s);
+        case 1: return launch_r<1, 1024>(p, n_obj, W, form, qnm, s);
 #endif
-        case 2: return launch_r<2, 1024>(p, n_obj, W, form, qn, addtid, s);
-        case 4: return launch_r<4, 1024>(p, n_obj, W, form, qn, addtid, s);
-        case 8: return launch_r<8, 1024>(p, n_obj, W, form, qn, addtid, s);
+        case 2: return launch_r<2, 1024>(p, n_obj, W, form, qnm, s);
+        case 4: return launch_r<4, 1024>(p, n_obj, W, form, qnm, s);
+        case 8: return launch_r<8, 1024>(p, n_obj, W, form, qnm, s);
         }
     }
     return (int)hipErrorInvalidValue;

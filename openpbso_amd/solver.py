@@ -315,7 +315,7 @@ class ModalSolver:
         self.engine.step(1)
         if not self.engine.emitted()[0, 0]:
             return                                   # clearAllForces: no SoundMessage (modal_solver.h:186-189)
-        if self.engine.qnorm_mode == capi.QNORM_ALL and len(self._queue_qnorm) < 3:
+        if self.engine.qnorm_mode != capi.QNORM_OFF and len(self._queue_qnorm) < 3:
             self._queue_qnorm.append(self.engine.qnorm(0, 0))     # try_enqueue, may drop (:273)
         self._queue_sound.append(self.engine.audio()[0].copy())   # enqueueSoundMessageNoFail (:275)
 

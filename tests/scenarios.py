@@ -64,7 +64,7 @@ def run_engine(objs, events, n_buffers, split=None, **engine_kw):
             eng.step(nb)
             audio.append(eng.audio().copy())
             emitted.append(eng.emitted().copy())
-            if eng.qnorm_mode == capi.QNORM_ALL:
+            if eng.qnorm_mode != capi.QNORM_OFF:
                 for oi in range(len(objs)):
                     for b in range(nb):
                         qn[(oi, done + b)] = eng.qnorm(oi, b).copy()

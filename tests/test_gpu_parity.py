@@ -55,13 +55,13 @@ def test_config1_wine_glass_one_impulse():
 
 @pytest.mark.parametrize("mpl", [1, 2, 4])
 @pytest.mark.parametrize("packed", ["0", "1"])
-@pytest.mark.parametrize("addtid", ["0", "1"])
-def test_config2_512_modes_poisson_train(mpl, packed, addtid, monkeypatch):
+@pytest.mark.parametrize("rotate", ["0", "1"])
+def test_config2_512_modes_poisson_train(mpl, packed, rotate, monkeypatch):
     """configs[1]: single object, 512 modes, Poisson impulse train; every team
-    shape (R oscillators per lane), both builds of the kernel (v_pk_* / scalar)
-    and both LDS tile-write forms (ds_write_addtid_b32 / ds_write_b32)."""
+    shape (R oscillators per lane), both builds of the kernel (v_pk_* / scalar),
+    with and without the wave-priority rotation (a scheduling hint only)."""
     monkeypatch.setenv("PBSO_IIR_PACKED", packed)
-    monkeypatch.setenv("PBSO_LDS_ADDTID", addtid)
+    monkeypatch.setenv("PBSO_ROTATE_PRIO", rotate)
     seed = synth.seed_for(2, 0)
     lam = synth.eigenvalues(512, seed)
     shapes = synth.mode_shapes(512, seed)
@@ -75,7 +75,7 @@ def test_config2_512_modes_poisson_train(mpl, packed, addtid, monkeypatch):
     want = run_oracle(objs, evs, NB)
     mx, l2 = _check(got, want)
     assert got["info"]["modes_per_lane"] == mpl
-    print(f"C2 R={mpl} packed={packed} addtid={addtid} max/peak={mx:.2e} relL2={l2:.2e}")
+    print(f"C2 R={mpl} packed={packed} rotate={rotate} max/peak={mx:.2e} relL2={l2:.2e}")
 
 
 @pytest.mark.parametrize("mpl", [4, 8])
@@ -309,6 +309,34 @@ def test_size_independent_properties_full_size_object():
     assert np.array_equal(s[:, 2 * B:], a[:, :-2 * B]) and not s[:, :2 * B].any()         # time shift
     doubled = [force_ev(i % 4, i, data=4.0 * data[i]) for i in range(n_obj)] + off
     assert np.array_equal(run_engine(objs, doubled, nb)["audio"], 4.0 * a)                # linearity (x4 exact)
+
+
+@pytest.mark.parametrize("form", [capi.FORM_VELOCITY, capi.FORM_DIRECT])
+def test_qnorm_closed_form_matches_per_sample_and_oracle(form):
+    """PBSO_QNORM_CLOSED: quadratic form of the buffer-start state in force-free /
+    impulse buffers, per-sample accumulation in dense-forced ones (here a Gaussian
+    spanning two buffers).  Audio must be bit-identical to the per-sample mode."""
+    n_modes, nb = 320, 12
+    lam = synth.eigenvalues(n_modes, 91)
+    rng = np.random.default_rng(91)
+    evs = [force_ev(0, 0, data=rng.standard_normal(n_modes) * 1e-3),
+           force_ev(3, 0, data=rng.standard_normal(n_modes) * 1e-3, force_type=1, width=2000.0),
+           force_ev(7, 0, data=rng.standard_normal(n_modes) * 1e-3),
+           force_ev(7, 0, data=rng.standard_normal(n_modes) * 1e-3),       # consumed at buffer 8
+           dict(t=0, obj=0, kind="use_transfer", use=False)]
+    objs = [ObjSpec(lam)]
+    a = run_engine(objs, evs, nb, qnorm=capi.QNORM_ALL, form=form)
+    c = run_engine(objs, evs, nb, qnorm=capi.QNORM_CLOSED, form=form)
+    want = run_oracle(objs, evs, nb)
+    assert np.array_equal(a["audio"], c["audio"])
+    tol = 2e-3 if form == capi.FORM_VELOCITY else 3e-2
+    for b in range(nb):
+        w = want["qnorm"][(0, b)]
+        scale = np.abs(w).max()
+        assert np.abs(c["qnorm"][(0, b)] - w).max() <= tol * scale, b
+        # against the per-sample fp32 accumulation of the same kernel: tighter
+        tol_self = 2e-5 if form == capi.FORM_VELOCITY else 2e-3    # direct form: q0 - q_prev cancels in fp32
+        assert np.abs(c["qnorm"][(0, b)] - a["qnorm"][(0, b)]).max() <= tol_self * scale + 1e-30, b
 
 
 def test_qnorm_off_gives_identical_audio():
