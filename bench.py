@@ -71,6 +71,20 @@ def build_inputs(args, rank):
     return lam, shapes, scripts
 
 
+def measured_traffic(args):
+    """HBM bytes per launch from the PMC passes kept under profiles/ (same config only)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        c = t["config"]
+        qn = "off" if args.no_qnorm else args.qnorm
+        if (c["objects_per_gpu"], c["modes"], c["buffers_per_step"], c["qnorm"], c["form"]) == (
+                args.objects, args.modes, args.buffers, qn, args.form):
+            return t["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(args, lam, shapes, scripts):
     """The fp64 oracle (a port: the reference itself cannot be built here) timed on
     this box's host cores on a bounded sample of the same workload."""
@@ -95,12 +109,20 @@ def cpu_baseline(args, lam, shapes, scripts):
     dp = orc._dp
     secs = lib.or_bench_run(n_obj, M, nb, ncores, dp(om), synth.RHO, synth.ALPHA, synth.BETA,
                             dp(hit_data), mask.tobytes(), None, 0)
+    secs_ftz = lib.or_bench_run(n_obj, M, nb, ncores, dp(om), synth.RHO, synth.ALPHA, synth.BETA,
+                                dp(hit_data), mask.tobytes(), None, 1)
+    one = lib.or_bench_run(1, M, nb, 1, dp(om), synth.RHO, synth.ALPHA, synth.BETA,
+                           dp(hit_data), mask.tobytes(), None, 0)
     samples = n_obj * nb * B
     return {
         "value": samples / secs, "unit": "audio samples/s", "cores": ncores, "kind": "port",
         "realtime_x": (nb * B / SAMPLE_RATE) / secs,
+        "value_flush_denormals": samples / secs_ftz,
+        "single_thread_one_object": {"value": nb * B / one, "realtime_x": (nb * B / SAMPLE_RATE) / one},
         "sample": f"{n_obj} objects x {M} modes x {nb} buffers (same generator/seeds as the GPU run), "
-                  f"fp64 oracle with qnorm, OpenMP over objects, default FP env (denormals kept), {secs:.2f} s",
+                  f"fp64 oracle (reference-literal loop incl. qnorm), OpenMP over objects on {ncores} threads: "
+                  f"{secs:.2f} s with the default FP environment, {secs_ftz:.2f} s with FTZ/DAZ; "
+                  f"one object on one thread (the reference's threading model): {one:.3f} s",
     }
 
 
@@ -212,7 +234,8 @@ def main():
                 "flop_per_mode_sample": FLOP_PER_MODE_SAMPLE, "kernel_ms": k_ms,
                 "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": bytes_alg},
-                "traffic": None,
+                "traffic": measured_traffic(args),
+                "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
             },
             "timing": {"device_pipeline_ms": d_ms, "host_plan_ms": plan_ms},
         }

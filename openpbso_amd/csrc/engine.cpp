@@ -68,6 +68,8 @@ void Engine::PlanSet::release() {
     h_stage_slot.release(); d_stage_slot.release(); h_proj.release(); d_proj.release();
     h_ffat.release(); d_ffat.release(); h_copy.release(); d_copy.release();
     h_xfer_init.release(); d_xfer_init.release();
+    h_prof_entries.release(); d_prof_entries.release(); h_prof_rows.release(); d_prof_rows.release();
+    h_chain_ptr.release(); d_chain_ptr.release();
 }
 
 // ---------------------------------------------------------------------------
@@ -132,6 +134,7 @@ Engine::~Engine() {
     d_ca_.release(); d_cb_.release(); d_sq_.release(); d_sd_.release(); d_c3_.release(); d_gq_.release();
     d_shapes_.release(); d_shape_off_.release(); d_n_modes_.release(); d_geom_.release();
     d_geom_off_.release(); d_psi_.release(); d_slots_.release(); d_xfer_.release();
+    d_arstate_.release(); d_tacc_.release();
     d_audio_.release(); d_qnorm_.release(); d_grows_[0].release(); d_grows_[1].release(); d_census_.release();
     for (hipEvent_t ev : {ev_prep_done_[0], ev_prep_done_[1], ev_k1_done_[0], ev_k1_done_[1]})
         if (ev) (void)hipEventDestroy(ev);
@@ -202,6 +205,7 @@ int Engine::init() {
     if (const char *v = std::getenv("PBSO_IIR_PACKED")) packed_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_CENSUS")) census_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_ROTATE_PRIO")) rotate_prio_ = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PBSO_DEVICE_PROFILES")) device_profiles_ = std::atoi(v) != 0;
     return PBSO_OK;
 }
 
@@ -544,6 +548,12 @@ int Engine::set_use_transfer(int obj, int use, int64_t not_before) {
     return PBSO_OK;
 }
 
+void Engine::release(ActiveForce &af) {
+    freed_this_plan_.push_back(af.slot);
+    if (af.ar_state >= 0) freed_ar_.push_back(af.ar_state);
+    af.ar_state = -1;
+}
+
 int Engine::alloc_slot() {
     if (!free_slots_.empty()) {
         int s = free_slots_.back();
@@ -588,7 +598,7 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
         HostForceMsg mess = std::move(o.force_q.front());
         o.force_q.pop_front();
         if (mess.clear_all) {                                           // :186-189
-            for (ActiveForce &af : o.active) freed_this_plan_.push_back(af.slot);
+            for (ActiveForce &af : o.active) release(af);
             o.active.clear();
             d.flags |= DESC_SKIP;
             emitted_[(size_t)oi * nb + b] = 0;
@@ -620,7 +630,7 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
         af.force = mess.force;
         bool slot_used = false;
         if (mess.sustained_start) {                                     // :190-194
-            for (ActiveForce &x : o.active) freed_this_plan_.push_back(x.slot);
+            for (ActiveForce &x : o.active) release(x);
             o.active.clear();
             o.sustained = true;
             o.active.push_back(af);
@@ -639,7 +649,7 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
             }
         }
         if (mess.sustained_end) {                                       // :201-204
-            for (ActiveForce &x : o.active) freed_this_plan_.push_back(x.slot);
+            for (ActiveForce &x : o.active) release(x);
             o.active.clear();
             o.sustained = false;
             slot_used = true;   // freed through the list (or below)
@@ -648,7 +658,99 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
     }
 
     // :206-240 time profile and spatial sum
-    if (!o.active.empty() || o.sustained) {
+    if ((!o.active.empty() || o.sustained) && device_profiles_) {
+        // Force::Add bookkeeping only (who is alive, _count, PointForce::used); the samples
+        // of Gaussian / AR profiles are generated on the device (K2, kernels_exact.hip)
+        const int row_begin = (int)slot_idx_.size();
+        const int entry_begin = (int)prof_entries_.size();
+        int n_point = 0;
+        bool dense = false;
+        auto emit = [&](ActiveForce &af, bool set_param) -> bool {
+            ForceProfile &f = af.force;
+            ProfEntry e;
+            std::memset(&e, 0, sizeof(e));
+            e.kind = f.type;
+            e.state = -1;
+            switch (f.type) {
+            case PBSO_POINT_FORCE:                                   // forces.h:81-90
+                if (f.used) return false;
+                f.used = true;
+                ++n_point;
+                break;
+            case PBSO_GAUSSIAN_FORCE:                                // forces.h:92-105
+                if (f.width == 0 || f.count >= f.cutoff * 2 * f.width_samples) return false;
+                e.count = f.count;
+                e.center = f.center;
+                e.width_samples = f.width_samples;
+                f.count += B_;
+                dense = true;
+                break;
+            default:                                                 // forces.h:107-137
+                if (af.ar_state < 0) {
+                    if (!free_ar_.empty()) { af.ar_state = free_ar_.back(); free_ar_.pop_back(); }
+                    else af.ar_state = (int)n_ar_states_++;
+                    e.flags |= 1;
+                }
+                if (set_param) {
+                    e.flags |= 2;
+                    e.a0 = o.arprm[0]; e.a1 = o.arprm[1]; e.sigma = o.arprm[2]; e.mu = o.arprm[3];
+                }
+                e.state = af.ar_state;
+                dense = true;
+                break;
+            }
+            prof_entries_.push_back(e);
+            return true;
+        };
+        if (!o.sustained) {
+            size_t w = 0;
+            for (size_t r = 0; r < o.active.size(); ++r) {
+                ActiveForce &af = o.active[r];
+                if (!emit(af, false)) {
+                    release(af);                                            // erase
+                } else {
+                    slot_idx_.push_back(af.slot);
+                    if (w != r) o.active[w] = std::move(af);
+                    ++w;
+                }
+            }
+            o.active.resize(w);
+        } else {
+            if (o.active.size() != 1)
+                return fail(PBSO_ERR_ASSERT, "Should only have 1 concurrent sustained force");   // assert :223
+            ActiveForce &af = o.active.front();
+            bool sp = false;
+            if (af.force_type == PBSO_AUTOREGRESSIVE_FORCE && o.arprm_full) {   // :226-236
+                o.arprm_full = false;
+                sp = true;
+            }
+            emit(af, sp);                        // the return value is ignored, modal_solver.h:238
+            slot_idx_.push_back(af.slot);
+        }
+        if ((int)slot_idx_.size() > row_begin && (dense || n_point)) {
+            d.frow = n_frows_++;
+            row_obj_.push_back(oi);
+            row_ptr_.push_back((int)slot_idx_.size());
+            if (!dense) {
+                d.flags |= DESC_IMPULSE;          // PointForce(s) only: n * delta[0], no profile row
+                d.tile_mask = 1u;
+                d.amp = (float)n_point;
+                prof_entries_.resize(entry_begin);
+            } else {
+                d.prow = n_prows_++;
+                d.tile_mask = n_tiles_ >= 32 ? 0xFFFFFFFFu : ((1u << n_tiles_) - 1u);
+                ProfRow pr = {d.prow, entry_begin, (int)prof_entries_.size()};
+                prof_rows_.push_back(pr);
+                if (chain_obj_ != oi) {           // rows of one object are contiguous (object-major plan)
+                    chain_ptr_.push_back((int)prof_rows_.size() - 1);
+                    chain_obj_ = oi;
+                }
+            }
+        } else {
+            slot_idx_.resize(row_begin);          // nothing active produced samples: a force-free buffer
+            prof_entries_.resize(entry_begin);
+        }
+    } else if (!o.active.empty() || o.sustained) {
         double *T = tbuf_.data();
         std::fill(T, T + t_extent_, 0.0);
         t_extent_ = 0;
@@ -659,7 +761,7 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
                 ActiveForce &af = o.active[r];
                 const bool added = af.force.add(T, B_, &t_extent_);
                 if (!added) {
-                    freed_this_plan_.push_back(af.slot);                    // erase
+                    release(af);                                            // erase
                 } else {
                     slot_idx_.push_back(af.slot);
                     if (w != r) o.active[w] = std::move(af);
@@ -691,7 +793,7 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
                 d.flags |= DESC_IMPULSE;                  // PointForce(s): amp * delta[0], no profile row
                 d.amp = (float)T[0];
             } else {
-                d.prow = (int)(tprof_.size() / b_pad_);
+                d.prow = n_prows_++;
                 const size_t off = tprof_.size();
                 tprof_.resize(off + b_pad_, 0.f);
                 for (int i = 0; i <= last_nz; ++i) tprof_[off + i] = (float)T[i];
@@ -754,6 +856,9 @@ int Engine::plan(int nb) {
     proj_.clear(); ffat_.clear(); freed_this_plan_.clear();
     n_xfer_scratch_ = 0;
     n_frows_ = 0;
+    n_prows_ = 0;
+    prof_entries_.clear(); prof_rows_.clear(); chain_ptr_.clear(); freed_ar_.clear();
+    chain_obj_ = -1;
     busy_.clear();
     for (int i = 0; i < N; ++i) {
         const Object &o = objs_[i];
@@ -819,6 +924,9 @@ int Engine::step(int nb, void *d_audio_user) {
         }
     }
     for (int s : freed_this_plan_) free_slots_.push_back(s);
+    for (int s : freed_ar_) free_ar_.push_back(s);
+    const int n_chains = (int)chain_ptr_.size();
+    chain_ptr_.push_back((int)prof_rows_.size());
     last_plan_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
     const int n_frows = n_frows_;
@@ -862,7 +970,16 @@ int Engine::step(int nb, void *d_audio_user) {
     HIPTRY(upload(ps.h_row_ptr, ps.d_row_ptr, row_ptr_.data(), row_ptr_.size(), sp));
     HIPTRY(upload(ps.h_slot_idx, ps.d_slot_idx, slot_idx_.data(), slot_idx_.size(), sp));
     HIPTRY(upload(ps.h_row_obj, ps.d_row_obj, row_obj_.data(), row_obj_.size(), sp));
-    HIPTRY(upload(ps.h_tprof, ps.d_tprof, tprof_.data(), tprof_.size(), sp));
+    if (device_profiles_) {
+        HIPTRY(ps.d_tprof.ensure(std::max<size_t>(1, (size_t)n_prows_) * b_pad_, false, sp));
+        HIPTRY(upload(ps.h_prof_entries, ps.d_prof_entries, prof_entries_.data(), prof_entries_.size(), sp));
+        HIPTRY(upload(ps.h_prof_rows, ps.d_prof_rows, prof_rows_.data(), prof_rows_.size(), sp));
+        HIPTRY(upload(ps.h_chain_ptr, ps.d_chain_ptr, chain_ptr_.data(), chain_ptr_.size(), sp));
+        HIPTRY(d_arstate_.ensure(std::max<size_t>(1, n_ar_states_), true, sp));
+        HIPTRY(d_tacc_.ensure(std::max<size_t>(1, (size_t)n_chains) * B_, false, sp));
+    } else {
+        HIPTRY(upload(ps.h_tprof, ps.d_tprof, tprof_.data(), tprof_.size(), sp));
+    }
     HIPTRY(upload(ps.h_stage, ps.d_stage, stage_.data(), stage_.size(), sp));
     HIPTRY(upload(ps.h_stage_slot, ps.d_stage_slot, stage_slot_.data(), stage_slot_.size(), sp));
     HIPTRY(upload(ps.h_proj, ps.d_proj, proj_.data(), proj_.size(), sp));
@@ -879,7 +996,10 @@ int Engine::step(int nb, void *d_audio_user) {
     HIPTRY(upload(ps.h_copy, ps.d_copy, cp.data(), cp.size(), sp));
     HIPTRY(hipEventRecord(ev_set_[cur_set_], sp));          // this set's pinned buffers are reusable
 
-    // K3 / scatter -> data slots ; K4 -> transfer rows ; combine -> g rows
+    // K2 -> time-profile rows ; K3 / scatter -> data slots ; K4 -> transfer rows ; combine -> g rows
+    if (device_profiles_)
+        LAUNCHTRY(launch_force_profiles(ps.d_chain_ptr.p, n_chains, ps.d_prof_rows.p, ps.d_prof_entries.p,
+                                        d_arstate_.p, d_tacc_.p, ps.d_tprof.p, B_, b_pad_, sp));
     LAUNCHTRY(launch_scatter_rows(ps.d_stage.p, ps.d_stage_slot.p, (int)stage_slot_.size(), d_slots_.p, m_pad_, sp));
     LAUNCHTRY(launch_modal_project(ps.d_proj.p, (int)proj_.size(), d_shapes_.p, d_shape_off_.p, d_n_modes_.p,
                                    d_slots_.p, m_pad_, sp));

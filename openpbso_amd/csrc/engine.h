@@ -67,6 +67,7 @@ struct HostForceMsg {                                    // ForceMessage, modal_
 
 struct ActiveForce {                                     // one entry of _activeForces
     int slot = -1;                                       // row of the device data-slot pool
+    int ar_state = -1;                                   // device ArState slot of an AutoregressiveForce
     int force_type = PBSO_POINT_FORCE;
     ForceProfile force;
 };
@@ -132,6 +133,7 @@ private:
     int hip_fail(hipError_t e, const char *what);
     bool valid_obj(int obj) const { return obj >= 0 && obj < (int)objs_.size(); }
     int alloc_slot();
+    void release(ActiveForce &af);
     int plan(int nb);                                    // host bookkeeping for one batch
     int plan_object(int o, int b, int nb, int64_t t);
     int plan_object_span(int o, int nb);
@@ -191,13 +193,25 @@ private:
         PinBuf<FfatEvent> h_ffat;   DevBuf<FfatEvent> d_ffat;
         PinBuf<int> h_copy;         DevBuf<int> d_copy;
         PinBuf<int> h_xfer_init;    DevBuf<int> d_xfer_init;
+        PinBuf<ProfEntry> h_prof_entries; DevBuf<ProfEntry> d_prof_entries;
+        PinBuf<ProfRow> h_prof_rows;      DevBuf<ProfRow> d_prof_rows;
+        PinBuf<int> h_chain_ptr;          DevBuf<int> d_chain_ptr;
         void release();
     } set_[2];
     DevBuf<float> d_grows_[2];                           // g rows, one arena per plan set
     // plan scratch (host)
     std::vector<int> row_ptr_, slot_idx_, row_obj_, stage_slot_, busy_;
     std::vector<float> tprof_;
-    int n_frows_ = 0;
+    int n_frows_ = 0, n_prows_ = 0;
+    // K2: device-side time profiles
+    bool device_profiles_ = true;                        // PBSO_DEVICE_PROFILES=0: host fp64 profiles, uploaded
+    std::vector<ProfEntry> prof_entries_;
+    std::vector<ProfRow> prof_rows_;
+    std::vector<int> chain_ptr_, free_ar_, freed_ar_;
+    int chain_obj_ = -1;
+    size_t n_ar_states_ = 0;
+    DevBuf<ArState> d_arstate_;
+    DevBuf<double> d_tacc_;
     std::vector<double> stage_;
     std::vector<ProjectEvent> proj_;
     std::vector<FfatEvent> ffat_;

@@ -90,6 +90,32 @@ int launch_force_combine(const int *row_ptr, const int *slot_idx, const int *row
                          const double *slots, const double *c3, float *grows, int m_pad,
                          hipStream_t stream);
 
+// ---- K2: force time profiles on the device (forces.h:81-137)
+struct ArState {         // AutoregressiveForce members that evolve (forces.h:62-72), one per live AR force
+    uint32_t x;          // std::default_random_engine (minstd_rand0) state
+    int32_t saved_available;
+    double saved;        // std::normal_distribution's cached second variate
+    double buf[3];
+    int32_t buf_idx;
+    int32_t pad;
+    double a[2], sigma, mu;
+};
+struct ProfEntry {       // one active force contributing to one forced buffer's time profile
+    int32_t kind;        // PBSO_POINT_FORCE / PBSO_GAUSSIAN_FORCE / PBSO_AUTOREGRESSIVE_FORCE
+    int32_t state;       // AR: ArState slot
+    int32_t flags;       // bit 0: default-construct the AR state first; bit 1: SetParam first
+    int32_t count, center, width_samples;     // Gaussian: _count at the start of this buffer
+    double a0, a1, sigma, mu;                 // SetParam values (bit 1)
+};
+struct ProfRow {         // one dense profile row = one (object, buffer)
+    int32_t prow;        // row of the tprof array to write
+    int32_t entry_begin, entry_end;
+};
+// chains: rows of one object in buffer order are generated by ONE thread (the AR state is sequential)
+int launch_force_profiles(const int *chain_ptr, int n_chains, const ProfRow *rows, const ProfEntry *entries,
+                          ArState *states, double *scratch, float *tprof, int frames, int b_pad,
+                          hipStream_t stream);
+
 struct FfatGeom {        // FFAT_Map<double,3> runtime fields, one per (object, mode)
     double k;
     double center3[3];

@@ -101,6 +101,109 @@ int launch_force_combine(const int *row_ptr, const int *slot_idx, const int *row
 }
 
 // ---------------------------------------------------------------------------
+// K2.  Force::Add for Gaussian and AR(2) forces (forces.h:92-128) in fp64, and the
+// libstdc++ objects AutoregressiveForce leans on (forces.h:71-72): minstd_rand0,
+// generate_canonical<double,53> (two engine draws, GCC 11 bits/random.tcc) and
+// normal_distribution's Marsaglia polar method.  Uniforms, products and the
+// rejection test are exact IEEE operations (this file is built without FMA
+// contraction), so the accepted pairs are the host's; only log/sqrt may differ
+// from glibc in the last place, far below the fp32 rounding of the profile.
+__device__ __forceinline__ uint32_t minstd_next(uint32_t &x) {
+    x = (uint32_t)(((unsigned long long)x * 16807ull) % 2147483647ull);
+    return x;
+}
+__device__ __forceinline__ double canonical53(uint32_t &x) {
+    const double R = 2147483646.0;                      // max - min + 1
+    const double R2 = 4611686009837453316.0;            // (double)((long double)R * R), as libstdc++ forms it
+    double sum = (double)(minstd_next(x) - 1u) * 1.0;
+    sum += (double)(minstd_next(x) - 1u) * R;
+    double ret = sum / R2;
+    if (ret >= 1.0) ret = 0.99999999999999988898;        // nextafter(1, 0)
+    return ret;
+}
+__device__ double normal01(ArState &s) {
+    if (s.saved_available) {
+        s.saved_available = 0;
+        return s.saved;
+    }
+    double x, y, r2;
+    do {
+        x = 2.0 * canonical53(s.x) - 1.0;
+        y = 2.0 * canonical53(s.x) - 1.0;
+        r2 = x * x + y * y;
+    } while (r2 > 1.0 || r2 == 0.0);
+    const double mult = sqrt(-2 * log(r2) / r2);
+    s.saved = x * mult;
+    s.saved_available = 1;
+    return y * mult;
+}
+
+// one thread per chain (= object with dense rows in this launch); scratch[chain][frames] fp64
+__global__ __launch_bounds__(64) void force_profile_kernel(
+    const int *__restrict__ chain_ptr, int n_chains, const ProfRow *__restrict__ rows,
+    const ProfEntry *__restrict__ entries, ArState *__restrict__ states, double *__restrict__ scratch,
+    float *__restrict__ tprof, int frames, int b_pad) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chains) return;
+    double *T = scratch + (size_t)c * frames;
+    for (int ri = chain_ptr[c]; ri < chain_ptr[c + 1]; ++ri) {
+        const ProfRow row = rows[ri];
+        for (int i = 0; i < frames; ++i) T[i] = 0.0;                    // setZero, modal_solver.h:206
+        for (int ei = row.entry_begin; ei < row.entry_end; ++ei) {
+            const ProfEntry e = entries[ei];
+            if (e.kind == 0) {                                           // PointForce, forces.h:81-90
+                T[0] += 1.;
+            } else if (e.kind == 1) {                                    // GaussianForce, forces.h:92-105
+                for (int ii = 0; ii < frames; ++ii) {
+                    const double z = (double)(e.count + ii - e.center) / (double)e.width_samples;
+                    T[ii] += exp(-0.5 * (z * z));
+                }
+            } else {                                                     // AutoregressiveForce, :107-128
+                ArState s = states[e.state];
+                if (e.flags & 1) {                                       // default-constructed, forces.h:73-76
+                    s.x = 1u; s.saved_available = 0; s.saved = 0.0;
+                    s.buf[0] = s.buf[1] = s.buf[2] = 0.0; s.buf_idx = 0;
+                    s.a[0] = 0.783; s.a[1] = 0.116; s.sigma = 0.00148; s.mu = 0.142;
+                }
+                if (e.flags & 2) {                                       // SetParam, forces.h:130-137
+                    s.buf[0] = s.buf[1] = s.buf[2] = 0.0;
+                    s.a[0] = e.a0; s.a[1] = e.a1; s.sigma = e.sigma; s.mu = e.mu;
+                }
+                double b0 = s.buf[0], b1 = s.buf[1], b2 = s.buf[2];
+                int idx = s.buf_idx;
+                for (int ii = 0; ii < frames; ++ii) {
+                    // _buf[(idx + 3 - jj - 1) % 3] for jj = 0, 1
+                    const double p1 = idx == 0 ? b2 : (idx == 1 ? b0 : b1);
+                    const double p2 = idx == 0 ? b1 : (idx == 1 ? b2 : b0);
+                    double mu_tilde = 0.0;
+                    mu_tilde += s.a[0] * p1;
+                    mu_tilde += s.a[1] * p2;
+                    mu_tilde += s.sigma * normal01(s);
+                    if (idx == 0) b0 = mu_tilde; else if (idx == 1) b1 = mu_tilde; else b2 = mu_tilde;
+                    idx = idx == 2 ? 0 : idx + 1;
+                    T[ii] += s.mu + mu_tilde;
+                }
+                s.buf[0] = b0; s.buf[1] = b1; s.buf[2] = b2;
+                s.buf_idx = idx;
+                states[e.state] = s;
+            }
+        }
+        float *out = tprof + (size_t)row.prow * b_pad;
+        for (int i = 0; i < frames; ++i) out[i] = (float)T[i];
+        for (int i = frames; i < b_pad; ++i) out[i] = 0.f;
+    }
+}
+
+int launch_force_profiles(const int *chain_ptr, int n_chains, const ProfRow *rows, const ProfEntry *entries,
+                          ArState *states, double *scratch, float *tprof, int frames, int b_pad,
+                          hipStream_t stream) {
+    if (n_chains <= 0) return 0;
+    hipLaunchKernelGGL(force_profile_kernel, dim3((n_chains + 63) / 64), dim3(64), 0, stream, chain_ptr,
+                       n_chains, rows, entries, states, scratch, tprof, frames, b_pad);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // K4.  One thread per (listener event, mode).
 __device__ __forceinline__ double dmin_(double x, double y) { return (y < x) ? y : x; }  // std::min
 __device__ __forceinline__ double dmax_(double x, double y) { return (x < y) ? y : x; }  // std::max

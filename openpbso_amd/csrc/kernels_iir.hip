@@ -219,7 +219,10 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     // row-sum phase: lanes 2k, 2k+1 own the two 32-float halves of row k
     const int rrow = lane >> 1;
     const bool owner = (lane & 1) == 0 && lane < 2 * TILE;
-    const f4 *rsrc = reinterpret_cast<const f4 *>(tile + (lane < 2 * TILE ? rrow : 0) * LDS_ROW + (lane & 1) * 32);
+    // lanes 54..63 own no row: they read rows 27..31 (inside the workgroup's LDS, values unused) so
+    // that every ds_read_b128 lane group stays on 16 distinct bank slots (clamping them to row 0 cost
+    // 15 % of the LDS cycles in bank conflicts)
+    const f4 *rsrc = reinterpret_cast<const f4 *>(tile + rrow * LDS_ROW + (lane & 1) * 32);
 
     // The SIMD arbiter serves equal-priority waves oldest first: left alone, the
     // four teams resident on a CU finish at ~57/66/83/100 % of the kernel and the

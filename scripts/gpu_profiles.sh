@@ -1,0 +1,38 @@
+#!/bin/bash
+# Collects the round's evidence under gpurun_out/ (copied to profiles/ afterwards):
+# rocprofv3 kernel-trace stats of the default bench command, PMC passes (own runs,
+# no trace domains besides kernel-trace), the workgroup census, and bench JSON lines.
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out/final
+export TMPDIR=/tmp
+R=$PWD
+echo "== env =="; (rocminfo | grep -E "Marketing Name|gfx9" | sort | uniq -c | head -4; lscpu | grep -E "Model name|^CPU\(s\)"; free -g | head -2) > gpurun_out/final/env.txt 2>&1; cat gpurun_out/final/env.txt
+echo "== bench default (with cpu baseline) =="; timeout 900 python bench.py > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err; echo rc=$?; cat gpurun_out/final/bench_default.json
+for q in closed off; do timeout 600 python bench.py --no-cpu-baseline --qnorm $q > gpurun_out/final/bench_qnorm_$q.json 2>/dev/null; done
+timeout 600 python bench.py --no-cpu-baseline --form direct > gpurun_out/final/bench_direct.json 2>/dev/null
+echo "== rocprofv3 kernel trace + stats of the default command =="
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/rocprof_stats -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/final/rocprof_stats.log 2>&1); echo rc=$?
+f=$(find gpurun_out/final/rocprof_stats -name "*kernel_stats.csv" | head -1); head -8 "$f" | cut -c1-260
+pmc() { name=$1; shift; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/final/pmc_$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/final/pmc_$name.log 2>&1); echo "pmc $name rc=$?"; }
+pmc sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU
+pmc sq2 SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE
+pmc fetch FETCH_SIZE
+pmc write WRITE_SIZE
+python - <<'PY' > gpurun_out/final/pmc_summary.txt
+import csv, glob, collections
+print("per-dispatch averages for pbso kernels (rocprofv3 --pmc, bench.py --steps 3 --warmup 1)")
+for name in ("sq1", "sq2", "fetch", "write"):
+    fs = glob.glob(f"gpurun_out/final/pmc_{name}/**/*counter_collection.csv", recursive=True)
+    if not fs: continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for r in csv.DictReader(open(fs[0])):
+        k = r["Kernel_Name"].split("(")[0][-48:]
+        if "pbso" not in r["Kernel_Name"]: continue
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+    for k in agg:
+        for c, v in sorted(agg[k].items()):
+            print(f"{name:6s} {k:50s} {c:24s} {v / cnt[(k, c)]:.6g}  (n={cnt[(k, c)]})")
+PY
+cat gpurun_out/final/pmc_summary.txt
+echo "== census =="; PBSO_CENSUS=1 timeout 300 python scripts/census.py 1024 2>&1 | grep -v amdgpu.ids > gpurun_out/final/census.txt; cat gpurun_out/final/census.txt

@@ -125,9 +125,11 @@ def test_ragged_objects_and_padding():
     _check(got, want)
 
 
-def test_gaussian_and_overlapping_forces_cross_terms():
+@pytest.mark.parametrize("device_profiles", ["1", "0"])
+def test_gaussian_and_overlapping_forces_cross_terms(device_profiles, monkeypatch):
     """Q2: applied force = (sum of data) x (sum of profiles); Gaussian forces
     spanning several buffers; a PointForce landing while a Gaussian is alive."""
+    monkeypatch.setenv("PBSO_DEVICE_PROFILES", device_profiles)
     m = 96
     lam = synth.eigenvalues(m, 5)
     rng = np.random.default_rng(5)
@@ -143,6 +145,33 @@ def test_gaussian_and_overlapping_forces_cross_terms():
     got = run_engine(objs, evs, 10)
     want = run_oracle(objs, evs, 10)
     _check(got, want)
+
+
+def test_device_and_host_profiles_agree_two_ar_objects(monkeypatch):
+    """Two objects scraping at once (identical default-seeded AR streams), a
+    second AR force started later on one of them, plus a Gaussian overlapping a point hit:
+    device-generated profiles (K2) vs host-generated ones."""
+    n_modes, nb = 128, 10
+    objs = [ObjSpec(synth.eigenvalues(n_modes, 300 + i)) for i in range(2)]
+    rng = np.random.default_rng(300)
+    evs = []
+    for i in range(2):
+        evs.append(force_ev(i, i, data=rng.standard_normal(n_modes) * 1e-3, force_type=2, start=True))
+        evs.append(force_ev(5, i, data=rng.standard_normal(n_modes) * 1e-3, force_type=2))
+        evs.append(dict(t=0, obj=i, kind="use_transfer", use=False))
+    evs.append(force_ev(7, 0, force_type=2, end=True))
+    evs.append(force_ev(8, 0, data=rng.standard_normal(n_modes) * 1e-3, force_type=1, width=900.0))
+    evs.append(force_ev(8, 0, data=rng.standard_normal(n_modes) * 1e-3))
+    evs.append(force_ev(8, 0, data=rng.standard_normal(n_modes) * 1e-3, force_type=2))   # plain (unsustained) AR force
+    monkeypatch.setenv("PBSO_DEVICE_PROFILES", "1")
+    dev = run_engine(objs, evs, nb, split=[4, 6])
+    monkeypatch.setenv("PBSO_DEVICE_PROFILES", "0")
+    host = run_engine(objs, evs, nb, split=[4, 6])
+    want = run_oracle(objs, evs, nb)
+    _check(dev, want)
+    _check(host, want)
+    peak = np.abs(host["audio"]).max(axis=1, keepdims=True)
+    assert (np.abs(dev["audio"] - host["audio"]) <= 2e-6 * peak).all()
 
 
 def test_one_message_per_buffer_queueing():
@@ -179,9 +208,12 @@ def test_clear_all_forces_emits_no_buffer():
     _check(got, want)
 
 
-def test_config5_sustained_ar_scraping_with_param_update():
+@pytest.mark.parametrize("device_profiles", ["1", "0"])
+def test_config5_sustained_ar_scraping_with_param_update(device_profiles, monkeypatch):
     """configs[4] shape (reduced): sustained AutoregressiveForce, one
-    GetModalForceFace message per buffer, AR parameters changed mid-run."""
+    GetModalForceFace message per buffer, AR parameters changed mid-run.
+    Time profiles from the device kernel (K2) and from the host path."""
+    monkeypatch.setenv("PBSO_DEVICE_PROFILES", device_profiles)
     n_modes, nb = 640, 24
     seed = synth.seed_for(5, 0)
     lam = synth.eigenvalues(n_modes, seed)
