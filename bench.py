@@ -47,6 +47,10 @@ def parse():
                     help="getQBufferNorm: per-sample accumulation (reference loop), closed form, or off")
     ap.add_argument("--no-qnorm", action="store_true", help="same as --qnorm off")
     ap.add_argument("--modes-per-lane", type=int, default=0)
+    ap.add_argument("--scenario", choices=["impulses", "scraping", "listener"], default="impulses",
+                    help="impulses: Poisson PointForce hits (headline, configs[1]/[3]); scraping: sustained "
+                         "AutoregressiveForce with one face hit per buffer (configs[4]); listener: impulses + FFAT maps "
+                         "and a new listener position every buffer (configs[2])")
     ap.add_argument("--gather", action="store_true", help="all-gather audio over RCCL inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-objects", type=int, default=0, help="objects in the CPU baseline sample (0 = auto)")
@@ -155,11 +159,30 @@ def main():
                  modes_per_lane=args.modes_per_lane, stream=stream)
     for i in range(args.objects):
         eng.add_object(lam[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
+        if args.scenario == "listener":
+            eng.set_ffat_maps(i, synth.ffat_maps(lam[i], synth.seed_for(3, rank * args.objects + i)))
     eng.finalize()
     n_hits = 0
+    total_buffers = (args.steps + args.warmup) * args.buffers
     for i in range(args.objects):
-        eng.set_use_transfer(i, False)                 # no FFAT maps in this config: unit transfer
         hits, vns = scripts[i]
+        if args.scenario == "scraping":
+            # tools/...:754-776 + :1127-1160: dummy start message, then one GetModalForceFace per frame
+            eng.set_use_transfer(i, False)
+            rng = np.random.default_rng(synth.seed_for(5, rank * args.objects + i))
+            assert eng.enqueue_force(i, ForceMessage(forceType=capi.AUTOREGRESSIVE_FORCE, sustainedForceStart=True), 0)
+            for b in range(1, total_buffers):
+                bary = rng.random(3)
+                assert eng.enqueue_force(i, ForceMessage(vids=rng.integers(0, synth.N_VERTS, 3), coords=bary / bary.sum(),
+                                                         vn=vns[b], forceType=capi.AUTOREGRESSIVE_FORCE), int(b))
+                n_hits += 1
+            continue
+        if args.scenario == "listener":
+            path = synth.listener_path(total_buffers) * (1.0 + 0.001 * i)
+            for b in range(total_buffers):
+                eng.compute_transfer(i, path[b], int(b))
+        else:
+            eng.set_use_transfer(i, False)             # no FFAT maps in this config: unit transfer
         for b in np.nonzero(hits >= 0)[0]:
             ok = eng.enqueue_force(i, ForceMessage(vid=int(hits[b]), vn=vns[b]), int(b))
             assert ok
@@ -220,10 +243,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"{args.objects} objects x {M} modes per GPU, Poisson impulse stream (~20 PointForce hits/s/object, "
-                            f"on-device vertex projection), {nb} buffers x 513 samples per step, unit transfer, "
+                "workload": f"{args.objects} objects x {M} modes per GPU, " + {
+                                "impulses": "Poisson impulse stream (~20 PointForce hits/s/object, on-device vertex projection), unit transfer, ",
+                                "scraping": "sustained AutoregressiveForce scraping (one GetModalForceFace message per buffer, "
+                                            "profiles generated on the device), unit transfer, ",
+                                "listener": "Poisson impulse stream + FFAT maps (16x16 cube faces) with a new listener position every buffer, ",
+                            }[args.scenario] + f"{nb} buffers x 513 samples per step, "
                             f"qnorm {'off' if args.no_qnorm else args.qnorm}, {args.form} recurrence form",
-                "objects_per_gpu": args.objects, "modes": M, "buffers_per_step": nb, "frames_per_buffer": B,
+                "scenario": args.scenario, "objects_per_gpu": args.objects, "modes": M, "buffers_per_step": nb, "frames_per_buffer": B,
                 "hits": n_hits, "modes_per_lane": info1["modes_per_lane"], "waves_per_object": info1["waves_per_object"],
                 "kernel_build": "packed" if os.environ.get("PBSO_IIR_PACKED", "0") != "0" else "scalar",
                 "gather": bool(gathered is not None), "parallelism": f"object-sharded x{world}",

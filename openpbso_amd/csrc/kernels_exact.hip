@@ -109,7 +109,11 @@ int launch_force_combine(const int *row_ptr, const int *slot_idx, const int *row
 // contraction), so the accepted pairs are the host's; only log/sqrt may differ
 // from glibc in the last place, far below the fp32 rounding of the profile.
 __device__ __forceinline__ uint32_t minstd_next(uint32_t &x) {
-    x = (uint32_t)(((unsigned long long)x * 16807ull) % 2147483647ull);
+    // x * 16807 mod (2^31 - 1) without a 64-bit division: 2^31 = 1 (mod M)
+    const unsigned long long p = (unsigned long long)x * 16807ull;
+    uint32_t r = (uint32_t)(p & 0x7FFFFFFFull) + (uint32_t)(p >> 31);
+    if (r >= 2147483647u) r -= 2147483647u;
+    x = r;
     return x;
 }
 __device__ __forceinline__ double canonical53(uint32_t &x) {
@@ -148,15 +152,27 @@ __global__ __launch_bounds__(64) void force_profile_kernel(
     double *T = scratch + (size_t)c * frames;
     for (int ri = chain_ptr[c]; ri < chain_ptr[c + 1]; ++ri) {
         const ProfRow row = rows[ri];
-        for (int i = 0; i < frames; ++i) T[i] = 0.0;                    // setZero, modal_solver.h:206
+        float *out = tprof + (size_t)row.prow * b_pad;
+        // one contributing force (the common case): samples go straight to the fp32 row,
+        // fire-and-forget stores.  Several: accumulate in fp64 in list order (modal_solver.h:206-218).
+        const bool single = row.entry_end - row.entry_begin == 1;
+        if (!single)
+            for (int i = 0; i < frames; ++i) T[i] = 0.0;
         for (int ei = row.entry_begin; ei < row.entry_end; ++ei) {
             const ProfEntry e = entries[ei];
             if (e.kind == 0) {                                           // PointForce, forces.h:81-90
-                T[0] += 1.;
+                if (single) {
+                    out[0] = 1.f;
+                    for (int i = 1; i < frames; ++i) out[i] = 0.f;
+                } else {
+                    T[0] += 1.;
+                }
             } else if (e.kind == 1) {                                    // GaussianForce, forces.h:92-105
                 for (int ii = 0; ii < frames; ++ii) {
                     const double z = (double)(e.count + ii - e.center) / (double)e.width_samples;
-                    T[ii] += exp(-0.5 * (z * z));
+                    const double v = exp(-0.5 * (z * z));
+                    if (single) out[ii] = (float)(0.0 + v);
+                    else T[ii] += v;
                 }
             } else {                                                     // AutoregressiveForce, :107-128
                 ArState s = states[e.state];
@@ -181,15 +197,17 @@ __global__ __launch_bounds__(64) void force_profile_kernel(
                     mu_tilde += s.sigma * normal01(s);
                     if (idx == 0) b0 = mu_tilde; else if (idx == 1) b1 = mu_tilde; else b2 = mu_tilde;
                     idx = idx == 2 ? 0 : idx + 1;
-                    T[ii] += s.mu + mu_tilde;
+                    const double v = s.mu + mu_tilde;
+                    if (single) out[ii] = (float)(0.0 + v);
+                    else T[ii] += v;
                 }
                 s.buf[0] = b0; s.buf[1] = b1; s.buf[2] = b2;
                 s.buf_idx = idx;
                 states[e.state] = s;
             }
         }
-        float *out = tprof + (size_t)row.prow * b_pad;
-        for (int i = 0; i < frames; ++i) out[i] = (float)T[i];
+        if (!single)
+            for (int i = 0; i < frames; ++i) out[i] = (float)T[i];
         for (int i = frames; i < b_pad; ++i) out[i] = 0.f;
     }
 }
