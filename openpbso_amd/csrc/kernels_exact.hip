@@ -108,116 +108,166 @@ int launch_force_combine(const int *row_ptr, const int *slot_idx, const int *row
 // rejection test are exact IEEE operations (this file is built without FMA
 // contraction), so the accepted pairs are the host's; only log/sqrt may differ
 // from glibc in the last place, far below the fp32 rounding of the profile.
-__device__ __forceinline__ uint32_t minstd_next(uint32_t &x) {
-    // x * 16807 mod (2^31 - 1) without a 64-bit division: 2^31 = 1 (mod M)
-    const unsigned long long p = (unsigned long long)x * 16807ull;
-    uint32_t r = (uint32_t)(p & 0x7FFFFFFFull) + (uint32_t)(p >> 31);
-    if (r >= 2147483647u) r -= 2147483647u;
-    x = r;
-    return x;
-}
-__device__ __forceinline__ double canonical53(uint32_t &x) {
-    const double R = 2147483646.0;                      // max - min + 1
-    const double R2 = 4611686009837453316.0;            // (double)((long double)R * R), as libstdc++ forms it
-    double sum = (double)(minstd_next(x) - 1u) * 1.0;
-    sum += (double)(minstd_next(x) - 1u) * R;
-    double ret = sum / R2;
-    if (ret >= 1.0) ret = 0.99999999999999988898;        // nextafter(1, 0)
-    return ret;
-}
-__device__ double normal01(ArState &s) {
-    if (s.saved_available) {
-        s.saved_available = 0;
-        return s.saved;
-    }
-    double x, y, r2;
-    do {
-        x = 2.0 * canonical53(s.x) - 1.0;
-        y = 2.0 * canonical53(s.x) - 1.0;
-        r2 = x * x + y * y;
-    } while (r2 > 1.0 || r2 == 0.0);
-    const double mult = sqrt(-2 * log(r2) / r2);
-    s.saved = x * mult;
-    s.saved_available = 1;
-    return y * mult;
+// a * b mod (2^31 - 1) for a, b < 2^31 (2^31 = 1 mod M: fold the 62-bit product twice)
+__device__ __forceinline__ uint32_t mulmod31(uint32_t a, uint32_t b) {
+    const unsigned long long p = (unsigned long long)a * b;
+    unsigned long long r = (p & 0x7FFFFFFFull) + (p >> 31);
+    r = (r & 0x7FFFFFFFull) + (r >> 31);
+    uint32_t q = (uint32_t)r;
+    if (q >= 2147483647u) q -= 2147483647u;
+    return q;
 }
 
-// one thread per chain (= object with dense rows in this launch); scratch[chain][frames] fp64
+// One WAVE per chain (= object with dense rows in this launch, rows in buffer order).
+// The serial parts of Force::Add are kept serial where the arithmetic demands it (the AR(2)
+// recurrence, lane 0) and spread over the 64 lanes where it does not:
+//  * normal variates: candidate pair c of a row uses engine draws 4c+1..4c+4, and the LCG
+//    jumps ahead in closed form (x_n = a^n x_0 mod M): lane j of a batch evaluates candidate
+//    64 k + j, a ballot orders the accepted pairs exactly as the sequential rejection loop
+//    would meet them, and the engine state after the row is the state after the last pair used;
+//  * Gaussian samples and the final fp32 stores are lane-parallel.
+// LDS: nrm[frames] doubles (normal variates, then mu-tilde) + acc[frames] doubles (several
+// forces in one buffer) + the new engine state.
 __global__ __launch_bounds__(64) void force_profile_kernel(
     const int *__restrict__ chain_ptr, int n_chains, const ProfRow *__restrict__ rows,
-    const ProfEntry *__restrict__ entries, ArState *__restrict__ states, double *__restrict__ scratch,
-    float *__restrict__ tprof, int frames, int b_pad) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const ProfEntry *__restrict__ entries, ArState *__restrict__ states, float *__restrict__ tprof,
+    int frames, int b_pad) {
+    extern __shared__ __attribute__((aligned(16))) double k2_lds[];
+    double *nrm = k2_lds;
+    double *acc = k2_lds + frames;
+    double *sh_saved = k2_lds + 2 * frames;                    // [0] saved variate
+    uint32_t *sh_u = reinterpret_cast<uint32_t *>(k2_lds + 2 * frames + 1);   // [0] engine x, [1] saved_available
+    const int c = blockIdx.x;
     if (c >= n_chains) return;
-    double *T = scratch + (size_t)c * frames;
+    const int lane = threadIdx.x;
+    // a^(4 lane) and a^256 (mod M), a = 16807
+    uint32_t a4 = 16807u;
+    a4 = mulmod31(a4, a4);
+    a4 = mulmod31(a4, a4);                                     // a^4
+    uint32_t pj = 1u, q64 = 1u;
+    for (int i = 0; i < 64; ++i) {
+        if (i < lane) pj = mulmod31(pj, a4);
+        q64 = mulmod31(q64, a4);
+    }
+    const double R = 2147483646.0;                             // max - min + 1
+    const double R2 = 4611686009837453316.0;                   // (double)((long double)R * R), as libstdc++ forms it
+
     for (int ri = chain_ptr[c]; ri < chain_ptr[c + 1]; ++ri) {
         const ProfRow row = rows[ri];
         float *out = tprof + (size_t)row.prow * b_pad;
-        // one contributing force (the common case): samples go straight to the fp32 row,
-        // fire-and-forget stores.  Several: accumulate in fp64 in list order (modal_solver.h:206-218).
-        const bool single = row.entry_end - row.entry_begin == 1;
-        if (!single)
-            for (int i = 0; i < frames; ++i) T[i] = 0.0;
+        const int n_ent = row.entry_end - row.entry_begin;
+        for (int i = lane; i < frames; i += 64) acc[i] = 0.0;                  // setZero, modal_solver.h:206
+        __syncthreads();
         for (int ei = row.entry_begin; ei < row.entry_end; ++ei) {
             const ProfEntry e = entries[ei];
-            if (e.kind == 0) {                                           // PointForce, forces.h:81-90
-                if (single) {
-                    out[0] = 1.f;
-                    for (int i = 1; i < frames; ++i) out[i] = 0.f;
-                } else {
-                    T[0] += 1.;
-                }
-            } else if (e.kind == 1) {                                    // GaussianForce, forces.h:92-105
-                for (int ii = 0; ii < frames; ++ii) {
+            if (e.kind == 0) {                                                 // PointForce, forces.h:81-90
+                if (lane == 0) acc[0] += 1.;
+            } else if (e.kind == 1) {                                          // GaussianForce, forces.h:92-105
+                for (int ii = lane; ii < frames; ii += 64) {
                     const double z = (double)(e.count + ii - e.center) / (double)e.width_samples;
-                    const double v = exp(-0.5 * (z * z));
-                    if (single) out[ii] = (float)(0.0 + v);
-                    else T[ii] += v;
+                    acc[ii] += exp(-0.5 * (z * z));
                 }
-            } else {                                                     // AutoregressiveForce, :107-128
-                ArState s = states[e.state];
-                if (e.flags & 1) {                                       // default-constructed, forces.h:73-76
+            } else {                                                           // AutoregressiveForce, :107-128
+                ArState s = states[e.state];                                   // uniform
+                if (e.flags & 1) {                                             // default-constructed, forces.h:73-76
                     s.x = 1u; s.saved_available = 0; s.saved = 0.0;
                     s.buf[0] = s.buf[1] = s.buf[2] = 0.0; s.buf_idx = 0;
                     s.a[0] = 0.783; s.a[1] = 0.116; s.sigma = 0.00148; s.mu = 0.142;
                 }
-                if (e.flags & 2) {                                       // SetParam, forces.h:130-137
+                if (e.flags & 2) {                                             // SetParam, forces.h:130-137
                     s.buf[0] = s.buf[1] = s.buf[2] = 0.0;
                     s.a[0] = e.a0; s.a[1] = e.a1; s.sigma = e.sigma; s.mu = e.mu;
                 }
-                double b0 = s.buf[0], b1 = s.buf[1], b2 = s.buf[2];
-                int idx = s.buf_idx;
-                for (int ii = 0; ii < frames; ++ii) {
-                    // _buf[(idx + 3 - jj - 1) % 3] for jj = 0, 1
-                    const double p1 = idx == 0 ? b2 : (idx == 1 ? b0 : b1);
-                    const double p2 = idx == 0 ? b1 : (idx == 1 ? b2 : b0);
-                    double mu_tilde = 0.0;
-                    mu_tilde += s.a[0] * p1;
-                    mu_tilde += s.a[1] * p2;
-                    mu_tilde += s.sigma * normal01(s);
-                    if (idx == 0) b0 = mu_tilde; else if (idx == 1) b1 = mu_tilde; else b2 = mu_tilde;
-                    idx = idx == 2 ? 0 : idx + 1;
-                    const double v = s.mu + mu_tilde;
-                    if (single) out[ii] = (float)(0.0 + v);
-                    else T[ii] += v;
+                // ---- the row's normal variates, in the order distribution(generator) returns them
+                const int sa = s.saved_available ? 1 : 0;
+                if (sa && lane == 0) nrm[0] = s.saved;
+                const int from_pairs = frames - sa;
+                const int pairs_needed = (from_pairs + 1) / 2;
+                if (lane == 0) { sh_u[0] = s.x; sh_u[1] = 0u; sh_saved[0] = 0.0; }
+                __syncthreads();
+                uint32_t xb = s.x;                                              // state before candidate 64 k
+                int acc_pairs = 0;
+                while (acc_pairs < pairs_needed) {
+                    uint32_t st = mulmod31(xb, pj);                             // state before candidate 64 k + lane
+                    const uint32_t d1 = (st = mulmod31(st, 16807u));
+                    const uint32_t d2 = (st = mulmod31(st, 16807u));
+                    const uint32_t d3 = (st = mulmod31(st, 16807u));
+                    const uint32_t d4 = (st = mulmod31(st, 16807u));
+                    // generate_canonical<double,53>: two draws each
+                    double s1 = (double)(d1 - 1u) * 1.0;
+                    s1 += (double)(d2 - 1u) * R;
+                    double c1 = s1 / R2;
+                    if (c1 >= 1.0) c1 = 0.99999999999999988898;
+                    double s2 = (double)(d3 - 1u) * 1.0;
+                    s2 += (double)(d4 - 1u) * R;
+                    double c2 = s2 / R2;
+                    if (c2 >= 1.0) c2 = 0.99999999999999988898;
+                    const double x = 2.0 * c1 - 1.0;
+                    const double y = 2.0 * c2 - 1.0;
+                    const double r2 = x * x + y * y;
+                    const bool ok = !(r2 > 1.0 || r2 == 0.0);
+                    const unsigned long long m = __ballot(ok);
+                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    const int idx = acc_pairs + rank;
+                    if (ok && idx < pairs_needed) {
+                        const double mult = sqrt(-2 * log(r2) / r2);
+                        const int p0 = sa + 2 * idx;
+                        nrm[p0] = y * mult;                                     // returned first
+                        if (p0 + 1 < frames) nrm[p0 + 1] = x * mult;            // the cached second variate
+                        if (idx == pairs_needed - 1) {
+                            sh_u[0] = st;                                       // engine state after this pair's draws
+                            if (p0 + 1 >= frames) { sh_u[1] = 1u; sh_saved[0] = x * mult; }
+                        }
+                    }
+                    acc_pairs += __popcll(m);
+                    xb = mulmod31(xb, q64);
                 }
-                s.buf[0] = b0; s.buf[1] = b1; s.buf[2] = b2;
-                s.buf_idx = idx;
-                states[e.state] = s;
+                __syncthreads();
+                // ---- AR(2), strictly sequential (forces.h:107-117): lane 0
+                if (lane == 0) {
+                    double b0 = s.buf[0], b1 = s.buf[1], b2 = s.buf[2];
+                    int idx = s.buf_idx;
+                    for (int ii = 0; ii < frames; ++ii) {
+                        const double p1 = idx == 0 ? b2 : (idx == 1 ? b0 : b1);   // _buf[(idx + 3 - 1) % 3]
+                        const double p2 = idx == 0 ? b1 : (idx == 1 ? b2 : b0);   // _buf[(idx + 3 - 2) % 3]
+                        double mu_tilde = 0.0;
+                        mu_tilde += s.a[0] * p1;
+                        mu_tilde += s.a[1] * p2;
+                        mu_tilde += s.sigma * nrm[ii];
+                        if (idx == 0) b0 = mu_tilde; else if (idx == 1) b1 = mu_tilde; else b2 = mu_tilde;
+                        idx = idx == 2 ? 0 : idx + 1;
+                        nrm[ii] = mu_tilde;
+                    }
+                    s.buf[0] = b0; s.buf[1] = b1; s.buf[2] = b2;
+                    s.buf_idx = idx;
+                    if (pairs_needed > 0) {
+                        s.x = sh_u[0];
+                        s.saved_available = (int)sh_u[1];
+                        s.saved = sh_saved[0];
+                    } else {
+                        s.saved_available = 0;                                  // only the cached variate was used
+                    }
+                    states[e.state] = s;
+                }
+                __syncthreads();
+                for (int ii = lane; ii < frames; ii += 64) acc[ii] += s.mu + nrm[ii];   // forceSpread(ii) += mu_e
             }
+            __syncthreads();
         }
-        if (!single)
-            for (int i = 0; i < frames; ++i) out[i] = (float)T[i];
-        for (int i = frames; i < b_pad; ++i) out[i] = 0.f;
+        (void)n_ent;
+        for (int i = lane; i < b_pad; i += 64) out[i] = i < frames ? (float)acc[i] : 0.f;
+        __syncthreads();
     }
 }
 
 int launch_force_profiles(const int *chain_ptr, int n_chains, const ProfRow *rows, const ProfEntry *entries,
                           ArState *states, double *scratch, float *tprof, int frames, int b_pad,
                           hipStream_t stream) {
+    (void)scratch;
     if (n_chains <= 0) return 0;
-    hipLaunchKernelGGL(force_profile_kernel, dim3((n_chains + 63) / 64), dim3(64), 0, stream, chain_ptr,
-                       n_chains, rows, entries, states, scratch, tprof, frames, b_pad);
+    const size_t lds = sizeof(double) * (2 * (size_t)frames + 2);
+    hipLaunchKernelGGL(force_profile_kernel, dim3(n_chains), dim3(64), lds, stream, chain_ptr, n_chains, rows,
+                       entries, states, tprof, frames, b_pad);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,182 @@
+// pbso_headless -- headless counterpart of the reference's GUI tool for the hot path.
+//
+// Takes the reference's command-line flags (tools/real_time_modal_sound.cpp:42-64:
+// -d/--data_dir, -name/--obj_name, -m/--mesh, -s/--surf_mode, -t/--material,
+// -p/--ffat_map) and its directory convention (:480-501), builds the solver the way
+// BuildSolver does (:309-345) through the C ABI, replaces the mouse by a hit script and
+// the camera by a listener script, steps N buffers on the MI355X and writes what
+// PaModalCallback would have played (:207-210, sound / 1e10) as a mono float32 WAV.
+//
+//   --hits FILE      lines: <buffer> <vertex_id> <nx> <ny> <nz> [point|gauss <width_us>|ar]
+//   --listener FILE  lines: <buffer> <x> <y> <z>          (computeTransfer at that buffer)
+//   --buffers N      number of 513-sample buffers (default 86 ~ 1 s)
+//   --out FILE       output WAV (default out.wav);  --raw FILE also dumps the fp32 sound values
+#include <dirent.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "openpbso_amd.h"
+
+static void die(const std::string &msg) {
+    std::fprintf(stderr, "pbso_headless: %s\n", msg.c_str());
+    std::exit(1);
+}
+static void check(pbso_engine *e, int rc, const char *what) {
+    if (rc < 0) die(std::string(what) + ": " + pbso_status_string(rc) + ": " + (e ? pbso_last_error(e) : ""));
+}
+
+// ListDirFiles(d, names, ".tet.obj") + Basename + prefix up to the first '.', tools/...:483-487
+static std::string guess_name(const std::string &dir) {
+    DIR *d = opendir(dir.c_str());
+    if (!d) die("cannot open data dir " + dir);
+    std::string found;
+    while (dirent *ent = readdir(d)) {
+        const std::string f = dir + "/" + ent->d_name;
+        if (ent->d_name[0] != '.' && f.find(".tet.obj") != std::string::npos) { found = ent->d_name; break; }
+    }
+    closedir(d);
+    if (found.empty()) die("no *.tet.obj in " + dir);
+    return found.substr(0, found.find_first_of("."));
+}
+
+static int count_obj_vertices(const std::string &path) {
+    std::ifstream f(path);
+    if (!f) return -1;
+    std::string line;
+    int n = 0;
+    while (std::getline(f, line))
+        if (line.size() > 1 && line[0] == 'v' && (line[1] == ' ' || line[1] == '\t')) ++n;
+    return n;
+}
+
+static void write_wav_f32(const std::string &path, const std::vector<float> &mono, int rate) {
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) die("cannot write " + path);
+    const uint32_t data_bytes = (uint32_t)(mono.size() * 4), riff = 36 + data_bytes, fmt_len = 16, byte_rate = rate * 4;
+    const uint16_t fmt = 3 /* IEEE float */, ch = 1, align = 4, bits = 32;
+    const uint32_t r = rate;
+    std::fwrite("RIFF", 1, 4, f); std::fwrite(&riff, 4, 1, f); std::fwrite("WAVEfmt ", 1, 8, f);
+    std::fwrite(&fmt_len, 4, 1, f); std::fwrite(&fmt, 2, 1, f); std::fwrite(&ch, 2, 1, f);
+    std::fwrite(&r, 4, 1, f); std::fwrite(&byte_rate, 4, 1, f); std::fwrite(&align, 2, 1, f); std::fwrite(&bits, 2, 1, f);
+    std::fwrite("data", 1, 4, f); std::fwrite(&data_bytes, 4, 1, f);
+    std::fwrite(mono.data(), 4, mono.size(), f);
+    std::fclose(f);
+}
+
+int main(int argc, char **argv) {
+    std::string d, name, mesh, modes, material, ffat, hits, listener, out = "out.wav", raw;
+    int n_buffers = 86;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&]() -> std::string { if (i + 1 >= argc) die("missing value for " + a); return argv[++i]; };
+        if (a == "-d" || a == "--data_dir") d = val();
+        else if (a == "-name" || a == "--obj_name") name = val();
+        else if (a == "-m" || a == "--mesh") mesh = val();
+        else if (a == "-s" || a == "--surf_mode") modes = val();
+        else if (a == "-t" || a == "--material") material = val();
+        else if (a == "-p" || a == "--ffat_map") ffat = val();
+        else if (a == "--hits") hits = val();
+        else if (a == "--listener") listener = val();
+        else if (a == "--buffers") n_buffers = std::atoi(val().c_str());
+        else if (a == "--out") out = val();
+        else if (a == "--raw") raw = val();
+        else die("unknown flag " + a);
+    }
+    if (!d.empty()) {                                   // fixed directory structure, tools/...:480-495
+        if (name.empty()) name = guess_name(d);
+        std::printf("object name: %s\n", name.c_str());
+        mesh = d + "/" + name + ".tet.obj";
+        modes = d + "/" + name + "_surf.modes";
+        material = d + "/" + name + "_material.txt";
+        ffat = d + "/" + name + "_ffat_maps";
+    }
+    if (modes.empty() || material.empty()) die("need -d <dir> or -s <modes> -t <material> [-m <obj>] [-p <ffat dir>]");
+
+    pbso_engine_desc desc;
+    std::memset(&desc, 0, sizeof(desc));
+    desc.abi_version = PBSO_ABI_VERSION;
+    desc.qnorm_mode = PBSO_QNORM_OFF;
+    pbso_engine *e = nullptr;
+    int rc = pbso_engine_create(&desc, &e);
+    check(e, rc, "engine_create");
+    int obj = -1, n_aud = 0;
+    check(e, pbso_add_object_from_files(e, modes.c_str(), material.c_str(), ffat.empty() ? nullptr : ffat.c_str(), &obj, &n_aud),
+          "add_object_from_files");
+    // assert(modes->numDOF() == V.rows()*3), tools/...:515
+    int n_dof = 0, n_modes = 0;
+    double *om = nullptr, *md = nullptr;
+    check(e, pbso_modes_read(modes.c_str(), &n_dof, &n_modes, &om, &md), "modes_read");
+    pbso_free(om);
+    pbso_free(md);
+    if (!mesh.empty()) {
+        const int nv = count_obj_vertices(mesh);
+        if (nv >= 0 && nv * 3 != n_dof) die("DOFs mismatch: .obj has " + std::to_string(nv) + " vertices, modes have nDOF " + std::to_string(n_dof));
+    }
+    std::printf("modes: %d of %d audible, nDOF %d\n", n_aud, n_modes, n_dof);
+    check(e, pbso_finalize(e), "finalize");
+
+    bool any_listener = false;
+    if (!listener.empty()) {
+        std::ifstream f(listener);
+        if (!f) die("cannot read " + listener);
+        std::string line;
+        while (std::getline(f, line)) {
+            if (line.empty() || line[0] == '#') continue;
+            std::istringstream iss(line);
+            long b; double p[3];
+            if (!(iss >> b >> p[0] >> p[1] >> p[2])) die("bad listener line: " + line);
+            check(e, pbso_compute_transfer(e, obj, p, b), "compute_transfer");
+            any_listener = true;
+        }
+    }
+    if (!any_listener) check(e, pbso_set_use_transfer(e, obj, 0, 0), "set_use_transfer");   // unit transfer
+    if (!hits.empty()) {
+        std::ifstream f(hits);
+        if (!f) die("cannot read " + hits);
+        std::string line;
+        while (std::getline(f, line)) {
+            if (line.empty() || line[0] == '#') continue;
+            std::istringstream iss(line);
+            long b; int vid; double n[3]; std::string type = "point";
+            if (!(iss >> b >> vid >> n[0] >> n[1] >> n[2])) die("bad hit line: " + line);
+            iss >> type;
+            pbso_force_msg m;
+            std::memset(&m, 0, sizeof(m));
+            m.data_kind = PBSO_DATA_VERTEX;
+            m.vids[0] = vid;
+            const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);   // VN.row(vid).normalized(), tools/...:607
+            for (int j = 0; j < 3; ++j) m.vn[j] = n[j] / len;
+            if (type == "gauss") { m.force_type = PBSO_GAUSSIAN_FORCE; iss >> m.gaussian_width_us; }
+            else if (type == "ar") m.force_type = PBSO_AUTOREGRESSIVE_FORCE;
+            else m.force_type = PBSO_POINT_FORCE;
+            rc = pbso_enqueue_force(e, obj, &m, b);
+            check(e, rc, "enqueue_force");
+            if (rc == 0) die("force queue full");
+        }
+    }
+    check(e, pbso_step(e, n_buffers), "step");
+    std::vector<float> sound((size_t)n_buffers * PBSO_FRAMES_PER_BUFFER), mono(sound.size());
+    check(e, pbso_read_audio(e, sound.data(), sound.size()), "read_audio");
+    for (size_t i = 0; i < sound.size(); ++i) mono[i] = (float)((double)sound[i] / 1E10);   // tools/...:208
+    write_wav_f32(out, mono, PBSO_SAMPLE_RATE);
+    if (!raw.empty()) {
+        FILE *f = std::fopen(raw.c_str(), "wb");
+        if (!f) die("cannot write " + raw);
+        std::fwrite(sound.data(), 4, sound.size(), f);
+        std::fclose(f);
+    }
+    pbso_engine_info info;
+    check(e, pbso_get_info(e, &info), "get_info");
+    std::printf("%d buffers (%.3f s of audio) in %.3f ms on the device -> %s\n", n_buffers,
+                n_buffers * (double)PBSO_FRAMES_PER_BUFFER / PBSO_SAMPLE_RATE, info.last_step_device_ms, out.c_str());
+    pbso_engine_destroy(e);
+    return 0;
+}
