@@ -57,7 +57,7 @@ def test_headless_directory_run_matches_oracle(tmp_path, oracle):
     (tmp_path / "hits.txt").write_text("# buffer vid nx ny nz type\n" + "".join(
         f"{b} {v} {n[0]} {n[1]} {n[2]} {t}\n" for b, v, n, t in hits))
     path = synth.listener_path(nb)
-    (tmp_path / "listener.txt").write_text("".join(f"{b} {p[0]!r} {p[1]!r} {p[2]!r}\n" for b, p in enumerate(path)))
+    (tmp_path / "listener.txt").write_text("".join(f"{b} {float(p[0])!r} {float(p[1])!r} {float(p[2])!r}\n" for b, p in enumerate(path)))
     r = subprocess.run([EXE, "-d", str(d), "--hits", str(tmp_path / "hits.txt"), "--listener", str(tmp_path / "listener.txt"),
                         "--buffers", str(nb), "--out", str(tmp_path / "o.wav"), "--raw", str(tmp_path / "o.raw")],
                        capture_output=True, text=True)
