@@ -37,8 +37,8 @@ FLOP_PER_MODE_SAMPLE = 10      # reference arithmetic incl. qnorm (SURVEY.md 8(d
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--objects", type=int, default=1024, help="objects per GPU")
     ap.add_argument("--modes", type=int, default=512)
     ap.add_argument("--buffers", type=int, default=86, help="audio buffers per step")

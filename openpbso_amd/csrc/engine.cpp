@@ -295,6 +295,7 @@ int Engine::set_ffat_maps(int obj, const pbso_ffat_map *maps, int n) {
 }
 
 int Engine::finalize() {
+    HIPTRY(hipSetDevice(desc_.device));      // the caller's thread may have another device current
     if (finalized_) return fail(PBSO_ERR_STATE, "finalize called twice");
     if (objs_.empty()) return fail(PBSO_ERR_STATE, "no objects");
     const int N = (int)objs_.size();
@@ -336,7 +337,8 @@ int Engine::finalize() {
             const size_t k = (size_t)i * m_pad_ + m;
             if (desc_.recurrence_form == PBSO_FORM_VELOCITY) {
                 ca[k] = (float)(-o.c2[m]);                     // eps^2
-                cb[k] = (float)((1.0 - o.c1[m]) - o.c2[m]);    // |1 - z|^2 = 1 - c1 - c2
+                cb[k] = -(float)((1.0 - o.c1[m]) - o.c2[m]);   // -e, e = |1 - z|^2 = 1 - c1 - c2 (stored negated:
+                                                               //  d = eps^2 d + (-e) q is then a plain v_fmac)
             } else {
                 ca[k] = (float)o.c1[m];
                 cb[k] = (float)o.c2[m];
@@ -899,6 +901,7 @@ static hipError_t upload(PinBuf<T> &h, DevBuf<T> &d, const T *src, size_t n, hip
 }
 
 int Engine::step(int nb, void *d_audio_user) {
+    HIPTRY(hipSetDevice(desc_.device));      // the caller's thread may have another device current
     if (!finalized_) return fail(PBSO_ERR_STATE, "step before finalize");
     if (nb <= 0) return fail(PBSO_ERR_INVALID, "n_buffers must be > 0");
     const int N = (int)objs_.size();
@@ -1052,6 +1055,7 @@ int Engine::step(int nb, void *d_audio_user) {
 }
 
 int Engine::sync() {
+    HIPTRY(hipSetDevice(desc_.device));      // the caller's thread may have another device current
     if (prep_stream_) HIPTRY(hipStreamSynchronize(prep_stream_));
     if (stream_) HIPTRY(hipStreamSynchronize(stream_));
     return PBSO_OK;
@@ -1120,6 +1124,7 @@ int Engine::get_latest_transfer(int obj, double *out) {
 
 // ModalSolver::computeTransfer(pos, T *trans), modal_solver.h:302-315, batched
 int Engine::compute_transfer_batch(int obj, const double *pos, int n_pos, double *out) {
+    HIPTRY(hipSetDevice(desc_.device));      // the caller's thread may have another device current
     if (!finalized_) return fail(PBSO_ERR_STATE, "compute_transfer_batch before finalize");
     if (!valid_obj(obj) || n_pos < 0 || (n_pos && (!pos || !out))) return fail(PBSO_ERR_INVALID, "arguments");
     Object &o = objs_[obj];

@@ -98,9 +98,9 @@ __device__ __forceinline__ void step_tile(V (&q)[NV], V (&d)[NV], const V (&ca)[
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             if (FORM == 0) {
-                // d_k = eps^2 d_{k-1} - e q_{k-1} + g T_k ;  q_k = q_{k-1} + d_k
+                // d_k = eps^2 d_{k-1} - e q_{k-1} + g T_k ;  q_k = q_{k-1} + d_k   (cb holds -e)
                 V a = ca[v] * d[v];
-                a = vfma(-cb[v], q[v], a);
+                a = vfma(cb[v], q[v], a);
                 if (forced) a = vfma(g[v], vsplat(a, tk), a);
                 d[v] = a;
                 q[v] = q[v] + a;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
                 V q0, s0;
                 if (FORM == 0) {
                     V a = ca[v] * d[v];
-                    a = vfma(-cb[v], q[v], a);
+                    a = vfma(cb[v], q[v], a);
                     if (f0 != 0.f) a = vfma(g_[v], vsplat(a, f0), a);
                     s0 = a;
                     q0 = q[v] + a;
