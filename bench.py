@@ -138,21 +138,30 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; PBSO_BENCH_BACKEND=gloo lets several ranks share one GPU (smoke test of the
+    # multi-rank path on a 1-GPU box: RCCL refuses two ranks on one device)
+    backend = os.environ.get("PBSO_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from openpbso_amd import Engine, ForceMessage, capi, synth
+    from openpbso_amd.distributed import gather_audio
 
     lam, shapes, scripts = build_inputs(args, rank)
     stream = torch.cuda.current_stream().cuda_stream
-    eng = Engine(device=local_rank,
+    eng = Engine(device=dev_index,
                  form=capi.FORM_VELOCITY if args.form == "velocity" else capi.FORM_DIRECT,
                  qnorm={"sample": capi.QNORM_ALL, "closed": capi.QNORM_CLOSED, "off": capi.QNORM_OFF}[
                      "off" if args.no_qnorm else args.qnorm],
@@ -195,7 +204,10 @@ def main():
     def one_step():
         eng.step(nb, into=audio.data_ptr())
         if gathered is not None:
-            dist.all_gather_into_tensor(gathered, audio)
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gathered, audio)
+            else:
+                gathered.copy_(gather_audio(audio.cpu()))
 
     for _ in range(args.warmup):
         one_step()
@@ -213,7 +225,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     info1 = eng.info()
