@@ -134,7 +134,7 @@ Engine::~Engine() {
     d_ca_.release(); d_cb_.release(); d_sq_.release(); d_sd_.release(); d_c3_.release(); d_gq_.release();
     d_shapes_.release(); d_shape_off_.release(); d_n_modes_.release(); d_geom_.release();
     d_geom_off_.release(); d_psi_.release(); d_slots_.release(); d_xfer_.release();
-    d_arstate_.release(); d_tacc_.release();
+    d_arstate_.release();
     d_audio_.release(); d_qnorm_.release(); d_grows_[0].release(); d_grows_[1].release(); d_census_.release();
     for (hipEvent_t ev : {ev_prep_done_[0], ev_prep_done_[1], ev_k1_done_[0], ev_k1_done_[1]})
         if (ev) (void)hipEventDestroy(ev);
@@ -979,7 +979,6 @@ int Engine::step(int nb, void *d_audio_user) {
         HIPTRY(upload(ps.h_prof_rows, ps.d_prof_rows, prof_rows_.data(), prof_rows_.size(), sp));
         HIPTRY(upload(ps.h_chain_ptr, ps.d_chain_ptr, chain_ptr_.data(), chain_ptr_.size(), sp));
         HIPTRY(d_arstate_.ensure(std::max<size_t>(1, n_ar_states_), true, sp));
-        HIPTRY(d_tacc_.ensure(std::max<size_t>(1, (size_t)n_chains) * B_, false, sp));
     } else {
         HIPTRY(upload(ps.h_tprof, ps.d_tprof, tprof_.data(), tprof_.size(), sp));
     }
@@ -1002,7 +1001,7 @@ int Engine::step(int nb, void *d_audio_user) {
     // K2 -> time-profile rows ; K3 / scatter -> data slots ; K4 -> transfer rows ; combine -> g rows
     if (device_profiles_)
         LAUNCHTRY(launch_force_profiles(ps.d_chain_ptr.p, n_chains, ps.d_prof_rows.p, ps.d_prof_entries.p,
-                                        d_arstate_.p, d_tacc_.p, ps.d_tprof.p, B_, b_pad_, sp));
+                                        d_arstate_.p, ps.d_tprof.p, B_, b_pad_, sp));
     LAUNCHTRY(launch_scatter_rows(ps.d_stage.p, ps.d_stage_slot.p, (int)stage_slot_.size(), d_slots_.p, m_pad_, sp));
     LAUNCHTRY(launch_modal_project(ps.d_proj.p, (int)proj_.size(), d_shapes_.p, d_shape_off_.p, d_n_modes_.p,
                                    d_slots_.p, m_pad_, sp));

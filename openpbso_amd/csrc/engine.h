@@ -211,7 +211,6 @@ private:
     int chain_obj_ = -1;
     size_t n_ar_states_ = 0;
     DevBuf<ArState> d_arstate_;
-    DevBuf<double> d_tacc_;
     std::vector<double> stage_;
     std::vector<ProjectEvent> proj_;
     std::vector<FfatEvent> ffat_;

@@ -111,10 +111,9 @@ struct ProfRow {         // one dense profile row = one (object, buffer)
     int32_t prow;        // row of the tprof array to write
     int32_t entry_begin, entry_end;
 };
-// chains: rows of one object in buffer order are generated by ONE thread (the AR state is sequential)
+// chains: rows of one object in buffer order are generated by ONE wave (the AR state is sequential)
 int launch_force_profiles(const int *chain_ptr, int n_chains, const ProfRow *rows, const ProfEntry *entries,
-                          ArState *states, double *scratch, float *tprof, int frames, int b_pad,
-                          hipStream_t stream);
+                          ArState *states, float *tprof, int frames, int b_pad, hipStream_t stream);
 
 struct FfatGeom {        // FFAT_Map<double,3> runtime fields, one per (object, mode)
     double k;

@@ -155,7 +155,6 @@ __global__ __launch_bounds__(64) void force_profile_kernel(
     for (int ri = chain_ptr[c]; ri < chain_ptr[c + 1]; ++ri) {
         const ProfRow row = rows[ri];
         float *out = tprof + (size_t)row.prow * b_pad;
-        const int n_ent = row.entry_end - row.entry_begin;
         for (int i = lane; i < frames; i += 64) acc[i] = 0.0;                  // setZero, modal_solver.h:206
         __syncthreads();
         for (int ei = row.entry_begin; ei < row.entry_end; ++ei) {
@@ -254,16 +253,13 @@ __global__ __launch_bounds__(64) void force_profile_kernel(
             }
             __syncthreads();
         }
-        (void)n_ent;
         for (int i = lane; i < b_pad; i += 64) out[i] = i < frames ? (float)acc[i] : 0.f;
         __syncthreads();
     }
 }
 
 int launch_force_profiles(const int *chain_ptr, int n_chains, const ProfRow *rows, const ProfEntry *entries,
-                          ArState *states, double *scratch, float *tprof, int frames, int b_pad,
-                          hipStream_t stream) {
-    (void)scratch;
+                          ArState *states, float *tprof, int frames, int b_pad, hipStream_t stream) {
     if (n_chains <= 0) return 0;
     const size_t lds = sizeof(double) * (2 * (size_t)frames + 2);
     hipLaunchKernelGGL(force_profile_kernel, dim3(n_chains), dim3(64), lds, stream, chain_ptr, n_chains, rows,

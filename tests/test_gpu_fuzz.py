@@ -1,0 +1,94 @@
+"""Randomised message scripts: the engine's planner + kernels against the oracle's
+ModalSolver::step for arbitrary interleavings of point / Gaussian / AR forces,
+sustained start / end, clearAllForces, AR parameter updates, listener moves and
+useTransfer toggles."""
+import numpy as np
+import pytest
+
+from openpbso_amd import synth
+from tests.scenarios import ObjSpec, force_ev, rel_errors, run_engine, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def random_script(rng, n_obj, n_modes, nb, with_maps):
+    evs = []
+    for oi in range(n_obj):
+        sustained = False
+        for b in range(nb):
+            r = rng.random()
+            n_msgs = 0 if r < 0.45 else (1 if r < 0.85 else 2)      # sometimes two messages in one frame (Q3)
+            for _ in range(n_msgs):
+                kind = rng.random()
+                data = rng.standard_normal(n_modes[oi]) * 1e-3
+                if sustained:
+                    if kind < 0.15:
+                        evs.append(force_ev(b, oi, force_type=2, end=True))
+                        sustained = False
+                    elif kind < 0.25:
+                        evs.append(dict(t=b, obj=oi, kind="arprm", a=[float(rng.uniform(0.3, 0.8)), float(rng.uniform(0.0, 0.15))],
+                                        sigma=float(rng.uniform(1e-3, 5e-3)), mu=float(rng.uniform(0.05, 0.3))))
+                    else:
+                        evs.append(force_ev(b, oi, data=data, force_type=2))
+                else:
+                    if kind < 0.45:
+                        evs.append(force_ev(b, oi, data=data))
+                    elif kind < 0.7:
+                        w = float(rng.choice([0.0, 60.0, 400.0, 2500.0, 9000.0]))
+                        evs.append(force_ev(b, oi, data=data, force_type=1, width=w))
+                    elif kind < 0.8:
+                        evs.append(force_ev(b, oi, data=data, force_type=2))            # plain AR force (lives forever)
+                    elif kind < 0.9:
+                        evs.append(force_ev(b, oi, data=data, force_type=2, start=True))
+                        sustained = True
+                    else:
+                        evs.append(force_ev(b, oi, clear=True))
+            if with_maps[oi]:
+                if rng.random() < 0.5:
+                    p = rng.standard_normal(3)
+                    p = p / np.linalg.norm(p) * rng.uniform(0.2, 2.0) + 1e-3
+                    evs.append(dict(t=b, obj=oi, kind="listener", pos=p))
+                if rng.random() < 0.15:
+                    evs.append(dict(t=b, obj=oi, kind="use_transfer", use=bool(rng.random() < 0.5)))
+        if not with_maps[oi]:
+            evs.append(dict(t=0, obj=oi, kind="use_transfer", use=False))
+    return evs
+
+
+def _legal(evs, objs, nb):
+    """drop scripts the reference itself would abort on (clearAllForces while sustained leaves
+    _sustainedForces set with an empty list: assert at modal_solver.h:223)"""
+    try:
+        run_oracle(objs, evs, nb)
+        return True
+    except AssertionError:
+        return False
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scripts_match_oracle(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n_obj = int(rng.integers(1, 5))
+    n_modes = [int(rng.choice([3, 40, 64, 100, 129, 300])) for _ in range(n_obj)]
+    nb = int(rng.integers(6, 16))
+    with_maps = [bool(rng.random() < 0.5) for _ in range(n_obj)]
+    objs = []
+    for oi in range(n_obj):
+        lam = synth.eigenvalues(n_modes[oi], 5000 + 10 * seed + oi)
+        objs.append(ObjSpec(lam, maps=synth.ffat_maps(lam, 7000 + seed + oi, dim=4) if with_maps[oi] else None))
+    evs = random_script(rng, n_obj, n_modes, nb, with_maps)
+    if not _legal(evs, objs, nb):
+        pytest.skip("script trips a live assert of the reference")
+    split = None
+    if nb > 8:
+        k = int(rng.integers(1, nb - 1))
+        split = [k, nb - k]
+    got = run_engine(objs, evs, nb, split=split)
+    want = run_oracle(objs, evs, nb)
+    assert np.array_equal(got["emitted"], want["emitted"])
+    mx, l2 = rel_errors(got["audio"], want["audio"])
+    assert (mx <= 5e-4).all() and (l2 <= 1e-3).all(), (mx, l2)
+    for a, w in zip(got["latest"], want["latest"]):
+        assert np.array_equal(a, w)
+    for key, w in want["qnorm"].items():
+        assert np.abs(got["qnorm"][key] - w).max() <= 2e-3 * max(np.abs(w).max(), 1e-30), key
