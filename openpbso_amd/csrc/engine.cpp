@@ -134,7 +134,7 @@ Engine::~Engine() {
     d_ca_.release(); d_cb_.release(); d_sq_.release(); d_sd_.release(); d_c3_.release(); d_gq_.release();
     d_shapes_.release(); d_shape_off_.release(); d_n_modes_.release(); d_geom_.release();
     d_geom_off_.release(); d_psi_.release(); d_slots_.release(); d_xfer_.release();
-    d_arstate_.release();
+    d_arstate_.release(); d_obj_map_.release();
     d_audio_.release(); d_qnorm_.release(); d_grows_[0].release(); d_grows_[1].release(); d_census_.release();
     for (hipEvent_t ev : {ev_prep_done_[0], ev_prep_done_[1], ev_k1_done_[0], ev_k1_done_[1]})
         if (ev) (void)hipEventDestroy(ev);
@@ -309,9 +309,14 @@ int Engine::finalize() {
     if (R != 0 && R != 1 && R != 2 && R != 4 && R != 8) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,4,8");
     auto waves_for = [&](int r) { return (mmax + 64 * r - 1) / (64 * r); };
     auto shape_ok = [&](int r) { return waves_for(r) <= maxW; };
+    auto total_waves = [&](int r) {          // every object gets the team its own size needs
+        long long w = 0;
+        for (const Object &o : objs_) w += std::max(1, (o.n_modes + 64 * r - 1) / (64 * r));
+        return w;
+    };
     if (R == 0) {
         for (int r : {4, 2, 1}) {
-            if (shape_ok(r) && ((long long)N * waves_for(r) >= 4096)) { R = r; break; }
+            if (shape_ok(r) && total_waves(r) >= 4096) { R = r; break; }
         }
         if (R == 0)
             for (int r : {1, 2, 4, 8})      // else: the most waves a supported shape gives
@@ -325,6 +330,26 @@ int Engine::finalize() {
     R_ = R;
     W_ = W;
     m_pad_ = 64 * R * W;
+    // size classes: objects whose own size needs the same number of waves share one launch of
+    // the oscillator bank (the SoA rows stay m_pad wide; a smaller team touches their head only)
+    {
+        std::vector<std::vector<int>> by_w(W + 1);
+        for (int i = 0; i < N; ++i)
+            by_w[std::max(1, (objs_[i].n_modes + 64 * R - 1) / (64 * R))].push_back(i);
+        classes_.clear();
+        std::vector<int> flat;
+        for (int w = W; w >= 1; --w) {                  // largest teams first
+            if (by_w[w].empty()) continue;
+            SizeClass c;
+            c.W = w;
+            c.first = (int)flat.size();
+            c.count = (int)by_w[w].size();
+            flat.insert(flat.end(), by_w[w].begin(), by_w[w].end());
+            classes_.push_back(c);
+        }
+        HIPTRY(d_obj_map_.ensure(flat.size()));
+        HIPTRY(hipMemcpy(d_obj_map_.p, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
 
     const size_t nm = (size_t)N * m_pad_;
     std::vector<float> ca(nm, 0.f), cb(nm, 0.f);
@@ -1033,10 +1058,13 @@ int Engine::step(int nb, void *d_audio_user) {
     kp.audio_stride = (long long)nb * B_;
     kp.rotate_prio = rotate_prio_ ? 1 : 0;
     HIPTRY(hipEventRecord(evq.k0, sk));
-    if (packed_ && R_ >= 2)
-        LAUNCHTRY(iir_packed::launch_iir_bank(kp, N, R_, W_, desc_.recurrence_form, desc_.qnorm_mode, sk));
-    else
-        LAUNCHTRY(iir_scalar::launch_iir_bank(kp, N, R_, W_, desc_.recurrence_form, desc_.qnorm_mode, sk));
+    for (const SizeClass &c : classes_) {
+        kp.obj_map = d_obj_map_.p + c.first;
+        if (packed_ && R_ >= 2)
+            LAUNCHTRY(iir_packed::launch_iir_bank(kp, c.count, R_, c.W, desc_.recurrence_form, desc_.qnorm_mode, sk));
+        else
+            LAUNCHTRY(iir_scalar::launch_iir_bank(kp, c.count, R_, c.W, desc_.recurrence_form, desc_.qnorm_mode, sk));
+    }
     HIPTRY(hipEventRecord(evq.k1, sk));
     // _latest_transfer = trans (modal_solver.h:251), then re-park a still-queued transfer
     LAUNCHTRY(launch_copy_rows(ps.d_copy.p, ps.d_copy.p + (n_cl + n_cq), n_cl, d_xfer_.p, m_pad_, sk));

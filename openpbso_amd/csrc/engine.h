@@ -162,6 +162,9 @@ private:
     // persistent device state
     DevBuf<float> d_ca_, d_cb_, d_sq_, d_sd_;
     DevBuf<double> d_c3_;
+    struct SizeClass { int W, first, count; };           // objects that need W waves: d_obj_map_[first, first+count)
+    std::vector<SizeClass> classes_;
+    DevBuf<int> d_obj_map_;
     DevBuf<float> d_gq_;                                 // closed-form qnorm: G11, 2 G12, G22 planes
     DevBuf<double> d_shapes_;
     DevBuf<long long> d_shape_off_;

@@ -44,6 +44,7 @@ struct IirParams {
     const float *tprof;          // [n_prows][b_pad]  dense force time profiles
     const double *xfer_rows;     // [n_rows][m_pad]   FFAT transfer rows (fp64)
     const int *xfer_init;        // [n_obj] row (or XFER_UNIT) in effect when the launch starts
+    const int *obj_map;          // [grid] workgroup -> object id (one launch per size class)
     float *audio;                // [n_obj][audio_stride]
     float *qnorm;                // [n_obj][nb][m_pad] or nullptr
     const float *gq;             // closed-form qnorm: planes G11, 2*G12, G22, each [n_obj][m_pad]; or nullptr

@@ -161,10 +161,11 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     float *__restrict__ p_sd, const BufDesc *__restrict__ p_desc, const float *__restrict__ p_grows,
     const float *__restrict__ p_tprof, const double *__restrict__ p_xfer_rows,
     const int *__restrict__ p_xfer_init, float *__restrict__ p_audio, float *__restrict__ p_qnorm,
-    const float *__restrict__ p_gq, unsigned long long *__restrict__ p_census, const IirDims p) {
+    const float *__restrict__ p_gq, const int *__restrict__ p_obj_map,
+    unsigned long long *__restrict__ p_census, const IirDims p) {
     constexpr bool QN = QNM != 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int obj = blockIdx.x;
+    const int obj = p_obj_map[blockIdx.x];
     unsigned long long census_t0 = 0, census_c0 = 0;
     if (p_census) {
         census_t0 = __builtin_amdgcn_s_memrealtime();
@@ -439,7 +440,7 @@ static int launch_one(const IirParams &p, int n_obj, int W, hipStream_t stream) 
     }
     const IirDims dims = {p.nb, p.n_tiles, p.m_pad, p.b_pad, p.audio_stride, p.rotate_prio, p.gq_plane};
     hipLaunchKernelGGL(kern, dim3(n_obj), dim3(64 * W), lds, stream, p.ca, p.cb, p.sq, p.sd, p.desc,
-                       p.grows, p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.census, dims);
+                       p.grows, p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.obj_map, p.census, dims);
     return (int)hipGetLastError();
 }
 

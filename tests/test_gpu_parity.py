@@ -125,6 +125,27 @@ def test_ragged_objects_and_padding():
     _check(got, want)
 
 
+def test_size_classes_mixed_team_shapes():
+    """objects needing 1, 3 and 8 waves in one engine: one launch of the oscillator bank
+    per team size, results independent of the grouping."""
+    sizes = [512, 40, 190, 512, 64, 130, 10]
+    objs, evs = [], []
+    rng = np.random.default_rng(12)
+    for i, m in enumerate(sizes):
+        objs.append(ObjSpec(synth.eigenvalues(m, synth.seed_for(8, i))))
+        evs.append(force_ev(i % 4, i, data=rng.standard_normal(m) * 1e-3))
+        evs.append(force_ev(5, i, data=rng.standard_normal(m) * 1e-3, force_type=1, width=700.0))
+        evs.append(dict(t=0, obj=i, kind="use_transfer", use=False))
+    want = run_oracle(objs, evs, 9)
+    for mpl in (0, 1, 2):
+        got = run_engine(objs, evs, 9, modes_per_lane=mpl, split=[4, 5])
+        _check(got, want)
+        for b in (0, 5, 8):
+            for i in range(len(sizes)):
+                w = want["qnorm"][(i, b)]
+                assert np.abs(got["qnorm"][(i, b)] - w).max() <= 2e-3 * max(np.abs(w).max(), 1e-30)
+
+
 @pytest.mark.parametrize("device_profiles", ["1", "0"])
 def test_gaussian_and_overlapping_forces_cross_terms(device_profiles, monkeypatch):
     """Q2: applied force = (sum of data) x (sum of profiles); Gaussian forces
