@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--settle", type=int, default=60,
+                    help="untimed steps run before the warm-up so that the shader clock has ramped (the first ~70 ms "
+                         "after idle run 10 %% slower, profiles/r01_clock_ramp.txt); reported as settle_steps")
     ap.add_argument("--objects", type=int, default=1024, help="objects per GPU")
     ap.add_argument("--modes", type=int, default=512)
     ap.add_argument("--buffers", type=int, default=86, help="audio buffers per step")
@@ -173,27 +176,31 @@ def main():
     eng.finalize()
     n_hits = 0
     total_buffers = (args.steps + args.warmup) * args.buffers
+    # the scripts start after the clock-settle steps; one hit at buffer 0 keeps the settle steps ringing
+    off = args.settle * args.buffers
     for i in range(args.objects):
         hits, vns = scripts[i]
+        if off and args.scenario != "scraping":
+            assert eng.enqueue_force(i, ForceMessage(vid=0, vn=vns[0]), 0)
         if args.scenario == "scraping":
             # tools/...:754-776 + :1127-1160: dummy start message, then one GetModalForceFace per frame
             eng.set_use_transfer(i, False)
             rng = np.random.default_rng(synth.seed_for(5, rank * args.objects + i))
-            assert eng.enqueue_force(i, ForceMessage(forceType=capi.AUTOREGRESSIVE_FORCE, sustainedForceStart=True), 0)
+            assert eng.enqueue_force(i, ForceMessage(forceType=capi.AUTOREGRESSIVE_FORCE, sustainedForceStart=True), off)
             for b in range(1, total_buffers):
                 bary = rng.random(3)
                 assert eng.enqueue_force(i, ForceMessage(vids=rng.integers(0, synth.N_VERTS, 3), coords=bary / bary.sum(),
-                                                         vn=vns[b], forceType=capi.AUTOREGRESSIVE_FORCE), int(b))
+                                                         vn=vns[b], forceType=capi.AUTOREGRESSIVE_FORCE), off + int(b))
                 n_hits += 1
             continue
         if args.scenario == "listener":
             path = synth.listener_path(total_buffers) * (1.0 + 0.001 * i)
             for b in range(total_buffers):
-                eng.compute_transfer(i, path[b], int(b))
+                eng.compute_transfer(i, path[b], off + int(b))
         else:
             eng.set_use_transfer(i, False)             # no FFAT maps in this config: unit transfer
         for b in np.nonzero(hits >= 0)[0]:
-            ok = eng.enqueue_force(i, ForceMessage(vid=int(hits[b]), vn=vns[b]), int(b))
+            ok = eng.enqueue_force(i, ForceMessage(vid=int(hits[b]), vn=vns[b]), off + int(b))
             assert ok
             n_hits += 1
 
@@ -209,7 +216,7 @@ def main():
             else:
                 gathered.copy_(gather_audio(audio.cpu()))
 
-    for _ in range(args.warmup):
+    for _ in range(args.settle + args.warmup):
         one_step()
     torch.cuda.synchronize()
     info0 = eng.info()
@@ -250,7 +257,7 @@ def main():
         out = {
             "metric": "audio samples/s & real-time x at N_obj x N_modes",
             "value": value, "unit": "audio samples/s", "realtime_x": rt,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

@@ -14,7 +14,7 @@ timeout 600 python bench.py --no-cpu-baseline --form direct > gpurun_out/final/b
 echo "== rocprofv3 kernel trace + stats of the default command =="
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/rocprof_stats -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/final/rocprof_stats.log 2>&1); echo rc=$?
 f=$(find gpurun_out/final/rocprof_stats -name "*kernel_stats.csv" | head -1); head -8 "$f" | cut -c1-260
-pmc() { name=$1; shift; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/final/pmc_$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/final/pmc_$name.log 2>&1); echo "pmc $name rc=$?"; }
+pmc() { name=$1; shift; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/final/pmc_$name -- python3 $R/bench.py --steps 3 --warmup 1 --settle 0 --no-cpu-baseline > $R/gpurun_out/final/pmc_$name.log 2>&1); echo "pmc $name rc=$?"; }
 pmc sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU
 pmc sq2 SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE
 pmc fetch FETCH_SIZE
@@ -36,3 +36,6 @@ for name in ("sq1", "sq2", "fetch", "write"):
 PY
 cat gpurun_out/final/pmc_summary.txt
 echo "== census =="; PBSO_CENSUS=1 timeout 300 python scripts/census.py 1024 2>&1 | grep -v amdgpu.ids > gpurun_out/final/census.txt; cat gpurun_out/final/census.txt
+echo "== issue-rate microbenchmarks =="
+for n in 3 4 5; do ./openpbso_amd/microbench${n}_gfx950 > gpurun_out/final/microbench$n.txt 2>&1; done
+cat gpurun_out/final/microbench4.txt gpurun_out/final/microbench5.txt
