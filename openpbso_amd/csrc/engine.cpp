@@ -131,7 +131,7 @@ Engine::Engine(const pbso_engine_desc &d) : desc_(d) {}
 Engine::~Engine() {
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (prep_stream_) (void)hipStreamSynchronize(prep_stream_);
-    d_ca_.release(); d_cb_.release(); d_sq_.release(); d_sd_.release(); d_c3_.release(); d_gq_.release();
+    d_ca_.release(); d_cb_.release(); d_sq_.release(); d_sd_.release(); d_ss_.release(); d_c3_.release(); d_gq_.release();
     d_shapes_.release(); d_shape_off_.release(); d_n_modes_.release(); d_geom_.release();
     d_geom_off_.release(); d_psi_.release(); d_slots_.release(); d_xfer_.release();
     d_arstate_.release(); d_obj_map_.release();
@@ -375,12 +375,14 @@ int Engine::finalize() {
     HIPTRY(d_cb_.ensure(nm));
     HIPTRY(d_sq_.ensure(nm));
     HIPTRY(d_sd_.ensure(nm));
+    HIPTRY(d_ss_.ensure(nm));
     HIPTRY(d_c3_.ensure(nm));
     HIPTRY(d_n_modes_.ensure(N));
     HIPTRY(hipMemcpy(d_ca_.p, ca.data(), nm * sizeof(float), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(d_cb_.p, cb.data(), nm * sizeof(float), hipMemcpyHostToDevice));
     HIPTRY(hipMemset(d_sq_.p, 0, nm * sizeof(float)));
     HIPTRY(hipMemset(d_sd_.p, 0, nm * sizeof(float)));
+    HIPTRY(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(d_ss_.p), 0x3F800000, nm));      // scale 1.0f: state stored unscaled
     HIPTRY(hipMemcpy(d_c3_.p, c3.data(), nm * sizeof(double), hipMemcpyHostToDevice));
     if (desc_.qnorm_mode == PBSO_QNORM_CLOSED) {
         // G = sum_{k=0}^{B-1} (A^k)' e1 e1' A^k per mode, in fp64, in the basis x = (q_k, q_k - q_{k-1})
@@ -1039,7 +1041,7 @@ int Engine::step(int nb, void *d_audio_user) {
     // ---- compute stream: K1 after its preparation (and, stream order, after the previous K1)
     HIPTRY(hipStreamWaitEvent(sk, ev_prep_done_[cur_set_], 0));
     IirParams kp;
-    kp.ca = d_ca_.p; kp.cb = d_cb_.p; kp.sq = d_sq_.p; kp.sd = d_sd_.p;
+    kp.ca = d_ca_.p; kp.cb = d_cb_.p; kp.sq = d_sq_.p; kp.sd = d_sd_.p; kp.ss = d_ss_.p;
     kp.desc = ps.d_desc.p;
     kp.grows = grows.p;
     kp.tprof = ps.d_tprof.p;
@@ -1121,14 +1123,17 @@ int Engine::read_qnorm(int obj, int buffer, float *out, int n) {
 int Engine::read_state(int obj, double *q1, double *q2, int n) {
     if (!finalized_) return fail(PBSO_ERR_STATE, "read_state before finalize");
     if (!valid_obj(obj) || n < 0 || n > m_pad_) return fail(PBSO_ERR_INVALID, "read_state arguments");
-    std::vector<float> a(n), b(n);
+    // the arrays hold (scale x state) and the scale (kernels_iir.hip, "scaled state")
+    std::vector<float> a(n), b(n), sc(n);
     HIPTRY(hipMemcpyAsync(a.data(), d_sq_.p + (size_t)obj * m_pad_, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
     HIPTRY(hipMemcpyAsync(b.data(), d_sd_.p + (size_t)obj * m_pad_, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    HIPTRY(hipMemcpyAsync(sc.data(), d_ss_.p + (size_t)obj * m_pad_, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
     int rc = sync();
     if (rc) return rc;
     for (int i = 0; i < n; ++i) {
-        q1[i] = a[i];
-        q2[i] = desc_.recurrence_form == PBSO_FORM_VELOCITY ? (double)a[i] - (double)b[i] : (double)b[i];
+        const double qa = (double)a[i] / (double)sc[i], qb = (double)b[i] / (double)sc[i];
+        q1[i] = qa;
+        q2[i] = desc_.recurrence_form == PBSO_FORM_VELOCITY ? qa - qb : qb;
     }
     return PBSO_OK;
 }

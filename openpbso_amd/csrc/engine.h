@@ -160,7 +160,7 @@ private:
     int cur_set_ = 0;
 
     // persistent device state
-    DevBuf<float> d_ca_, d_cb_, d_sq_, d_sd_;
+    DevBuf<float> d_ca_, d_cb_, d_sq_, d_sd_, d_ss_;
     DevBuf<double> d_c3_;
     struct SizeClass { int W, first, count; };           // objects that need W waves: d_obj_map_[first, first+count)
     std::vector<SizeClass> classes_;

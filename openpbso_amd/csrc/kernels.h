@@ -38,7 +38,8 @@ static_assert(sizeof(BufDesc) == 32, "BufDesc is read with one s_load_dwordx8");
 
 struct IirParams {
     const float *ca, *cb;        // [n_obj][m_pad] coefficients (form dependent)
-    float *sq, *sd;              // [n_obj][m_pad] state (form dependent)
+    float *sq, *sd;              // [n_obj][m_pad] state (form dependent), times the per-mode scale in ss
+    float *ss;                   // [n_obj][m_pad] scale carried by the stored state (1 = unscaled; kernels_iir.hip)
     const BufDesc *desc;         // [n_obj][nb]
     const float *grows;          // [n_frows][m_pad]  g = (float)(c3 * S)
     const float *tprof;          // [n_prows][b_pad]  dense force time profiles

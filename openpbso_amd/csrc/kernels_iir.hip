@@ -77,7 +77,9 @@ template <class V> struct lanes_of { static constexpr int n = 1; };
 template <> struct lanes_of<v2f> { static constexpr int n = 2; };
 
 // FMODE: 0 force-free, 1 dense time profile tp[0..TILE), 2 impulse (amp at sample 0 only)
-template <class V, int NV, int FORM, bool QN, int FMODE>
+// SCALED: the state registers hold (transfer weight x state), so the lane's output is a
+// plain sum of its modes (one add instead of a multiply + FMA per pair of modes).
+template <class V, int NV, int FORM, bool QN, int FMODE, bool SCALED>
 __device__ __forceinline__ void step_tile(V (&q)[NV], V (&d)[NV], const V (&ca)[NV], const V (&cb)[NV],
                                           const V (&g)[NV], const V (&t)[NV], V (&qn)[NV],
                                           const float *__restrict__ tp, float amp, f4 (&rv)[8],
@@ -114,8 +116,13 @@ __device__ __forceinline__ void step_tile(V (&q)[NV], V (&d)[NV], const V (&ca)[
             }
             // the lane's own modes are summed with scalar FMAs: a packed product
             // would need an extra add to fold its two halves
-            p = (v == 0) ? vget<0>(t[v]) * vget<0>(q[v]) : fmaf(vget<0>(t[v]), vget<0>(q[v]), p);
-            if (lanes_of<V>::n == 2) p = fmaf(vget<1>(t[v]), vget<1>(q[v]), p);
+            if (SCALED) {
+                p = (v == 0) ? vget<0>(q[v]) : p + vget<0>(q[v]);
+                if (lanes_of<V>::n == 2) p = p + vget<1>(q[v]);
+            } else {
+                p = (v == 0) ? vget<0>(t[v]) * vget<0>(q[v]) : fmaf(vget<0>(t[v]), vget<0>(q[v]), p);
+                if (lanes_of<V>::n == 2) p = fmaf(vget<1>(t[v]), vget<1>(q[v]), p);
+            }
             if (QN) qn[v] = vfma(q[v], q[v], qn[v]);
         }
         // LDS address = M0 (this wave's tile, set by the caller) + offset + 4 * lane
@@ -158,7 +165,7 @@ struct IirDims {
 template <class V, int NV, int FORM, int QNM, int MAXT>
 __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     const float *__restrict__ p_ca, const float *__restrict__ p_cb, float *__restrict__ p_sq,
-    float *__restrict__ p_sd, const BufDesc *__restrict__ p_desc, const float *__restrict__ p_grows,
+    float *__restrict__ p_sd, float *__restrict__ p_ss, const BufDesc *__restrict__ p_desc, const float *__restrict__ p_grows,
     const float *__restrict__ p_tprof, const double *__restrict__ p_xfer_rows,
     const int *__restrict__ p_xfer_init, float *__restrict__ p_audio, float *__restrict__ p_qnorm,
     const float *__restrict__ p_gq, const int *__restrict__ p_obj_map,
@@ -192,12 +199,59 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
         vset(g_[r / VW], r % VW, 0.f);
         vset(qn[r / VW], r % VW, 0.f);
     }
+    // Scaled state.  The output of a mode is t * q with a transfer weight t that only changes
+    // between buffers, and the recurrence is linear: the registers hold Q = t q, D = t d, the
+    // lane's output is then a plain sum, the force gain becomes t g and qnorm sqrt(sum Q^2) / t.
+    // The state arrays keep (Q, D) together with the scale they carry (p_ss; 1 = unscaled), so a
+    // launch boundary changes nothing.  A wave leaves the scaled representation (wave-uniform
+    // `scaled`) while any of its modes has a weight it cannot divide by or that would push the
+    // state out of fp32 range; it then steps exactly like the literal t * q form.  Padding
+    // oscillators (all-zero coefficients, state always 0) take weight 1.
+    bool dead[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        dead[r] = (r % VW ? vget<1>(ca[r / VW]) : vget<0>(ca[r / VW])) == 0.f && (r % VW ? vget<1>(cb[r / VW]) : vget<0>(cb[r / VW])) == 0.f;
+    bool scaled = false;
+    auto usable = [](float x) { return x >= 0x1p-20f && x <= 0x1p40f; };
+    auto elem = [](const V &v, int e) { return e ? vget<1>(v) : vget<0>(v); };
+    // move the state from scale `from` (per mode) to the weights tn, or to scale 1 if some tn is unusable
+    auto rescale = [&](const V (&from)[NV], const V (&tn)[NV]) {
+        bool ok = true, same = true, unit = true;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            ok = ok && usable(elem(tn[r / VW], r % VW));
+            same = same && elem(tn[r / VW], r % VW) == elem(from[r / VW], r % VW);
+            unit = unit && elem(from[r / VW], r % VW) == 1.f;
+        }
+        ok = __all(ok);
+        if (ok) {
+            if (!__all(same)) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float f = elem(tn[r / VW], r % VW) / elem(from[r / VW], r % VW);
+                    vset(q[r / VW], r % VW, elem(q[r / VW], r % VW) * f);
+                    vset(d[r / VW], r % VW, elem(d[r / VW], r % VW) * f);
+                }
+            }
+        } else if (!__all(unit)) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                vset(q[r / VW], r % VW, elem(q[r / VW], r % VW) / elem(from[r / VW], r % VW));
+                vset(d[r / VW], r % VW, elem(d[r / VW], r % VW) / elem(from[r / VW], r % VW));
+            }
+        }
+        scaled = ok;
+    };
     {
         const int row0 = p_xfer_init[obj];
+        V s0[NV];
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-            vset(t[r / VW], r % VW,
-                 row0 >= 0 ? (float)p_xfer_rows[(size_t)row0 * p.m_pad + tid + r * rowlen] : 1e7f);
+        for (int r = 0; r < R; ++r) {
+            vset(s0[r / VW], r % VW, p_ss[mbase + r * rowlen]);
+            const float tr = row0 >= 0 ? (float)p_xfer_rows[(size_t)row0 * p.m_pad + tid + r * rowlen] : 1e7f;
+            vset(t[r / VW], r % VW, dead[r] ? 1.f : tr);
+        }
+        rescale(s0, t);
     }
 
     V g11[NV], g12[NV], g22[NV];                     // QNM == 2: G11, 2 G12, G22 of every mode
@@ -316,15 +370,23 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
             continue;
         }
         if (trow != XFER_KEEP) {
+            V tn[NV], from[NV];
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                vset(t[r / VW], r % VW,
-                     trow >= 0 ? (float)p_xfer_rows[(size_t)trow * p.m_pad + tid + r * rowlen] : 1e7f);
+            for (int r = 0; r < R; ++r) {
+                const float tr = trow >= 0 ? (float)p_xfer_rows[(size_t)trow * p.m_pad + tid + r * rowlen] : 1e7f;
+                vset(tn[r / VW], r % VW, dead[r] ? 1.f : tr);
+                vset(from[r / VW], r % VW, scaled ? elem(t[r / VW], r % VW) : 1.f);
+            }
+            rescale(from, tn);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) t[v] = tn[v];
         }
         if (frow >= 0) {
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                vset(g_[r / VW], r % VW, p_grows[(size_t)frow * p.m_pad + tid + r * rowlen]);
+            for (int r = 0; r < R; ++r) {
+                const float gr = p_grows[(size_t)frow * p.m_pad + tid + r * rowlen];
+                vset(g_[r / VW], r % VW, scaled ? gr * elem(t[r / VW], r % VW) : gr);
+            }
         }
         const bool impulse = (flags & DESC_IMPULSE) != 0;
         const bool dense = frow >= 0 && !impulse;
@@ -377,16 +439,21 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
             }
             asm volatile("s_mov_b32 m0, %0" ::"s"(tile_m0) : "memory");
             const bool hit = frow >= 0 && ((mask >> tl) & 1u);
-            if (hit && impulse) {
-                step_tile<V, NV, FORM, QNM == 1, 2>(q, d, ca, cb, g_, t, qn, nullptr, amp, rv, rsum);
-            } else if (hit) {
-                step_tile<V, NV, FORM, QN, 1>(q, d, ca, cb, g_, t, qn, tprow + tl * TILE, 0.f, rv, rsum);
-            } else if (QNM == 2) {
-                if (accum) step_tile<V, NV, FORM, true, 0>(q, d, ca, cb, g_, t, qn, nullptr, 0.f, rv, rsum);
-                else step_tile<V, NV, FORM, false, 0>(q, d, ca, cb, g_, t, qn, nullptr, 0.f, rv, rsum);
-            } else {
-                step_tile<V, NV, FORM, QN, 0>(q, d, ca, cb, g_, t, qn, nullptr, 0.f, rv, rsum);
-            }
+            auto run_tile = [&](auto sc) {
+                constexpr bool SC = decltype(sc)::value;
+                if (hit && impulse) {
+                    step_tile<V, NV, FORM, QNM == 1, 2, SC>(q, d, ca, cb, g_, t, qn, nullptr, amp, rv, rsum);
+                } else if (hit) {
+                    step_tile<V, NV, FORM, QN, 1, SC>(q, d, ca, cb, g_, t, qn, tprow + tl * TILE, 0.f, rv, rsum);
+                } else if (QNM == 2) {
+                    if (accum) step_tile<V, NV, FORM, true, 0, SC>(q, d, ca, cb, g_, t, qn, nullptr, 0.f, rv, rsum);
+                    else step_tile<V, NV, FORM, false, 0, SC>(q, d, ca, cb, g_, t, qn, nullptr, 0.f, rv, rsum);
+                } else {
+                    step_tile<V, NV, FORM, QN, 0, SC>(q, d, ca, cb, g_, t, qn, nullptr, 0.f, rv, rsum);
+                }
+            };
+            if (scaled) run_tile(std::true_type{});
+            else run_tile(std::false_type{});
 
             if (have_prev) retire(rsum);
             have_prev = true;
@@ -402,7 +469,8 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
             for (int r = 0; r < R; ++r) {
                 const float e0 = vget<0>(qn[r / VW]), e1 = vget<1>(qn[r / VW]);
                 // (the closed form can round a tiny sum below zero)
-                p_qnorm[((size_t)obj * p.nb + b) * p.m_pad + tid + r * rowlen] = sqrtf(fmaxf(r % VW ? e1 : e0, 0.f));
+                const float nrm = sqrtf(fmaxf(r % VW ? e1 : e0, 0.f));
+                p_qnorm[((size_t)obj * p.nb + b) * p.m_pad + tid + r * rowlen] = scaled ? nrm / elem(t[r / VW], r % VW) : nrm;
             }
         }
     }
@@ -421,6 +489,7 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     for (int r = 0; r < R; ++r) {
         p_sq[mbase + r * rowlen] = r % VW ? vget<1>(q[r / VW]) : vget<0>(q[r / VW]);
         p_sd[mbase + r * rowlen] = r % VW ? vget<1>(d[r / VW]) : vget<0>(d[r / VW]);
+        p_ss[mbase + r * rowlen] = scaled ? elem(t[r / VW], r % VW) : 1.f;
     }
 }
 
@@ -439,7 +508,7 @@ static int launch_one(const IirParams &p, int n_obj, int W, hipStream_t stream) 
         if (e != hipSuccess) return (int)e;
     }
     const IirDims dims = {p.nb, p.n_tiles, p.m_pad, p.b_pad, p.audio_stride, p.rotate_prio, p.gq_plane};
-    hipLaunchKernelGGL(kern, dim3(n_obj), dim3(64 * W), lds, stream, p.ca, p.cb, p.sq, p.sd, p.desc,
+    hipLaunchKernelGGL(kern, dim3(n_obj), dim3(64 * W), lds, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc,
                        p.grows, p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.obj_map, p.census, dims);
     return (int)hipGetLastError();
 }

@@ -279,6 +279,42 @@ def test_config3_moving_listener_ffat():
         assert np.array_equal(a, w)
 
 
+def test_transfer_weights_outside_the_scaled_state_range():
+    """The oscillator kernel keeps (transfer weight x state) in registers while every weight of a wave
+    is in [2^-20, 2^40] and falls back to the literal t*q form otherwise (kernels_iir.hip, "scaled
+    state").  Zero, tiny and huge FFAT values on some modes, on some cube faces only, force the
+    fallback and both transitions while the listener moves; results must not depend on it."""
+    n_modes, nb = 192, 14
+    lam = synth.eigenvalues(n_modes, 77)
+    maps = synth.ffat_maps(lam, 77)
+    n_face = len(maps[0]["psi"]) // 6
+    for m in maps:
+        m["psi"] = np.array(m["psi"], dtype=np.float64)
+    maps[3]["psi"][:] = 0.0                                  # weight 0 everywhere: wave 0 never scales
+    maps[70]["psi"][:2 * n_face] = 0.0                       # weight 0 through the +-x faces only
+    maps[71]["psi"][2 * n_face:4 * n_face] *= 1e-16          # tiny through +-y
+    maps[140]["psi"][4 * n_face:] *= 1e9                     # huge through +-z
+    rng = np.random.default_rng(77)
+    # listener hops between faces: +x, +y, +z, -x, ... (off-axis so that no direction component is 0)
+    dirs = np.array([[1, .2, .3], [.2, 1, .3], [.2, .3, 1], [-1, .2, .3], [.3, -1, .2], [.2, .3, -1]], dtype=float)
+    evs = [force_ev(0, 0, data=rng.standard_normal(n_modes) * 1e-3),
+           force_ev(5, 0, data=rng.standard_normal(n_modes) * 1e-3, force_type=1, width=600.0)]
+    evs += [dict(t=b, obj=0, kind="listener", pos=0.6 * dirs[b % 6] / np.linalg.norm(dirs[b % 6])) for b in range(nb)]
+    objs = [ObjSpec(lam, maps=maps)]
+    want = run_oracle(objs, evs, nb)
+    lt = want["latest"][0]
+    assert lt[3] == 0.0 and min(lt[71], lt[140]) >= 0.0 and (lt < 2.0 ** -20).any()     # the fallback is exercised
+    for split, mpl in ((None, 0), ([3, 1, 4, 6], 1), ([2, 12], 2)):
+        got = run_engine(objs, evs, nb, split=split, modes_per_lane=mpl)
+        _check(got, want)
+        assert np.array_equal(got["latest"][0], want["latest"][0])
+        for b in range(nb):
+            w = want["qnorm"][(0, b)]
+            assert np.abs(got["qnorm"][(0, b)] - w).max() <= 2e-3 * max(np.abs(w).max(), 1e-30)
+        q1, q2 = got["state"][0]
+        np.testing.assert_allclose(q1, want["state"][0][0], rtol=0, atol=2e-3 * np.abs(want["state"][0][0]).max())
+
+
 def test_transfer_queue_and_use_transfer_toggle():
     """1-slot transfer queue: with useTransfer off the queued update waits;
     latest falls back to the 1e7 unit; back on, the queued one is taken."""
