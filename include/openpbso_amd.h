@@ -176,6 +176,12 @@ typedef struct pbso_force_msg {
 /* ModalSolver::enqueueForceMessage (modal_solver.h:329-333): 1 = enqueued,
  * 0 = the 1023-slot queue is full.                                            */
 int pbso_enqueue_force(pbso_engine *e, int object_id, const pbso_force_msg *m, int64_t not_before);
+/* The same for a pre-scheduled force script (the throughput harness drives the
+ * engine from a script instead of a GUI thread): n messages, message i for object_ids[i] with
+ * stamp not_before[i], enqueued in order.  accepted[i] (may be NULL) receives each call's
+ * result; returns the number enqueued, or a negative pbso_status on the first hard error.     */
+int pbso_enqueue_force_batch(pbso_engine *e, int n, const int *object_ids, const pbso_force_msg *msgs,
+                             const int64_t *not_before, unsigned char *accepted);
 /* ModalSolver::enqueueArprmMessageNoFail (modal_solver.h:382-393); 1-slot queue */
 int pbso_enqueue_arprm(pbso_engine *e, int object_id, const double a[2], double sigma,
                        double mu, int64_t not_before);

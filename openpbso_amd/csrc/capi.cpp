@@ -247,6 +247,22 @@ int pbso_enqueue_force(pbso_engine *e, int obj, const pbso_force_msg *m, int64_t
     GUARD_END(e)
 }
 
+int pbso_enqueue_force_batch(pbso_engine *e, int n, const int *objs, const pbso_force_msg *msgs,
+                             const int64_t *nb, unsigned char *accepted) {
+    NEED(e);
+    if (n < 0 || (n && (!objs || !msgs || !nb))) return PBSO_ERR_INVALID;
+    GUARD_BEGIN
+    int taken = 0;
+    for (int i = 0; i < n; ++i) {
+        const int rc = e->impl->enqueue_force(objs[i], msgs[i], nb[i]);
+        if (rc < 0) return rc;
+        if (accepted) accepted[i] = rc ? 1 : 0;
+        taken += rc ? 1 : 0;
+    }
+    return taken;
+    GUARD_END(e)
+}
+
 int pbso_enqueue_arprm(pbso_engine *e, int obj, const double a[2], double sigma, double mu, int64_t nb) {
     NEED(e);
     if (!a) return PBSO_ERR_INVALID;

@@ -28,6 +28,16 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+# numpy view of capi.ForceMsg (same layout: checked at import)
+FORCE_MSG_DTYPE = np.dtype([("force_type", np.int32), ("gaussian_width_us", np.float64),
+                            ("sustained_force_start", np.int32), ("sustained_force_end", np.int32),
+                            ("clear_all_forces", np.int32), ("data_kind", np.int32), ("data", np.uintp),
+                            ("n_data", np.int32), ("vids", np.int32, 3), ("coords", np.float64, 3),
+                            ("vn", np.float64, 3)], align=True)
+assert FORCE_MSG_DTYPE.itemsize == C.sizeof(capi.ForceMsg) and all(
+    FORCE_MSG_DTYPE.fields[n][1] == getattr(capi.ForceMsg, n).offset for n, _ in capi.ForceMsg._fields_)
+
+
 class ForceMessage:
     """ForceMessage<double> (modal_solver.h:27-77).
 
@@ -184,6 +194,33 @@ class Engine:
     # -- messages -------------------------------------------------------------
     def enqueue_force(self, obj, msg, not_before=0):
         return bool(self._chk(self._l.pbso_enqueue_force(self._h, obj, C.byref(msg.to_c()), not_before)))
+
+    @staticmethod
+    def hit_messages(objs, vids, vns, not_before, coords=None, force_type=capi.POINT_FORCE):
+        """(object ids, pbso_force_msg array, stamps) ready for enqueue_force_batch.  Vertex hits
+        (GetModalForceVertex): vids [n]; face hits (GetModalForceFace): vids [n][3] and barycentric
+        coords [n][3]; vns [n][3]; objs / not_before int arrays [n]."""
+        objs = np.ascontiguousarray(objs, dtype=np.int32)
+        stamps = np.ascontiguousarray(not_before, dtype=np.int64)
+        n = objs.size
+        msgs = np.zeros(n, dtype=FORCE_MSG_DTYPE)
+        msgs["force_type"] = force_type
+        if coords is None:
+            msgs["data_kind"] = capi.DATA_VERTEX
+            msgs["vids"][:, 0] = vids
+        else:
+            msgs["data_kind"] = capi.DATA_FACE
+            msgs["vids"] = np.asarray(vids).reshape(n, 3)
+            msgs["coords"] = np.asarray(coords, dtype=np.float64).reshape(n, 3)
+        msgs["vn"] = np.asarray(vns, dtype=np.float64).reshape(n, 3)
+        return objs, msgs, stamps
+
+    def enqueue_force_batch(self, objs, msgs, not_before):
+        """pbso_enqueue_force_batch: one call for a whole step of the force script; returns the
+        number of messages the queues took."""
+        return self._chk(self._l.pbso_enqueue_force_batch(
+            self._h, objs.size, objs.ctypes.data_as(C.POINTER(C.c_int)), msgs.ctypes.data_as(C.POINTER(capi.ForceMsg)),
+            not_before.ctypes.data_as(C.POINTER(C.c_int64)), None))
 
     def enqueue_arprm(self, obj, a, sigma, mu, not_before=0):
         a = np.ascontiguousarray(a, dtype=np.float64)

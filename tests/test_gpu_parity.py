@@ -11,7 +11,7 @@ fp64 helper kernels (projection, FFAT lookup) are bit-exact and tested as such.
 import numpy as np
 import pytest
 
-from openpbso_amd import capi, synth
+from openpbso_amd import ForceMessage, capi, synth
 from tests.scenarios import B, ObjSpec, force_ev, rel_errors, run_engine, run_oracle
 
 pytestmark = pytest.mark.gpu
@@ -313,6 +313,58 @@ def test_transfer_weights_outside_the_scaled_state_range():
             assert np.abs(got["qnorm"][(0, b)] - w).max() <= 2e-3 * max(np.abs(w).max(), 1e-30)
         q1, q2 = got["state"][0]
         np.testing.assert_allclose(q1, want["state"][0][0], rtol=0, atol=2e-3 * np.abs(want["state"][0][0]).max())
+
+
+def test_force_script_batch_enqueue_matches_single_calls():
+    """pbso_enqueue_force_batch (one call per step of a pre-scheduled script) == the same messages
+    through pbso_enqueue_force, bit for bit; vertex and face hits; queue-full results reported."""
+    from openpbso_amd import Engine
+    n_obj, n_modes, nb = 5, 96, 12
+    rng = np.random.default_rng(31)
+    lams = [synth.eigenvalues(n_modes, 300 + i) for i in range(n_obj)]
+    shapes = [synth.mode_shapes(n_modes, 300 + i) for i in range(n_obj)]
+    n = 40
+    objs = rng.integers(0, n_obj, n)
+    stamps = np.sort(rng.integers(0, nb, n))
+    vids = rng.integers(0, synth.N_VERTS, (n, 3))
+    bary = rng.random((n, 3))
+    bary /= bary.sum(axis=1, keepdims=True)
+    vns = synth.unit_normals(n, 31)
+
+    def run(batch, face):
+        eng = Engine()
+        try:
+            for i in range(n_obj):
+                eng.add_object(lams[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
+            eng.finalize()
+            for i in range(n_obj):
+                eng.set_use_transfer(i, False)
+            if batch:
+                args = Engine.hit_messages(objs, vids if face else vids[:, 0], vns, stamps, coords=bary if face else None)
+                assert eng.enqueue_force_batch(*args) == n
+            else:
+                for j in range(n):
+                    m = ForceMessage(vids=vids[j], coords=bary[j], vn=vns[j]) if face else ForceMessage(vid=int(vids[j, 0]), vn=vns[j])
+                    assert eng.enqueue_force(int(objs[j]), m, int(stamps[j]))
+            eng.step(nb)
+            return eng.audio().copy()
+        finally:
+            eng.close()
+
+    for face in (False, True):
+        a, b = run(False, face), run(True, face)
+        assert np.abs(a).max() > 0 and np.array_equal(a, b)
+
+    # a full queue: the batch call reports how many messages were taken (modal_solver.h:329-333)
+    eng = Engine()
+    try:
+        eng.add_object(lams[0], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[0])
+        eng.finalize()
+        k = 1100
+        args = Engine.hit_messages(np.zeros(k, dtype=np.int32), np.zeros(k, dtype=np.int32), np.tile(vns[0], (k, 1)), np.arange(k))
+        assert eng.enqueue_force_batch(*args) == 1023
+    finally:
+        eng.close()
 
 
 def test_transfer_queue_and_use_transfer_toggle():
