@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--settle", type=int, default=60,
+    ap.add_argument("--settle", type=int, default=30,
                     help="untimed steps run before the warm-up so that the shader clock has ramped (the first ~70 ms "
                          "after idle run 10 %% slower, profiles/r01_clock_ramp.txt); reported as settle_steps")
     ap.add_argument("--objects", type=int, default=1024, help="objects per GPU")
@@ -64,7 +64,7 @@ def build_inputs(args, rank):
     """Deterministic per-rank inputs: eigenvalues, mode shapes, hit script."""
     from openpbso_amd import synth
     n_obj, M = args.objects, args.modes
-    total_buffers = (args.steps + args.warmup) * args.buffers
+    total_buffers = (args.steps + args.warmup + args.settle) * args.buffers
     lam = np.empty((n_obj, M))
     shapes = []
     scripts = []
@@ -176,13 +176,11 @@ def main():
     eng.finalize()
     n_hits = 0
     feed_obj, feed_vid, feed_vn, feed_t, feed_bary = [], [], [], [], []
-    total_buffers = (args.steps + args.warmup) * args.buffers
-    # the scripts start after the clock-settle steps; one hit at buffer 0 keeps the settle steps ringing
-    off = args.settle * args.buffers
+    n_steps_all = args.settle + args.warmup + args.steps      # the clock-settle steps run the same script
+    total_buffers = n_steps_all * args.buffers
+    off = 0
     for i in range(args.objects):
         hits, vns = scripts[i]
-        if off and args.scenario != "scraping":
-            assert eng.enqueue_force(i, ForceMessage(vid=0, vn=vns[0]), 0)
         if args.scenario == "scraping":
             # tools/...:754-776 + :1127-1160: dummy start message, then one GetModalForceFace per frame
             eng.set_use_transfer(i, False)
@@ -213,7 +211,7 @@ def main():
     # the hit script is fed one step ahead with ONE pbso_enqueue_force_batch call per step (the
     # reference's force queue holds 1023 messages per object, modal_solver.h:105, so a long run
     # cannot be queued up front); message arrays are built here, outside the timed region
-    feeds = [None] * (args.warmup + args.steps)
+    feeds = [None] * n_steps_all
     if feed_obj:
         fo, fv, fn, ft = (np.concatenate(x) for x in (feed_obj, feed_vid, feed_vn, feed_t))
         fb = np.concatenate(feed_bary) if feed_bary else None
@@ -221,8 +219,8 @@ def main():
         order = np.lexsort((fo, ft))                 # time-major: per object the stamps stay ascending
         fo, fv, fn, ft, step_of = fo[order], fv[order], fn[order], ft[order], step_of[order]
         fb = fb[order] if fb is not None else None
-        bounds = np.searchsorted(step_of, np.arange(args.warmup + args.steps + 1))
-        for k in range(args.warmup + args.steps):
+        bounds = np.searchsorted(step_of, np.arange(n_steps_all + 1))
+        for k in range(n_steps_all):
             a, b = bounds[k], bounds[k + 1]
             feeds[k] = eng.hit_messages(fo[a:b], fv[a:b], fn[a:b], ft[a:b] + off, coords=None if fb is None else fb[a:b],
                                         force_type=capi.AUTOREGRESSIVE_FORCE if args.scenario == "scraping" else capi.POINT_FORCE)
@@ -246,9 +244,7 @@ def main():
             else:
                 gathered.copy_(gather_audio(audio.cpu()))
 
-    for _ in range(args.settle):
-        one_step()
-    for k in range(args.warmup):
+    for k in range(args.settle + args.warmup):
         one_step(k)
     torch.cuda.synchronize()
     info0 = eng.info()
@@ -258,7 +254,7 @@ def main():
     enqueue_s[0] = 0.0
     t0 = time.perf_counter()
     for k in range(args.steps):
-        one_step(args.warmup + k)
+        one_step(args.settle + args.warmup + k)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
