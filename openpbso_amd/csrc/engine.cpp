@@ -173,7 +173,7 @@ int Engine::init() {
     if (desc_.frames_per_buffer > 0) B_ = desc_.frames_per_buffer;
     if (desc_.sample_rate > 0) rate_ = desc_.sample_rate;
     if (B_ % TILE != 0 || B_ / TILE > MAX_TILES)
-        return fail(PBSO_ERR_INVALID, "frames_per_buffer must be a multiple of 57 (<= 1824); the reference uses 513");
+        return fail(PBSO_ERR_INVALID, "frames_per_buffer must be a multiple of the 27-sample tile (at most 32 tiles); the reference uses 513");
     n_tiles_ = B_ / TILE;
     b_pad_ = (B_ + 15) / 16 * 16;
     if (desc_.recurrence_form != PBSO_FORM_VELOCITY && desc_.recurrence_form != PBSO_FORM_DIRECT)

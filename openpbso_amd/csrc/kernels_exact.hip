@@ -222,17 +222,60 @@ __global__ __launch_bounds__(64) void force_profile_kernel(
                     xb = mulmod31(xb, q64);
                 }
                 __syncthreads();
-                // ---- AR(2), strictly sequential (forces.h:107-117): lane 0
+                // ---- AR(2), strictly sequential (forces.h:107-117): lane 0.  The products
+                // sigma * n_k are formed lane-parallel first (the same rounded product the loop would
+                // add); the serial part then runs in blocks of 8 with the next block's inputs already
+                // in registers, so only the four dependent fp64 operations of a step remain on the
+                // critical path (LDS latency and the _buf index arithmetic are off it).
+                for (int ii = lane; ii < frames; ii += 64) nrm[ii] = s.sigma * nrm[ii];
+                __syncthreads();
                 if (lane == 0) {
                     double b0 = s.buf[0], b1 = s.buf[1], b2 = s.buf[2];
                     int idx = s.buf_idx;
-                    for (int ii = 0; ii < frames; ++ii) {
-                        const double p1 = idx == 0 ? b2 : (idx == 1 ? b0 : b1);   // _buf[(idx + 3 - 1) % 3]
-                        const double p2 = idx == 0 ? b1 : (idx == 1 ? b2 : b0);   // _buf[(idx + 3 - 2) % 3]
+                    int ii = 0;
+                    if (frames >= 8) {
+                        double p1 = idx == 0 ? b2 : (idx == 1 ? b0 : b1);       // _buf[(idx + 3 - 1) % 3]
+                        double p2 = idx == 0 ? b1 : (idx == 1 ? b2 : b0);       // _buf[(idx + 3 - 2) % 3]
+                        double p3 = 0.0;
+                        double cur[8], nxt[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) cur[j] = nrm[j];
+                        for (; ii + 8 <= frames; ii += 8) {
+                            const bool more = ii + 16 <= frames;
+                            if (more) {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) nxt[j] = nrm[ii + 8 + j];
+                            }
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                double mu_tilde = 0.0;
+                                mu_tilde += s.a[0] * p1;
+                                mu_tilde += s.a[1] * p2;
+                                mu_tilde += cur[j];
+                                p3 = p2; p2 = p1; p1 = mu_tilde;
+                                cur[j] = mu_tilde;
+                            }
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) nrm[ii + j] = cur[j];
+                            if (more) {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) cur[j] = nxt[j];
+                            }
+                        }
+                        // value k of this row went to _buf[(idx + k) % 3]: the last three, back in place
+                        const int s1 = (idx + ii - 1) % 3, s2 = (idx + ii - 2) % 3, s3 = (idx + ii - 3) % 3;
+                        if (s1 == 0) b0 = p1; else if (s1 == 1) b1 = p1; else b2 = p1;
+                        if (s2 == 0) b0 = p2; else if (s2 == 1) b1 = p2; else b2 = p2;
+                        if (s3 == 0) b0 = p3; else if (s3 == 1) b1 = p3; else b2 = p3;
+                        idx = (idx + ii) % 3;
+                    }
+                    for (; ii < frames; ++ii) {
+                        const double p1 = idx == 0 ? b2 : (idx == 1 ? b0 : b1);
+                        const double p2 = idx == 0 ? b1 : (idx == 1 ? b2 : b0);
                         double mu_tilde = 0.0;
                         mu_tilde += s.a[0] * p1;
                         mu_tilde += s.a[1] * p2;
-                        mu_tilde += s.sigma * nrm[ii];
+                        mu_tilde += nrm[ii];
                         if (idx == 0) b0 = mu_tilde; else if (idx == 1) b1 = mu_tilde; else b2 = mu_tilde;
                         idx = idx == 2 ? 0 : idx + 1;
                         nrm[ii] = mu_tilde;
