@@ -227,7 +227,7 @@ typedef struct pbso_engine_info {
     int frames_per_buffer;
     int modes_padded;         /* oscillators per object after padding */
     int modes_per_lane;
-    int waves_per_object;
+    int waves_per_object;     /* largest team (workgroup) in waves */
     int lds_bytes_per_workgroup;
     int64_t buffers_done;
     double last_step_kernel_ms;       /* HIP-event time of the oscillator-bank kernel, last step */
@@ -241,6 +241,8 @@ typedef struct pbso_engine_info {
     double total_device_ms;
     double total_host_plan_ms;
     int64_t total_steps;
+    int n_teams;              /* workgroups of the oscillator bank per launch (objects with more than
+                               * 16 waves of modes are stepped by several) */
 } pbso_engine_info;
 int pbso_get_info(pbso_engine *e, pbso_engine_info *out);
 /* diagnostics (engine created with env PBSO_CENSUS=1): for every object's

@@ -65,7 +65,7 @@ class EngineInfo(C.Structure):
                 ("last_step_host_plan_ms", C.c_double), ("last_step_forced_rows", C.c_int64),
                 ("last_step_transfer_rows", C.c_int64),
                 ("total_kernel_ms", C.c_double), ("total_device_ms", C.c_double),
-                ("total_host_plan_ms", C.c_double), ("total_steps", C.c_int64)]
+                ("total_host_plan_ms", C.c_double), ("total_steps", C.c_int64), ("n_teams", C.c_int)]
 
 
 _lib = None

@@ -134,7 +134,7 @@ Engine::~Engine() {
     d_ca_.release(); d_cb_.release(); d_sq_.release(); d_sd_.release(); d_ss_.release(); d_c3_.release(); d_gq_.release();
     d_shapes_.release(); d_shape_off_.release(); d_n_modes_.release(); d_geom_.release();
     d_geom_off_.release(); d_psi_.release(); d_slots_.release(); d_xfer_.release();
-    d_arstate_.release(); d_obj_map_.release();
+    d_arstate_.release(); d_teams_.release(); d_split_.release(); d_audio_parts_.release();
     d_audio_.release(); d_qnorm_.release(); d_grows_[0].release(); d_grows_[1].release(); d_census_.release();
     for (hipEvent_t ev : {ev_prep_done_[0], ev_prep_done_[1], ev_k1_done_[0], ev_k1_done_[1]})
         if (ev) (void)hipEventDestroy(ev);
@@ -299,46 +299,54 @@ int Engine::finalize() {
     if (finalized_) return fail(PBSO_ERR_STATE, "finalize called twice");
     if (objs_.empty()) return fail(PBSO_ERR_STATE, "no objects");
     const int N = (int)objs_.size();
-    int mmax = 1;
-    for (const Object &o : objs_) mmax = std::max(mmax, o.n_modes);
-    // team shape: R oscillators per lane, W waves per object.  The VALU issue
-    // rate needs ~4 waves per SIMD (4096 on the chip, profiles/r01_microbench.txt):
-    // take the largest R that still gives that many waves, else the most waves.
-    const int maxW = MAX_WAVES_PER_OBJECT;
+    // Team shape: R oscillators per lane; an object of n modes needs ceil(n / 64R) waves, cut into
+    // teams (workgroups) of at most MAX_WAVES_PER_TEAM waves.  The VALU issue rate needs ~4 waves per
+    // SIMD (4096 on the chip, profiles/r01_microbench.txt): take the largest R that still gives that
+    // many waves; below that the launch is latency-bound and one mode per lane spreads it widest.
     int R = desc_.modes_per_lane;
     if (R != 0 && R != 1 && R != 2 && R != 4 && R != 8) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,4,8");
-    auto waves_for = [&](int r) { return (mmax + 64 * r - 1) / (64 * r); };
-    auto shape_ok = [&](int r) { return waves_for(r) <= maxW; };
-    auto total_waves = [&](int r) {          // every object gets the team its own size needs
+    auto waves_of = [&](const Object &o, int r) { return std::max(1, (o.n_modes + 64 * r - 1) / (64 * r)); };
+    auto total_waves = [&](int r) {
         long long w = 0;
-        for (const Object &o : objs_) w += std::max(1, (o.n_modes + 64 * r - 1) / (64 * r));
+        for (const Object &o : objs_) w += waves_of(o, r);
         return w;
     };
     if (R == 0) {
-        for (int r : {4, 2, 1}) {
-            if (shape_ok(r) && total_waves(r) >= 4096) { R = r; break; }
-        }
-        if (R == 0)
-            for (int r : {1, 2, 4, 8})      // else: the most waves a supported shape gives
-                if (shape_ok(r)) { R = r; break; }
-        if (R == 0) return fail(PBSO_ERR_INVALID, "object too large: more than 8192 modes per object not supported yet");
-    } else if (!shape_ok(R)) {
-        return fail(PBSO_ERR_INVALID, "modes_per_lane too small for this object size (at most 16 waves per object)");
+        R = 1;
+        for (int r : {4, 2})
+            if (total_waves(r) >= 4096) { R = r; break; }
     }
-    int W = waves_for(R);
-    if (W > maxW) return fail(PBSO_ERR_INVALID, "object too large: more than 8192 modes per object not supported yet");
+    int wmax = 1;
+    for (const Object &o : objs_) wmax = std::max(wmax, waves_of(o, R));
     R_ = R;
-    W_ = W;
-    m_pad_ = 64 * R * W;
-    // size classes: objects whose own size needs the same number of waves share one launch of
-    // the oscillator bank (the SoA rows stay m_pad wide; a smaller team touches their head only)
+    m_pad_ = 64 * R * wmax;
+    // teams, grouped into size classes (one launch of the oscillator bank per team size, largest
+    // first); the SoA rows stay m_pad wide and a team touches its own columns only
     {
-        std::vector<std::vector<int>> by_w(W + 1);
-        for (int i = 0; i < N; ++i)
-            by_w[std::max(1, (objs_[i].n_modes + 64 * R - 1) / (64 * R))].push_back(i);
+        std::vector<std::vector<TeamDesc>> by_w(MAX_WAVES_PER_TEAM + 1);
+        std::vector<SplitObj> split;
+        n_part_rows_ = 0;
+        W_ = 1;
+        for (int i = 0; i < N; ++i) {
+            const int w = waves_of(objs_[i], R);
+            const int parts = (w + MAX_WAVES_PER_TEAM - 1) / MAX_WAVES_PER_TEAM;
+            const int base = w / parts, rem = w % parts;
+            int w0 = 0;
+            if (parts > 1) {
+                SplitObj so = {i, n_part_rows_, parts, 0};
+                split.push_back(so);
+            }
+            for (int pi = 0; pi < parts; ++pi) {
+                const int wp = base + (pi < rem ? 1 : 0);
+                TeamDesc td = {i, 64 * R * w0, parts > 1 ? n_part_rows_++ : -1, 0};
+                by_w[wp].push_back(td);
+                W_ = std::max(W_, wp);
+                w0 += wp;
+            }
+        }
         classes_.clear();
-        std::vector<int> flat;
-        for (int w = W; w >= 1; --w) {                  // largest teams first
+        std::vector<TeamDesc> flat;
+        for (int w = MAX_WAVES_PER_TEAM; w >= 1; --w) {
             if (by_w[w].empty()) continue;
             SizeClass c;
             c.W = w;
@@ -347,8 +355,15 @@ int Engine::finalize() {
             flat.insert(flat.end(), by_w[w].begin(), by_w[w].end());
             classes_.push_back(c);
         }
-        HIPTRY(d_obj_map_.ensure(flat.size()));
-        HIPTRY(hipMemcpy(d_obj_map_.p, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));
+        for (size_t k = 0; k < flat.size(); ++k) flat[k].id = (int)k;
+        n_teams_ = (int)flat.size();
+        n_split_ = (int)split.size();
+        HIPTRY(d_teams_.ensure(flat.size()));
+        HIPTRY(hipMemcpy(d_teams_.p, flat.data(), flat.size() * sizeof(TeamDesc), hipMemcpyHostToDevice));
+        if (n_split_) {
+            HIPTRY(d_split_.ensure(split.size()));
+            HIPTRY(hipMemcpy(d_split_.p, split.data(), split.size() * sizeof(SplitObj), hipMemcpyHostToDevice));
+        }
     }
 
     const size_t nm = (size_t)N * m_pad_;
@@ -1053,21 +1068,27 @@ int Engine::step(int nb, void *d_audio_user) {
     kp.gq_plane = (long long)N * m_pad_;
     kp.census = nullptr;
     if (census_) {
-        HIPTRY(d_census_.ensure((size_t)N * 6, false, sk));
+        HIPTRY(d_census_.ensure((size_t)n_teams_ * 6, false, sk));
         kp.census = d_census_.p;
     }
     kp.nb = nb; kp.n_tiles = n_tiles_; kp.m_pad = m_pad_; kp.b_pad = b_pad_;
     kp.audio_stride = (long long)nb * B_;
     kp.rotate_prio = rotate_prio_ ? 1 : 0;
     HIPTRY(hipEventRecord(evq.k0, sk));
+    kp.audio_parts = nullptr;
+    if (n_part_rows_) {
+        HIPTRY(d_audio_parts_.ensure((size_t)n_part_rows_ * nb * B_, false, sk));
+        kp.audio_parts = d_audio_parts_.p;
+    }
     for (const SizeClass &c : classes_) {
-        kp.obj_map = d_obj_map_.p + c.first;
+        kp.teams = d_teams_.p + c.first;
         if (packed_ && R_ >= 2)
             LAUNCHTRY(iir_packed::launch_iir_bank(kp, c.count, R_, c.W, desc_.recurrence_form, desc_.qnorm_mode, sk));
         else
             LAUNCHTRY(iir_scalar::launch_iir_bank(kp, c.count, R_, c.W, desc_.recurrence_form, desc_.qnorm_mode, sk));
     }
     HIPTRY(hipEventRecord(evq.k1, sk));
+    LAUNCHTRY(launch_sum_parts(d_split_.p, n_split_, d_audio_parts_.p, audio, (long long)nb * B_, sk));
     // _latest_transfer = trans (modal_solver.h:251), then re-park a still-queued transfer
     LAUNCHTRY(launch_copy_rows(ps.d_copy.p, ps.d_copy.p + (n_cl + n_cq), n_cl, d_xfer_.p, m_pad_, sk));
     LAUNCHTRY(launch_copy_rows(ps.d_copy.p + n_cl, ps.d_copy.p + (n_cl + n_cq) + n_cl, n_cq, d_xfer_.p, m_pad_, sk));
@@ -1100,7 +1121,7 @@ int Engine::read_audio(float *out, size_t n) {
 
 int Engine::read_census(unsigned long long *out, size_t n) {
     if (!census_ || !d_census_.p) return fail(PBSO_ERR_STATE, "census not enabled (PBSO_CENSUS=1) or no step yet");
-    if (n != (size_t)objs_.size() * 6) return fail(PBSO_ERR_INVALID, "read_census size mismatch");
+    if (n != (size_t)n_teams_ * 6) return fail(PBSO_ERR_INVALID, "read_census size mismatch (6 words per team)");
     HIPTRY(hipMemcpyAsync(out, d_census_.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
     return sync();
 }
@@ -1200,6 +1221,7 @@ int Engine::info(pbso_engine_info *out) {
     out->modes_padded = m_pad_;
     out->modes_per_lane = R_;
     out->waves_per_object = W_;
+    out->n_teams = n_teams_;
     out->lds_bytes_per_workgroup = finalized_ ? (int)iir_lds_bytes(W_, n_tiles_) : 0;
     out->buffers_done = buffers_done_;
     out->last_step_host_plan_ms = last_plan_ms_;

@@ -162,9 +162,12 @@ private:
     // persistent device state
     DevBuf<float> d_ca_, d_cb_, d_sq_, d_sd_, d_ss_;
     DevBuf<double> d_c3_;
-    struct SizeClass { int W, first, count; };           // objects that need W waves: d_obj_map_[first, first+count)
+    struct SizeClass { int W, first, count; };           // teams of W waves: d_teams_[first, first+count)
     std::vector<SizeClass> classes_;
-    DevBuf<int> d_obj_map_;
+    DevBuf<TeamDesc> d_teams_;
+    DevBuf<SplitObj> d_split_;                           // objects stepped by more than one team
+    DevBuf<float> d_audio_parts_;                        // [n_part_rows_][nb * B] their partial sample sums
+    int n_teams_ = 0, n_split_ = 0, n_part_rows_ = 0;
     DevBuf<float> d_gq_;                                 // closed-form qnorm: G11, 2 G12, G22 planes
     DevBuf<double> d_shapes_;
     DevBuf<long long> d_shape_off_;

@@ -36,6 +36,18 @@ struct BufDesc {
 };
 static_assert(sizeof(BufDesc) == 32, "BufDesc is read with one s_load_dwordx8");
 
+// One workgroup ("team") of the oscillator bank: W waves stepping the columns
+// [col0, col0 + 64 W R) of one object's SoA rows.  Objects that need more than
+// MAX_WAVES_PER_OBJECT waves -- or that are worth spreading over several CUs -- are cut into
+// several teams; each then writes its partial per-sample sums to row `part_row` of
+// IirParams::audio_parts and sum_parts_kernel adds the rows in a fixed order.
+struct TeamDesc {
+    int obj;
+    int col0;
+    int part_row;                // -1: the team is the whole object and writes the audio itself
+    int id;                      // global team index (census)
+};
+
 struct IirParams {
     const float *ca, *cb;        // [n_obj][m_pad] coefficients (form dependent)
     float *sq, *sd;              // [n_obj][m_pad] state (form dependent), times the per-mode scale in ss
@@ -45,12 +57,13 @@ struct IirParams {
     const float *tprof;          // [n_prows][b_pad]  dense force time profiles
     const double *xfer_rows;     // [n_rows][m_pad]   FFAT transfer rows (fp64)
     const int *xfer_init;        // [n_obj] row (or XFER_UNIT) in effect when the launch starts
-    const int *obj_map;          // [grid] workgroup -> object id (one launch per size class)
+    const TeamDesc *teams;       // [grid] workgroup -> (object, first column, output row); one launch per team size
+    float *audio_parts;          // [n_part_rows][audio_stride] partial sums of objects split over several teams
     float *audio;                // [n_obj][audio_stride]
     float *qnorm;                // [n_obj][nb][m_pad] or nullptr
     const float *gq;             // closed-form qnorm: planes G11, 2*G12, G22, each [n_obj][m_pad]; or nullptr
     long long gq_plane;          // elements per plane
-    unsigned long long *census;  // diagnostics: [n_obj][6] = start, end (100 MHz), HW_ID, XCC_ID, clk0, clk1; or nullptr
+    unsigned long long *census;  // diagnostics: [n_teams][6] = start, end (100 MHz), HW_ID, XCC_ID, clk0, clk1; or nullptr
     int nb, n_tiles, m_pad, b_pad;
     long long audio_stride;
     int rotate_prio;             // rotate s_setprio per tile (fair progress of resident teams)
@@ -72,7 +85,7 @@ int launch_iir_bank(const IirParams &p, int n_obj, int modes_per_lane, int waves
 inline size_t iir_lds_bytes(int W, int n_tiles) {
     return sizeof(float) * (size_t)W * (TILE * LDS_ROW + (size_t)(n_tiles + 1) * TILE);
 }
-constexpr int MAX_WAVES_PER_OBJECT = 16;
+constexpr int MAX_WAVES_PER_TEAM = 16;     // 1024 threads; larger objects are cut into several teams
 
 // ---- exact fp64 helper kernels (kernels_exact.hip, built with -ffp-contract=off)
 struct ProjectEvent {
@@ -139,6 +152,10 @@ struct FfatEvent {
 int launch_ffat_lookup(const FfatEvent *events, int n_events, const FfatGeom *geom,
                        const long long *geom_off, const int *n_modes, const double *psi,
                        double *rows, int m_pad, hipStream_t stream);
+// audio[obj][i] = sum over the object's teams, in team order (deterministic)
+struct SplitObj { int obj, first_row, n_rows, pad; };
+int launch_sum_parts(const SplitObj *split, int n_split, const float *parts, float *audio, long long stride,
+                     hipStream_t stream);
 int launch_copy_rows(const int *src_row, const int *dst_row, int n, double *rows, int m_pad,
                      hipStream_t stream);
 

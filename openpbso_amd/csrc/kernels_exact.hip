@@ -402,6 +402,27 @@ int launch_ffat_lookup(const FfatEvent *events, int n_events, const FfatGeom *ge
 }
 
 // ---------------------------------------------------------------------------
+// Objects stepped by several teams: add the teams' partial sample sums, team 0 first.
+__global__ __launch_bounds__(256) void sum_parts_kernel(const SplitObj *__restrict__ split,
+                                                        const float *__restrict__ parts,
+                                                        float *__restrict__ audio, long long stride) {
+    const SplitObj so = split[blockIdx.y];
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= stride) return;
+    float acc = parts[(size_t)so.first_row * stride + i];
+    for (int r = 1; r < so.n_rows; ++r) acc += parts[(size_t)(so.first_row + r) * stride + i];
+    audio[(size_t)so.obj * stride + i] = acc;
+}
+
+int launch_sum_parts(const SplitObj *split, int n_split, const float *parts, float *audio, long long stride,
+                     hipStream_t stream) {
+    if (n_split <= 0) return 0;
+    dim3 grid((unsigned)((stride + 255) / 256), n_split);
+    hipLaunchKernelGGL(sum_parts_kernel, grid, dim3(256), 0, stream, split, parts, audio, stride);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void copy_rows_kernel(const int *__restrict__ src_row,
                                                         const int *__restrict__ dst_row,
                                                         double *rows, int m_pad) {

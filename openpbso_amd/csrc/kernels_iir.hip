@@ -168,11 +168,13 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     float *__restrict__ p_sd, float *__restrict__ p_ss, const BufDesc *__restrict__ p_desc, const float *__restrict__ p_grows,
     const float *__restrict__ p_tprof, const double *__restrict__ p_xfer_rows,
     const int *__restrict__ p_xfer_init, float *__restrict__ p_audio, float *__restrict__ p_qnorm,
-    const float *__restrict__ p_gq, const int *__restrict__ p_obj_map,
+    const float *__restrict__ p_gq, const TeamDesc *__restrict__ p_teams, float *__restrict__ p_audio_parts,
     unsigned long long *__restrict__ p_census, const IirDims p) {
     constexpr bool QN = QNM != 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int obj = p_obj_map[blockIdx.x];
+    const TeamDesc team = p_teams[blockIdx.x];
+    const int obj = team.obj;
+    const int col = team.col0 + threadIdx.x;          // this lane's first column of the object's rows
     unsigned long long census_t0 = 0, census_c0 = 0;
     if (p_census) {
         census_t0 = __builtin_amdgcn_s_memrealtime();
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     const int rowlen = blockDim.x;
     float *tile = lds + wave * (TILE * LDS_ROW);
     const unsigned tile_m0 = (unsigned)wave * (unsigned)(TILE * LDS_ROW * sizeof(float));
-    const size_t mbase = (size_t)obj * p.m_pad + tid;
+    const size_t mbase = (size_t)obj * p.m_pad + col;
 
     constexpr int VW = lanes_of<V>::n;
     constexpr int R = NV * VW;                       // oscillators per lane; slice r = v * VW + e
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             vset(s0[r / VW], r % VW, p_ss[mbase + r * rowlen]);
-            const float tr = row0 >= 0 ? (float)p_xfer_rows[(size_t)row0 * p.m_pad + tid + r * rowlen] : 1e7f;
+            const float tr = row0 >= 0 ? (float)p_xfer_rows[(size_t)row0 * p.m_pad + col + r * rowlen] : 1e7f;
             vset(t[r / VW], r % VW, dead[r] ? 1.f : tr);
         }
         rescale(s0, t);
@@ -265,7 +267,8 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     }
 
     const BufDesc *__restrict__ dsc = p_desc + (size_t)obj * p.nb;
-    float *__restrict__ aout = p_audio + (size_t)obj * p.audio_stride;
+    float *__restrict__ aout = team.part_row >= 0 ? p_audio_parts + (size_t)team.part_row * p.audio_stride
+                                                  : p_audio + (size_t)obj * p.audio_stride;
     const int NT = p.n_tiles;
     const int B = NT * TILE;
     const int ring = NT + 1;                         // tile slots in the row-sum ring
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
             if (QN) {
 #pragma unroll
                 for (int r = 0; r < R; ++r)
-                    p_qnorm[((size_t)obj * p.nb + b) * p.m_pad + tid + r * rowlen] = 0.f;
+                    p_qnorm[((size_t)obj * p.nb + b) * p.m_pad + col + r * rowlen] = 0.f;
             }
             continue;
         }
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
             V tn[NV], from[NV];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const float tr = trow >= 0 ? (float)p_xfer_rows[(size_t)trow * p.m_pad + tid + r * rowlen] : 1e7f;
+                const float tr = trow >= 0 ? (float)p_xfer_rows[(size_t)trow * p.m_pad + col + r * rowlen] : 1e7f;
                 vset(tn[r / VW], r % VW, dead[r] ? 1.f : tr);
                 vset(from[r / VW], r % VW, scaled ? elem(t[r / VW], r % VW) : 1.f);
             }
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
         if (frow >= 0) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const float gr = p_grows[(size_t)frow * p.m_pad + tid + r * rowlen];
+                const float gr = p_grows[(size_t)frow * p.m_pad + col + r * rowlen];
                 vset(g_[r / VW], r % VW, scaled ? gr * elem(t[r / VW], r % VW) : gr);
             }
         }
@@ -470,19 +473,19 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
                 const float e0 = vget<0>(qn[r / VW]), e1 = vget<1>(qn[r / VW]);
                 // (the closed form can round a tiny sum below zero)
                 const float nrm = sqrtf(fmaxf(r % VW ? e1 : e0, 0.f));
-                p_qnorm[((size_t)obj * p.nb + b) * p.m_pad + tid + r * rowlen] = scaled ? nrm / elem(t[r / VW], r % VW) : nrm;
+                p_qnorm[((size_t)obj * p.nb + b) * p.m_pad + col + r * rowlen] = scaled ? nrm / elem(t[r / VW], r % VW) : nrm;
             }
         }
     }
     flush();
     if (p_census && tid == 0) {
         // where and when this workgroup ran (placement / residency diagnostics)
-        p_census[(size_t)obj * 6 + 0] = census_t0;
-        p_census[(size_t)obj * 6 + 1] = __builtin_amdgcn_s_memrealtime();
-        p_census[(size_t)obj * 6 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
-        p_census[(size_t)obj * 6 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
-        p_census[(size_t)obj * 6 + 4] = census_c0;                                    // shader clock at start
-        p_census[(size_t)obj * 6 + 5] = __builtin_amdgcn_s_memtime();                 // ... and at the end
+        p_census[(size_t)team.id * 6 + 0] = census_t0;
+        p_census[(size_t)team.id * 6 + 1] = __builtin_amdgcn_s_memrealtime();
+        p_census[(size_t)team.id * 6 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        p_census[(size_t)team.id * 6 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+        p_census[(size_t)team.id * 6 + 4] = census_c0;                                    // shader clock at start
+        p_census[(size_t)team.id * 6 + 5] = __builtin_amdgcn_s_memtime();                 // ... and at the end
     }
 
 #pragma unroll
@@ -509,7 +512,7 @@ static int launch_one(const IirParams &p, int n_obj, int W, hipStream_t stream) 
     }
     const IirDims dims = {p.nb, p.n_tiles, p.m_pad, p.b_pad, p.audio_stride, p.rotate_prio, p.gq_plane};
     hipLaunchKernelGGL(kern, dim3(n_obj), dim3(64 * W), lds, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc,
-                       p.grows, p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.obj_map, p.census, dims);
+                       p.grows, p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.teams, p.audio_parts, p.census, dims);
     return (int)hipGetLastError();
 }
 
@@ -531,7 +534,7 @@ static int launch_r(const IirParams &p, int n_obj, int W, int form, int qnm, hip
 int launch_iir_bank(const IirParams &p, int n_obj, int R, int W, int form, int qnm, hipStream_t s) {
     if (n_obj <= 0) return 0;
     if (qnm < 0 || qnm > 2) return (int)hipErrorInvalidValue;
-    if (W < 1 || W > MAX_WAVES_PER_OBJECT) return (int)hipErrorInvalidValue;
+    if (W < 1 || W > MAX_WAVES_PER_TEAM) return (int)hipErrorInvalidValue;
     if (W <= 4) {
         switch (R) {
 #if !PBSO_IIR_PACKED

@@ -280,8 +280,8 @@ class Engine:
         return q1[:n], q2[:n]
 
     def census(self):
-        """per-object workgroup (start, end [100 MHz ticks], HW_ID, XCC_ID) of the last launch (PBSO_CENSUS=1)."""
-        n = len(self.n_modes) * 6
+        """per-workgroup (start, end [100 MHz ticks], HW_ID, XCC_ID, clock start/end) of the last launch (PBSO_CENSUS=1)."""
+        n = self.info()["n_teams"] * 6
         out = np.empty(n, dtype=np.uint64)
         self._chk(self._l.pbso_read_census(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), n))
         return out.reshape(-1, 6)
