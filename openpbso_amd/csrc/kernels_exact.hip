@@ -118,17 +118,20 @@ __device__ __forceinline__ uint32_t mulmod31(uint32_t a, uint32_t b) {
     return q;
 }
 
-// One WAVE per chain (= object with dense rows in this launch, rows in buffer order).
-// The serial parts of Force::Add are kept serial where the arithmetic demands it (the AR(2)
-// recurrence, lane 0) and spread over the 64 lanes where it does not:
+// One workgroup of K2_THREADS per chain (= object with dense rows in this launch, rows in buffer
+// order).  The serial parts of Force::Add are kept serial where the arithmetic demands it (the
+// AR(2) recurrence, thread 0) and spread over the threads where it does not:
 //  * normal variates: candidate pair c of a row uses engine draws 4c+1..4c+4, and the LCG
-//    jumps ahead in closed form (x_n = a^n x_0 mod M): lane j of a batch evaluates candidate
-//    64 k + j, a ballot orders the accepted pairs exactly as the sequential rejection loop
-//    would meet them, and the engine state after the row is the state after the last pair used;
+//    jumps ahead in closed form (x_n = a^n x_0 mod M): thread j of a batch evaluates candidate
+//    K2_THREADS k + j, per-wave ballots plus the waves' counts order the accepted pairs exactly as
+//    the sequential rejection loop would meet them, and the engine state after the row is the
+//    state after the last pair used;
 //  * Gaussian samples and the final fp32 stores are lane-parallel.
 // LDS: nrm[frames] doubles (normal variates, then mu-tilde) + acc[frames] doubles (several
 // forces in one buffer) + the new engine state.
-__global__ __launch_bounds__(64) void force_profile_kernel(
+constexpr int K2_THREADS = 256;           // candidate pairs evaluated per batch
+
+__global__ __launch_bounds__(K2_THREADS) void force_profile_kernel(
     const int *__restrict__ chain_ptr, int n_chains, const ProfRow *__restrict__ rows,
     const ProfEntry *__restrict__ entries, ArState *__restrict__ states, float *__restrict__ tprof,
     int frames, int b_pad) {
@@ -137,37 +140,51 @@ __global__ __launch_bounds__(64) void force_profile_kernel(
     double *acc = k2_lds + frames;
     double *sh_saved = k2_lds + 2 * frames;                    // [0] saved variate
     uint32_t *sh_u = reinterpret_cast<uint32_t *>(k2_lds + 2 * frames + 1);   // [0] engine x, [1] saved_available
+    uint32_t *sh_cnt = sh_u + 2;                               // [2][waves] accepted pairs per wave, by batch parity
     const int c = blockIdx.x;
     if (c >= n_chains) return;
-    const int lane = threadIdx.x;
-    // a^(4 lane) and a^256 (mod M), a = 16807
+    const int lane = threadIdx.x;                              // 0 .. K2_THREADS-1: one candidate pair per batch
+    const int wv = threadIdx.x >> 6;
+    constexpr int NWV = K2_THREADS / 64;
+    // a^(4 lane) and a^(4 K2_THREADS) (mod M), a = 16807
     uint32_t a4 = 16807u;
     a4 = mulmod31(a4, a4);
     a4 = mulmod31(a4, a4);                                     // a^4
     uint32_t pj = 1u, q64 = 1u;
-    for (int i = 0; i < 64; ++i) {
+    for (int i = 0; i < K2_THREADS; ++i) {
         if (i < lane) pj = mulmod31(pj, a4);
         q64 = mulmod31(q64, a4);
     }
     const double R = 2147483646.0;                             // max - min + 1
     const double R2 = 4611686009837453316.0;                   // (double)((long double)R * R), as libstdc++ forms it
 
+    // The AutoregressiveForce a chain keeps using stays in registers between rows (global
+    // round trips per row cost more than the row's arithmetic): every thread holds the engine
+    // state and parameters, thread 0 also the AR history; written back when another state
+    // is needed and at the end of the chain.
+    int cached = -1;
+    ArState s;
     for (int ri = chain_ptr[c]; ri < chain_ptr[c + 1]; ++ri) {
         const ProfRow row = rows[ri];
         float *out = tprof + (size_t)row.prow * b_pad;
-        for (int i = lane; i < frames; i += 64) acc[i] = 0.0;                  // setZero, modal_solver.h:206
+        for (int i = lane; i < frames; i += K2_THREADS) acc[i] = 0.0;                  // setZero, modal_solver.h:206
         __syncthreads();
         for (int ei = row.entry_begin; ei < row.entry_end; ++ei) {
             const ProfEntry e = entries[ei];
             if (e.kind == 0) {                                                 // PointForce, forces.h:81-90
                 if (lane == 0) acc[0] += 1.;
             } else if (e.kind == 1) {                                          // GaussianForce, forces.h:92-105
-                for (int ii = lane; ii < frames; ii += 64) {
+                for (int ii = lane; ii < frames; ii += K2_THREADS) {
                     const double z = (double)(e.count + ii - e.center) / (double)e.width_samples;
                     acc[ii] += exp(-0.5 * (z * z));
                 }
             } else {                                                           // AutoregressiveForce, :107-128
-                ArState s = states[e.state];                                   // uniform
+                if (e.state != cached) {                                       // uniform
+                    if (cached >= 0 && lane == 0) states[cached] = s;
+                    __syncthreads();
+                    s = states[e.state];
+                    cached = e.state;
+                }
                 if (e.flags & 1) {                                             // default-constructed, forces.h:73-76
                     s.x = 1u; s.saved_available = 0; s.saved = 0.0;
                     s.buf[0] = s.buf[1] = s.buf[2] = 0.0; s.buf_idx = 0;
@@ -184,10 +201,10 @@ __global__ __launch_bounds__(64) void force_profile_kernel(
                 const int pairs_needed = (from_pairs + 1) / 2;
                 if (lane == 0) { sh_u[0] = s.x; sh_u[1] = 0u; sh_saved[0] = 0.0; }
                 __syncthreads();
-                uint32_t xb = s.x;                                              // state before candidate 64 k
+                uint32_t xb = s.x;                                              // state before candidate K2_THREADS k
                 int acc_pairs = 0;
-                while (acc_pairs < pairs_needed) {
-                    uint32_t st = mulmod31(xb, pj);                             // state before candidate 64 k + lane
+                for (int batch = 0; acc_pairs < pairs_needed; ++batch) {
+                    uint32_t st = mulmod31(xb, pj);                             // state before candidate K2_THREADS k + lane
                     const uint32_t d1 = (st = mulmod31(st, 16807u));
                     const uint32_t d2 = (st = mulmod31(st, 16807u));
                     const uint32_t d3 = (st = mulmod31(st, 16807u));
@@ -205,9 +222,19 @@ __global__ __launch_bounds__(64) void force_profile_kernel(
                     const double y = 2.0 * c2 - 1.0;
                     const double r2 = x * x + y * y;
                     const bool ok = !(r2 > 1.0 || r2 == 0.0);
+                    // accepted pairs in candidate order: waves in order, lanes in order within a wave
                     const unsigned long long m = __ballot(ok);
+                    uint32_t *cnt = sh_cnt + (batch & 1) * NWV;
+                    if ((lane & 63) == 0) cnt[wv] = (uint32_t)__popcll(m);
+                    __syncthreads();
+                    int before = 0, total = 0;
+                    for (int w = 0; w < NWV; ++w) {
+                        const int cw = (int)cnt[w];
+                        if (w < wv) before += cw;
+                        total += cw;
+                    }
                     const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    const int idx = acc_pairs + rank;
+                    const int idx = acc_pairs + before + rank;
                     if (ok && idx < pairs_needed) {
                         const double mult = sqrt(-2 * log(r2) / r2);
                         const int p0 = sa + 2 * idx;
@@ -218,7 +245,7 @@ __global__ __launch_bounds__(64) void force_profile_kernel(
                             if (p0 + 1 >= frames) { sh_u[1] = 1u; sh_saved[0] = x * mult; }
                         }
                     }
-                    acc_pairs += __popcll(m);
+                    acc_pairs += total;
                     xb = mulmod31(xb, q64);
                 }
                 __syncthreads();
@@ -227,7 +254,7 @@ __global__ __launch_bounds__(64) void force_profile_kernel(
                 // add); the serial part then runs in blocks of 8 with the next block's inputs already
                 // in registers, so only the four dependent fp64 operations of a step remain on the
                 // critical path (LDS latency and the _buf index arithmetic are off it).
-                for (int ii = lane; ii < frames; ii += 64) nrm[ii] = s.sigma * nrm[ii];
+                for (int ii = lane; ii < frames; ii += K2_THREADS) nrm[ii] = s.sigma * nrm[ii];
                 __syncthreads();
                 if (lane == 0) {
                     double b0 = s.buf[0], b1 = s.buf[1], b2 = s.buf[2];
@@ -248,8 +275,9 @@ __global__ __launch_bounds__(64) void force_profile_kernel(
                             }
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
-                                double mu_tilde = 0.0;
-                                mu_tilde += s.a[0] * p1;
+                                // forces.h:110-114 starts from 0.0: 0.0 + x == x except for the sign of
+                                // a zero, which no sample can see (T += mu + mu_tilde)
+                                double mu_tilde = s.a[0] * p1;
                                 mu_tilde += s.a[1] * p2;
                                 mu_tilde += cur[j];
                                 p3 = p2; p2 = p1; p1 = mu_tilde;
@@ -282,30 +310,30 @@ __global__ __launch_bounds__(64) void force_profile_kernel(
                     }
                     s.buf[0] = b0; s.buf[1] = b1; s.buf[2] = b2;
                     s.buf_idx = idx;
-                    if (pairs_needed > 0) {
-                        s.x = sh_u[0];
-                        s.saved_available = (int)sh_u[1];
-                        s.saved = sh_saved[0];
-                    } else {
-                        s.saved_available = 0;                                  // only the cached variate was used
-                    }
-                    states[e.state] = s;
                 }
                 __syncthreads();
-                for (int ii = lane; ii < frames; ii += 64) acc[ii] += s.mu + nrm[ii];   // forceSpread(ii) += mu_e
+                if (pairs_needed > 0) {                                         // every thread: the engine after this row
+                    s.x = sh_u[0];
+                    s.saved_available = (int)sh_u[1];
+                    s.saved = sh_saved[0];
+                } else {
+                    s.saved_available = 0;                                      // only the cached variate was used
+                }
+                for (int ii = lane; ii < frames; ii += K2_THREADS) acc[ii] += s.mu + nrm[ii];   // forceSpread(ii) += mu_e
             }
             __syncthreads();
         }
-        for (int i = lane; i < b_pad; i += 64) out[i] = i < frames ? (float)acc[i] : 0.f;
+        for (int i = lane; i < b_pad; i += K2_THREADS) out[i] = i < frames ? (float)acc[i] : 0.f;
         __syncthreads();
     }
+    if (cached >= 0 && lane == 0) states[cached] = s;
 }
 
 int launch_force_profiles(const int *chain_ptr, int n_chains, const ProfRow *rows, const ProfEntry *entries,
                           ArState *states, float *tprof, int frames, int b_pad, hipStream_t stream) {
     if (n_chains <= 0) return 0;
-    const size_t lds = sizeof(double) * (2 * (size_t)frames + 2);
-    hipLaunchKernelGGL(force_profile_kernel, dim3(n_chains), dim3(64), lds, stream, chain_ptr, n_chains, rows,
+    const size_t lds = sizeof(double) * (2 * (size_t)frames + 2) + sizeof(uint32_t) * 2 * (K2_THREADS / 64);
+    hipLaunchKernelGGL(force_profile_kernel, dim3(n_chains), dim3(K2_THREADS), lds, stream, chain_ptr, n_chains, rows,
                        entries, states, tprof, frames, b_pad);
     return (int)hipGetLastError();
 }
