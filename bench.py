@@ -37,7 +37,7 @@ FLOP_PER_MODE_SAMPLE = 10      # reference arithmetic incl. qnorm (SURVEY.md 8(d
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--settle", type=int, default=30,
                     help="untimed steps run before the warm-up so that the shader clock has ramped (the first ~70 ms "
