@@ -180,6 +180,10 @@ int Engine::init() {
         return fail(PBSO_ERR_INVALID, "recurrence_form");
     if (desc_.qnorm_mode < PBSO_QNORM_OFF || desc_.qnorm_mode > PBSO_QNORM_CLOSED)
         return fail(PBSO_ERR_INVALID, "qnorm_mode");
+    {
+        const int r = desc_.modes_per_lane;
+        if (r != 0 && r != 1 && r != 2 && r != 4 && r != 8) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,4,8");
+    }
     int ndev = 0;
     HIPTRY(hipGetDeviceCount(&ndev));
     if (ndev <= 0) return fail(PBSO_ERR_HIP, "no HIP device: this engine has no CPU fallback");
@@ -195,7 +199,15 @@ int Engine::init() {
     HIPTRY(hipEventCreateWithFlags(&ev_set_[1], hipEventDisableTiming));
     // preparation of step k+1 (plan upload, projection, FFAT lookup, force combination)
     // runs on its own stream beside the oscillator bank of step k
-    HIPTRY(hipStreamCreateWithFlags(&prep_stream_, hipStreamNonBlocking));
+    // High priority: its kernels are small, the oscillator bank waits for them, and the runtime maps
+    // streams of different priority to different hardware queues -- with equal priority the two
+    // engine streams can land on ONE queue when the process owns many streams (torch + RCCL under
+    // torch.distributed.run did exactly that: no overlap, +12 % per step).
+    {
+        int least = 0, greatest = 0;
+        HIPTRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPTRY(hipStreamCreateWithPriority(&prep_stream_, hipStreamNonBlocking, greatest));
+    }
     for (int i = 0; i < 2; ++i) {
         HIPTRY(hipEventCreateWithFlags(&ev_prep_done_[i], hipEventDisableTiming));
         HIPTRY(hipEventCreateWithFlags(&ev_k1_done_[i], hipEventDisableTiming));

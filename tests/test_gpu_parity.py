@@ -541,3 +541,35 @@ def test_error_paths_match_reference_asserts():
         # 1023-slot force queue
         ok = [eng.enqueue_force(0, ForceMessage(data=np.zeros(32))) for _ in range(1025)]
         assert sum(ok) == 1023 and not ok[-1]
+
+
+def test_degenerate_objects_and_arguments():
+    """An object with no audible mode at all (numModesAudible can return 0, ModeData.h:120-148), one
+    with a single mode, invalid calls answered with a status instead of undefined behaviour."""
+    from openpbso_amd import Engine
+    from openpbso_amd.solver import PbsoError
+    lam1 = synth.eigenvalues(1, 5)
+    with Engine() as eng:
+        a = eng.add_object(np.zeros(0), synth.RHO, synth.ALPHA, synth.BETA)
+        b = eng.add_object(lam1, synth.RHO, synth.ALPHA, synth.BETA)
+        eng.finalize()
+        eng.set_use_transfer(a, False)
+        eng.set_use_transfer(b, False)
+        assert eng.enqueue_force(a, ForceMessage(data=np.zeros(0)))
+        assert eng.enqueue_force(b, ForceMessage(data=np.array([2e-3])))
+        with pytest.raises(PbsoError):
+            eng.step(0)
+        with pytest.raises(PbsoError):
+            eng.enqueue_force(7, ForceMessage(data=np.zeros(1)))
+        with pytest.raises(PbsoError):
+            eng.enqueue_force(b, ForceMessage(data=np.zeros(1), forceType=9))
+        eng.step(3)
+        audio = eng.audio()
+        assert not audio[a].any() and np.abs(audio[b]).max() > 0
+        want = run_oracle([ObjSpec(lam1)], [force_ev(0, 0, data=np.array([2e-3])), dict(t=0, obj=0, kind="use_transfer", use=False)], 3)
+        assert np.abs(audio[b] - want["audio"][0]).max() <= TOL_MAX * np.abs(want["audio"][0]).max()
+    with pytest.raises(PbsoError):
+        with Engine() as eng:
+            eng.finalize()                                   # no objects
+    with pytest.raises(PbsoError):
+        Engine(modes_per_lane=3)
