@@ -168,7 +168,11 @@ def main():
     from openpbso_amd.distributed import gather_audio
 
     lam, shapes, scripts = build_inputs(args, rank)
-    stream = torch.cuda.current_stream().cuda_stream
+    # a real (non-null) stream: handle 0 would make the engine create its own, and the RCCL gather
+    # orders itself after the CURRENT torch stream
+    run_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(run_stream)
+    stream = run_stream.cuda_stream
     eng = Engine(device=dev_index,
                  form=capi.FORM_VELOCITY if args.form == "velocity" else capi.FORM_DIRECT,
                  qnorm={"sample": capi.QNORM_ALL, "closed": capi.QNORM_CLOSED, "off": capi.QNORM_OFF}[
@@ -231,10 +235,18 @@ def main():
                                         force_type=capi.AUTOREGRESSIVE_FORCE if args.scenario == "scraping" else capi.POINT_FORCE)
 
     nb = args.buffers
-    audio = torch.empty((args.objects, nb * B), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world * args.objects, nb * B), dtype=torch.float32, device=dev) if (args.gather and world > 1) else None
-
+    # --gather: the finished buffers of all ranks are all-gathered over RCCL.  Audio and
+    # gather targets are double-buffered and the collective is asynchronous on RCCL's own stream, so the
+    # gather of step k runs beside the oscillator bank of step k+1; it is waited for only when its
+    # buffers are reused (and before the clock stops).
+    do_gather = args.gather and use_dist
+    n_buf = 2 if do_gather else 1
+    audios = [torch.empty((args.objects, nb * B), dtype=torch.float32, device=dev) for _ in range(n_buf)]
+    audio = audios[0]
+    gathered = [torch.empty((world * args.objects, nb * B), dtype=torch.float32, device=dev) for _ in range(n_buf)] if do_gather else None
+    pending = [None] * n_buf
     enqueue_s = [0.0]
+    n_calls = [0]
 
     def one_step(k=-1):
         if k >= 0 and feeds[k] is not None:
@@ -242,15 +254,27 @@ def main():
             taken = eng.enqueue_force_batch(*feeds[k])
             enqueue_s[0] += time.perf_counter() - te
             assert taken == feeds[k][0].size, "force queue overflow"
-        eng.step(nb, into=audio.data_ptr())
-        if gathered is not None:
+        slot = n_calls[0] % n_buf
+        n_calls[0] += 1
+        if pending[slot] is not None:
+            pending[slot].wait()
+            pending[slot] = None
+        eng.step(nb, into=audios[slot].data_ptr())
+        if do_gather:
             if backend == "nccl":
-                dist.all_gather_into_tensor(gathered, audio)
+                pending[slot] = dist.all_gather_into_tensor(gathered[slot], audios[slot], async_op=True)
             else:
-                gathered.copy_(gather_audio(audio.cpu()))
+                gathered[slot].copy_(gather_audio(audios[slot].cpu()))
+
+    def drain():
+        for i, w in enumerate(pending):
+            if w is not None:
+                w.wait()
+                pending[i] = None
 
     for k in range(args.settle + args.warmup):
         one_step(k)
+    drain()
     torch.cuda.synchronize()
     info0 = eng.info()
     if use_dist:
@@ -260,6 +284,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         one_step(args.settle + args.warmup + k)
+    drain()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -270,7 +295,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     info1 = eng.info()
-    assert torch.isfinite(audio).all()
+    assert all(torch.isfinite(a).all() for a in audios)
+    if do_gather and backend == "nccl":
+        last = (n_calls[0] - 1) % n_buf
+        assert torch.equal(gathered[last][rank * args.objects:(rank + 1) * args.objects], audios[last])
 
     if rank == 0:
         total_obj = world * args.objects
@@ -306,7 +334,7 @@ def main():
                 "scenario": args.scenario, "objects_per_gpu": args.objects, "modes": M, "buffers_per_step": nb, "frames_per_buffer": B,
                 "hits": n_hits, "modes_per_lane": info1["modes_per_lane"], "waves_per_object": info1["waves_per_object"],
                 "kernel_build": "packed" if os.environ.get("PBSO_IIR_PACKED", "0") != "0" else "scalar",
-                "gather": bool(gathered is not None), "parallelism": f"object-sharded x{world}",
+                "gather": bool(do_gather), "parallelism": f"object-sharded x{world}",
             },
             "roofline": {
                 "bound": "valu", "kernel": "iir_bank_kernel",
