@@ -218,6 +218,7 @@ int Engine::init() {
     if (const char *v = std::getenv("PBSO_CENSUS")) census_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_ROTATE_PRIO")) rotate_prio_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_DEVICE_PROFILES")) device_profiles_ = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PBSO_CHUNK_BUFFERS")) chunk_buffers_ = std::max(1, std::atoi(v));
     return PBSO_OK;
 }
 
@@ -520,7 +521,7 @@ int Engine::enqueue_force(int obj, const pbso_force_msg &m, int64_t not_before) 
     h.clear_all = m.clear_all_forces != 0;
     h.data_kind = m.data_kind;
     h.not_before = not_before;
-    h.force = ForceProfile::make(m.force_type, m.gaussian_width_us, rate_);
+    h.gaussian_width_us = m.gaussian_width_us;      // the Force object itself is built when the message is dequeued
     switch (m.data_kind) {
     case PBSO_DATA_EXPLICIT:
         if (!m.data || m.n_data != o.n_modes)
@@ -657,7 +658,7 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
             for (ActiveForce &af : o.active) release(af);
             o.active.clear();
             d.flags |= DESC_SKIP;
-            emitted_[(size_t)oi * nb + b] = 0;
+            emitted_[(size_t)oi * plan_nb_total_ + plan_b0_ + b] = 0;
             return PBSO_OK;
         }
         // the message's modal data becomes one immutable row of the slot pool
@@ -683,7 +684,7 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
         ActiveForce af;
         af.slot = slot;
         af.force_type = mess.force_type;
-        af.force = mess.force;
+        af.force = ForceProfile::make(mess.force_type, mess.gaussian_width_us, rate_);   // fresh Force, tools/...:281-294
         bool slot_used = false;
         if (mess.sustained_start) {                                     // :190-194
             for (ActiveForce &x : o.active) release(x);
@@ -906,7 +907,6 @@ int Engine::plan(int nb) {
     HIPTRY(ps.h_xfer_init.ensure(N));
     const BufDesc dflt = {-1, -1, 0u, 0.f, XFER_KEEP, 0u, {0, 0}};
     std::fill(ps.h_desc.p, ps.h_desc.p + (size_t)N * nb, dflt);
-    emitted_.assign((size_t)N * nb, 1);
     row_ptr_.assign(1, 0);
     slot_idx_.clear(); row_obj_.clear(); tprof_.clear(); stage_.clear(); stage_slot_.clear();
     proj_.clear(); ffat_.clear(); freed_this_plan_.clear();
@@ -954,12 +954,45 @@ static hipError_t upload(PinBuf<T> &h, DevBuf<T> &d, const T *src, size_t n, hip
     return hipMemcpyAsync(d.p, h.p, n * sizeof(T), hipMemcpyHostToDevice, s);
 }
 
+// One step = nb buffers for every object.  Long steps are cut into launches of at most
+// chunk_buffers_ buffers so that the host plans chunk c+1 while the device runs chunk c (the same
+// overlap consecutive steps have); results do not depend on the cut (state, force lists and queues
+// carry over exactly as between steps).
 int Engine::step(int nb, void *d_audio_user) {
     HIPTRY(hipSetDevice(desc_.device));      // the caller's thread may have another device current
     if (!finalized_) return fail(PBSO_ERR_STATE, "step before finalize");
     if (nb <= 0) return fail(PBSO_ERR_INVALID, "n_buffers must be > 0");
     const int N = (int)objs_.size();
+    float *audio = (float *)d_audio_user;
+    // outputs of the whole step (growth drains the device first, see DevBuf::ensure)
+    if (!audio) {
+        HIPTRY(d_audio_.ensure((size_t)N * nb * B_, false, stream_));
+        audio = d_audio_.p;
+    }
+    if (desc_.qnorm_mode != PBSO_QNORM_OFF) HIPTRY(d_qnorm_.ensure((size_t)N * nb * m_pad_, false, stream_));
+    if (n_part_rows_) HIPTRY(d_audio_parts_.ensure((size_t)n_part_rows_ * nb * B_, false, stream_));
+    emitted_.assign((size_t)N * nb, 1);
+    const int64_t step_id = tot_steps_;
+    double plan_ms = 0;
+    for (int b0 = 0; b0 < nb; b0 += chunk_buffers_) {
+        int rc = step_chunk(std::min(chunk_buffers_, nb - b0), b0, nb, audio, step_id);
+        if (rc != PBSO_OK) return rc;
+        plan_ms += last_plan_ms_;
+    }
+    LAUNCHTRY(launch_sum_parts(d_split_.p, n_split_, d_audio_parts_.p, audio, (long long)nb * B_, stream_));
+    last_plan_ms_ = plan_ms;
+    tot_plan_ms_ += plan_ms;
+    tot_steps_ += 1;
+    last_audio_ = audio;
+    last_nb_ = nb;
+    return PBSO_OK;
+}
+
+int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_id) {
+    const int N = (int)objs_.size();
     PlanSet &ps = set_[cur_set_];
+    plan_b0_ = b0;
+    plan_nb_total_ = nb_total;
     HIPTRY(hipEventSynchronize(ev_set_[cur_set_]));      // this set's previous uploads are done
 
     const auto t0 = std::chrono::steady_clock::now();
@@ -994,13 +1027,7 @@ int Engine::step(int nb, void *d_audio_user) {
     // device arenas (growth drains the device first, see DevBuf::ensure)
     HIPTRY(d_slots_.ensure(std::max<size_t>(1, n_slots_) * m_pad_, true, sp));
     HIPTRY(grows.ensure(std::max<size_t>(1, (size_t)n_frows) * m_pad_, false, sp));
-    float *audio = (float *)d_audio_user;
-    if (!audio) {
-        HIPTRY(d_audio_.ensure((size_t)N * nb * B_, false, sk));
-        audio = d_audio_.p;
-    }
     const bool qn = desc_.qnorm_mode != PBSO_QNORM_OFF;
-    if (qn) HIPTRY(d_qnorm_.ensure((size_t)N * nb * m_pad_, false, sk));
 
     if (ev_pending_.size() >= 256) {          // bound the number of live events
         int hrc = harvest_timing();
@@ -1016,6 +1043,7 @@ int Engine::step(int nb, void *d_audio_user) {
         HIPTRY(hipEventCreate(&evq.p0));
         HIPTRY(hipEventCreate(&evq.p1));
     }
+    evq.step_id = step_id;
     // ---- preparation stream: this set's device buffers are free once the oscillator
     //      bank that last read them (two steps ago) has finished
     HIPTRY(hipStreamWaitEvent(sp, ev_k1_done_[cur_set_], 0));
@@ -1074,8 +1102,10 @@ int Engine::step(int nb, void *d_audio_user) {
     kp.tprof = ps.d_tprof.p;
     kp.xfer_rows = d_xfer_.p;
     kp.xfer_init = ps.d_xfer_init.p;
-    kp.audio = audio;
+    kp.audio = audio + (size_t)b0 * B_;
     kp.qnorm = qn ? d_qnorm_.p : nullptr;
+    kp.qn_nb = nb_total;
+    kp.qn_b0 = b0;
     kp.gq = d_gq_.p;
     kp.gq_plane = (long long)N * m_pad_;
     kp.census = nullptr;
@@ -1084,14 +1114,10 @@ int Engine::step(int nb, void *d_audio_user) {
         kp.census = d_census_.p;
     }
     kp.nb = nb; kp.n_tiles = n_tiles_; kp.m_pad = m_pad_; kp.b_pad = b_pad_;
-    kp.audio_stride = (long long)nb * B_;
+    kp.audio_stride = (long long)nb_total * B_;
     kp.rotate_prio = rotate_prio_ ? 1 : 0;
     HIPTRY(hipEventRecord(evq.k0, sk));
-    kp.audio_parts = nullptr;
-    if (n_part_rows_) {
-        HIPTRY(d_audio_parts_.ensure((size_t)n_part_rows_ * nb * B_, false, sk));
-        kp.audio_parts = d_audio_parts_.p;
-    }
+    kp.audio_parts = n_part_rows_ ? d_audio_parts_.p + (size_t)b0 * B_ : nullptr;
     for (const SizeClass &c : classes_) {
         kp.teams = d_teams_.p + c.first;
         if (packed_ && R_ >= 2)
@@ -1100,17 +1126,12 @@ int Engine::step(int nb, void *d_audio_user) {
             LAUNCHTRY(iir_scalar::launch_iir_bank(kp, c.count, R_, c.W, desc_.recurrence_form, desc_.qnorm_mode, sk));
     }
     HIPTRY(hipEventRecord(evq.k1, sk));
-    LAUNCHTRY(launch_sum_parts(d_split_.p, n_split_, d_audio_parts_.p, audio, (long long)nb * B_, sk));
     // _latest_transfer = trans (modal_solver.h:251), then re-park a still-queued transfer
     LAUNCHTRY(launch_copy_rows(ps.d_copy.p, ps.d_copy.p + (n_cl + n_cq), n_cl, d_xfer_.p, m_pad_, sk));
     LAUNCHTRY(launch_copy_rows(ps.d_copy.p + n_cl, ps.d_copy.p + (n_cl + n_cq) + n_cl, n_cq, d_xfer_.p, m_pad_, sk));
     HIPTRY(hipEventRecord(evq.p1, sk));
     HIPTRY(hipEventRecord(ev_k1_done_[cur_set_], sk));
     ev_pending_.push_back(evq);
-    tot_plan_ms_ += last_plan_ms_;
-    tot_steps_ += 1;
-    last_audio_ = audio;
-    last_nb_ = nb;
     buffers_done_ += nb;
     cur_set_ ^= 1;
     return PBSO_OK;
@@ -1255,13 +1276,18 @@ int Engine::harvest_timing() {
     int rc = sync();
     if (rc) return rc;
     for (EvQuad &q : ev_pending_) {
-        float ms = 0;
+        float ms = 0, ms2 = 0;
         HIPTRY(hipEventElapsedTime(&ms, q.k0, q.k1));
-        last_kernel_ms_ = ms;
+        HIPTRY(hipEventElapsedTime(&ms2, q.p0, q.p1));
+        if (q.step_id != harvest_step_) {          // "last step" sums the launches of one step
+            harvest_step_ = q.step_id;
+            last_kernel_ms_ = 0;
+            last_device_ms_ = 0;
+        }
+        last_kernel_ms_ += ms;
         tot_kernel_ms_ += ms;
-        HIPTRY(hipEventElapsedTime(&ms, q.p0, q.p1));
-        last_device_ms_ = ms;
-        tot_device_ms_ += ms;
+        last_device_ms_ += ms2;
+        tot_device_ms_ += ms2;
         ev_free_.push_back(q);
     }
     ev_pending_.clear();

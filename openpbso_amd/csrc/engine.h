@@ -61,7 +61,7 @@ struct HostForceMsg {                                    // ForceMessage, modal_
     std::vector<double> data;
     int vids[3] = {0, 0, 0};
     double coords[3] = {0, 0, 0}, vn[3] = {0, 0, 0};
-    ForceProfile force;
+    double gaussian_width_us = 0;                        // GaussianForce(width); a queued message carries a pristine Force
     int64_t not_before = 0;
 };
 
@@ -116,6 +116,7 @@ public:
     int set_use_transfer(int obj, int use, int64_t not_before);
     int get_latest_transfer(int obj, double *out);
     int step(int n_buffers, void *d_audio);
+    int step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_id);   // one launch of at most chunk_buffers_ buffers
     int sync();
     int read_audio(float *out, size_t n);
     int read_emitted(unsigned char *out, size_t n);
@@ -149,7 +150,7 @@ private:
     hipEvent_t ev_prep_done_[2] = {nullptr, nullptr}, ev_k1_done_[2] = {nullptr, nullptr};
     int xfer_cap_ = 0;                                   // scratch transfer rows per plan set
     hipEvent_t ev_set_[2] = {nullptr, nullptr};
-    struct EvQuad { hipEvent_t k0, k1, p0, p1; };
+    struct EvQuad { hipEvent_t k0, k1, p0, p1; int64_t step_id; };
     std::vector<EvQuad> ev_free_, ev_pending_;           // one quad per step, harvested in info()
     int harvest_timing();
     double tot_kernel_ms_ = 0, tot_device_ms_ = 0, tot_plan_ms_ = 0, last_kernel_ms_ = 0, last_device_ms_ = 0;
@@ -224,6 +225,9 @@ private:
     std::vector<double> tbuf_;
     int n_xfer_scratch_ = 0;
     double last_plan_ms_ = 0;
+    int chunk_buffers_ = 128;                            // longer steps are cut into launches of this many buffers
+    int plan_b0_ = 0, plan_nb_total_ = 0;                // where the chunk being planned sits in the step
+    int64_t harvest_step_ = -1;
     int64_t last_frows_ = 0, last_trows_ = 0;
 };
 

@@ -58,6 +58,7 @@ struct IirParams {
     const double *xfer_rows;     // [n_rows][m_pad]   FFAT transfer rows (fp64)
     const int *xfer_init;        // [n_obj] row (or XFER_UNIT) in effect when the launch starts
     const TeamDesc *teams;       // [grid] workgroup -> (object, first column, output row); one launch per team size
+    int qn_nb, qn_b0;            // qnorm is [n_obj][qn_nb][m_pad]; this launch fills buffers qn_b0 .. qn_b0 + nb - 1
     float *audio_parts;          // [n_part_rows][audio_stride] partial sums of objects split over several teams
     float *audio;                // [n_obj][audio_stride]
     float *qnorm;                // [n_obj][nb][m_pad] or nullptr

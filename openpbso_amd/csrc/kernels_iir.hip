@@ -156,6 +156,7 @@ struct IirDims {
     long long audio_stride;
     int rotate_prio;
     long long gq_plane;          // elements between the G11 / 2 G12 / G22 planes
+    int qn_nb, qn_b0;            // qnorm is [n_obj][qn_nb][m_pad]; this launch fills buffers qn_b0 ..
 };
 
 // QNM: 0 no qnorm; 1 per-sample accumulation (the reference's loop, modal_solver.h:270);
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
             if (QN) {
 #pragma unroll
                 for (int r = 0; r < R; ++r)
-                    p_qnorm[((size_t)obj * p.nb + b) * p.m_pad + col + r * rowlen] = 0.f;
+                    p_qnorm[((size_t)obj * p.qn_nb + p.qn_b0 + b) * p.m_pad + col + r * rowlen] = 0.f;
             }
             continue;
         }
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
                 const float e0 = vget<0>(qn[r / VW]), e1 = vget<1>(qn[r / VW]);
                 // (the closed form can round a tiny sum below zero)
                 const float nrm = sqrtf(fmaxf(r % VW ? e1 : e0, 0.f));
-                p_qnorm[((size_t)obj * p.nb + b) * p.m_pad + col + r * rowlen] = scaled ? nrm / elem(t[r / VW], r % VW) : nrm;
+                p_qnorm[((size_t)obj * p.qn_nb + p.qn_b0 + b) * p.m_pad + col + r * rowlen] = scaled ? nrm / elem(t[r / VW], r % VW) : nrm;
             }
         }
     }
@@ -510,7 +511,7 @@ static int launch_one(const IirParams &p, int n_obj, int W, hipStream_t stream) 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    const IirDims dims = {p.nb, p.n_tiles, p.m_pad, p.b_pad, p.audio_stride, p.rotate_prio, p.gq_plane};
+    const IirDims dims = {p.nb, p.n_tiles, p.m_pad, p.b_pad, p.audio_stride, p.rotate_prio, p.gq_plane, p.qn_nb, p.qn_b0};
     hipLaunchKernelGGL(kern, dim3(n_obj), dim3(64 * W), lds, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc,
                        p.grows, p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.teams, p.audio_parts, p.census, dims);
     return (int)hipGetLastError();
