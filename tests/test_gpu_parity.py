@@ -573,3 +573,30 @@ def test_degenerate_objects_and_arguments():
             eng.finalize()                                   # no objects
     with pytest.raises(PbsoError):
         Engine(modes_per_lane=3)
+
+
+def test_long_steps_cut_into_launches(monkeypatch):
+    """A step longer than PBSO_CHUNK_BUFFERS is run as several launches (the host plans the next one
+    while the device runs the current): audio, qnorm, emitted flags and state are bit-identical to the
+    single launch, also for objects stepped by several teams and with a clearAllForces hole."""
+    nb = 11
+    rng = np.random.default_rng(5)
+    sizes = [1500, 70]
+    objs = [ObjSpec(synth.eigenvalues(m, 70 + i)) for i, m in enumerate(sizes)]
+    evs = []
+    for i, m in enumerate(sizes):
+        evs += [force_ev(0, i, data=rng.standard_normal(m) * 1e-3), force_ev(3, i, data=rng.standard_normal(m) * 1e-3, force_type=2),
+                force_ev(6, i, clear=True), force_ev(8, i, data=rng.standard_normal(m) * 1e-3, force_type=1, width=900.0),
+                dict(t=0, obj=i, kind="use_transfer", use=False)]
+    monkeypatch.setenv("PBSO_CHUNK_BUFFERS", "1000")
+    one = run_engine(objs, evs, nb, modes_per_lane=1)
+    for chunk in ("1", "4"):
+        monkeypatch.setenv("PBSO_CHUNK_BUFFERS", chunk)
+        cut = run_engine(objs, evs, nb, modes_per_lane=1)
+        assert np.array_equal(one["audio"], cut["audio"]) and np.array_equal(one["emitted"], cut["emitted"])
+        assert not one["emitted"][:, 6].any()
+        for key in one["qnorm"]:
+            assert np.array_equal(one["qnorm"][key], cut["qnorm"][key]), key
+        for a, b in zip(one["state"], cut["state"]):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    _check(one, run_oracle(objs, evs, nb))
