@@ -21,7 +21,10 @@
  *    is the first buffer the first pbso_step() produces.  `not_before` stamps
  *    let a batch caller say at which buffer a message becomes visible to the
  *    simulation thread's try_dequeue (the GUI thread's wall-clock in the
- *    reference).  not_before = 0 means "already there".
+ *    reference).  not_before = 0 means "already there".  Stamped calls other than force
+ *    messages (AR parameters, listener position, use-transfer flag) of one object form a FIFO in
+ *    stamp order: an AR-parameter message that finds the 1-slot queue full waits there -- the
+ *    NoFail spin of modal_solver.h:382-393 -- and so do the calls stamped behind it.
  *  - the HIP path is the only path: there is no CPU fallback.
  */
 #ifndef OPENPBSO_AMD_H

@@ -57,3 +57,17 @@ print("within-CU (max-min) duration spread us: median %.0f, max %.0f; slowest CU
     np.median([s_[0] for s_ in spreads]), spreads[-1][0], sorted(dur[key == max(set(key.tolist()), key=lambda kk: dur[key == kk].max())].round().tolist())))
 cyc = (c[:, 5].astype(np.int64) - c[:, 4].astype(np.int64))
 print(f"per-WG shader cycles: min {cyc.min():.3e} median {np.median(cyc):.3e} max {cyc.max():.3e}")
+# does the finishing order inside a CU follow the wave slot of the workgroup?
+wid = (hw & 0xF).astype(int)
+for w in sorted(set(wid.tolist())):
+    m = wid == w
+    print(f"  wave slot {w}: n={m.sum()} duration median {np.median(dur[m]):.0f} us (min {dur[m].min():.0f}, max {dur[m].max():.0f})")
+order = np.argsort(t0, kind="stable")
+rank_in_cu = np.zeros(len(t0), dtype=int)
+for kk in set(key.tolist()):
+    idx = np.nonzero(key == kk)[0]
+    idx = idx[np.argsort(c[idx, 0].astype(np.int64) * 0 + idx)]          # dispatch order = team index order
+    rank_in_cu[idx] = np.arange(len(idx))
+for r in sorted(set(rank_in_cu.tolist())):
+    m = rank_in_cu == r
+    print(f"  {r}-th team dispatched to its CU: duration median {np.median(dur[m]):.0f} us")

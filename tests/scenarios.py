@@ -96,7 +96,11 @@ def run_oracle(objs, events, n_buffers):
         if o.maps is not None:
             s.read_ffat_maps(_oracle_maps(o.maps))
         evs = sorted([e for e in events if e["obj"] == oi], key=lambda e: e["t"])
-        pending_arprm = []
+        # Model of the caller (GUI) thread for stamped scripts, the same on both sides of the comparison:
+        # force messages go straight to the 1023-slot queue; the other calls of an object form a FIFO
+        # in stamp order, and enqueueArprmMessageNoFail on a full 1-slot queue SPINS (modal_solver.h:
+        # 382-393) -- it, and the calls behind it, wait until a step() has drained the slot.
+        gui = []
         ei = 0
         for b in range(n_buffers):
             while ei < len(evs) and evs[ei]["t"] <= b:
@@ -115,19 +119,19 @@ def run_oracle(objs, events, n_buffers):
                         data = np.zeros(n)
                     f = orc.make_force(ev["force_type"], ev["width"])
                     assert s.enqueue_force(data, f, ev["start"], ev["end"], ev["clear"])
-                elif k == "arprm":
-                    pending_arprm.append(ev)
+                else:
+                    gui.append(ev)
+            while gui:
+                ev = gui[0]
+                k = ev["kind"]
+                if k == "arprm":
+                    if not s.enqueue_arprm(ev["a"], ev["sigma"], ev["mu"]):
+                        break                                   # spinning: nothing behind it happens yet
                 elif k == "listener":
                     s.compute_transfer(ev["pos"])
                 elif k == "use_transfer":
                     s.set_use_transfer(ev["use"])
-            # enqueueArprmMessageNoFail: the GUI spins until the 1-slot queue drains
-            while pending_arprm:
-                ev = pending_arprm[0]
-                if s.enqueue_arprm(ev["a"], ev["sigma"], ev["mu"]):
-                    pending_arprm.pop(0)
-                else:
-                    break
+                gui.pop(0)
             r = s.step()
             if r is None:
                 emitted[oi, b] = False

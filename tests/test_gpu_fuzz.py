@@ -2,6 +2,8 @@
 ModalSolver::step for arbitrary interleavings of point / Gaussian / AR forces,
 sustained start / end, clearAllForces, AR parameter updates, listener moves and
 useTransfer toggles."""
+import os
+
 import numpy as np
 import pytest
 
@@ -65,7 +67,7 @@ def _legal(evs, objs, nb):
         return False
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PBSO_FUZZ_SEEDS", "200"))))
 def test_random_scripts_match_oracle(seed):
     rng = np.random.default_rng(1000 + seed)
     n_obj = int(rng.integers(1, 5))
@@ -90,5 +92,12 @@ def test_random_scripts_match_oracle(seed):
     assert (mx <= 5e-4).all() and (l2 <= 1e-3).all(), (mx, l2)
     for a, w in zip(got["latest"], want["latest"]):
         assert np.array_equal(a, w)
+    # qnorm: 2e-3 of the buffer's largest entry, plus 2e-6 of the object's peak over the run -- the ringing
+    # left behind by a smooth (Gaussian) pulse is a 1e-4 residue of the response during the pulse, and
+    # fp32 resolves it only relative to that response (seed 519)
+    peak = {}
+    for (oi, _), w in want["qnorm"].items():
+        peak[oi] = max(peak.get(oi, 0.0), float(np.abs(w).max()))
     for key, w in want["qnorm"].items():
-        assert np.abs(got["qnorm"][key] - w).max() <= 2e-3 * max(np.abs(w).max(), 1e-30), key
+        tol = 2e-3 * max(np.abs(w).max(), 1e-30) + 2e-6 * peak[key[0]]
+        assert np.abs(got["qnorm"][key] - w).max() <= tol, key
