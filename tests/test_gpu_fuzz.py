@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from openpbso_amd import synth
+from openpbso_amd import capi, synth
 from tests.scenarios import ObjSpec, force_ev, rel_errors, run_engine, run_oracle
 
 pytestmark = pytest.mark.gpu
@@ -67,25 +67,37 @@ def _legal(evs, objs, nb):
         return False
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("PBSO_FUZZ_SEEDS", "200"))))
-def test_random_scripts_match_oracle(seed):
+def _run_seed(seed, size_choices, engine_kw, projected_hits=False):
     rng = np.random.default_rng(1000 + seed)
     n_obj = int(rng.integers(1, 5))
-    n_modes = [int(rng.choice([3, 40, 64, 100, 129, 300])) for _ in range(n_obj)]
+    n_modes = [int(rng.choice(size_choices)) for _ in range(n_obj)]
     nb = int(rng.integers(6, 16))
     with_maps = [bool(rng.random() < 0.5) for _ in range(n_obj)]
     objs = []
     for oi in range(n_obj):
         lam = synth.eigenvalues(n_modes[oi], 5000 + 10 * seed + oi)
-        objs.append(ObjSpec(lam, maps=synth.ffat_maps(lam, 7000 + seed + oi, dim=4) if with_maps[oi] else None))
+        objs.append(ObjSpec(lam, shapes=synth.mode_shapes(n_modes[oi], 6000 + seed + oi) if projected_hits else None,
+                            maps=synth.ffat_maps(lam, 7000 + seed + oi, dim=4) if with_maps[oi] else None))
     evs = random_script(rng, n_obj, n_modes, nb, with_maps)
+    if projected_hits:
+        # replace the explicit modal data of about half of the messages by a vertex or face hit
+        # (GetModalForceVertex / GetModalForceFace on the device)
+        for e in evs:
+            if e["kind"] == "force" and e["data"] is not None and rng.random() < 0.5:
+                e["data"] = None
+                e["vn"] = synth.unit_normals(1, int(rng.integers(1 << 30)))[0]
+                if rng.random() < 0.5:
+                    e["vid"] = int(rng.integers(0, synth.N_VERTS))
+                else:
+                    bary = rng.random(3)
+                    e["vids"], e["coords"] = rng.integers(0, synth.N_VERTS, 3), bary / bary.sum()
     if not _legal(evs, objs, nb):
         pytest.skip("script trips a live assert of the reference")
     split = None
     if nb > 8:
         k = int(rng.integers(1, nb - 1))
         split = [k, nb - k]
-    got = run_engine(objs, evs, nb, split=split)
+    got = run_engine(objs, evs, nb, split=split, **engine_kw)
     want = run_oracle(objs, evs, nb)
     assert np.array_equal(got["emitted"], want["emitted"])
     mx, l2 = rel_errors(got["audio"], want["audio"])
@@ -101,3 +113,18 @@ def test_random_scripts_match_oracle(seed):
     for key, w in want["qnorm"].items():
         tol = 2e-3 * max(np.abs(w).max(), 1e-30) + 2e-6 * peak[key[0]]
         assert np.abs(got["qnorm"][key] - w).max() <= tol, key
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PBSO_FUZZ_SEEDS", "200"))))
+def test_random_scripts_match_oracle(seed):
+    _run_seed(seed, [3, 40, 64, 100, 129, 300], {})
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PBSO_FUZZ_SHAPE_SEEDS", "60"))))
+def test_random_scripts_random_engine_shapes(seed, monkeypatch):
+    """the same scripts with on-device hit projection, objects stepped by several teams, every
+    modes-per-lane setting, both qnorm modes and launches cut at random lengths"""
+    rng = np.random.default_rng(77000 + seed)
+    monkeypatch.setenv("PBSO_CHUNK_BUFFERS", str(int(rng.choice([1, 2, 5, 128]))))
+    kw = dict(modes_per_lane=int(rng.choice([0, 1, 2, 4, 8])), qnorm=int(rng.choice([capi.QNORM_ALL, capi.QNORM_CLOSED])))
+    _run_seed(seed + 100000, [5, 64, 200, 1100, 2100], kw, projected_hits=True)
