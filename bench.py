@@ -333,7 +333,6 @@ def main():
                             f"qnorm {'off' if args.no_qnorm else args.qnorm}, {args.form} recurrence form",
                 "scenario": args.scenario, "objects_per_gpu": args.objects, "modes": M, "buffers_per_step": nb, "frames_per_buffer": B,
                 "hits": n_hits, "modes_per_lane": info1["modes_per_lane"], "waves_per_object": info1["waves_per_object"],
-                "kernel_build": "packed" if os.environ.get("PBSO_IIR_PACKED", "0") != "0" else "scalar",
                 "gather": bool(do_gather), "parallelism": f"object-sharded x{world}",
             },
             "roofline": {

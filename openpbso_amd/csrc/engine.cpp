@@ -214,7 +214,6 @@ int Engine::init() {
     }
     tbuf_.assign(B_, 0.0);
     // which build of the oscillator bank to launch (see kernels_iir.hip)
-    if (const char *v = std::getenv("PBSO_IIR_PACKED")) packed_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_CENSUS")) census_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_ROTATE_PRIO")) rotate_prio_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_DEVICE_PROFILES")) device_profiles_ = std::atoi(v) != 0;
@@ -1120,10 +1119,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.audio_parts = n_part_rows_ ? d_audio_parts_.p + (size_t)b0 * B_ : nullptr;
     for (const SizeClass &c : classes_) {
         kp.teams = d_teams_.p + c.first;
-        if (packed_ && R_ >= 2)
-            LAUNCHTRY(iir_packed::launch_iir_bank(kp, c.count, R_, c.W, desc_.recurrence_form, desc_.qnorm_mode, sk));
-        else
-            LAUNCHTRY(iir_scalar::launch_iir_bank(kp, c.count, R_, c.W, desc_.recurrence_form, desc_.qnorm_mode, sk));
+        LAUNCHTRY(iir_scalar::launch_iir_bank(kp, c.count, R_, c.W, desc_.recurrence_form, desc_.qnorm_mode, sk));
     }
     HIPTRY(hipEventRecord(evq.k1, sk));
     // _latest_transfer = trans (modal_solver.h:251), then re-park a still-queued transfer

@@ -143,7 +143,6 @@ private:
     int B_ = PBSO_FRAMES_PER_BUFFER, rate_ = PBSO_SAMPLE_RATE, n_tiles_ = 9, b_pad_ = 528;
     int R_ = 0, W_ = 0, m_pad_ = 0;
     bool finalized_ = false, own_stream_ = false;
-    bool packed_ = false;                                // PBSO_IIR_PACKED=1: v_pk_*_f32 build of K1 (measured 2-3 % slower)
     int t_extent_ = 0;                                   // leading samples of tbuf_ that may be non-zero
     hipStream_t stream_ = nullptr;                       // oscillator bank (caller's stream if given)
     hipStream_t prep_stream_ = nullptr;                  // plan upload + projection + FFAT + combine

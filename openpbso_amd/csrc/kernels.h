@@ -70,16 +70,11 @@ struct IirParams {
     int rotate_prio;             // rotate s_setprio per tile (fair progress of resident teams)
 };
 
-// launches the oscillator bank; returns hipError_t as int.  Two builds of the
-// same source: packed (float2 mode pairs, v_pk_*_f32; R >= 2) and scalar.
-// Supported shapes: W <= 16 waves per object, R in {1,2,4,8}.
-namespace iir_packed {
+// launches the oscillator bank for n_teams teams of waves_per_team waves; returns hipError_t as int.
+// Supported shapes: waves_per_team <= MAX_WAVES_PER_TEAM, R in {1,2,4,8}.
 // qnorm_mode: 0 off, 1 per-sample, 2 closed form (needs IirParams::gq).
-int launch_iir_bank(const IirParams &p, int n_obj, int modes_per_lane, int waves_per_object,
-                    int form, int qnorm_mode, hipStream_t stream);
-}
 namespace iir_scalar {
-int launch_iir_bank(const IirParams &p, int n_obj, int modes_per_lane, int waves_per_object,
+int launch_iir_bank(const IirParams &p, int n_teams, int modes_per_lane, int waves_per_team,
                     int form, int qnorm_mode, hipStream_t stream);
 }
 // per wave: one [TILE][LDS_ROW] transpose tile + a ring of (n_tiles + 1) tiles of row sums

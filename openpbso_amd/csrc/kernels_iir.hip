@@ -13,7 +13,6 @@
 // rate, not by HBM: per oscillator-sample it issues
 //   velocity form:  v_mul, v_fma [, v_fma force], v_add, v_fma out [, v_fma qnorm]
 //   direct form:    v_mul [, v_fma force], v_fma, v_fma out [, v_fma qnorm]
-// (pairs of modes fuse into v_pk_* in the "packed" build of this file).
 //
 // Per-sample reduction over modes.  Each lane first sums its own R modes
 // (p = sum_r t_r q_r), then the 64 lane partials of TILE = 27 consecutive
@@ -33,27 +32,13 @@
 
 #include "kernels.h"
 
-// built twice (Makefile), both with -fno-slp-vectorize so that the instruction
-// selection is the one written here:
-//   PBSO_IIR_PACKED=1 -> namespace iir_packed: a lane's modes are held as float2
-//     pairs and stepped with v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 (2 FMAs
-//     per lane per instruction; faster than v_fma_f32 from ~3 waves per SIMD on,
-//     profiles/r01_microbench.txt);
-//   PBSO_IIR_PACKED=0 -> namespace iir_scalar: plain v_fma_f32.
-// The engine picks one at run time.
-#ifndef PBSO_IIR_PACKED
-#define PBSO_IIR_PACKED 1
-#endif
-#if PBSO_IIR_PACKED
-#define PBSO_IIR_NS iir_packed
-#else
-#define PBSO_IIR_NS iir_scalar
-#endif
+// Built with -fno-slp-vectorize so that the instruction selection is the one written here (plain
+// VOP2 v_mul / v_fmac / v_add).  A float2 variant on v_pk_*_f32 measured 2-3 % slower (the packed
+// ops issue at half rate) and was dropped.
 
 namespace pbso {
-namespace PBSO_IIR_NS {
+namespace iir_scalar {
 
-typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 template <int K0, int N, class F>
@@ -64,24 +49,12 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-// lane-local vector of oscillators: float (1 mode) or float2 (2 modes, v_pk_*)
-__device__ __forceinline__ float vfma(float a, float b, float c) { return fmaf(a, b, c); }
-__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ float vsplat(float, float x) { return x; }
-__device__ __forceinline__ v2f vsplat(v2f, float x) { return (v2f){x, x}; }
-template <int E> __device__ __forceinline__ float vget(float v) { return v; }
-template <int E> __device__ __forceinline__ float vget(v2f v) { return E == 0 ? v.x : v.y; }
-__device__ __forceinline__ void vset(float &v, int, float x) { v = x; }
-__device__ __forceinline__ void vset(v2f &v, int e, float x) { if (e == 0) v.x = x; else v.y = x; }
-template <class V> struct lanes_of { static constexpr int n = 1; };
-template <> struct lanes_of<v2f> { static constexpr int n = 2; };
-
 // FMODE: 0 force-free, 1 dense time profile tp[0..TILE), 2 impulse (amp at sample 0 only)
 // SCALED: the state registers hold (transfer weight x state), so the lane's output is a
 // plain sum of its modes (one add instead of a multiply + FMA per pair of modes).
-template <class V, int NV, int FORM, bool QN, int FMODE, bool SCALED>
-__device__ __forceinline__ void step_tile(V (&q)[NV], V (&d)[NV], const V (&ca)[NV], const V (&cb)[NV],
-                                          const V (&g)[NV], const V (&t)[NV], V (&qn)[NV],
+template <int R, int FORM, bool QN, int FMODE, bool SCALED>
+__device__ __forceinline__ void step_tile(float (&q)[R], float (&d)[R], const float (&ca)[R], const float (&cb)[R],
+                                          const float (&g)[R], const float (&t)[R], float (&qn)[R],
                                           const float *__restrict__ tp, float amp, f4 (&rv)[8],
                                           float &rsum) {
     // dense profile: fetch the tile's 27 values into SGPRs up front (one wait)
@@ -98,32 +71,28 @@ __device__ __forceinline__ void step_tile(V (&q)[NV], V (&d)[NV], const V (&ca)[
         if (FMODE == 2 && k == 0) tk = amp;
         float p = 0.f;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
+        for (int v = 0; v < R; ++v) {
             if (FORM == 0) {
                 // d_k = eps^2 d_{k-1} - e q_{k-1} + g T_k ;  q_k = q_{k-1} + d_k   (cb holds -e)
-                V a = ca[v] * d[v];
-                a = vfma(cb[v], q[v], a);
-                if (forced) a = vfma(g[v], vsplat(a, tk), a);
+                float a = ca[v] * d[v];
+                a = fmaf(cb[v], q[v], a);
+                if (forced) a = fmaf(g[v], tk, a);
                 d[v] = a;
                 q[v] = q[v] + a;
             } else {
                 // q_k = c1 q_{k-1} + c2 q_{k-2} + g T_k   (d holds q_{k-2})
-                V a = cb[v] * d[v];
-                if (forced) a = vfma(g[v], vsplat(a, tk), a);
-                const V qk = vfma(ca[v], q[v], a);
+                float a = cb[v] * d[v];
+                if (forced) a = fmaf(g[v], tk, a);
+                const float qk = fmaf(ca[v], q[v], a);
                 d[v] = q[v];
                 q[v] = qk;
             }
-            // the lane's own modes are summed with scalar FMAs: a packed product
-            // would need an extra add to fold its two halves
             if (SCALED) {
-                p = (v == 0) ? vget<0>(q[v]) : p + vget<0>(q[v]);
-                if (lanes_of<V>::n == 2) p = p + vget<1>(q[v]);
+                p = (v == 0) ? q[v] : p + q[v];
             } else {
-                p = (v == 0) ? vget<0>(t[v]) * vget<0>(q[v]) : fmaf(vget<0>(t[v]), vget<0>(q[v]), p);
-                if (lanes_of<V>::n == 2) p = fmaf(vget<1>(t[v]), vget<1>(q[v]), p);
+                p = (v == 0) ? t[v] * q[v] : fmaf(t[v], q[v], p);
             }
-            if (QN) qn[v] = vfma(q[v], q[v], qn[v]);
+            if (QN) qn[v] = fmaf(q[v], q[v], qn[v]);
         }
         // LDS address = M0 (this wave's tile, set by the caller) + offset + 4 * lane
         asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(p), "n"(k * LDS_ROW * 4) : "memory");
@@ -131,7 +100,7 @@ __device__ __forceinline__ void step_tile(V (&q)[NV], V (&d)[NV], const V (&ca)[
             // pin the qnorm accumulators here: without it the q^2 FMAs of a whole
             // tile are sunk to the tile's end and TILE*R q values stay live.
 #pragma unroll
-            for (int v = 0; v < NV; ++v) asm volatile("" : "+v"(qn[v]));
+            for (int v = 0; v < R; ++v) asm volatile("" : "+v"(qn[v]));
         }
         // two adds of the previous tile's row sum per sample (samples 1..16): they
         // are independent of the recurrence and fill its dependency stalls
@@ -163,7 +132,7 @@ struct IirDims {
 //      2 closed form: in a buffer that is force-free after its first sample,
 //        sum_k q_k^2 = x0' G x0 with x0 = (q_0, q_0 - q_-1) after sample 0 and G = sum_k (A^k)' e1 e1' A^k
 //        precomputed per mode in fp64; buffers with a dense profile accumulate per sample.
-template <class V, int NV, int FORM, int QNM, int MAXT>
+template <int R, int FORM, int QNM, int MAXT>
 __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     const float *__restrict__ p_ca, const float *__restrict__ p_cb, float *__restrict__ p_sq,
     float *__restrict__ p_sd, float *__restrict__ p_ss, const BufDesc *__restrict__ p_desc, const float *__restrict__ p_grows,
@@ -190,17 +159,15 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     const unsigned tile_m0 = (unsigned)wave * (unsigned)(TILE * LDS_ROW * sizeof(float));
     const size_t mbase = (size_t)obj * p.m_pad + col;
 
-    constexpr int VW = lanes_of<V>::n;
-    constexpr int R = NV * VW;                       // oscillators per lane; slice r = v * VW + e
-    V ca[NV], cb[NV], q[NV], d[NV], g_[NV], t[NV], qn[NV];
+    float ca[R], cb[R], q[R], d[R], g_[R], t[R], qn[R];   // R oscillators per lane, slice r at column col + r * rowlen
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        vset(ca[r / VW], r % VW, p_ca[mbase + r * rowlen]);
-        vset(cb[r / VW], r % VW, p_cb[mbase + r * rowlen]);
-        vset(q[r / VW], r % VW, p_sq[mbase + r * rowlen]);
-        vset(d[r / VW], r % VW, p_sd[mbase + r * rowlen]);
-        vset(g_[r / VW], r % VW, 0.f);
-        vset(qn[r / VW], r % VW, 0.f);
+        ca[r] = (p_ca[mbase + r * rowlen]);
+        cb[r] = (p_cb[mbase + r * rowlen]);
+        q[r] = (p_sq[mbase + r * rowlen]);
+        d[r] = (p_sd[mbase + r * rowlen]);
+        g_[r] = (0.f);
+        qn[r] = (0.f);
     }
     // Scaled state.  The output of a mode is t * q with a transfer weight t that only changes
     // between buffers, and the recurrence is linear: the registers hold Q = t q, D = t d, the
@@ -213,57 +180,56 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     bool dead[R];
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        dead[r] = (r % VW ? vget<1>(ca[r / VW]) : vget<0>(ca[r / VW])) == 0.f && (r % VW ? vget<1>(cb[r / VW]) : vget<0>(cb[r / VW])) == 0.f;
+        dead[r] = ca[r] == 0.f && cb[r] == 0.f;
     bool scaled = false;
     auto usable = [](float x) { return x >= 0x1p-20f && x <= 0x1p40f; };
-    auto elem = [](const V &v, int e) { return e ? vget<1>(v) : vget<0>(v); };
     // move the state from scale `from` (per mode) to the weights tn, or to scale 1 if some tn is unusable
-    auto rescale = [&](const V (&from)[NV], const V (&tn)[NV]) {
+    auto rescale = [&](const float (&from)[R], const float (&tn)[R]) {
         bool ok = true, same = true, unit = true;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            ok = ok && usable(elem(tn[r / VW], r % VW));
-            same = same && elem(tn[r / VW], r % VW) == elem(from[r / VW], r % VW);
-            unit = unit && elem(from[r / VW], r % VW) == 1.f;
+            ok = ok && usable(tn[r]);
+            same = same && tn[r] == from[r];
+            unit = unit && from[r] == 1.f;
         }
         ok = __all(ok);
         if (ok) {
             if (!__all(same)) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const float f = elem(tn[r / VW], r % VW) / elem(from[r / VW], r % VW);
-                    vset(q[r / VW], r % VW, elem(q[r / VW], r % VW) * f);
-                    vset(d[r / VW], r % VW, elem(d[r / VW], r % VW) * f);
+                    const float f = tn[r] / from[r];
+                    q[r] = (q[r] * f);
+                    d[r] = (d[r] * f);
                 }
             }
         } else if (!__all(unit)) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                vset(q[r / VW], r % VW, elem(q[r / VW], r % VW) / elem(from[r / VW], r % VW));
-                vset(d[r / VW], r % VW, elem(d[r / VW], r % VW) / elem(from[r / VW], r % VW));
+                q[r] = (q[r] / from[r]);
+                d[r] = (d[r] / from[r]);
             }
         }
         scaled = ok;
     };
     {
         const int row0 = p_xfer_init[obj];
-        V s0[NV];
+        float s0[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            vset(s0[r / VW], r % VW, p_ss[mbase + r * rowlen]);
+            s0[r] = (p_ss[mbase + r * rowlen]);
             const float tr = row0 >= 0 ? (float)p_xfer_rows[(size_t)row0 * p.m_pad + col + r * rowlen] : 1e7f;
-            vset(t[r / VW], r % VW, dead[r] ? 1.f : tr);
+            t[r] = (dead[r] ? 1.f : tr);
         }
         rescale(s0, t);
     }
 
-    V g11[NV], g12[NV], g22[NV];                     // QNM == 2: G11, 2 G12, G22 of every mode
+    float g11[R], g12[R], g22[R];                     // QNM == 2: G11, 2 G12, G22 of every mode
     if (QNM == 2) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            vset(g11[r / VW], r % VW, p_gq[mbase + r * rowlen]);
-            vset(g12[r / VW], r % VW, p_gq[p.gq_plane + mbase + r * rowlen]);
-            vset(g22[r / VW], r % VW, p_gq[2 * p.gq_plane + mbase + r * rowlen]);
+            g11[r] = (p_gq[mbase + r * rowlen]);
+            g12[r] = (p_gq[p.gq_plane + mbase + r * rowlen]);
+            g22[r] = (p_gq[2 * p.gq_plane + mbase + r * rowlen]);
         }
     }
 
@@ -374,22 +340,22 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
             continue;
         }
         if (trow != XFER_KEEP) {
-            V tn[NV], from[NV];
+            float tn[R], from[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float tr = trow >= 0 ? (float)p_xfer_rows[(size_t)trow * p.m_pad + col + r * rowlen] : 1e7f;
-                vset(tn[r / VW], r % VW, dead[r] ? 1.f : tr);
-                vset(from[r / VW], r % VW, scaled ? elem(t[r / VW], r % VW) : 1.f);
+                tn[r] = (dead[r] ? 1.f : tr);
+                from[r] = (scaled ? t[r] : 1.f);
             }
             rescale(from, tn);
 #pragma unroll
-            for (int v = 0; v < NV; ++v) t[v] = tn[v];
+            for (int v = 0; v < R; ++v) t[v] = tn[v];
         }
         if (frow >= 0) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float gr = p_grows[(size_t)frow * p.m_pad + col + r * rowlen];
-                vset(g_[r / VW], r % VW, scaled ? gr * elem(t[r / VW], r % VW) : gr);
+                g_[r] = (scaled ? gr * t[r] : gr);
             }
         }
         const bool impulse = (flags & DESC_IMPULSE) != 0;
@@ -398,29 +364,29 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
         const float *__restrict__ tprow = p_tprof + (size_t)(prow >= 0 ? prow : 0) * p.b_pad;
         if (QN) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) vset(qn[r / VW], r % VW, 0.f);
+            for (int r = 0; r < R; ++r) qn[r] = (0.f);
         }
         if (QNM == 2 && !dense) {
             // x0 = state after sample 0, with exactly the arithmetic sample 0 will use
             const float f0 = (frow >= 0 && (mask & 1u)) ? amp : 0.f;
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                V q0, s0;
+            for (int v = 0; v < R; ++v) {
+                float q0, s0;
                 if (FORM == 0) {
-                    V a = ca[v] * d[v];
-                    a = vfma(cb[v], q[v], a);
-                    if (f0 != 0.f) a = vfma(g_[v], vsplat(a, f0), a);
+                    float a = ca[v] * d[v];
+                    a = fmaf(cb[v], q[v], a);
+                    if (f0 != 0.f) a = fmaf(g_[v], f0, a);
                     s0 = a;
                     q0 = q[v] + a;
                 } else {
-                    V a = cb[v] * d[v];
-                    if (f0 != 0.f) a = vfma(g_[v], vsplat(a, f0), a);
-                    q0 = vfma(ca[v], q[v], a);
+                    float a = cb[v] * d[v];
+                    if (f0 != 0.f) a = fmaf(g_[v], f0, a);
+                    q0 = fmaf(ca[v], q[v], a);
                     s0 = q0 - q[v];             // G is kept in the (q, q - q_prev) basis for both forms
                 }
-                V e = g22[v] * s0 * s0;
-                e = vfma(g12[v] * q0, s0, e);
-                qn[v] = vfma(g11[v] * q0, q0, e);
+                float e = g22[v] * s0 * s0;
+                e = fmaf(g12[v] * q0, s0, e);
+                qn[v] = fmaf(g11[v] * q0, q0, e);
             }
         }
         const int g0 = g;
@@ -446,14 +412,14 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
             auto run_tile = [&](auto sc) {
                 constexpr bool SC = decltype(sc)::value;
                 if (hit && impulse) {
-                    step_tile<V, NV, FORM, QNM == 1, 2, SC>(q, d, ca, cb, g_, t, qn, nullptr, amp, rv, rsum);
+                    step_tile<R, FORM, QNM == 1, 2, SC>(q, d, ca, cb, g_, t, qn, nullptr, amp, rv, rsum);
                 } else if (hit) {
-                    step_tile<V, NV, FORM, QN, 1, SC>(q, d, ca, cb, g_, t, qn, tprow + tl * TILE, 0.f, rv, rsum);
+                    step_tile<R, FORM, QN, 1, SC>(q, d, ca, cb, g_, t, qn, tprow + tl * TILE, 0.f, rv, rsum);
                 } else if (QNM == 2) {
-                    if (accum) step_tile<V, NV, FORM, true, 0, SC>(q, d, ca, cb, g_, t, qn, nullptr, 0.f, rv, rsum);
-                    else step_tile<V, NV, FORM, false, 0, SC>(q, d, ca, cb, g_, t, qn, nullptr, 0.f, rv, rsum);
+                    if (accum) step_tile<R, FORM, true, 0, SC>(q, d, ca, cb, g_, t, qn, nullptr, 0.f, rv, rsum);
+                    else step_tile<R, FORM, false, 0, SC>(q, d, ca, cb, g_, t, qn, nullptr, 0.f, rv, rsum);
                 } else {
-                    step_tile<V, NV, FORM, QN, 0, SC>(q, d, ca, cb, g_, t, qn, nullptr, 0.f, rv, rsum);
+                    step_tile<R, FORM, QN, 0, SC>(q, d, ca, cb, g_, t, qn, nullptr, 0.f, rv, rsum);
                 }
             };
             if (scaled) run_tile(std::true_type{});
@@ -471,10 +437,9 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
         if (QN) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const float e0 = vget<0>(qn[r / VW]), e1 = vget<1>(qn[r / VW]);
                 // (the closed form can round a tiny sum below zero)
-                const float nrm = sqrtf(fmaxf(r % VW ? e1 : e0, 0.f));
-                p_qnorm[((size_t)obj * p.qn_nb + p.qn_b0 + b) * p.m_pad + col + r * rowlen] = scaled ? nrm / elem(t[r / VW], r % VW) : nrm;
+                const float nrm = sqrtf(fmaxf(qn[r], 0.f));
+                p_qnorm[((size_t)obj * p.qn_nb + p.qn_b0 + b) * p.m_pad + col + r * rowlen] = scaled ? nrm / t[r] : nrm;
             }
         }
     }
@@ -491,21 +456,16 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        p_sq[mbase + r * rowlen] = r % VW ? vget<1>(q[r / VW]) : vget<0>(q[r / VW]);
-        p_sd[mbase + r * rowlen] = r % VW ? vget<1>(d[r / VW]) : vget<0>(d[r / VW]);
-        p_ss[mbase + r * rowlen] = scaled ? elem(t[r / VW], r % VW) : 1.f;
+        p_sq[mbase + r * rowlen] = q[r];
+        p_sd[mbase + r * rowlen] = d[r];
+        p_ss[mbase + r * rowlen] = scaled ? t[r] : 1.f;
     }
 }
 
 template <int R, int FORM, int QNM, int MAXT>
 static int launch_one(const IirParams &p, int n_obj, int W, hipStream_t stream) {
     const size_t lds = iir_lds_bytes(W, p.n_tiles);
-#if PBSO_IIR_PACKED
-    auto kern = R >= 2 ? iir_bank_kernel<v2f, (R >= 2 ? R / 2 : 1), FORM, QNM, MAXT> : nullptr;
-    if (R < 2) return (int)hipErrorInvalidValue;      // one mode per lane has nothing to pack
-#else
-    auto kern = iir_bank_kernel<float, R, FORM, QNM, MAXT>;
-#endif
+    auto kern = iir_bank_kernel<R, FORM, QNM, MAXT>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -531,25 +491,21 @@ static int launch_r(const IirParams &p, int n_obj, int W, int form, int qnm, hip
 
 // teams of up to 4 waves use the 256-thread build (no VGPR cap in practice);
 // larger teams (objects with more than 256 R modes) the 1024-thread build.
-// R in {1,2,4,8} for both (R = 1 only in the scalar build).
+// R in {1,2,4,8} for both.
 int launch_iir_bank(const IirParams &p, int n_obj, int R, int W, int form, int qnm, hipStream_t s) {
     if (n_obj <= 0) return 0;
     if (qnm < 0 || qnm > 2) return (int)hipErrorInvalidValue;
     if (W < 1 || W > MAX_WAVES_PER_TEAM) return (int)hipErrorInvalidValue;
     if (W <= 4) {
         switch (R) {
-#if !PBSO_IIR_PACKED
         case 1: return launch_r<1, 256>(p, n_obj, W, form, qnm, s);
-#endif
         case 2: return launch_r<2, 256>(p, n_obj, W, form, qnm, s);
         case 4: return launch_r<4, 256>(p, n_obj, W, form, qnm, s);
         case 8: return launch_r<8, 256>(p, n_obj, W, form, qnm, s);
         }
     } else {
         switch (R) {
-#if !PBSO_IIR_PACKED
         case 1: return launch_r<1, 1024>(p, n_obj, W, form, qnm, s);
-#endif
         case 2: return launch_r<2, 1024>(p, n_obj, W, form, qnm, s);
         case 4: return launch_r<4, 1024>(p, n_obj, W, form, qnm, s);
         case 8: return launch_r<8, 1024>(p, n_obj, W, form, qnm, s);
@@ -558,5 +514,5 @@ int launch_iir_bank(const IirParams &p, int n_obj, int R, int W, int form, int q
     return (int)hipErrorInvalidValue;
 }
 
-}  // namespace PBSO_IIR_NS
+}  // namespace iir_scalar
 }  // namespace pbso

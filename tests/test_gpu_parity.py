@@ -54,13 +54,10 @@ def test_config1_wine_glass_one_impulse():
 
 
 @pytest.mark.parametrize("mpl", [1, 2, 4])
-@pytest.mark.parametrize("packed", ["0", "1"])
 @pytest.mark.parametrize("rotate", ["0", "1"])
-def test_config2_512_modes_poisson_train(mpl, packed, rotate, monkeypatch):
+def test_config2_512_modes_poisson_train(mpl, rotate, monkeypatch):
     """configs[1]: single object, 512 modes, Poisson impulse train; every team
-    shape (R oscillators per lane), both builds of the kernel (v_pk_* / scalar),
-    with and without the wave-priority rotation (a scheduling hint only)."""
-    monkeypatch.setenv("PBSO_IIR_PACKED", packed)
+    shape (R oscillators per lane), with and without the wave-priority rotation (a scheduling hint only)."""
     monkeypatch.setenv("PBSO_ROTATE_PRIO", rotate)
     seed = synth.seed_for(2, 0)
     lam = synth.eigenvalues(512, seed)
@@ -75,15 +72,13 @@ def test_config2_512_modes_poisson_train(mpl, packed, rotate, monkeypatch):
     want = run_oracle(objs, evs, NB)
     mx, l2 = _check(got, want)
     assert got["info"]["modes_per_lane"] == mpl
-    print(f"C2 R={mpl} packed={packed} rotate={rotate} max/peak={mx:.2e} relL2={l2:.2e}")
+    print(f"C2 R={mpl} rotate={rotate} max/peak={mx:.2e} relL2={l2:.2e}")
 
 
 @pytest.mark.parametrize("mpl", [4, 8])
-@pytest.mark.parametrize("packed", ["0", "1"])
-def test_config5_shape_large_objects(mpl, packed, monkeypatch):
+def test_config5_shape_large_objects(mpl, monkeypatch):
     """configs[4] object size: 4096 modes per object -> teams of 16 / 8 waves
     (the 1024-thread build of the kernel), Gaussian + point forces."""
-    monkeypatch.setenv("PBSO_IIR_PACKED", packed)
     n_modes, nb = 4096, 10
     objs, evs = [], []
     rng = np.random.default_rng(55)

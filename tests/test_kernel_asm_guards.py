@@ -15,13 +15,13 @@ CSRC = os.path.join(ROOT, "openpbso_amd", "csrc")
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
 def test_iir_kernel_generated_code(tmp_path):
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-DPBSO_IIR_PACKED=0",
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize",
                     "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
                     os.path.join(CSRC, "kernels_iir.hip"), "-o", str(tmp_path / "k.s")], check=True, capture_output=True)
     asm = open(tmp_path / "k.s").read()
     kernels = re.split(r"\n(?=_ZN4pbso10iir_scalar15iir_bank_kernel\S*:)", asm)[1:]
     assert len(kernels) >= 20
-    headline = [k for k in kernels if k.startswith("_ZN4pbso10iir_scalar15iir_bank_kernelIfLi2ELi0ELi1ELi256E")]
+    headline = [k for k in kernels if k.startswith("_ZN4pbso10iir_scalar15iir_bank_kernelILi2ELi0ELi1ELi256E")]
     assert len(headline) == 1
     for k in kernels:
         body = k.split("s_endpgm")[0]
@@ -35,6 +35,6 @@ def test_iir_kernel_generated_code(tmp_path):
     hot = [l for l in h.splitlines() if re.match(r"\s+v_(fma|fmac|mul|add)_f32", l)]
     assert hot and all("_e64" not in l for l in hot)            # VOP2 only in the arithmetic
     meta = asm[asm.find(".amdgpu_metadata"):]
-    m = re.search(r"\.name:\s+_ZN4pbso10iir_scalar15iir_bank_kernelIfLi2ELi0ELi1ELi256E.*?\.vgpr_count:\s+(\d+)", meta, re.S)
+    m = re.search(r"\.name:\s+_ZN4pbso10iir_scalar15iir_bank_kernelILi2ELi0ELi1ELi256E.*?\.vgpr_count:\s+(\d+)", meta, re.S)
     if m:
         assert int(m.group(1)) <= 128                            # 4 waves per SIMD need <= 128 VGPRs
