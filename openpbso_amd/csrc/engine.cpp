@@ -961,6 +961,8 @@ int Engine::step(int nb, void *d_audio_user) {
     HIPTRY(hipSetDevice(desc_.device));      // the caller's thread may have another device current
     if (!finalized_) return fail(PBSO_ERR_STATE, "step before finalize");
     if (nb <= 0) return fail(PBSO_ERR_INVALID, "n_buffers must be > 0");
+    if (failed_) return fail(PBSO_ERR_STATE, "an earlier step failed half-way (" + failed_why_ + "): queues and force lists are no "
+                                             "longer consistent, create a new engine");
     const int N = (int)objs_.size();
     float *audio = (float *)d_audio_user;
     // outputs of the whole step (growth drains the device first, see DevBuf::ensure)
@@ -975,7 +977,12 @@ int Engine::step(int nb, void *d_audio_user) {
     double plan_ms = 0;
     for (int b0 = 0; b0 < nb; b0 += chunk_buffers_) {
         int rc = step_chunk(std::min(chunk_buffers_, nb - b0), b0, nb, audio, step_id);
-        if (rc != PBSO_OK) return rc;
+        if (rc != PBSO_OK) {
+            // the reference would have aborted here (assert) or be equally stuck (device error)
+            failed_ = true;
+            failed_why_ = err_;
+            return rc;
+        }
         plan_ms += last_plan_ms_;
     }
     LAUNCHTRY(launch_sum_parts(d_split_.p, n_split_, d_audio_parts_.p, audio, (long long)nb * B_, stream_));

@@ -224,6 +224,8 @@ private:
     std::vector<double> tbuf_;
     int n_xfer_scratch_ = 0;
     double last_plan_ms_ = 0;
+    bool failed_ = false;                                // a step failed after it had started to consume messages
+    std::string failed_why_;
     int chunk_buffers_ = 128;                            // longer steps are cut into launches of this many buffers
     int plan_b0_ = 0, plan_nb_total_ = 0;                // where the chunk being planned sits in the step
     int64_t harvest_step_ = -1;

@@ -595,3 +595,24 @@ def test_long_steps_cut_into_launches(monkeypatch):
         for a, b in zip(one["state"], cut["state"]):
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     _check(one, run_oracle(objs, evs, nb))
+
+
+def test_live_assert_of_the_reference_is_a_status_and_poisons_the_engine():
+    """clearAllForces during a sustained force leaves _sustainedForces set with an empty list: the
+    reference's next step() dies on the assert at modal_solver.h:223.  The engine answers
+    PBSO_ERR_ASSERT, and -- its queues consumed half-way -- refuses further steps."""
+    from openpbso_amd import Engine
+    from openpbso_amd.solver import PbsoError
+    lam = synth.eigenvalues(16, 4)
+    with Engine() as eng:
+        eng.add_object(lam, synth.RHO, synth.ALPHA, synth.BETA)
+        eng.finalize()
+        eng.set_use_transfer(0, False)
+        assert eng.enqueue_force(0, ForceMessage(data=np.ones(16) * 1e-3, forceType=capi.AUTOREGRESSIVE_FORCE, sustainedForceStart=True), 0)
+        assert eng.enqueue_force(0, ForceMessage(clearAllForces=True), 1)
+        with pytest.raises(PbsoError) as ei:
+            eng.step(4)
+        assert ei.value.status == capi.ERR_ASSERT
+        with pytest.raises(PbsoError) as ei:
+            eng.step(1)
+        assert ei.value.status == capi.ERR_STATE
