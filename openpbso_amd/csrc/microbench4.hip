@@ -4,6 +4,7 @@
 //   (b) the velocity-form body for R modes per lane, registers only
 //   (c) (b) + ds_write_addtid_b32 per sample
 //   (d) (c) + the lagged row sums (8 ds_read_b128 per tile, 32 adds spread over the samples)
+//   (e) (b) + one ds_write_b64 per TWO samples: no cheaper than (c), the cost is not the instruction count
 // Each at 4 waves per SIMD (256-thread workgroups, 4 per CU) like the headline launch.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -23,14 +24,15 @@ __global__ __launch_bounds__(256) void body_kernel(float *out, int tiles, float 
         q[r] = threadIdx.x * 1e-3f + r; d[r] = 1e-3f * (r + 1); qn[r] = 0;
         asm volatile("" : "+v"(ca[r]), "+v"(cb[r]), "+v"(t[r]));
     }
-    float acc = 0, rs[8 * 4];
+    float acc = 0, rs[8 * 4], pprev = 0;
+    const unsigned waddr = (unsigned)(wave * 27 * 68 * 4 + lane * 8);
 #pragma unroll
     for (int j = 0; j < 32; ++j) rs[j] = 0;
     const unsigned m0 = wave * 27 * 68 * 4;
     const float4 *rsrc = (const float4 *)(tile + (lane >> 1) * 68 + (lane & 1) * 32);
     if (LDS) asm volatile("s_mov_b32 m0, %0" ::"s"(m0) : "memory");
     for (int tl = 0; tl < tiles; ++tl) {
-        if (LDS >= 2) {
+        if (LDS == 2) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { float4 v = rsrc[j]; rs[4 * j] = v.x; rs[4 * j + 1] = v.y; rs[4 * j + 2] = v.z; rs[4 * j + 3] = v.w; }
         }
@@ -64,9 +66,16 @@ __global__ __launch_bounds__(256) void body_kernel(float *out, int tiles, float 
 #pragma unroll
                 for (int r = 0; r < R; ++r) { d[r] = a[r]; q[r] = q[r] + a[r]; SB; }
             }
-            if (LDS) asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(p), "n"(0) : "memory");
+            if (LDS == 3) {
+                // two samples per LDS instruction: ds_write_b64 with a per-lane address
+                if (k & 1) {
+                    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(waddr), "v"(__builtin_bit_cast(double, (float __attribute__((ext_vector_type(2)))){pprev, p})), "n"(0) : "memory");
+                } else {
+                    pprev = p;
+                }
+            } else if (LDS) asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(p), "n"(0) : "memory");
             else acc += p;
-            if (LDS >= 2) {
+            if (LDS == 2) {
                 if (k < 16) { acc += rs[2 * k]; asm volatile("" : "+v"(acc)); acc += rs[2 * k + 1]; asm volatile("" : "+v"(acc)); }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -129,7 +138,7 @@ static void run_body(float *d, const char *name) {
     const size_t lds = 4 * 27 * 68 * 4;
     float ms = time_kernel([&] { hipLaunchKernelGGL((body_kernel<R, LDS, ORDER>), dim3(256 * wps), dim3(256), lds, 0, d, tiles, 0.9995f, 2e-4f); });
     const double ws = (double)tiles * 27 * wps, mhz = clock_mhz();
-    const double valu = 5.0 * R + (LDS >= 2 ? 32.0 / 27 : (LDS ? 0 : 1));
+    const double valu = 5.0 * R + (LDS == 2 ? 32.0 / 27 : (LDS ? 0 : 1));
     const double cyc = ms * 1e-3 * mhz * 1e6 / ws;
     printf("R=%d order=%d %-34s clock %4.0f MHz  real cycles per wave-sample per SIMD = %5.1f  (%.1f VALU -> %.2f cycles per VALU instruction)\n", R, ORDER, name, mhz, cyc, valu,
            cyc / valu);
@@ -151,6 +160,8 @@ int main() {
     run_body<2, 1, 1>(d, "body + addtid write");
     run_body<2, 2, 0>(d, "body + write + lagged row sums");
     run_body<2, 2, 1>(d, "body + write + lagged row sums");
+    run_body<2, 3, 0>(d, "body + ds_write_b64 per 2 samples");
+    run_body<4, 3, 0>(d, "body + ds_write_b64 per 2 samples");
     run_body<4, 0, 0>(d, "body, registers only");
     run_body<4, 0, 1>(d, "body, registers only");
     run_body<4, 1, 0>(d, "body + addtid write");
