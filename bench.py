@@ -337,6 +337,9 @@ def main():
             },
             "roofline": {
                 "bound": "valu", "kernel": "iir_bank_kernel",
+                "bound_note": "fp32 vector-ALU issue (no dense contraction on this path, so neither hbm nor mfma binds); the peak "
+                              "used, 157.3 TFLOP/s, is also the dense fp32 MFMA peak of MI355X_MICROARCH.md, so frac is the "
+                              "same number under either label; the hbm fraction is in roofline.hbm",
                 "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS,
                 "flop_per_mode_sample": FLOP_PER_MODE_SAMPLE, "kernel_ms": k_ms,
                 "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
