@@ -17,12 +17,14 @@ f=$(find gpurun_out/final/rocprof_stats -name "*kernel_stats.csv" | head -1); he
 pmc() { name=$1; shift; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/final/pmc_$name -- python3 $R/bench.py --steps 3 --warmup 1 --settle 0 --no-cpu-baseline > $R/gpurun_out/final/pmc_$name.log 2>&1); echo "pmc $name rc=$?"; }
 pmc sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU
 pmc sq2 SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE
+pmc sq3 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32
+pmc sq4 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FLOPS_FP32 SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_INSTS_LDS_STORE SQ_INSTS_LDS_LOAD SQ_ACTIVE_INST_VALU2 SQ_IFETCH
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 python - <<'PY' > gpurun_out/final/pmc_summary.txt
 import csv, glob, collections
 print("per-dispatch averages for pbso kernels (rocprofv3 --pmc, bench.py --steps 3 --warmup 1)")
-for name in ("sq1", "sq2", "fetch", "write"):
+for name in ("sq1", "sq2", "sq3", "sq4", "fetch", "write"):
     fs = glob.glob(f"gpurun_out/final/pmc_{name}/**/*counter_collection.csv", recursive=True)
     if not fs: continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
