@@ -8,8 +8,82 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 namespace pbso {
+
+// Persistent helper threads of the planner: run(n, job) executes job(0) on the caller and job(1..n-1) on
+// the workers and returns when all are done.
+class PlanPool {
+public:
+    explicit PlanPool(int workers) {
+        for (int i = 0; i < workers; ++i) th_.emplace_back([this, i] { loop(i + 1); });
+    }
+    ~PlanPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+            ++gen_;
+        }
+        cv_.notify_all();
+        for (std::thread &t : th_) t.join();
+    }
+    int workers() const { return (int)th_.size(); }
+    void run(int n, const std::function<void(int)> &job) {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &job;
+            active_ = n;
+            pending_ = std::min(n - 1, (int)th_.size());
+            ++gen_;
+        }
+        cv_.notify_all();
+        job(0);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+    }
+
+private:
+    void loop(int idx) {
+        int seen = 0;
+        for (;;) {
+            const std::function<void(int)> *job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                if (idx >= active_) continue;
+                job = job_;
+            }
+            (*job)(idx);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                --pending_;
+            }
+            done_.notify_one();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)> *job_ = nullptr;
+    int gen_ = 0, active_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+
+void PlanCtx::begin() {
+    row_ptr.clear(); slot_idx.clear(); row_obj.clear(); stage_slot.clear(); chain_ptr.clear();
+    tprof.clear(); prof_entries.clear(); prof_rows.clear(); stage.clear(); proj.clear(); ffat.clear();
+    forced.clear(); freed_this_plan.clear(); freed_ar.clear();
+    n_frows = n_prows = n_xfer = 0;
+    chain_obj = -1;
+    rc = 0;
+    err.clear();
+}
 
 // ---------------------------------------------------------------------------
 template <class T>
@@ -129,6 +203,7 @@ void ForceProfile::set_param(const double a_[2], double sigma_, double mu_) {   
 Engine::Engine(const pbso_engine_desc &d) : desc_(d) {}
 
 Engine::~Engine() {
+    delete pool_;
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (prep_stream_) (void)hipStreamSynchronize(prep_stream_);
     d_ca_.release(); d_cb_.release(); d_sq_.release(); d_sd_.release(); d_ss_.release(); d_c3_.release(); d_gq_.release();
@@ -212,7 +287,9 @@ int Engine::init() {
         HIPTRY(hipEventCreateWithFlags(&ev_prep_done_[i], hipEventDisableTiming));
         HIPTRY(hipEventCreateWithFlags(&ev_k1_done_[i], hipEventDisableTiming));
     }
-    tbuf_.assign(B_, 0.0);
+    if (const char *v = std::getenv("PBSO_PLAN_THREADS")) plan_threads_ = std::min(16, std::max(1, std::atoi(v)));
+    ctx_.resize(plan_threads_);
+    for (PlanCtx &c : ctx_) c.tbuf.assign(B_, 0.0);
     // which build of the oscillator bank to launch (see kernels_iir.hip)
     if (const char *v = std::getenv("PBSO_CENSUS")) census_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_ROTATE_PRIO")) rotate_prio_ = std::atoi(v) != 0;
@@ -604,24 +681,24 @@ int Engine::set_use_transfer(int obj, int use, int64_t not_before) {
     return PBSO_OK;
 }
 
-void Engine::release(ActiveForce &af) {
-    freed_this_plan_.push_back(af.slot);
-    if (af.ar_state >= 0) freed_ar_.push_back(af.ar_state);
+void Engine::release(PlanCtx &c, ActiveForce &af) {
+    c.freed_this_plan.push_back(af.slot);
+    if (af.ar_state >= 0) c.freed_ar.push_back(af.ar_state);
     af.ar_state = -1;
 }
 
-int Engine::alloc_slot() {
-    if (!free_slots_.empty()) {
-        int s = free_slots_.back();
-        free_slots_.pop_back();
+int Engine::alloc_slot(PlanCtx &c) {
+    if (!c.free_slots.empty()) {
+        int s = c.free_slots.back();
+        c.free_slots.pop_back();
         return s;
     }
-    return (int)n_slots_++;
+    return (int)n_slots_.fetch_add(1);
 }
 
 // ---------------------------------------------------------------------------
 // One object, one buffer: ModalSolver::step lines 184-256.
-int Engine::plan_object(int oi, int b, int nb, int64_t t) {
+int Engine::plan_object(PlanCtx &c, int oi, int b, int nb, int64_t t) {
     Object &o = objs_[oi];
     const int N = (int)objs_.size();
     BufDesc &d = set_[cur_set_].h_desc.p[(size_t)oi * nb + b];
@@ -637,9 +714,9 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
             if (!o.trans_full) {                  // try_enqueue; a full queue drops the update
                 FfatEvent fe;
                 fe.obj = oi;
-                fe.row = 2 * N + cur_set_ * xfer_cap_ + n_xfer_scratch_++;
+                fe.row = c.xfer_base + c.n_xfer++;
                 fe.pos[0] = ev.v[0]; fe.pos[1] = ev.v[1]; fe.pos[2] = ev.v[2];
-                ffat_.push_back(fe);
+                c.ffat.push_back(fe);
                 o.trans_full = true;
                 o.trans_row = fe.row;
             }
@@ -654,20 +731,20 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
         HostForceMsg mess = std::move(o.force_q.front());
         o.force_q.pop_front();
         if (mess.clear_all) {                                           // :186-189
-            for (ActiveForce &af : o.active) release(af);
+            for (ActiveForce &af : o.active) release(c, af);
             o.active.clear();
             d.flags |= DESC_SKIP;
             emitted_[(size_t)oi * plan_nb_total_ + plan_b0_ + b] = 0;
             return PBSO_OK;
         }
         // the message's modal data becomes one immutable row of the slot pool
-        const int slot = alloc_slot();
+        const int slot = alloc_slot(c);
         if (mess.data_kind == PBSO_DATA_EXPLICIT || mess.data_kind == PBSO_DATA_ZERO) {
-            const size_t off = stage_.size();
-            stage_.resize(off + m_pad_, 0.0);
+            const size_t off = c.stage.size();
+            c.stage.resize(off + m_pad_, 0.0);
             if (mess.data_kind == PBSO_DATA_EXPLICIT)
-                std::copy(mess.data.begin(), mess.data.end(), stage_.begin() + off);
-            stage_slot_.push_back(slot);
+                std::copy(mess.data.begin(), mess.data.end(), c.stage.begin() + off);
+            c.stage_slot.push_back(slot);
         } else {
             ProjectEvent pe;
             pe.obj = oi;
@@ -678,7 +755,7 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
                 pe.coords[j] = mess.coords[j];
                 pe.vn[j] = mess.vn[j];
             }
-            proj_.push_back(pe);
+            c.proj.push_back(pe);
         }
         ActiveForce af;
         af.slot = slot;
@@ -686,7 +763,7 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
         af.force = ForceProfile::make(mess.force_type, mess.gaussian_width_us, rate_);   // fresh Force, tools/...:281-294
         bool slot_used = false;
         if (mess.sustained_start) {                                     // :190-194
-            for (ActiveForce &x : o.active) release(x);
+            for (ActiveForce &x : o.active) release(c, x);
             o.active.clear();
             o.sustained = true;
             o.active.push_back(af);
@@ -697,28 +774,28 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
             slot_used = true;
         } else {                                                        // :197-200 data only
             if (o.active.empty())
-                return fail(PBSO_ERR_ASSERT, "sustained force list is empty (reference dereferences begin() of an empty list)");
+                return cfail(c, PBSO_ERR_ASSERT, "sustained force list is empty (reference dereferences begin() of an empty list)");
             if (o.active.front().slot != slot) {
-                freed_this_plan_.push_back(o.active.front().slot);
+                c.freed_this_plan.push_back(o.active.front().slot);
                 o.active.front().slot = slot;
                 slot_used = true;
             }
         }
         if (mess.sustained_end) {                                       // :201-204
-            for (ActiveForce &x : o.active) release(x);
+            for (ActiveForce &x : o.active) release(c, x);
             o.active.clear();
             o.sustained = false;
             slot_used = true;   // freed through the list (or below)
         }
-        if (!slot_used) freed_this_plan_.push_back(slot);
+        if (!slot_used) c.freed_this_plan.push_back(slot);
     }
 
     // :206-240 time profile and spatial sum
     if ((!o.active.empty() || o.sustained) && device_profiles_) {
         // Force::Add bookkeeping only (who is alive, _count, PointForce::used); the samples
         // of Gaussian / AR profiles are generated on the device (K2, kernels_exact.hip)
-        const int row_begin = (int)slot_idx_.size();
-        const int entry_begin = (int)prof_entries_.size();
+        const int row_begin = (int)c.slot_idx.size();
+        const int entry_begin = (int)c.prof_entries.size();
         int n_point = 0;
         bool dense = false;
         auto emit = [&](ActiveForce &af, bool set_param) -> bool {
@@ -743,8 +820,8 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
                 break;
             default:                                                 // forces.h:107-137
                 if (af.ar_state < 0) {
-                    if (!free_ar_.empty()) { af.ar_state = free_ar_.back(); free_ar_.pop_back(); }
-                    else af.ar_state = (int)n_ar_states_++;
+                    if (!c.free_ar.empty()) { af.ar_state = c.free_ar.back(); c.free_ar.pop_back(); }
+                    else af.ar_state = (int)n_ar_states_.fetch_add(1);
                     e.flags |= 1;
                 }
                 if (set_param) {
@@ -755,7 +832,7 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
                 dense = true;
                 break;
             }
-            prof_entries_.push_back(e);
+            c.prof_entries.push_back(e);
             return true;
         };
         if (!o.sustained) {
@@ -763,9 +840,9 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
             for (size_t r = 0; r < o.active.size(); ++r) {
                 ActiveForce &af = o.active[r];
                 if (!emit(af, false)) {
-                    release(af);                                            // erase
+                    release(c, af);                                            // erase
                 } else {
-                    slot_idx_.push_back(af.slot);
+                    c.slot_idx.push_back(af.slot);
                     if (w != r) o.active[w] = std::move(af);
                     ++w;
                 }
@@ -773,7 +850,7 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
             o.active.resize(w);
         } else {
             if (o.active.size() != 1)
-                return fail(PBSO_ERR_ASSERT, "Should only have 1 concurrent sustained force");   // assert :223
+                return cfail(c, PBSO_ERR_ASSERT, "Should only have 1 concurrent sustained force");   // assert :223
             ActiveForce &af = o.active.front();
             bool sp = false;
             if (af.force_type == PBSO_AUTOREGRESSIVE_FORCE && o.arprm_full) {   // :226-236
@@ -781,45 +858,46 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
                 sp = true;
             }
             emit(af, sp);                        // the return value is ignored, modal_solver.h:238
-            slot_idx_.push_back(af.slot);
+            c.slot_idx.push_back(af.slot);
         }
-        if ((int)slot_idx_.size() > row_begin && (dense || n_point)) {
-            d.frow = n_frows_++;
-            row_obj_.push_back(oi);
-            row_ptr_.push_back((int)slot_idx_.size());
+        if ((int)c.slot_idx.size() > row_begin && (dense || n_point)) {
+            d.frow = c.n_frows++;
+            c.forced.push_back(&d);
+            c.row_obj.push_back(oi);
+            c.row_ptr.push_back((int)c.slot_idx.size());
             if (!dense) {
                 d.flags |= DESC_IMPULSE;          // PointForce(s) only: n * delta[0], no profile row
                 d.tile_mask = 1u;
                 d.amp = (float)n_point;
-                prof_entries_.resize(entry_begin);
+                c.prof_entries.resize(entry_begin);
             } else {
-                d.prow = n_prows_++;
+                d.prow = c.n_prows++;
                 d.tile_mask = n_tiles_ >= 32 ? 0xFFFFFFFFu : ((1u << n_tiles_) - 1u);
-                ProfRow pr = {d.prow, entry_begin, (int)prof_entries_.size()};
-                prof_rows_.push_back(pr);
-                if (chain_obj_ != oi) {           // rows of one object are contiguous (object-major plan)
-                    chain_ptr_.push_back((int)prof_rows_.size() - 1);
-                    chain_obj_ = oi;
+                ProfRow pr = {d.prow, entry_begin, (int)c.prof_entries.size()};
+                c.prof_rows.push_back(pr);
+                if (c.chain_obj != oi) {           // rows of one object are contiguous (object-major plan)
+                    c.chain_ptr.push_back((int)c.prof_rows.size() - 1);
+                    c.chain_obj = oi;
                 }
             }
         } else {
-            slot_idx_.resize(row_begin);          // nothing active produced samples: a force-free buffer
-            prof_entries_.resize(entry_begin);
+            c.slot_idx.resize(row_begin);          // nothing active produced samples: a force-free buffer
+            c.prof_entries.resize(entry_begin);
         }
     } else if (!o.active.empty() || o.sustained) {
-        double *T = tbuf_.data();
-        std::fill(T, T + t_extent_, 0.0);
-        t_extent_ = 0;
-        const int row_begin = (int)slot_idx_.size();
+        double *T = c.tbuf.data();
+        std::fill(T, T + c.t_extent, 0.0);
+        c.t_extent = 0;
+        const int row_begin = (int)c.slot_idx.size();
         if (!o.sustained) {
             size_t w = 0;
             for (size_t r = 0; r < o.active.size(); ++r) {
                 ActiveForce &af = o.active[r];
-                const bool added = af.force.add(T, B_, &t_extent_);
+                const bool added = af.force.add(T, B_, &c.t_extent);
                 if (!added) {
-                    release(af);                                            // erase
+                    release(c, af);                                            // erase
                 } else {
-                    slot_idx_.push_back(af.slot);
+                    c.slot_idx.push_back(af.slot);
                     if (w != r) o.active[w] = std::move(af);
                     ++w;
                 }
@@ -827,35 +905,36 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
             o.active.resize(w);
         } else {
             if (o.active.size() != 1)
-                return fail(PBSO_ERR_ASSERT, "Should only have 1 concurrent sustained force");   // assert :223
+                return cfail(c, PBSO_ERR_ASSERT, "Should only have 1 concurrent sustained force");   // assert :223
             ActiveForce &af = o.active.front();
             if (af.force_type == PBSO_AUTOREGRESSIVE_FORCE && o.arprm_full) {   // :226-236
                 o.arprm_full = false;
                 af.force.set_param(o.arprm, o.arprm[2], o.arprm[3]);
             }
-            af.force.add(T, B_, &t_extent_);
-            slot_idx_.push_back(af.slot);
+            af.force.add(T, B_, &c.t_extent);
+            c.slot_idx.push_back(af.slot);
         }
         uint32_t mask = 0;
         int last_nz = -1;
-        for (int i = 0; i < t_extent_; ++i)
+        for (int i = 0; i < c.t_extent; ++i)
             if (T[i] != 0.0) { mask |= 1u << (i / TILE); last_nz = i; }
-        if ((int)slot_idx_.size() > row_begin && mask) {
-            d.frow = n_frows_++;
+        if ((int)c.slot_idx.size() > row_begin && mask) {
+            d.frow = c.n_frows++;
+            c.forced.push_back(&d);
             d.tile_mask = mask;
-            row_obj_.push_back(oi);
-            row_ptr_.push_back((int)slot_idx_.size());
+            c.row_obj.push_back(oi);
+            c.row_ptr.push_back((int)c.slot_idx.size());
             if (last_nz == 0) {
                 d.flags |= DESC_IMPULSE;                  // PointForce(s): amp * delta[0], no profile row
                 d.amp = (float)T[0];
             } else {
-                d.prow = n_prows_++;
-                const size_t off = tprof_.size();
-                tprof_.resize(off + b_pad_, 0.f);
-                for (int i = 0; i <= last_nz; ++i) tprof_[off + i] = (float)T[i];
+                d.prow = c.n_prows++;
+                const size_t off = c.tprof.size();
+                c.tprof.resize(off + b_pad_, 0.f);
+                for (int i = 0; i <= last_nz; ++i) c.tprof[off + i] = (float)T[i];
             }
         } else {
-            slot_idx_.resize(row_begin);          // S * 0 == 0: a force-free buffer
+            c.slot_idx.resize(row_begin);          // S * 0 == 0: a force-free buffer
         }
     }
 
@@ -875,7 +954,7 @@ int Engine::plan_object(int oi, int b, int nb, int64_t t) {
 
 // All buffers of one object.  Objects are independent, and between stamped
 // messages an idle object needs no bookkeeping at all: jump to the next stamp.
-int Engine::plan_object_span(int oi, int nb) {
+int Engine::plan_object_span(PlanCtx &c, int oi, int nb) {
     Object &o = objs_[oi];
     int b = 0;
     while (b < nb) {
@@ -892,7 +971,7 @@ int Engine::plan_object_span(int oi, int nb) {
             b = (int)(next - buffers_done_);
             continue;
         }
-        int rc = plan_object(oi, b, nb, t);
+        int rc = plan_object(c, oi, b, nb, t);
         if (rc != PBSO_OK) return rc;
         ++b;
     }
@@ -906,14 +985,6 @@ int Engine::plan(int nb) {
     HIPTRY(ps.h_xfer_init.ensure(N));
     const BufDesc dflt = {-1, -1, 0u, 0.f, XFER_KEEP, 0u, {0, 0}};
     std::fill(ps.h_desc.p, ps.h_desc.p + (size_t)N * nb, dflt);
-    row_ptr_.assign(1, 0);
-    slot_idx_.clear(); row_obj_.clear(); tprof_.clear(); stage_.clear(); stage_slot_.clear();
-    proj_.clear(); ffat_.clear(); freed_this_plan_.clear();
-    n_xfer_scratch_ = 0;
-    n_frows_ = 0;
-    n_prows_ = 0;
-    prof_entries_.clear(); prof_rows_.clear(); chain_ptr_.clear(); freed_ar_.clear();
-    chain_obj_ = -1;
     busy_.clear();
     for (int i = 0; i < N; ++i) {
         const Object &o = objs_[i];
@@ -922,21 +993,88 @@ int Engine::plan(int nb) {
             o.sustained || (!o.use_transfer && o.latest_row != XFER_UNIT))
             busy_.push_back(i);
     }
+    // contiguous shares of the busy objects, one planning context (host thread) each
+    const int nbusy = (int)busy_.size();
+    const int T = std::max(1, std::min(plan_threads_, nbusy / 64));
+    std::vector<int> lo(T + 1);
+    for (int t = 0; t <= T; ++t) lo[t] = (int)((long long)nbusy * t / T);
     // every stamped computeTransfer that can fire in this batch may need one scratch row
-    size_t need = 0;
-    for (int i : busy_)
-        for (const TimedEvent &ev : objs_[i].pending)
-            if (ev.kind == TimedEvent::TRANSFER && ev.not_before < buffers_done_ + nb) ++need;
-    if ((int)need > xfer_cap_) {
-        const int ncap = std::max<int>((int)need, 2 * xfer_cap_ + 16);
+    std::vector<size_t> need(T, 0);
+    size_t need_all = 0;
+    for (int t = 0; t < T; ++t) {
+        for (int k = lo[t]; k < lo[t + 1]; ++k)
+            for (const TimedEvent &ev : objs_[busy_[k]].pending)
+                if (ev.kind == TimedEvent::TRANSFER && ev.not_before < buffers_done_ + nb) ++need[t];
+        need_all += need[t];
+    }
+    if ((int)need_all > xfer_cap_) {
+        const int ncap = std::max<int>((int)need_all, 2 * xfer_cap_ + 16);
         // rows [2N + s*cap, ...) change meaning with cap: nothing may be in flight (ensure() drains)
         HIPTRY(d_xfer_.ensure((size_t)(2 * N + 2 * ncap) * m_pad_, true, stream_));
         HIPTRY(hipDeviceSynchronize());
         xfer_cap_ = ncap;
     }
-    for (int i : busy_) {
-        int rc = plan_object_span(i, nb);
-        if (rc != PBSO_OK) return rc;
+    {
+        int xb = 2 * N + cur_set_ * xfer_cap_;
+        for (int t = 0; t < T; ++t) {
+            ctx_[t].begin();
+            ctx_[t].xfer_base = xb;
+            xb += (int)need[t];
+        }
+    }
+    auto job = [&](int t) {
+        PlanCtx &c = ctx_[t];
+        for (int k = lo[t]; k < lo[t + 1]; ++k) {
+            c.rc = plan_object_span(c, busy_[k], nb);
+            if (c.rc != PBSO_OK) return;
+        }
+    };
+    if (T > 1) {
+        if (!pool_) pool_ = new PlanPool(plan_threads_ - 1);
+        pool_->run(T, job);
+    } else {
+        job(0);
+    }
+    for (int t = 0; t < T; ++t)
+        if (ctx_[t].rc != PBSO_OK) return fail(ctx_[t].rc, ctx_[t].err);
+
+    // merge in object order: the numbering is the one a single context would have produced
+    row_ptr_.assign(1, 0);
+    slot_idx_.clear(); row_obj_.clear(); tprof_.clear(); stage_.clear(); stage_slot_.clear();
+    proj_.clear(); ffat_.clear(); prof_entries_.clear(); prof_rows_.clear(); chain_ptr_.clear();
+    n_frows_ = 0;
+    n_prows_ = 0;
+    for (int t = 0; t < T; ++t) {
+        PlanCtx &c = ctx_[t];
+        const int base_f = n_frows_, base_p = n_prows_, base_s = (int)slot_idx_.size();
+        const int base_e = (int)prof_entries_.size(), base_r = (int)prof_rows_.size();
+        if (t > 0) {
+            for (BufDesc *d : c.forced) {
+                d->frow += base_f;
+                if (d->prow >= 0) d->prow += base_p;
+            }
+        }
+        for (int e : c.row_ptr) row_ptr_.push_back(base_s + e);
+        slot_idx_.insert(slot_idx_.end(), c.slot_idx.begin(), c.slot_idx.end());
+        row_obj_.insert(row_obj_.end(), c.row_obj.begin(), c.row_obj.end());
+        tprof_.insert(tprof_.end(), c.tprof.begin(), c.tprof.end());
+        prof_entries_.insert(prof_entries_.end(), c.prof_entries.begin(), c.prof_entries.end());
+        for (ProfRow r : c.prof_rows) {
+            r.prow += base_p;
+            r.entry_begin += base_e;
+            r.entry_end += base_e;
+            prof_rows_.push_back(r);
+        }
+        for (int ci : c.chain_ptr) chain_ptr_.push_back(base_r + ci);
+        stage_.insert(stage_.end(), c.stage.begin(), c.stage.end());
+        stage_slot_.insert(stage_slot_.end(), c.stage_slot.begin(), c.stage_slot.end());
+        proj_.insert(proj_.end(), c.proj.begin(), c.proj.end());
+        ffat_.insert(ffat_.end(), c.ffat.begin(), c.ffat.end());
+        n_frows_ += c.n_frows;
+        n_prows_ += c.n_prows;
+        // what this pass released becomes reusable from the next plan on (this launch still reads it)
+        c.free_slots.insert(c.free_slots.end(), c.freed_this_plan.begin(), c.freed_this_plan.end());
+        c.free_ar.insert(c.free_ar.end(), c.freed_ar.begin(), c.freed_ar.end());
     }
     return PBSO_OK;
 }
@@ -1019,8 +1157,6 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
             o.trans_row = N + i;
         }
     }
-    for (int s : freed_this_plan_) free_slots_.push_back(s);
-    for (int s : freed_ar_) free_ar_.push_back(s);
     const int n_chains = (int)chain_ptr_.size();
     chain_ptr_.push_back((int)prof_rows_.size());
     last_plan_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1031,7 +1167,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     hipStream_t sp = prep_stream_, sk = stream_;
     DevBuf<float> &grows = d_grows_[cur_set_];
     // device arenas (growth drains the device first, see DevBuf::ensure)
-    HIPTRY(d_slots_.ensure(std::max<size_t>(1, n_slots_) * m_pad_, true, sp));
+    HIPTRY(d_slots_.ensure(std::max<size_t>(1, n_slots_.load()) * m_pad_, true, sp));
     HIPTRY(grows.ensure(std::max<size_t>(1, (size_t)n_frows) * m_pad_, false, sp));
     const bool qn = desc_.qnorm_mode != PBSO_QNORM_OFF;
 
@@ -1066,7 +1202,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         HIPTRY(upload(ps.h_prof_entries, ps.d_prof_entries, prof_entries_.data(), prof_entries_.size(), sp));
         HIPTRY(upload(ps.h_prof_rows, ps.d_prof_rows, prof_rows_.data(), prof_rows_.size(), sp));
         HIPTRY(upload(ps.h_chain_ptr, ps.d_chain_ptr, chain_ptr_.data(), chain_ptr_.size(), sp));
-        HIPTRY(d_arstate_.ensure(std::max<size_t>(1, n_ar_states_), true, sp));
+        HIPTRY(d_arstate_.ensure(std::max<size_t>(1, n_ar_states_.load()), true, sp));
     } else {
         HIPTRY(upload(ps.h_tprof, ps.d_tprof, tprof_.data(), tprof_.size(), sp));
     }

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <atomic>
 #include <deque>
 #include <random>
 #include <string>
@@ -65,6 +66,34 @@ struct HostForceMsg {                                    // ForceMessage, modal_
     int64_t not_before = 0;
 };
 
+// _queue_force (modal_solver.h:105): FIFO of at most 1023 messages.  A ring that grows by doubling and
+// never shrinks: no allocation per message (a node-based queue filled by the caller's thread and drained
+// by the planner's threads makes every message a cross-thread free).
+class ForceQueue {
+public:
+    bool empty() const { return n_ == 0; }
+    size_t size() const { return n_; }
+    HostForceMsg &front() { return buf_[head_]; }
+    const HostForceMsg &front() const { return buf_[head_]; }
+    HostForceMsg &back() { return buf_[(head_ + n_ - 1) & (buf_.size() - 1)]; }
+    void pop_front() { head_ = (head_ + 1) & (buf_.size() - 1); --n_; }
+    void push_back(HostForceMsg &&m) {
+        if (n_ == buf_.size()) grow();
+        buf_[(head_ + n_) & (buf_.size() - 1)] = std::move(m);
+        ++n_;
+    }
+
+private:
+    void grow() {
+        std::vector<HostForceMsg> nb(buf_.empty() ? 8 : 2 * buf_.size());
+        for (size_t i = 0; i < n_; ++i) nb[i] = std::move(buf_[(head_ + i) & (buf_.size() - 1)]);
+        buf_.swap(nb);
+        head_ = 0;
+    }
+    std::vector<HostForceMsg> buf_;                      // capacity is a power of two
+    size_t head_ = 0, n_ = 0;
+};
+
 struct ActiveForce {                                     // one entry of _activeForces
     int slot = -1;                                       // row of the device data-slot pool
     int ar_state = -1;                                   // device ArState slot of an AutoregressiveForce
@@ -89,7 +118,7 @@ struct Object {
     std::vector<FfatGeom> geom;                          // index = modeId
     std::vector<double> psi;
     // run-time state of the ModalSolver this object stands for
-    std::deque<HostForceMsg> force_q;                    // _queue_force (1023 usable slots)
+    ForceQueue force_q;                                  // _queue_force (1023 usable slots)
     std::vector<ActiveForce> active;                     // _activeForces
     bool sustained = false;                              // _sustainedForces
     bool arprm_full = false;                             // _queue_arprm (1 slot)
@@ -100,6 +129,29 @@ struct Object {
     int latest_row = XFER_UNIT;                          // where _latest_transfer lives (XFER_UNIT or own row)
     std::deque<TimedEvent> pending;                      // stamped arprm / transfer / use-transfer calls
 };
+
+// Everything one planning pass over a contiguous range of objects produces.  The planner runs one
+// context per host thread (objects are independent, modal_solver.h:100-126) and merges them in object
+// order, so forced-row / profile-row numbering does not depend on the thread count; only the ids of
+// the pooled data slots do, and those are storage locations without meaning.
+struct PlanCtx {
+    std::vector<int> row_ptr, slot_idx, row_obj, stage_slot, chain_ptr;   // row_ptr: END offset of each forced row in slot_idx
+    std::vector<float> tprof;
+    std::vector<ProfEntry> prof_entries;
+    std::vector<ProfRow> prof_rows;
+    std::vector<double> stage;
+    std::vector<ProjectEvent> proj;
+    std::vector<FfatEvent> ffat;
+    std::vector<BufDesc *> forced;                       // descriptors holding context-local frow / prow numbers
+    std::vector<int> free_slots, freed_this_plan, free_ar, freed_ar;     // this context's share of the slot / AR-state pools
+    std::vector<double> tbuf;
+    int t_extent = 0, n_frows = 0, n_prows = 0, n_xfer = 0, xfer_base = 0, chain_obj = -1;
+    int rc = 0;
+    std::string err;
+    void begin();
+};
+
+class PlanPool;
 
 class Engine {
 public:
@@ -133,17 +185,17 @@ private:
     int fail(int code, const std::string &msg);
     int hip_fail(hipError_t e, const char *what);
     bool valid_obj(int obj) const { return obj >= 0 && obj < (int)objs_.size(); }
-    int alloc_slot();
-    void release(ActiveForce &af);
+    int alloc_slot(PlanCtx &c);
+    void release(PlanCtx &c, ActiveForce &af);
     int plan(int nb);                                    // host bookkeeping for one batch
-    int plan_object(int o, int b, int nb, int64_t t);
-    int plan_object_span(int o, int nb);
+    int plan_object(PlanCtx &c, int o, int b, int nb, int64_t t);
+    int plan_object_span(PlanCtx &c, int o, int nb);
+    static int cfail(PlanCtx &c, int code, const char *msg) { c.err = msg; return code; }
 
     pbso_engine_desc desc_;
     int B_ = PBSO_FRAMES_PER_BUFFER, rate_ = PBSO_SAMPLE_RATE, n_tiles_ = 9, b_pad_ = 528;
     int R_ = 0, W_ = 0, m_pad_ = 0;
     bool finalized_ = false, own_stream_ = false;
-    int t_extent_ = 0;                                   // leading samples of tbuf_ that may be non-zero
     hipStream_t stream_ = nullptr;                       // oscillator bank (caller's stream if given)
     hipStream_t prep_stream_ = nullptr;                  // plan upload + projection + FFAT + combine
     hipEvent_t ev_prep_done_[2] = {nullptr, nullptr}, ev_k1_done_[2] = {nullptr, nullptr};
@@ -183,8 +235,7 @@ private:
     bool rotate_prio_ = true;                            // PBSO_ROTATE_PRIO: see kernels_iir.hip
     float *last_audio_ = nullptr;
     int last_nb_ = 0;
-    size_t n_slots_ = 0;
-    std::vector<int> free_slots_, freed_this_plan_;
+    std::atomic<size_t> n_slots_{0};
 
     // per-launch plan, double-buffered (host pinned + device copies)
     struct PlanSet {
@@ -213,16 +264,20 @@ private:
     bool device_profiles_ = true;                        // PBSO_DEVICE_PROFILES=0: host fp64 profiles, uploaded
     std::vector<ProfEntry> prof_entries_;
     std::vector<ProfRow> prof_rows_;
-    std::vector<int> chain_ptr_, free_ar_, freed_ar_;
-    int chain_obj_ = -1;
-    size_t n_ar_states_ = 0;
+    std::vector<int> chain_ptr_;
+    std::atomic<size_t> n_ar_states_{0};
     DevBuf<ArState> d_arstate_;
     std::vector<double> stage_;
     std::vector<ProjectEvent> proj_;
     std::vector<FfatEvent> ffat_;
     std::vector<unsigned char> emitted_;
-    std::vector<double> tbuf_;
-    int n_xfer_scratch_ = 0;
+    // planner threads (PBSO_PLAN_THREADS, default 1): ctx_[t] plans a contiguous share of the busy objects.
+    // More than one only pays when the threads share a last-level cache with the caller: on the 2-socket
+    // EPYC hosts of the MI355X boxes unpinned helpers made planning AND the caller's enqueue slower (the
+    // queues' cache lines migrate between cores every step), so the default is the caller's thread alone.
+    std::vector<PlanCtx> ctx_;
+    PlanPool *pool_ = nullptr;
+    int plan_threads_ = 1;
     double last_plan_ms_ = 0;
     bool failed_ = false;                                // a step failed after it had started to consume messages
     std::string failed_why_;

@@ -616,3 +616,49 @@ def test_live_assert_of_the_reference_is_a_status_and_poisons_the_engine():
         with pytest.raises(PbsoError) as ei:
             eng.step(1)
         assert ei.value.status == capi.ERR_STATE
+
+
+@pytest.mark.parametrize("device_profiles", ["1", "0"])
+def test_planner_on_several_threads_gives_the_same_plan(device_profiles, monkeypatch):
+    """PBSO_PLAN_THREADS > 1: per-thread planning contexts merged in object order.  Audio, qnorm and the
+    emitted flags must be bit-identical to the single-thread plan (only pooled slot ids may differ), for
+    every kind of force, listener moves and a launch cut in two."""
+    monkeypatch.setenv("PBSO_DEVICE_PROFILES", device_profiles)
+    n_obj, n_modes, nb = 300, 24, 9
+    rng = np.random.default_rng(404)
+    objs, evs = [], []
+    for i in range(n_obj):
+        lam = synth.eigenvalues(n_modes, 11000 + i)
+        with_maps = i % 7 == 0
+        objs.append(ObjSpec(lam, shapes=synth.mode_shapes(n_modes, 12000 + i) if i % 3 == 0 else None,
+                            maps=synth.ffat_maps(lam, 13000 + i, dim=4) if with_maps else None))
+        for b in range(nb):
+            r = rng.random()
+            if r < 0.25:
+                if i % 3 == 0 and rng.random() < 0.5:
+                    evs.append(force_ev(b, i, vid=int(rng.integers(0, synth.N_VERTS)), vn=synth.unit_normals(1, int(rng.integers(1 << 30)))[0]))
+                else:
+                    evs.append(force_ev(b, i, data=rng.standard_normal(n_modes) * 1e-3))
+            elif r < 0.35:
+                evs.append(force_ev(b, i, data=rng.standard_normal(n_modes) * 1e-3, force_type=1, width=float(rng.choice([60.0, 900.0, 6000.0]))))
+            elif r < 0.40:
+                evs.append(force_ev(b, i, data=rng.standard_normal(n_modes) * 1e-3, force_type=2))
+            if with_maps and rng.random() < 0.6:
+                p = rng.standard_normal(3)
+                evs.append(dict(t=b, obj=i, kind="listener", pos=p / np.linalg.norm(p) * 0.7 + 1e-3))
+        if not with_maps:
+            evs.append(dict(t=0, obj=i, kind="use_transfer", use=False))
+    monkeypatch.setenv("PBSO_PLAN_THREADS", "1")
+    one = run_engine(objs, evs, nb, split=[4, 5])
+    for threads in ("2", "4"):
+        monkeypatch.setenv("PBSO_PLAN_THREADS", threads)
+        many = run_engine(objs, evs, nb, split=[4, 5])
+        assert np.array_equal(one["audio"], many["audio"]) and np.array_equal(one["emitted"], many["emitted"])
+        for key in one["qnorm"]:
+            assert np.array_equal(one["qnorm"][key], many["qnorm"][key]), key
+        for a, b in zip(one["latest"], many["latest"]):
+            assert np.array_equal(a, b)
+    sub = [0, 7, 150, 299]
+    want = run_oracle([objs[i] for i in sub], [dict(e, obj=sub.index(e["obj"])) for e in evs if e["obj"] in sub], nb)
+    mx, l2 = rel_errors(one["audio"][sub], want["audio"])
+    assert (mx <= TOL_MAX).all() and (l2 <= TOL_L2).all(), (mx, l2)
