@@ -13,14 +13,27 @@
 #include <mutex>
 #include <thread>
 
+#include <pthread.h>
+#include <sched.h>
+
 namespace pbso {
 
 // Persistent helper threads of the planner: run(n, job) executes job(0) on the caller and job(1..n-1) on
 // the workers and returns when all are done.
 class PlanPool {
 public:
-    explicit PlanPool(int workers) {
-        for (int i = 0; i < workers; ++i) th_.emplace_back([this, i] { loop(i + 1); });
+    // pin_near >= 0: helper i is pinned to a core next to that cpu (same 8-core complex), so that the
+    // queues the caller fills stay within one last-level cache (PBSO_PLAN_PIN=1)
+    explicit PlanPool(int workers, int pin_near = -1) {
+        for (int i = 0; i < workers; ++i) {
+            th_.emplace_back([this, i] { loop(i + 1); });
+            if (pin_near >= 0) {
+                cpu_set_t set;
+                CPU_ZERO(&set);
+                CPU_SET((pin_near & ~7) | ((pin_near + i + 1) & 7), &set);
+                (void)pthread_setaffinity_np(th_.back().native_handle(), sizeof(set), &set);
+            }
+        }
     }
     ~PlanPool() {
         {
@@ -1030,7 +1043,10 @@ int Engine::plan(int nb) {
         }
     };
     if (T > 1) {
-        if (!pool_) pool_ = new PlanPool(plan_threads_ - 1);
+        if (!pool_) {
+            const char *pin = std::getenv("PBSO_PLAN_PIN");
+            pool_ = new PlanPool(plan_threads_ - 1, pin && std::atoi(pin) ? sched_getcpu() : -1);
+        }
         pool_->run(T, job);
     } else {
         job(0);

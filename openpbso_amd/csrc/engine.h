@@ -274,7 +274,8 @@ private:
     // planner threads (PBSO_PLAN_THREADS, default 1): ctx_[t] plans a contiguous share of the busy objects.
     // More than one only pays when the threads share a last-level cache with the caller: on the 2-socket
     // EPYC hosts of the MI355X boxes unpinned helpers made planning AND the caller's enqueue slower (the
-    // queues' cache lines migrate between cores every step), so the default is the caller's thread alone.
+    // queues' cache lines migrate between cores every step), so the default is the caller's thread alone;
+    // PBSO_PLAN_PIN=1 pins the helpers into the caller's 8-core complex (4 threads: 0.69 -> 0.35 ms).
     std::vector<PlanCtx> ctx_;
     PlanPool *pool_ = nullptr;
     int plan_threads_ = 1;
