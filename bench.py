@@ -58,6 +58,9 @@ def parse():
                     help="impulses: Poisson PointForce hits (headline, configs[1]/[3]); scraping: sustained "
                          "AutoregressiveForce with one face hit per buffer (configs[4]); listener: impulses + FFAT maps "
                          "and a new listener position every buffer (configs[2])")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --objects is the TOTAL, split evenly over the ranks (BASELINE configs[3] as written: "
+                         "1024 objects over 8 GPUs); default is weak scaling, --objects per GPU")
     ap.add_argument("--gather", action="store_true", help="all-gather audio over RCCL inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-objects", type=int, default=0, help="objects in the CPU baseline sample (0 = auto)")
@@ -160,6 +163,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    if args.strong:
+        if args.objects % world:
+            raise SystemExit("--strong needs --objects divisible by the number of ranks")
+        args.objects //= world
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
@@ -321,7 +328,7 @@ def main():
             "value": value, "unit": "audio samples/s", "realtime_x": rt,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"{args.objects} objects x {M} modes per GPU, " + {
