@@ -301,6 +301,7 @@ int Engine::init() {
         HIPTRY(hipEventCreateWithFlags(&ev_k1_done_[i], hipEventDisableTiming));
     }
     if (const char *v = std::getenv("PBSO_PLAN_THREADS")) plan_threads_ = std::min(16, std::max(1, std::atoi(v)));
+    if (const char *v = std::getenv("PBSO_PLAN_GRAIN")) plan_grain_ = std::max(1, std::atoi(v));
     ctx_.resize(plan_threads_);
     for (PlanCtx &c : ctx_) c.tbuf.assign(B_, 0.0);
     // which build of the oscillator bank to launch (see kernels_iir.hip)
@@ -1008,7 +1009,7 @@ int Engine::plan(int nb) {
     }
     // contiguous shares of the busy objects, one planning context (host thread) each
     const int nbusy = (int)busy_.size();
-    const int T = std::max(1, std::min(plan_threads_, nbusy / 64));
+    const int T = std::max(1, std::min(plan_threads_, nbusy / plan_grain_));      // at least plan_grain_ objects per thread
     std::vector<int> lo(T + 1);
     for (int t = 0; t <= T; ++t) lo[t] = (int)((long long)nbusy * t / T);
     // every stamped computeTransfer that can fire in this batch may need one scratch row

@@ -278,7 +278,7 @@ private:
     // PBSO_PLAN_PIN=1 pins the helpers into the caller's 8-core complex (4 threads: 0.69 -> 0.35 ms).
     std::vector<PlanCtx> ctx_;
     PlanPool *pool_ = nullptr;
-    int plan_threads_ = 1;
+    int plan_threads_ = 1, plan_grain_ = 64;
     double last_plan_ms_ = 0;
     bool failed_ = false;                                // a step failed after it had started to consume messages
     std::string failed_why_;
