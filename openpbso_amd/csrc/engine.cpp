@@ -426,13 +426,20 @@ int Engine::finalize() {
     // teams, grouped into size classes (one launch of the oscillator bank per team size, largest
     // first); the SoA rows stay m_pad wide and a team touches its own columns only
     {
+        // Team size.  A full chip (>= 4096 waves) runs whole objects as teams of up to 16 waves.  Below
+        // that the launch is bound by the per-sample latency of a wave, which is shortest when the
+        // wave shares its SIMD / CU with as few others as possible (measured: 8 x 4096 modes 425 -> 570 x
+        // real time with 2-wave teams, 1 x 512 modes 778 -> 822 x with 1-wave teams): spread the waves
+        // evenly over the 256 CUs.
+        int team_cap = (int)std::min<long long>(MAX_WAVES_PER_TEAM, std::max<long long>(1, (total_waves(R) + 255) / 256));
+        if (const char *v = std::getenv("PBSO_TEAM_WAVES")) team_cap = std::min(MAX_WAVES_PER_TEAM, std::max(1, std::atoi(v)));
         std::vector<std::vector<TeamDesc>> by_w(MAX_WAVES_PER_TEAM + 1);
         std::vector<SplitObj> split;
         n_part_rows_ = 0;
         W_ = 1;
         for (int i = 0; i < N; ++i) {
             const int w = waves_of(objs_[i], R);
-            const int parts = (w + MAX_WAVES_PER_TEAM - 1) / MAX_WAVES_PER_TEAM;
+            const int parts = (w + team_cap - 1) / team_cap;
             const int base = w / parts, rem = w % parts;
             int w0 = 0;
             if (parts > 1) {

@@ -10,7 +10,7 @@ except Exception as e:
     print("  bad json", e); print(open(sys.argv[1].replace(".json", ".err")).read()[-600:])
 PY
 }
-run c2_1x512 --objects 1 --modes 512 --steps 10 --warmup 2
-run c3_64x256_listener --objects 64 --modes 256 --scenario listener --steps 10 --warmup 2
-run c5_8x4096_scraping --objects 8 --modes 4096 --scenario scraping --steps 6 --warmup 2
+run c2_1x512 --objects 1 --modes 512 --steps 40 --warmup 2
+run c3_64x256_listener --objects 64 --modes 256 --scenario listener --steps 40 --warmup 2
+run c5_8x4096_scraping --objects 8 --modes 4096 --scenario scraping --steps 40 --warmup 2
 PBSO_DEVICE_PROFILES=0 run c5_8x4096_scraping_hostprof --objects 8 --modes 4096 --scenario scraping --steps 6 --warmup 2

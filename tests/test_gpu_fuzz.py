@@ -116,7 +116,9 @@ def _run_seed(seed, size_choices, engine_kw, projected_hits=False):
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PBSO_FUZZ_SEEDS", "200"))))
-def test_random_scripts_match_oracle(seed):
+def test_random_scripts_match_oracle(seed, monkeypatch):
+    if seed % 2:
+        monkeypatch.setenv("PBSO_TEAM_WAVES", "16")     # whole objects as teams, as on a full chip
     _run_seed(seed, [3, 40, 64, 100, 129, 300], {})
 
 
@@ -126,5 +128,8 @@ def test_random_scripts_random_engine_shapes(seed, monkeypatch):
     modes-per-lane setting, both qnorm modes and launches cut at random lengths"""
     rng = np.random.default_rng(77000 + seed)
     monkeypatch.setenv("PBSO_CHUNK_BUFFERS", str(int(rng.choice([1, 2, 5, 128]))))
+    cap = int(rng.choice([0, 2, 16, 16]))            # 0: the engine's own choice (one wave per CU for engines this small)
+    if cap:
+        monkeypatch.setenv("PBSO_TEAM_WAVES", str(cap))
     kw = dict(modes_per_lane=int(rng.choice([0, 1, 2, 4, 8])), qnorm=int(rng.choice([capi.QNORM_ALL, capi.QNORM_CLOSED])))
     _run_seed(seed + 100000, [5, 64, 200, 1100, 2100], kw, projected_hits=True)

@@ -88,10 +88,15 @@ def test_config5_shape_large_objects(mpl, monkeypatch):
         evs.append(force_ev(0, i, data=rng.standard_normal(n_modes) * 1e-3, force_type=1, width=1500.0))
         evs.append(force_ev(3, i, data=rng.standard_normal(n_modes) * 1e-3))
         evs.append(dict(t=0, obj=i, kind="use_transfer", use=False))
-    got = run_engine(objs, evs, nb, modes_per_lane=mpl)
     want = run_oracle(objs, evs, nb)
+    monkeypatch.setenv("PBSO_TEAM_WAVES", "16")      # whole objects as teams (what a full chip runs)
+    got = run_engine(objs, evs, nb, modes_per_lane=mpl)
     _check(got, want)
-    assert got["info"]["waves_per_object"] == 4096 // (64 * mpl)
+    assert got["info"]["waves_per_object"] == 4096 // (64 * mpl) and got["info"]["n_teams"] == 2
+    monkeypatch.delenv("PBSO_TEAM_WAVES")            # a nearly empty chip: one wave per CU
+    got = run_engine(objs, evs, nb, modes_per_lane=mpl)
+    _check(got, want)
+    assert got["info"]["waves_per_object"] == 1 and got["info"]["n_teams"] == 2 * 4096 // (64 * mpl)
 
 
 def test_direct_form_reference_literal_arithmetic():
