@@ -404,8 +404,7 @@ int Engine::finalize() {
     const int N = (int)objs_.size();
     // Team shape: R oscillators per lane; an object of n modes needs ceil(n / 64R) waves, cut into
     // teams (workgroups) of at most MAX_WAVES_PER_TEAM waves.  The VALU issue rate needs ~4 waves per
-    // SIMD (4096 on the chip, profiles/r01_microbench.txt): take the largest R that still gives that
-    // many waves; below that the launch is latency-bound and one mode per lane spreads it widest.
+    // SIMD (4096 on the chip, profiles/r01_microbench.txt).
     int R = desc_.modes_per_lane;
     if (R != 0 && R != 1 && R != 2 && R != 4 && R != 8) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,4,8");
     auto waves_of = [&](const Object &o, int r) { return std::max(1, (o.n_modes + 64 * r - 1) / (64 * r)); };
@@ -415,9 +414,13 @@ int Engine::finalize() {
         return w;
     };
     if (R == 0) {
-        R = 1;
-        for (int r : {4, 2})
-            if (total_waves(r) >= 4096) { R = r; break; }
+        // the fewest modes per lane whose waves are all resident at once (16 waves per CU is what the
+        // LDS tiles allow: 4096 on the chip) -- a second round of workgroups costs more than the
+        // deeper per-lane work (768 x 512: 2.83 ms with R = 1 in two rounds, 1.93 ms with R = 2);
+        // engines beyond that take R = 4 (R = 8 needs more registers than 4 waves per SIMD leave)
+        R = 4;
+        for (int r : {1, 2, 4})
+            if (total_waves(r) <= 4096) { R = r; break; }
     }
     int wmax = 1;
     for (const Object &o : objs_) wmax = std::max(wmax, waves_of(o, R));
