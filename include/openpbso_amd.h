@@ -88,7 +88,7 @@ typedef struct pbso_engine_desc {
     int sample_rate;          /* 0 -> 44100 */
     int recurrence_form;      /* enum pbso_recurrence_form */
     int qnorm_mode;           /* enum pbso_qnorm_mode */
-    int modes_per_lane;       /* 0 = auto; 1, 2, 4 or 8 oscillators per lane */
+    int modes_per_lane;       /* 0 = auto; 1, 2, 3, 4 or 8 oscillators per lane */
     void *stream;             /* hipStream_t to launch on; NULL -> engine-owned non-blocking stream (the
                                * legacy null stream cannot be selected: order other work on it with
                                * pbso_sync).  A second, engine-owned high-priority stream prepares the

@@ -270,7 +270,7 @@ int Engine::init() {
         return fail(PBSO_ERR_INVALID, "qnorm_mode");
     {
         const int r = desc_.modes_per_lane;
-        if (r != 0 && r != 1 && r != 2 && r != 4 && r != 8) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,4,8");
+        if (r != 0 && r != 1 && r != 2 && r != 3 && r != 4 && r != 8) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,3,4,8");
     }
     int ndev = 0;
     HIPTRY(hipGetDeviceCount(&ndev));
@@ -406,7 +406,7 @@ int Engine::finalize() {
     // teams (workgroups) of at most MAX_WAVES_PER_TEAM waves.  The VALU issue rate needs ~4 waves per
     // SIMD (4096 on the chip, profiles/r01_microbench.txt).
     int R = desc_.modes_per_lane;
-    if (R != 0 && R != 1 && R != 2 && R != 4 && R != 8) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,4,8");
+    if (R != 0 && R != 1 && R != 2 && R != 3 && R != 4 && R != 8) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,3,4,8");
     auto waves_of = [&](const Object &o, int r) { return std::max(1, (o.n_modes + 64 * r - 1) / (64 * r)); };
     auto total_waves = [&](int r) {
         long long w = 0;
@@ -416,11 +416,19 @@ int Engine::finalize() {
     if (R == 0) {
         // the fewest modes per lane whose waves are all resident at once (16 waves per CU is what the
         // LDS tiles allow: 4096 on the chip) -- a second round of workgroups costs more than the
-        // deeper per-lane work (768 x 512: 2.83 ms with R = 1 in two rounds, 1.93 ms with R = 2);
-        // engines beyond that take R = 4 (R = 8 needs more registers than 4 waves per SIMD leave)
-        R = 4;
-        for (int r : {1, 2, 4})
+        // deeper per-lane work (768 x 512: 2.83 ms with R = 1 in two rounds, 1.93 ms with R = 2).
+        // Engines that cannot be resident at once with R <= 4 minimise rounds x instructions per
+        // wave-sample (5 R + 2.2); R = 8 needs more registers than 4 waves per SIMD leave.
+        R = 0;
+        for (int r : {1, 2, 3, 4})
             if (total_waves(r) <= 4096) { R = r; break; }
+        if (R == 0) {
+            double best = 0;
+            for (int r : {1, 2, 3, 4}) {
+                const double cost = (double)((total_waves(r) + 4095) / 4096) * (5.0 * r + 2.2);
+                if (R == 0 || cost < best) { R = r; best = cost; }
+            }
+        }
     }
     int wmax = 1;
     for (const Object &o : objs_) wmax = std::max(wmax, waves_of(o, R));

@@ -491,7 +491,7 @@ static int launch_r(const IirParams &p, int n_obj, int W, int form, int qnm, hip
 
 // teams of up to 4 waves use the 256-thread build (no VGPR cap in practice);
 // larger teams (objects with more than 256 R modes) the 1024-thread build.
-// R in {1,2,4,8} for both.
+// R in {1,2,3,4,8} for both.
 int launch_iir_bank(const IirParams &p, int n_obj, int R, int W, int form, int qnm, hipStream_t s) {
     if (n_obj <= 0) return 0;
     if (qnm < 0 || qnm > 2) return (int)hipErrorInvalidValue;
@@ -500,6 +500,7 @@ int launch_iir_bank(const IirParams &p, int n_obj, int R, int W, int form, int q
         switch (R) {
         case 1: return launch_r<1, 256>(p, n_obj, W, form, qnm, s);
         case 2: return launch_r<2, 256>(p, n_obj, W, form, qnm, s);
+        case 3: return launch_r<3, 256>(p, n_obj, W, form, qnm, s);
         case 4: return launch_r<4, 256>(p, n_obj, W, form, qnm, s);
         case 8: return launch_r<8, 256>(p, n_obj, W, form, qnm, s);
         }
@@ -507,6 +508,7 @@ int launch_iir_bank(const IirParams &p, int n_obj, int R, int W, int form, int q
         switch (R) {
         case 1: return launch_r<1, 1024>(p, n_obj, W, form, qnm, s);
         case 2: return launch_r<2, 1024>(p, n_obj, W, form, qnm, s);
+        case 3: return launch_r<3, 1024>(p, n_obj, W, form, qnm, s);
         case 4: return launch_r<4, 1024>(p, n_obj, W, form, qnm, s);
         case 8: return launch_r<8, 1024>(p, n_obj, W, form, qnm, s);
         }

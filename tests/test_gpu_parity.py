@@ -53,7 +53,7 @@ def test_config1_wine_glass_one_impulse():
         assert np.abs(a - w).max() <= 2e-3 * max(np.abs(want["state"][0][0]).max(), 1e-300)
 
 
-@pytest.mark.parametrize("mpl", [1, 2, 4])
+@pytest.mark.parametrize("mpl", [1, 2, 3, 4])
 @pytest.mark.parametrize("rotate", ["0", "1"])
 def test_config2_512_modes_poisson_train(mpl, rotate, monkeypatch):
     """configs[1]: single object, 512 modes, Poisson impulse train; every team
@@ -389,7 +389,7 @@ def test_objects_split_over_several_teams():
     evs += [dict(t=b, obj=1, kind="listener", pos=path[b]) for b in range(nb)]
     want = run_oracle(objs, evs, nb)
     ref = None
-    for mpl, split in ((0, None), (1, [3, 4]), (4, None), (8, [1, 6])):
+    for mpl, split in ((0, None), (1, [3, 4]), (3, None), (4, None), (8, [1, 6])):
         got = run_engine(objs, evs, nb, modes_per_lane=mpl, split=split)
         assert got["info"]["n_teams"] > 3 or mpl == 8
         _check(got, want)
@@ -572,7 +572,7 @@ def test_degenerate_objects_and_arguments():
         with Engine() as eng:
             eng.finalize()                                   # no objects
     with pytest.raises(PbsoError):
-        Engine(modes_per_lane=3)
+        Engine(modes_per_lane=5)
 
 
 def test_long_steps_cut_into_launches(monkeypatch):
