@@ -252,14 +252,7 @@ int pbso_enqueue_force_batch(pbso_engine *e, int n, const int *objs, const pbso_
     NEED(e);
     if (n < 0 || (n && (!objs || !msgs || !nb))) return PBSO_ERR_INVALID;
     GUARD_BEGIN
-    int taken = 0;
-    for (int i = 0; i < n; ++i) {
-        const int rc = e->impl->enqueue_force(objs[i], msgs[i], nb[i]);
-        if (rc < 0) return rc;
-        if (accepted) accepted[i] = rc ? 1 : 0;
-        taken += rc ? 1 : 0;
-    }
-    return taken;
+    return e->impl->enqueue_force_batch(n, objs, msgs, nb, accepted);
     GUARD_END(e)
 }
 

@@ -616,12 +616,12 @@ int Engine::finalize() {
 
 // ---------------------------------------------------------------------------
 // ModalSolver::enqueueForceMessage, modal_solver.h:329-333
-int Engine::enqueue_force(int obj, const pbso_force_msg &m, int64_t not_before) {
-    if (!finalized_) return fail(PBSO_ERR_STATE, "enqueue_force before finalize");
-    if (!valid_obj(obj)) return fail(PBSO_ERR_INVALID, "object id");
+int Engine::enqueue_force_impl(int obj, const pbso_force_msg &m, int64_t not_before, const char **why) {
+    if (!finalized_) { *why = "enqueue_force before finalize"; return PBSO_ERR_STATE; }
+    if (!valid_obj(obj)) { *why = "object id"; return PBSO_ERR_INVALID; }
     Object &o = objs_[obj];
     if (m.force_type < PBSO_POINT_FORCE || m.force_type > PBSO_AUTOREGRESSIVE_FORCE)
-        return fail(PBSO_ERR_INVALID, "unrecognized force type");             // assert modal_solver.h:73
+        { *why = "unrecognized force type"; return PBSO_ERR_INVALID; }             // assert modal_solver.h:73
     HostForceMsg h;
     h.force_type = m.force_type;
     h.sustained_start = m.sustained_force_start != 0;
@@ -633,16 +633,16 @@ int Engine::enqueue_force(int obj, const pbso_force_msg &m, int64_t not_before) 
     switch (m.data_kind) {
     case PBSO_DATA_EXPLICIT:
         if (!m.data || m.n_data != o.n_modes)
-            return fail(PBSO_ERR_INVALID, "dimension of force message incorrect");   // assert :258
+            { *why = "dimension of force message incorrect"; return PBSO_ERR_INVALID; }   // assert :258
         h.data.assign(m.data, m.data + m.n_data);
         break;
     case PBSO_DATA_VERTEX:
     case PBSO_DATA_FACE: {
-        if (!o.n_dof) return fail(PBSO_ERR_INVALID, "object has no mode shapes for on-device projection");
+        if (!o.n_dof) { *why = "object has no mode shapes for on-device projection"; return PBSO_ERR_INVALID; }
         const int nv = o.n_dof / 3;
         const int cnt = m.data_kind == PBSO_DATA_VERTEX ? 1 : 3;
         for (int j = 0; j < cnt; ++j)
-            if (m.vids[j] < 0 || m.vids[j] >= nv) return fail(PBSO_ERR_INVALID, "vertex id out of range");
+            if (m.vids[j] < 0 || m.vids[j] >= nv) { *why = "vertex id out of range"; return PBSO_ERR_INVALID; }
         for (int j = 0; j < 3; ++j) {
             h.vids[j] = m.vids[j];
             h.coords[j] = m.coords[j];
@@ -653,13 +653,56 @@ int Engine::enqueue_force(int obj, const pbso_force_msg &m, int64_t not_before) 
     case PBSO_DATA_ZERO:
         break;
     default:
-        return fail(PBSO_ERR_INVALID, "data_kind");
+        { *why = "data_kind"; return PBSO_ERR_INVALID; }
     }
     if (o.force_q.size() >= 1023) return 0;      // ReaderWriterQueue(512): ceilToPow2(513)-1 usable slots
     // keep arrival order monotone: a message cannot overtake an earlier one (FIFO)
     if (!o.force_q.empty()) h.not_before = std::max(h.not_before, o.force_q.back().not_before);
     o.force_q.push_back(std::move(h));
     return 1;
+}
+
+int Engine::enqueue_force(int obj, const pbso_force_msg &m, int64_t not_before) {
+    const char *why = "";
+    const int rc = enqueue_force_impl(obj, m, not_before, &why);
+    return rc < 0 ? fail(rc, why) : rc;
+}
+
+// A whole step of a force script.  Messages of one object keep their order.  With planner threads
+// (PBSO_PLAN_THREADS > 1) every thread enqueues the messages of its own range of objects.
+int Engine::enqueue_force_batch(int n, const int *objs, const pbso_force_msg *msgs, const int64_t *stamps,
+                                unsigned char *accepted) {
+    const int N = (int)objs_.size();
+    const int T = (plan_threads_ > 1 && n >= 4096 && N >= 64) ? plan_threads_ : 1;
+    std::vector<int> taken(T, 0), rcs(T, 0);
+    std::vector<const char *> whys(T, "");
+    auto job = [&](int t) {
+        const int lo = (int)((long long)N * t / T), hi = (int)((long long)N * (t + 1) / T);
+        for (int i = 0; i < n; ++i) {
+            const int o = objs[i];
+            const bool mine = (o >= lo && o < hi) || (t == 0 && (o < 0 || o >= N));   // bad ids: reported by thread 0
+            if (!mine) continue;
+            const int rc = enqueue_force_impl(o, msgs[i], stamps[i], &whys[t]);
+            if (rc < 0) { rcs[t] = rc; return; }
+            if (accepted) accepted[i] = rc ? 1 : 0;
+            taken[t] += rc ? 1 : 0;
+        }
+    };
+    if (T > 1) {
+        if (!pool_) {
+            const char *pin = std::getenv("PBSO_PLAN_PIN");
+            pool_ = new PlanPool(plan_threads_ - 1, pin && std::atoi(pin) ? sched_getcpu() : -1);
+        }
+        pool_->run(T, job);
+    } else {
+        job(0);
+    }
+    int total = 0;
+    for (int t = 0; t < T; ++t) {
+        if (rcs[t] < 0) return fail(rcs[t], whys[t]);
+        total += taken[t];
+    }
+    return total;
 }
 
 static void push_timed(std::deque<TimedEvent> &q, const TimedEvent &ev) {

@@ -162,6 +162,7 @@ public:
     int set_ffat_maps(int obj, const pbso_ffat_map *maps, int n);
     int finalize();
     int enqueue_force(int obj, const pbso_force_msg &m, int64_t not_before);
+    int enqueue_force_batch(int n, const int *objs, const pbso_force_msg *msgs, const int64_t *stamps, unsigned char *accepted);
     int enqueue_arprm(int obj, const double a[2], double sigma, double mu, int64_t not_before);
     int compute_transfer(int obj, const double pos[3], int64_t not_before);
     int compute_transfer_batch(int obj, const double *pos, int n_pos, double *out);
@@ -185,6 +186,7 @@ private:
     int fail(int code, const std::string &msg);
     int hip_fail(hipError_t e, const char *what);
     bool valid_obj(int obj) const { return obj >= 0 && obj < (int)objs_.size(); }
+    int enqueue_force_impl(int obj, const pbso_force_msg &m, int64_t not_before, const char **why);
     int alloc_slot(PlanCtx &c);
     void release(PlanCtx &c, ActiveForce &af);
     int plan(int nb);                                    // host bookkeeping for one batch

@@ -667,3 +667,33 @@ def test_planner_on_several_threads_gives_the_same_plan(device_profiles, monkeyp
     want = run_oracle([objs[i] for i in sub], [dict(e, obj=sub.index(e["obj"])) for e in evs if e["obj"] in sub], nb)
     mx, l2 = rel_errors(one["audio"][sub], want["audio"])
     assert (mx <= TOL_MAX).all() and (l2 <= TOL_L2).all(), (mx, l2)
+
+
+def test_batch_enqueue_on_several_threads(monkeypatch):
+    """pbso_enqueue_force_batch with planner threads: every thread enqueues the messages of its own
+    objects (per-object order kept); same audio as one thread, same count, queue-full results."""
+    from openpbso_amd import Engine
+    n_obj, n_modes, nb, n = 200, 16, 6, 6000
+    rng = np.random.default_rng(8)
+    lams = [synth.eigenvalues(n_modes, 20000 + i) for i in range(n_obj)]
+    shapes = [synth.mode_shapes(n_modes, 21000 + i) for i in range(n_obj)]
+    objs = rng.integers(0, n_obj, n)
+    stamps = np.sort(rng.integers(0, nb, n))
+    vids = rng.integers(0, synth.N_VERTS, n)
+    vns = synth.unit_normals(n, 5)
+
+    def run(threads):
+        monkeypatch.setenv("PBSO_PLAN_THREADS", threads)
+        with Engine() as eng:
+            for i in range(n_obj):
+                eng.add_object(lams[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
+            eng.finalize()
+            for i in range(n_obj):
+                eng.set_use_transfer(i, False)
+            taken = eng.enqueue_force_batch(*Engine.hit_messages(objs, vids, vns, stamps))
+            eng.step(nb)
+            return taken, eng.audio().copy()
+
+    t1, a1 = run("1")
+    t4, a4 = run("4")
+    assert t1 == t4 == n and np.abs(a1).max() > 0 and np.array_equal(a1, a4)
