@@ -34,10 +34,6 @@ VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak (= fp32 MFMA dense peak), same
 FLOP_PER_MODE_SAMPLE = 10      # reference arithmetic incl. qnorm
 
 
-# the engine overlaps two HIP streams; keep enough hardware queues for them next to torch's and RCCL's
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)

@@ -227,6 +227,11 @@ Engine::~Engine() {
     for (hipEvent_t ev : {ev_prep_done_[0], ev_prep_done_[1], ev_k1_done_[0], ev_k1_done_[1]})
         if (ev) (void)hipEventDestroy(ev);
     if (prep_stream_) (void)hipStreamDestroy(prep_stream_);
+    for (hipStream_t cs : class_stream_)
+        if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    for (hipEvent_t ev : ev_join_)
+        if (ev) (void)hipEventDestroy(ev);
     set_[0].release();
     set_[1].release();
     for (hipEvent_t ev : {ev_set_[0], ev_set_[1]})
@@ -478,6 +483,14 @@ int Engine::finalize() {
         }
         for (size_t k = 0; k < flat.size(); ++k) flat[k].id = (int)k;
         n_teams_ = (int)flat.size();
+        total_team_waves_ = total_waves(R);
+        if (classes_.size() > 1 && !ev_fork_) {
+            HIPTRY(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+            for (int i = 0; i < N_CLASS_STREAMS; ++i) {
+                HIPTRY(hipStreamCreateWithFlags(&class_stream_[i], hipStreamNonBlocking));
+                HIPTRY(hipEventCreateWithFlags(&ev_join_[i], hipEventDisableTiming));
+            }
+        }
         n_split_ = (int)split.size();
         HIPTRY(d_teams_.ensure(flat.size()));
         HIPTRY(hipMemcpy(d_teams_.p, flat.data(), flat.size() * sizeof(TeamDesc), hipMemcpyHostToDevice));
@@ -1338,9 +1351,29 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.rotate_prio = rotate_prio_ ? 1 : 0;
     HIPTRY(hipEventRecord(evq.k0, sk));
     kp.audio_parts = n_part_rows_ ? d_audio_parts_.p + (size_t)b0 * B_ : nullptr;
-    for (const SizeClass &c : classes_) {
+    // side by side only while everything is resident at once; classes that fill the chip on their own
+    // run faster one after the other (512 x 512 + 4096 x 64: 3.1 ms in sequence, 3.7 ms side by side)
+    const bool fork = classes_.size() > 1 && ev_fork_ && total_team_waves_ <= 4096;
+    if (fork) HIPTRY(hipEventRecord(ev_fork_, sk));
+    bool used[N_CLASS_STREAMS] = {false, false, false};
+    for (size_t ci = 0; ci < classes_.size(); ++ci) {
+        const SizeClass &c = classes_[ci];
+        hipStream_t s = sk;
+        if (fork && ci > 0) {
+            const int j = (int)((ci - 1) % N_CLASS_STREAMS);
+            s = class_stream_[j];
+            if (!used[j]) {
+                HIPTRY(hipStreamWaitEvent(s, ev_fork_, 0));
+                used[j] = true;
+            }
+        }
         kp.teams = d_teams_.p + c.first;
-        LAUNCHTRY(iir_scalar::launch_iir_bank(kp, c.count, R_, c.W, desc_.recurrence_form, desc_.qnorm_mode, sk));
+        LAUNCHTRY(iir_scalar::launch_iir_bank(kp, c.count, R_, c.W, desc_.recurrence_form, desc_.qnorm_mode, s));
+    }
+    for (int j = 0; j < N_CLASS_STREAMS; ++j) {
+        if (!used[j]) continue;
+        HIPTRY(hipEventRecord(ev_join_[j], class_stream_[j]));
+        HIPTRY(hipStreamWaitEvent(sk, ev_join_[j], 0));
     }
     HIPTRY(hipEventRecord(evq.k1, sk));
     // _latest_transfer = trans (modal_solver.h:251), then re-park a still-queued transfer

@@ -201,6 +201,11 @@ private:
     hipStream_t stream_ = nullptr;                       // oscillator bank (caller's stream if given)
     hipStream_t prep_stream_ = nullptr;                  // plan upload + projection + FFAT + combine
     hipEvent_t ev_prep_done_[2] = {nullptr, nullptr}, ev_k1_done_[2] = {nullptr, nullptr};
+    // engines with several team sizes: the size classes are launched side by side on these streams
+    // (one class alone rarely fills the chip), forked from and joined into stream_ with events
+    static constexpr int N_CLASS_STREAMS = 3;
+    hipStream_t class_stream_[N_CLASS_STREAMS] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork_ = nullptr, ev_join_[N_CLASS_STREAMS] = {nullptr, nullptr, nullptr};
     int xfer_cap_ = 0;                                   // scratch transfer rows per plan set
     hipEvent_t ev_set_[2] = {nullptr, nullptr};
     struct EvQuad { hipEvent_t k0, k1, p0, p1; int64_t step_id; };
@@ -222,6 +227,7 @@ private:
     DevBuf<SplitObj> d_split_;                           // objects stepped by more than one team
     DevBuf<float> d_audio_parts_;                        // [n_part_rows_][nb * B] their partial sample sums
     int n_teams_ = 0, n_split_ = 0, n_part_rows_ = 0;
+    long long total_team_waves_ = 0;
     DevBuf<float> d_gq_;                                 // closed-form qnorm: G11, 2 G12, G22 planes
     DevBuf<double> d_shapes_;
     DevBuf<long long> d_shape_off_;
