@@ -1351,11 +1351,13 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.rotate_prio = rotate_prio_ ? 1 : 0;
     HIPTRY(hipEventRecord(evq.k0, sk));
     kp.audio_parts = n_part_rows_ ? d_audio_parts_.p + (size_t)b0 * B_ : nullptr;
-    // side by side only while everything is resident at once; classes that fill the chip on their own
-    // run faster one after the other (512 x 512 + 4096 x 64: 3.1 ms in sequence, 3.7 ms side by side)
+    // Side by side only while everything is resident at once (largest teams first, on the engine's
+    // stream); an engine that needs several rounds of workgroups runs its classes one after the other
+    // (512 x 512 + 4096 x 64: 3.1 ms in sequence, 3.7 ms side by side -- teams of different size fragment
+    // the CUs' LDS and wave slots).
+    bool used[N_CLASS_STREAMS] = {false, false, false};
     const bool fork = classes_.size() > 1 && ev_fork_ && total_team_waves_ <= 4096;
     if (fork) HIPTRY(hipEventRecord(ev_fork_, sk));
-    bool used[N_CLASS_STREAMS] = {false, false, false};
     for (size_t ci = 0; ci < classes_.size(); ++ci) {
         const SizeClass &c = classes_[ci];
         hipStream_t s = sk;

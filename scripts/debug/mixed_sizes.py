@@ -35,3 +35,5 @@ run([512] * 1024, "1024 x 512")
 run([512] * 512 + [64] * 4096, "512 x 512 + 4096 x 64")
 run([2048] * 128 + [128] * 2048, "128 x 2048 + 2048 x 128")
 run([1024] * 256 + [300] * 600 + [50] * 1000, "256 x 1024 + 600 x 300 + 1000 x 50")
+run([512] * 1900 + [4096] * 10, "1900 x 512 + 10 x 4096")
+run([512] * 512 + [64] * 4096 + [2000] * 6, "512 x 512 + 4096 x 64 + 6 x 2000")
