@@ -4,18 +4,22 @@
 // ModalIntegrator::Step (modal_integrator.h:103-113) for a whole batch of
 // objects and buffers in one launch.
 //
-// Mapping.  One workgroup = one object ("team" of W waves).  A lane owns R
-// oscillators: mode m = r * (64 W) + tid, so every r-slice of the SoA arrays
-// is one contiguous, coalesced row.  Coefficients, state, g = c3*S, the
+// Mapping.  One workgroup = one "team" of W waves stepping the columns
+// [col0, col0 + 64 W R) of one object's SoA rows (a whole object, or one part of
+// an object that needs more waves than a team may have -- kernels.h TeamDesc).  A
+// lane owns R oscillators: column = col0 + r * (64 W) + tid, so every r-slice is
+// one contiguous, coalesced row.  Coefficients, state, the force gain, the
 // transfer weights and the qnorm accumulators live in VGPRs for the whole
 // launch; descriptors and force time profiles are uniform over the team and
 // are read with scalar loads.  The loop is bound by the fp32 vector ALU issue
 // rate, not by HBM: per oscillator-sample it issues
-//   velocity form:  v_mul, v_fma [, v_fma force], v_add, v_fma out [, v_fma qnorm]
-//   direct form:    v_mul [, v_fma force], v_fma, v_fma out [, v_fma qnorm]
+//   velocity form:  v_mul, v_fmac [, v_fmac force], v_add, [v_fmac qnorm,] and 1/R..1 op for the output
+//   direct form:    v_mul [, v_fmac force], v_fmac, ...
+// The registers hold the state multiplied by the transfer weight ("scaled state", see the
+// kernel body), which turns the output into a plain sum over the lane's modes.
 //
 // Per-sample reduction over modes.  Each lane first sums its own R modes
-// (p = sum_r t_r q_r), then the 64 lane partials of TILE = 27 consecutive
+// (p = sum_r t_r q_r; with the scaled state simply sum_r Q_r), then the 64 lane partials of TILE = 27 consecutive
 // samples are transposed through a per-wave LDS tile P[27][68]: lane l writes
 // P[k][l] while stepping sample k (ds_write_addtid_b32: no address VGPR, half
 // the issue cost of ds_write_b32).  The row sums are taken ONE TILE LATER:
