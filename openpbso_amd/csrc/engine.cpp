@@ -222,7 +222,7 @@ Engine::~Engine() {
     d_ca_.release(); d_cb_.release(); d_sq_.release(); d_sd_.release(); d_ss_.release(); d_c3_.release(); d_gq_.release();
     d_shapes_.release(); d_shape_off_.release(); d_n_modes_.release(); d_geom_.release();
     d_geom_off_.release(); d_psi_.release(); d_slots_.release(); d_xfer_.release();
-    d_arstate_.release(); d_teams_.release(); d_split_.release(); d_audio_parts_.release();
+    d_arstate_.release(); d_board_.release(); d_teams_.release(); d_split_.release(); d_audio_parts_.release();
     d_audio_.release(); d_qnorm_.release(); d_grows_[0].release(); d_grows_[1].release(); d_census_.release();
     for (hipEvent_t ev : {ev_prep_done_[0], ev_prep_done_[1], ev_k1_done_[0], ev_k1_done_[1]})
         if (ev) (void)hipEventDestroy(ev);
@@ -311,7 +311,7 @@ int Engine::init() {
     for (PlanCtx &c : ctx_) c.tbuf.assign(B_, 0.0);
     // which build of the oscillator bank to launch (see kernels_iir.hip)
     if (const char *v = std::getenv("PBSO_CENSUS")) census_ = std::atoi(v) != 0;
-    if (const char *v = std::getenv("PBSO_ROTATE_PRIO")) rotate_prio_ = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PBSO_ROTATE_PRIO")) rotate_prio_ = std::min(2, std::max(0, std::atoi(v)));
     if (const char *v = std::getenv("PBSO_DEVICE_PROFILES")) device_profiles_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_CHUNK_BUFFERS")) chunk_buffers_ = std::max(1, std::atoi(v));
     return PBSO_OK;
@@ -620,6 +620,8 @@ int Engine::finalize() {
         }
     }
     HIPTRY(hipMemcpy(d_n_modes_.p, nmodes.data(), N * sizeof(int), hipMemcpyHostToDevice));
+    HIPTRY(d_board_.ensure(4096));
+    HIPTRY(hipMemset(d_board_.p, 0, 4096 * sizeof(unsigned)));
     // transfer rows: [0,N) _latest_transfer, [N,2N) the 1-slot transfer queue, then per-launch scratch
     HIPTRY(d_xfer_.ensure((size_t)2 * N * m_pad_));
     HIPTRY(hipMemset(d_xfer_.p, 0, (size_t)2 * N * m_pad_ * sizeof(double)));
@@ -1348,7 +1350,10 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     }
     kp.nb = nb; kp.n_tiles = n_tiles_; kp.m_pad = m_pad_; kp.b_pad = b_pad_;
     kp.audio_stride = (long long)nb_total * B_;
-    kp.rotate_prio = rotate_prio_ ? 1 : 0;
+    // the per-CU progress feedback only pays when several teams compete for every SIMD
+    kp.rotate_prio = (rotate_prio_ == 2 && total_team_waves_ < 3072) ? 1 : rotate_prio_;
+    kp.board = d_board_.p;
+    kp.launch_seq = ++launch_seq_;
     HIPTRY(hipEventRecord(evq.k0, sk));
     kp.audio_parts = n_part_rows_ ? d_audio_parts_.p + (size_t)b0 * B_ : nullptr;
     // Side by side only while everything is resident at once (largest teams first, on the engine's

@@ -240,7 +240,9 @@ private:
     DevBuf<float> d_audio_, d_qnorm_;
     DevBuf<unsigned long long> d_census_;                // PBSO_CENSUS=1: per-workgroup placement/timing
     bool census_ = false;
-    bool rotate_prio_ = true;                            // PBSO_ROTATE_PRIO: see kernels_iir.hip
+    int rotate_prio_ = 2;                                // PBSO_ROTATE_PRIO: 0 off, 1 rotation, 2 rotation + per-CU progress feedback
+    DevBuf<unsigned> d_board_;                           // per-CU progress words of the feedback
+    unsigned launch_seq_ = 0;                            // PBSO_ROTATE_PRIO: see kernels_iir.hip
     float *last_audio_ = nullptr;
     int last_nb_ = 0;
     std::atomic<size_t> n_slots_{0};

@@ -67,7 +67,9 @@ struct IirParams {
     unsigned long long *census;  // diagnostics: [n_teams][6] = start, end (100 MHz), HW_ID, XCC_ID, clk0, clk1; or nullptr
     int nb, n_tiles, m_pad, b_pad;
     long long audio_stride;
-    int rotate_prio;             // rotate s_setprio per tile (fair progress of resident teams)
+    int rotate_prio;             // 1: rotate s_setprio per tile (fair progress of resident teams); 2: + progress feedback per CU
+    unsigned *board;             // [4096] per-CU progress words for rotate_prio == 2
+    unsigned launch_seq;
 };
 
 // launches the oscillator bank for n_teams teams of waves_per_team waves; returns hipError_t as int.

@@ -130,6 +130,7 @@ struct IirDims {
     int rotate_prio;
     long long gq_plane;          // elements between the G11 / 2 G12 / G22 planes
     int qn_nb, qn_b0;            // qnorm is [n_obj][qn_nb][m_pad]; this launch fills buffers qn_b0 ..
+    unsigned launch_seq;
 };
 
 // QNM: 0 no qnorm; 1 per-sample accumulation (the reference's loop, modal_solver.h:270);
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     float *__restrict__ p_sd, float *__restrict__ p_ss, const BufDesc *__restrict__ p_desc, const float *__restrict__ p_grows,
     const float *__restrict__ p_tprof, const double *__restrict__ p_xfer_rows,
     const int *__restrict__ p_xfer_init, float *__restrict__ p_audio, float *__restrict__ p_qnorm,
-    const float *__restrict__ p_gq, const TeamDesc *__restrict__ p_teams, float *__restrict__ p_audio_parts,
+    const float *__restrict__ p_gq, const TeamDesc *__restrict__ p_teams, float *__restrict__ p_audio_parts, unsigned *__restrict__ p_board,
     unsigned long long *__restrict__ p_census, const IirDims p) {
     constexpr bool QN = QNM != 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -261,6 +262,12 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     // Performance hint only: results do not depend on it.
     const int wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 0xF;   // HW_REG_HW_ID.WAVE_ID
     const bool ROTATE = p.rotate_prio != 0;
+    // progress feedback (rotate_prio == 2): the waves of a CU publish their tile count; a wave that is
+    // behind the leader of its CU raises its priority
+    const bool FEEDBACK = p.rotate_prio == 2;
+    unsigned *board = p_board + (((__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u) << 8) | ((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 8) & 0xFFu));
+    unsigned seen = 0;                                // what the board held one buffer ago (lane 0)
+    int boost = 0;
 
     // state of the one-tile lag (all wave-uniform)
     bool have_prev = false, prev_last = false, settle = false;
@@ -403,8 +410,17 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
             f4 rv[8];
             load_rows(rv);
             float rsum = 0.f;
+            if (FEEDBACK && tl == 0) {
+                // once per buffer: read what the CU's leader had published a buffer ago, publish own progress
+                const unsigned prev = __builtin_amdgcn_readfirstlane(seen);
+                const int lead = (prev >> 20) == (p.launch_seq & 0xFFFu) ? (int)(prev & 0xFFFFFu) - (b - 1) : 0;
+                boost = lead >= 2 ? 2 : (lead >= 1 ? 1 : 0);
+                if (lane == 0) seen = atomicMax(board, ((p.launch_seq & 0xFFFu) << 20) | (unsigned)b);
+            }
             if (ROTATE) {
-                switch ((wave_slot + g) & 3) {
+                int pr = ((wave_slot + g) & 3) + boost;
+                pr = pr > 3 ? 3 : pr;
+                switch (pr) {
                 case 0: __builtin_amdgcn_s_setprio(0); break;
                 case 1: __builtin_amdgcn_s_setprio(1); break;
                 case 2: __builtin_amdgcn_s_setprio(2); break;
@@ -475,9 +491,9 @@ static int launch_one(const IirParams &p, int n_obj, int W, hipStream_t stream) 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    const IirDims dims = {p.nb, p.n_tiles, p.m_pad, p.b_pad, p.audio_stride, p.rotate_prio, p.gq_plane, p.qn_nb, p.qn_b0};
+    const IirDims dims = {p.nb, p.n_tiles, p.m_pad, p.b_pad, p.audio_stride, p.rotate_prio, p.gq_plane, p.qn_nb, p.qn_b0, p.launch_seq};
     hipLaunchKernelGGL(kern, dim3(n_obj), dim3(64 * W), lds, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc,
-                       p.grows, p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.teams, p.audio_parts, p.census, dims);
+                       p.grows, p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.teams, p.audio_parts, p.board, p.census, dims);
     return (int)hipGetLastError();
 }
 

@@ -54,7 +54,7 @@ def test_config1_wine_glass_one_impulse():
 
 
 @pytest.mark.parametrize("mpl", [1, 2, 3, 4])
-@pytest.mark.parametrize("rotate", ["0", "1"])
+@pytest.mark.parametrize("rotate", ["0", "1", "2"])
 def test_config2_512_modes_poisson_train(mpl, rotate, monkeypatch):
     """configs[1]: single object, 512 modes, Poisson impulse train; every team
     shape (R oscillators per lane), with and without the wave-priority rotation (a scheduling hint only)."""
