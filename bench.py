@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--objects", type=int, default=1024, help="objects per GPU")
     ap.add_argument("--modes", type=int, default=512)
     ap.add_argument("--buffers", type=int, default=86, help="audio buffers per step")
-    ap.add_argument("--form", choices=["velocity", "direct"], default="velocity")
+    ap.add_argument("--form", choices=["block", "velocity", "direct"], default="block")
     ap.add_argument("--qnorm", choices=["sample", "closed", "off"], default="sample",
                     help="getQBufferNorm: per-sample accumulation (reference loop), closed form, or off")
     ap.add_argument("--no-qnorm", action="store_true", help="same as --qnorm off")
@@ -177,7 +177,7 @@ def main():
     torch.cuda.set_stream(run_stream)
     stream = run_stream.cuda_stream
     eng = Engine(device=dev_index,
-                 form=capi.FORM_VELOCITY if args.form == "velocity" else capi.FORM_DIRECT,
+                 form={"block": capi.FORM_BLOCK, "velocity": capi.FORM_VELOCITY, "direct": capi.FORM_DIRECT}[args.form],
                  qnorm={"sample": capi.QNORM_ALL, "closed": capi.QNORM_CLOSED, "off": capi.QNORM_OFF}[
                      "off" if args.no_qnorm else args.qnorm],
                  modes_per_lane=args.modes_per_lane, stream=stream)

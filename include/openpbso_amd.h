@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PBSO_ABI_VERSION 1
+#define PBSO_ABI_VERSION 2
 #define PBSO_SAMPLE_RATE 44100          /* config.h:13 */
 #define PBSO_FRAMES_PER_BUFFER 513      /* config.h:14 */
 
@@ -67,8 +67,15 @@ enum pbso_force_data_kind {
 };
 
 enum pbso_recurrence_form {
-    PBSO_FORM_VELOCITY = 0,   /* default: state (q, q-q_prev), coefficients (eps^2, 1-c1-c2): fp32-safe */
-    PBSO_FORM_DIRECT = 1      /* the reference's literal q = c1 q1 + c2 q2 + c3 Q in fp32 */
+    PBSO_FORM_BLOCK = 0,      /* default: block state-space form.  Between forces a mode is autonomous, so the 16
+                                 samples after a state x = (q, q-q_prev) are e1' A^j x and the state 16 samples on
+                                 is A^16 x: the sum over modes becomes a [16 x 2M].[2M x 16 blocks] product on the
+                                 f32 matrix pipe (exact f32 FMA chains), the state advances 33 times per buffer
+                                 instead of 513.  Buffers with a dense force profile (Gaussian / AR) step every
+                                 sample as PBSO_FORM_VELOCITY does.  Needs frames_per_buffer = 513 (else the
+                                 engine runs PBSO_FORM_VELOCITY); qnorm is evaluated in closed form.            */
+    PBSO_FORM_VELOCITY = 1,   /* per-sample recurrence, state (q, q-q_prev), coefficients (eps^2, 1-c1-c2): fp32-safe */
+    PBSO_FORM_DIRECT = 2      /* per-sample, the reference's literal q = c1 q1 + c2 q2 + c3 Q in fp32 */
 };
 
 enum pbso_qnorm_mode {
@@ -88,7 +95,7 @@ typedef struct pbso_engine_desc {
     int sample_rate;          /* 0 -> 44100 */
     int recurrence_form;      /* enum pbso_recurrence_form */
     int qnorm_mode;           /* enum pbso_qnorm_mode */
-    int modes_per_lane;       /* 0 = auto; 1, 2, 3, 4 or 8 oscillators per lane */
+    int modes_per_lane;       /* 0 = auto; 1, 2, 3, 4 or 8 oscillators per lane (block form: 1, 2 or 4) */
     void *stream;             /* hipStream_t to launch on; NULL -> engine-owned non-blocking stream (the
                                * legacy null stream cannot be selected: order other work on it with
                                * pbso_sync).  A second, engine-owned high-priority stream prepares the
@@ -249,12 +256,14 @@ typedef struct pbso_engine_info {
     int64_t total_steps;
     int n_teams;              /* workgroups of the oscillator bank per launch (objects with more than
                                * 16 waves of modes are stepped by several) */
+    int recurrence_form;      /* the form that runs (PBSO_FORM_BLOCK falls back to VELOCITY when
+                               * frames_per_buffer != 513) */
 } pbso_engine_info;
 int pbso_get_info(pbso_engine *e, pbso_engine_info *out);
 /* diagnostics (engine created with env PBSO_CENSUS=1): for every object's
  * workgroup of the last oscillator-bank launch: start, end (100 MHz ticks),
  * HW_REG_HW_ID, HW_REG_XCC_ID, shader-clock count at start and end.
- * out[n_objects][6].                                                          */
+ * out[n_teams][12]; words 6..9 (block form): shader cycles of wave 0 spent in the buffer head, the MFMA pipeline, the barrier, the combine.                                                         */
 int pbso_read_census(pbso_engine *e, unsigned long long *out, size_t n);
 
 #ifdef __cplusplus

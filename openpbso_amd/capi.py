@@ -8,12 +8,12 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libopenpbso_amd.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_STATE, ERR_IO, ERR_MISSING_MAP, ERR_ASSERT, ERR_NOMEM = -1, -2, -3, -4, -5, -6, -7
 POINT_FORCE, GAUSSIAN_FORCE, AUTOREGRESSIVE_FORCE = 0, 1, 2
 DATA_EXPLICIT, DATA_VERTEX, DATA_FACE, DATA_ZERO = 0, 1, 2, 3
-FORM_VELOCITY, FORM_DIRECT = 0, 1
+FORM_BLOCK, FORM_VELOCITY, FORM_DIRECT = 0, 1, 2
 QNORM_OFF, QNORM_ALL, QNORM_CLOSED = 0, 1, 2
 
 # every symbol include/openpbso_amd.h declares
@@ -65,7 +65,8 @@ class EngineInfo(C.Structure):
                 ("last_step_host_plan_ms", C.c_double), ("last_step_forced_rows", C.c_int64),
                 ("last_step_transfer_rows", C.c_int64),
                 ("total_kernel_ms", C.c_double), ("total_device_ms", C.c_double),
-                ("total_host_plan_ms", C.c_double), ("total_steps", C.c_int64), ("n_teams", C.c_int)]
+                ("total_host_plan_ms", C.c_double), ("total_steps", C.c_int64), ("n_teams", C.c_int),
+                ("recurrence_form", C.c_int)]
 
 
 _lib = None

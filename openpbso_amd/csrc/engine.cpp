@@ -269,8 +269,13 @@ int Engine::init() {
         return fail(PBSO_ERR_INVALID, "frames_per_buffer must be a multiple of the 27-sample tile (at most 32 tiles); the reference uses 513");
     n_tiles_ = B_ / TILE;
     b_pad_ = (B_ + 15) / 16 * 16;
-    if (desc_.recurrence_form != PBSO_FORM_VELOCITY && desc_.recurrence_form != PBSO_FORM_DIRECT)
+    if (desc_.recurrence_form != PBSO_FORM_BLOCK && desc_.recurrence_form != PBSO_FORM_VELOCITY &&
+        desc_.recurrence_form != PBSO_FORM_DIRECT)
         return fail(PBSO_ERR_INVALID, "recurrence_form");
+    form_ = desc_.recurrence_form;
+    // the block form tiles a buffer as 1 + 2 * 16 * 16 samples (the reference's 513); other lengths step per sample
+    if (form_ == PBSO_FORM_BLOCK && B_ != 1 + 2 * BLOCK_J * BLOCK_N) form_ = PBSO_FORM_VELOCITY;
+    if (const char *v = std::getenv("PBSO_BLOCK_TEAM_WAVES")) block_team_waves_ = std::min(MAX_WAVES_PER_BLOCK_TEAM, std::max(1, std::atoi(v)));
     if (desc_.qnorm_mode < PBSO_QNORM_OFF || desc_.qnorm_mode > PBSO_QNORM_CLOSED)
         return fail(PBSO_ERR_INVALID, "qnorm_mode");
     {
@@ -412,12 +417,22 @@ int Engine::finalize() {
     // SIMD (4096 on the chip, profiles/r01_microbench.txt).
     int R = desc_.modes_per_lane;
     if (R != 0 && R != 1 && R != 2 && R != 3 && R != 4 && R != 8) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,3,4,8");
+    const bool block = form_ == PBSO_FORM_BLOCK;
+    if (block && R == 3) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,4,8 in the block form");
     auto waves_of = [&](const Object &o, int r) { return std::max(1, (o.n_modes + 64 * r - 1) / (64 * r)); };
     auto total_waves = [&](int r) {
         long long w = 0;
         for (const Object &o : objs_) w += waves_of(o, r);
         return w;
     };
+    if (R == 0 && block) {
+        // The block form is paced by the matrix pipe: two waves per SIMD keep it busy (one issues MFMAs while
+        // the other steps its coarse recurrence), and a wave holds 32 R operand registers for its W table.
+        // The fewest modes per lane that fit the chip at two waves per SIMD; more objects run in rounds.
+        R = 4;
+        for (int r : {1, 2, 4})
+            if (total_waves(r) <= 2048) { R = r; break; }
+    }
     if (R == 0) {
         // the fewest modes per lane whose waves are all resident at once (16 waves per CU is what the
         // LDS tiles allow: 4096 on the chip) -- a second round of workgroups costs more than the
@@ -447,8 +462,10 @@ int Engine::finalize() {
         // wave shares its SIMD / CU with as few others as possible (measured: 8 x 4096 modes 425 -> 570 x
         // real time with 2-wave teams, 1 x 512 modes 778 -> 822 x with 1-wave teams): spread the waves
         // evenly over the 256 CUs.
-        int team_cap = (int)std::min<long long>(MAX_WAVES_PER_TEAM, std::max<long long>(1, (total_waves(R) + 255) / 256));
-        if (const char *v = std::getenv("PBSO_TEAM_WAVES")) team_cap = std::min(MAX_WAVES_PER_TEAM, std::max(1, std::atoi(v)));
+        const int team_max = block ? (R == 8 ? 4 : MAX_WAVES_PER_BLOCK_TEAM) : MAX_WAVES_PER_TEAM;
+        int team_cap = (int)std::min<long long>(team_max, std::max<long long>(1, (total_waves(R) + 255) / 256));
+        if (const char *v = std::getenv("PBSO_TEAM_WAVES")) team_cap = std::min(team_max, std::max(1, std::atoi(v)));
+        if (block && block_team_waves_ > 0) team_cap = block_team_waves_;
         std::vector<std::vector<TeamDesc>> by_w(MAX_WAVES_PER_TEAM + 1);
         std::vector<SplitObj> split;
         n_part_rows_ = 0;
@@ -509,7 +526,7 @@ int Engine::finalize() {
         nmodes[i] = o.n_modes;
         for (int m = 0; m < o.n_modes; ++m) {
             const size_t k = (size_t)i * m_pad_ + m;
-            if (desc_.recurrence_form == PBSO_FORM_VELOCITY) {
+            if (form_ != PBSO_FORM_DIRECT) {
                 ca[k] = (float)(-o.c2[m]);                     // eps^2
                 cb[k] = -(float)((1.0 - o.c1[m]) - o.c2[m]);   // -e, e = |1 - z|^2 = 1 - c1 - c2 (stored negated:
                                                                //  d = eps^2 d + (-e) q is then a plain v_fmac)
@@ -533,7 +550,7 @@ int Engine::finalize() {
     HIPTRY(hipMemset(d_sd_.p, 0, nm * sizeof(float)));
     HIPTRY(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(d_ss_.p), 0x3F800000, nm));      // scale 1.0f: state stored unscaled
     HIPTRY(hipMemcpy(d_c3_.p, c3.data(), nm * sizeof(double), hipMemcpyHostToDevice));
-    if (desc_.qnorm_mode == PBSO_QNORM_CLOSED) {
+    if (desc_.qnorm_mode == PBSO_QNORM_CLOSED || (block && desc_.qnorm_mode != PBSO_QNORM_OFF)) {
         // G = sum_{k=0}^{B-1} (A^k)' e1 e1' A^k per mode, in fp64, in the basis x = (q_k, q_k - q_{k-1})
         // (well conditioned at low frequency; the direct-form kernel forms the difference itself):
         // A = [[1-e, eps^2], [-e, eps^2]], e = 1 - c1 - c2, eps^2 = -c2.  Row r_k = e1' A^k: r_{k+1} = r_k A.
@@ -557,6 +574,39 @@ int Engine::finalize() {
         }
         HIPTRY(d_gq_.ensure(3 * nm));
         HIPTRY(hipMemcpy(d_gq_.p, gq.data(), 3 * nm * sizeof(float), hipMemcpyHostToDevice));
+    }
+
+    if (block) {
+        // Block form: per mode the one-sample matrix in the basis x = (q, q - q_prev) is
+        // A = [[1 - e, eps^2], [-e, eps^2]] (e = 1 - c1 - c2, eps^2 = -c2).  Row 0 of A^j, j = 1..16, gives the
+        // output weights (a_j, b_j); P = A^16 advances the state by one block.  All in fp64, rounded once.
+        // P11 is stored as P11 - 1 (q' = q + (P11 - 1) q + P12 d keeps the small angle of low modes).
+        std::vector<float> pc(4 * nm, 0.f), wt((size_t)nm / 2 * 64, 0.f);
+        for (int i = 0; i < N; ++i) {
+            const Object &o = objs_[i];
+            for (int m = 0; m < o.n_modes; ++m) {
+                const double eps2 = -o.c2[m], e = (1.0 - o.c1[m]) - o.c2[m];
+                const double a00 = 1.0 - e, a01 = eps2, a10 = -e, a11 = eps2;
+                double p00 = 1, p01 = 0, p10 = 0, p11 = 1;                 // A^j, starting from I
+                const size_t k = (size_t)i * m_pad_ + m;
+                float *w = wt.data() + (k / 2) * 64 + 16 * (2 * (k & 1));  // lane = 16 * (2 * mode-of-pair + comp) + (j - 1)
+                for (int j = 1; j <= BLOCK_J; ++j) {
+                    const double n00 = a00 * p00 + a01 * p10, n01 = a00 * p01 + a01 * p11;
+                    const double n10 = a10 * p00 + a11 * p10, n11 = a10 * p01 + a11 * p11;
+                    p00 = n00; p01 = n01; p10 = n10; p11 = n11;
+                    w[j - 1] = (float)p00;
+                    w[16 + j - 1] = (float)p01;
+                }
+                pc[k] = (float)(p00 - 1.0);
+                pc[nm + k] = (float)p01;
+                pc[2 * nm + k] = (float)p10;
+                pc[3 * nm + k] = (float)p11;
+            }
+        }
+        HIPTRY(d_pc_.ensure(4 * nm));
+        HIPTRY(hipMemcpy(d_pc_.p, pc.data(), 4 * nm * sizeof(float), hipMemcpyHostToDevice));
+        HIPTRY(d_wtab_.ensure(wt.size()));
+        HIPTRY(hipMemcpy(d_wtab_.p, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
     }
 
     // mode shapes: mode-major (ModeData.h:24) -> vertex-major [dof][m_pad]
@@ -1345,7 +1395,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.gq_plane = (long long)N * m_pad_;
     kp.census = nullptr;
     if (census_) {
-        HIPTRY(d_census_.ensure((size_t)n_teams_ * 6, false, sk));
+        HIPTRY(d_census_.ensure((size_t)n_teams_ * CENSUS_WORDS, false, sk));
         kp.census = d_census_.p;
     }
     kp.nb = nb; kp.n_tiles = n_tiles_; kp.m_pad = m_pad_; kp.b_pad = b_pad_;
@@ -1354,6 +1404,9 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.rotate_prio = (rotate_prio_ == 2 && total_team_waves_ < 3072) ? 1 : rotate_prio_;
     kp.board = d_board_.p;
     kp.launch_seq = ++launch_seq_;
+    kp.pc = d_pc_.p;
+    kp.wtab = d_wtab_.p;
+    kp.frames = B_;
     HIPTRY(hipEventRecord(evq.k0, sk));
     kp.audio_parts = n_part_rows_ ? d_audio_parts_.p + (size_t)b0 * B_ : nullptr;
     // Side by side only while everything is resident at once (largest teams first, on the engine's
@@ -1375,7 +1428,10 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
             }
         }
         kp.teams = d_teams_.p + c.first;
-        LAUNCHTRY(iir_scalar::launch_iir_bank(kp, c.count, R_, c.W, desc_.recurrence_form, desc_.qnorm_mode, s));
+        if (form_ == PBSO_FORM_BLOCK)
+            LAUNCHTRY(iir_block::launch_iir_block(kp, c.count, R_, c.W, desc_.qnorm_mode, s));
+        else
+            LAUNCHTRY(iir_scalar::launch_iir_bank(kp, c.count, R_, c.W, form_ == PBSO_FORM_DIRECT ? 1 : 0, desc_.qnorm_mode, s));
     }
     for (int j = 0; j < N_CLASS_STREAMS; ++j) {
         if (!used[j]) continue;
@@ -1411,7 +1467,7 @@ int Engine::read_audio(float *out, size_t n) {
 
 int Engine::read_census(unsigned long long *out, size_t n) {
     if (!census_ || !d_census_.p) return fail(PBSO_ERR_STATE, "census not enabled (PBSO_CENSUS=1) or no step yet");
-    if (n != (size_t)n_teams_ * 6) return fail(PBSO_ERR_INVALID, "read_census size mismatch (6 words per team)");
+    if (n != (size_t)n_teams_ * CENSUS_WORDS) return fail(PBSO_ERR_INVALID, "read_census size mismatch (12 words per team)");
     HIPTRY(hipMemcpyAsync(out, d_census_.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
     return sync();
 }
@@ -1444,7 +1500,7 @@ int Engine::read_state(int obj, double *q1, double *q2, int n) {
     for (int i = 0; i < n; ++i) {
         const double qa = (double)a[i] / (double)sc[i], qb = (double)b[i] / (double)sc[i];
         q1[i] = qa;
-        q2[i] = desc_.recurrence_form == PBSO_FORM_VELOCITY ? qa - qb : qb;
+        q2[i] = form_ != PBSO_FORM_DIRECT ? qa - qb : qb;
     }
     return PBSO_OK;
 }
@@ -1512,7 +1568,8 @@ int Engine::info(pbso_engine_info *out) {
     out->modes_per_lane = R_;
     out->waves_per_object = W_;
     out->n_teams = n_teams_;
-    out->lds_bytes_per_workgroup = finalized_ ? (int)iir_lds_bytes(W_, n_tiles_) : 0;
+    out->lds_bytes_per_workgroup = !finalized_ ? 0 : form_ == PBSO_FORM_BLOCK ? (int)block_lds_bytes(W_) : (int)iir_lds_bytes(W_, n_tiles_);
+    out->recurrence_form = form_;
     out->buffers_done = buffers_done_;
     out->last_step_host_plan_ms = last_plan_ms_;
     out->last_step_forced_rows = last_frows_;

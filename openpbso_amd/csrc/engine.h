@@ -229,6 +229,9 @@ private:
     int n_teams_ = 0, n_split_ = 0, n_part_rows_ = 0;
     long long total_team_waves_ = 0;
     DevBuf<float> d_gq_;                                 // closed-form qnorm: G11, 2 G12, G22 planes
+    DevBuf<float> d_pc_, d_wtab_;                        // block form: P = A^16 planes and the MFMA W table (kernels_block.hip)
+    int form_ = PBSO_FORM_BLOCK;                         // the form that runs (block falls back to velocity for odd buffer lengths)
+    int block_team_waves_ = 0;                           // PBSO_BLOCK_TEAM_WAVES: waves per team of the block form (0 = policy)
     DevBuf<double> d_shapes_;
     DevBuf<long long> d_shape_off_;
     DevBuf<int> d_n_modes_;

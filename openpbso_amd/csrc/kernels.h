@@ -15,6 +15,7 @@ constexpr int TILE = 27;
 // group on 16 distinct 4-bank slots (68 mod 64 = 4).
 constexpr int LDS_ROW = 68;
 constexpr int MAX_TILES = 32;          // tile mask is 32 bits
+constexpr int CENSUS_WORDS = 12;       // diagnostics row per workgroup (PBSO_CENSUS=1)
 
 // transfer-row codes in BufDesc::trow
 constexpr int XFER_KEEP = -1;          // keep _latest_transfer
@@ -64,12 +65,16 @@ struct IirParams {
     float *qnorm;                // [n_obj][nb][m_pad] or nullptr
     const float *gq;             // closed-form qnorm: planes G11, 2*G12, G22, each [n_obj][m_pad]; or nullptr
     long long gq_plane;          // elements per plane
-    unsigned long long *census;  // diagnostics: [n_teams][6] = start, end (100 MHz), HW_ID, XCC_ID, clk0, clk1; or nullptr
+    unsigned long long *census;  // diagnostics: [n_teams][CENSUS_WORDS] = start, end (100 MHz), HW_ID, XCC_ID, clk0, clk1, (block form) cycles in head / pipeline / barrier / combine; or nullptr
     int nb, n_tiles, m_pad, b_pad;
     long long audio_stride;
     int rotate_prio;             // 1: rotate s_setprio per tile (fair progress of resident teams); 2: + progress feedback per CU
     unsigned *board;             // [4096] per-CU progress words for rotate_prio == 2
     unsigned launch_seq;
+    // block state-space form (kernels_block.hip)
+    const float *pc;             // planes P11 - 1, P12, P21, P22 of P = A^16 in the (q, q - q_prev) basis, each [n_obj][m_pad] (stride gq_plane)
+    const float *wtab;           // [n_obj * m_pad / 2][64]: MFMA A operand per pair of columns (a_j, b_j of both modes, j = 1..16)
+    int frames;                  // samples per buffer
 };
 
 // launches the oscillator bank for n_teams teams of waves_per_team waves; returns hipError_t as int.
@@ -84,6 +89,19 @@ inline size_t iir_lds_bytes(int W, int n_tiles) {
     return sizeof(float) * (size_t)W * (TILE * LDS_ROW + (size_t)(n_tiles + 1) * TILE);
 }
 constexpr int MAX_WAVES_PER_TEAM = 16;     // 1024 threads; larger objects are cut into several teams
+
+// ---- K1b: block state-space form of the oscillator bank on the f32 matrix pipe (kernels_block.hip)
+constexpr int BLOCK_J = 16;                // samples per block = rows of v_mfma_f32_16x16x4_f32
+constexpr int BLOCK_N = 16;                // blocks per group = its columns; a buffer is 1 + n_groups * 256 samples
+constexpr int BLOCK_STAGE_FLOATS = 2080;   // per wave: block-start states of one slice, [16 blocks][64 lanes][Q, D] + 2 per row
+constexpr int BLOCK_RING_FLOATS = 516;     // per wave and buffer parity: the wave's partial sums of one buffer
+constexpr int MAX_WAVES_PER_BLOCK_TEAM = 8;
+inline size_t block_lds_bytes(int W) { return sizeof(float) * (size_t)W * (BLOCK_STAGE_FLOATS + 2 * BLOCK_RING_FLOATS); }
+namespace iir_block {
+// modes_per_lane in {1,2,4}; qnorm_mode 0 off, otherwise closed form (+ per-sample in literal buffers)
+int launch_iir_block(const IirParams &p, int n_teams, int modes_per_lane, int waves_per_team, int qnorm_mode,
+                     hipStream_t stream);
+}
 
 // ---- exact fp64 helper kernels (kernels_exact.hip, built with -ffp-contract=off)
 struct ProjectEvent {

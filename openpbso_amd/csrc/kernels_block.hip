@@ -1,0 +1,530 @@
+// K1b: damped-IIR oscillator bank in BLOCK STATE-SPACE form (gfx950, wave64, f32 MFMA).
+//
+// Replaces the same reference code as K1 (kernels_iir.hip): the hot loop of ModalSolver::step
+// (modal_solver.h:262-272) around ModalIntegrator::Step (modal_integrator.h:103-113).
+//
+// Idea.  A mode's recurrence q_k = c1 q_{k-1} + c2 q_{k-2} (+ force) is linear and, between
+// forces, autonomous.  With the state x = (q, d = q - q_prev) and A the one-sample matrix in that
+// basis, the J = 16 samples after a state x are e1' A^j x, j = 1..16 -- two products per mode and
+// sample with coefficients (a_j, b_j) that depend on the mode only -- and the state 16 samples
+// later is P x, P = A^16.  The reference's forces arrive at the first sample of an audio buffer
+// (modal_solver.h:184) and 513 = 1 + 2 * 16 * 16, so a buffer is
+//     sample 0      literal per-sample step (velocity form, exactly K1's arithmetic) incl. the impulse,
+//     2 groups of 16 blocks of 16 samples:
+//        VALU   the lane that owns a mode steps x <- P x sixteen times (4 FMA each) and parks the
+//               sixteen block-start states in LDS,
+//        MFMA   Y[16 samples][16 blocks] += W[16][4] . X[4][16]  per pair of modes
+//               (v_mfma_f32_16x16x4_f32: exact f32, a k-ordered fmaf chain; W = (a_j, b_j) of two
+//               modes, constant per object, resident in VGPRs for the whole launch).
+// The sum over modes -- the reference's q.dot(transfer), modal_solver.h:267-269 -- IS the
+// contraction index: with the scaled state (Q = transfer x q, see K1) no weights are left.
+// Per mode-sample this costs 4 flop on the matrix pipe and 0.25 VALU instead of K1's ~5 VALU
+// (the reference: 10 flop), and the rounding error is smaller than K1's (33 state updates per
+// buffer instead of 513; measured 5e-6 of peak against 5e-5, scripts/debug/block_numerics.py).
+//
+// Buffers with a dense force time profile (Gaussian, AR: forces.h:92-128) and waves whose
+// transfer weights are outside the scaled-state range step every sample literally (velocity form)
+// with a simple LDS row-sum reduction.
+//
+// qnorm (getQBufferNorm, modal_solver.h:270-273): closed form x0' G x0 of the state after sample 0
+// in block buffers (the per-sample state never exists here), per-sample accumulation in literal ones.
+//
+// Layout.  Team / column mapping as K1: workgroup = W waves, lane owns R modes, slice r at column
+// col0 + r * 64 W + tid.  MFMA k-step = two adjacent columns (pair): lane l holds
+//   A[j = l & 15][k = l >> 4]   = W-table entry: k = 2 * (mode of the pair) + (0: a_{j+1}, 1: b_{j+1})
+//   B[k = l >> 4][n = l & 15]   = state component k of block n, read back from the LDS staging area
+//   D[i = 4 (l >> 4) + v][n]    = output sample 16 n + i of the group, v = 0..3
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace pbso {
+namespace iir_block {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int BJ = BLOCK_J, BN = BLOCK_N;
+constexpr int GROUP = BJ * BN;                     // 256 samples
+// staging: [16 blocks][64 lanes][Q, D] (one ds_write_b64 per coarse step); the row stride of 130 floats
+// (= 2 mod 32) puts the 32 lanes of every ds_read_b32 lane group (2 components x 16 blocks) on 32 distinct banks
+constexpr int ST_ROW = 130;
+constexpr int LIT_ROW = 68;                        // literal path: [16 samples][64 lanes] tile, 16-B aligned rows
+constexpr int ST_FLOATS = BLOCK_STAGE_FLOATS;
+constexpr int RING = BLOCK_RING_FLOATS;            // per wave and parity: samples 1..512 at [0..511], sample 0 at [512]
+static_assert(BN * ST_ROW <= ST_FLOATS && BJ * LIT_ROW <= ST_FLOATS, "staging area");
+
+struct BlkDims {
+    int nb, m_pad, b_pad, frames, n_groups;
+    long long audio_stride;
+    long long plane;             // elements between the planes of p_gq / p_pc
+    int qn_nb, qn_b0;
+};
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// sum over the 64 lanes without LDS traffic: four DPP adds inside every row of 16, then the four row sums
+__device__ __forceinline__ float wave_sum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});     // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});     // row_mirror
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+template <int K0, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (N > 0) {
+        f(std::integral_constant<int, K0>{});
+        static_for<K0 + 1, N - 1>(f);
+    }
+}
+
+template <int R, int QNM, int MAXT>
+__global__ __launch_bounds__(MAXT) void iir_block_kernel(
+    const float *__restrict__ p_ca, const float *__restrict__ p_cb, float *__restrict__ p_sq,
+    float *__restrict__ p_sd, float *__restrict__ p_ss, const BufDesc *__restrict__ p_desc,
+    const float *__restrict__ p_grows, const float *__restrict__ p_tprof, const double *__restrict__ p_xfer_rows,
+    const int *__restrict__ p_xfer_init, float *__restrict__ p_audio, float *__restrict__ p_qnorm,
+    const float *__restrict__ p_gq, const float *__restrict__ p_pc, const float *__restrict__ p_wtab,
+    const TeamDesc *__restrict__ p_teams, float *__restrict__ p_audio_parts, unsigned long long *__restrict__ p_census,
+    const BlkDims p) {
+    constexpr bool QN = QNM != 0;
+    constexpr int NG = 2;                              // groups per buffer (513 = 1 + 2 * 256; checked at launch)
+    constexpr int U = NG * R;                          // slices per buffer: (group, r)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const TeamDesc team = p_teams[blockIdx.x];
+    const int obj = team.obj;
+    unsigned long long census_t0 = 0, census_c0 = 0;
+    if (p_census) {
+        census_t0 = __builtin_amdgcn_s_memrealtime();
+        census_c0 = __builtin_amdgcn_s_memtime();
+    }
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = blockDim.x >> 6;
+    const unsigned rowlen = blockDim.x;
+    const unsigned utid = threadIdx.x;
+    // uniform (SGPR) row bases + an UNSIGNED 32-bit lane offset: every access is saddr + voffset, no 64-bit
+    // address VGPRs per array and slice (they cost 16 R registers when the index is a signed int)
+    const size_t ubase = (size_t)obj * p.m_pad + team.col0;
+    const float *__restrict__ b_ca = p_ca + ubase;
+    const float *__restrict__ b_cb = p_cb + ubase;
+    const float *__restrict__ b_gq = p_gq + ubase;
+    float *__restrict__ b_qn = p_qnorm + ((size_t)obj * p.qn_nb + p.qn_b0) * p.m_pad + team.col0;
+    constexpr int WAVE_FLOATS = ST_FLOATS + 2 * RING;
+    float *stage = lds + wave * WAVE_FLOATS;
+    float *ring = stage + ST_FLOATS;                   // [2][RING]
+
+    // per-mode registers for the whole launch: scaled state, coarse step P - I / P, transfer weight
+    float q[R], d[R], e11[R], p12[R], p21[R], p22[R], t[R];
+    bool dead[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned k = r * rowlen + utid;
+        q[r] = (p_sq + ubase)[k];
+        d[r] = (p_sd + ubase)[k];
+        e11[r] = (p_pc + ubase)[k];
+        p12[r] = (p_pc + p.plane + ubase)[k];
+        p21[r] = (p_pc + 2 * p.plane + ubase)[k];
+        p22[r] = (p_pc + 3 * p.plane + ubase)[k];
+        dead[r] = b_ca[k] == 0.f && b_cb[k] == 0.f;
+    }
+    // W table: one VGPR per pair of columns, [pair][64 lanes]; this wave's slice r covers the pairs
+    // (team.col0 + r * rowlen + 64 * wave) / 2 + s, s = 0..31
+    float wreg[R][32];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float *__restrict__ wsrc = p_wtab + ((ubase + r * rowlen + 64 * wave) / 2) * 64;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) wreg[r][s] = wsrc[s * 64 + lane];
+    }
+
+    // ---- scaled state (as K1): registers hold Q = t q, D = t d while every weight of the wave is usable
+    bool scaled = false;
+    auto usable = [](float x) { return x >= 0x1p-20f && x <= 0x1p40f; };
+    auto rescale = [&](const float (&from)[R], const float (&tn)[R]) {
+        bool ok = true, same = true, unit = true;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            ok = ok && usable(tn[r]);
+            same = same && tn[r] == from[r];
+            unit = unit && from[r] == 1.f;
+        }
+        ok = __all(ok);
+        if (ok) {
+            if (!__all(same)) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float f = tn[r] / from[r];
+                    q[r] = q[r] * f;
+                    d[r] = d[r] * f;
+                }
+            }
+        } else if (!__all(unit)) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                q[r] = q[r] / from[r];
+                d[r] = d[r] / from[r];
+            }
+        }
+        scaled = ok;
+    };
+    {
+        const int row0 = p_xfer_init[obj];
+        float s0[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            s0[r] = (p_ss + ubase)[r * rowlen + utid];
+            const float tr = row0 >= 0 ? (float)(p_xfer_rows + (size_t)row0 * p.m_pad + team.col0)[r * rowlen + utid] : 1e7f;
+            t[r] = dead[r] ? 1.f : tr;
+        }
+        rescale(s0, t);
+    }
+
+    const BufDesc *__restrict__ dsc = p_desc + (size_t)obj * p.nb;
+    float *__restrict__ aout = team.part_row >= 0 ? p_audio_parts + (size_t)team.part_row * p.audio_stride
+                                                  : p_audio + (size_t)obj * p.audio_stride;
+    const int B = p.frames;
+
+    // B-operand read base: component k = lane >> 4 (k & 1: Q / D plane, k >> 1: which mode of the pair), block n = lane & 15
+    const float *bsrc = stage + (lane & 15) * ST_ROW + 2 * (lane >> 5) + ((lane >> 4) & 1);
+    f2 *wdst = reinterpret_cast<f2 *>(stage + 2 * lane);
+    // literal path: row sums of the [16][64] tile: lane -> row (lane & 15), quarter (lane >> 4)
+    const f4 *lsrc = reinterpret_cast<const f4 *>(stage + (lane & 15) * LIT_ROW + (lane >> 4) * 16);
+
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    // Inputs of a buffer that come from memory -- per-sample coefficients (sample 0 and literal buffers),
+    // qnorm matrices, the force gain row, the new transfer row -- are fetched while the previous buffer's
+    // last slice runs on the matrix pipe, so that a buffer never starts with a round trip to L2 / HBM.
+    float nca[R], ncb[R], ng11[R], ng12[R], ng22[R], ngr[R];
+    float ntr[R];
+    // (lane offsets used inside the buffer loop are laundered through an empty asm: otherwise LICM hoists one
+    //  64-bit address per array and slice out of the loop and keeps 16 R VGPRs alive for the whole kernel)
+    auto lane_off = [&]() {
+        unsigned v = utid;
+        asm volatile("" : "+v"(v));
+        return v;
+    };
+    auto prefetch = [&](const BufDesc &nd) {
+        const unsigned utid = lane_off();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const unsigned k = r * rowlen + utid;
+            nca[r] = b_ca[k];
+            ncb[r] = b_cb[k];
+            if (QN) {
+                ng11[r] = b_gq[k];
+                ng12[r] = (b_gq + p.plane)[k];
+                ng22[r] = (b_gq + 2 * p.plane)[k];
+            }
+        }
+        if (nd.frow >= 0) {
+            const float *__restrict__ gsrc = p_grows + (size_t)nd.frow * p.m_pad + team.col0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) ngr[r] = gsrc[r * rowlen + utid];
+        }
+        if (nd.trow >= 0) {
+            const double *__restrict__ tsrc = p_xfer_rows + (size_t)nd.trow * p.m_pad + team.col0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) ntr[r] = (float)tsrc[r * rowlen + utid];     // (fp64 rows: the FFAT kernel is bit-exact with the oracle)
+        }
+    };
+
+    // one coarse step of slice r: park the block-start state of block n, then x <- P x
+    auto coarse = [&](int r, int n) {
+        wdst[n * (ST_ROW / 2)] = f2{q[r], d[r]};
+        const float qa = fmaf(e11[r], q[r], q[r]);
+        const float da = p21[r] * q[r];
+        q[r] = fmaf(p12[r], d[r], qa);
+        d[r] = fmaf(p22[r], d[r], da);
+    };
+
+    // diagnostics (PBSO_CENSUS=1): where wave 0's shader cycles go
+    unsigned long long cy_head = 0, cy_pipe = 0, cy_bar = 0, cy_comb = 0, cy_mark = 0;
+    auto lap = [&](unsigned long long &acc) {
+        if (p_census) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            acc += now - cy_mark;
+            cy_mark = now;
+        }
+    };
+    BufDesc next = dsc[0];
+    prefetch(next);
+    if (p_census) cy_mark = __builtin_amdgcn_s_memtime();
+    for (int b = 0; b < p.nb; ++b) {
+        const BufDesc cur = next;
+        next = dsc[b + 1 < p.nb ? b + 1 : b];
+        const int frow = cur.frow;
+        const int prow = cur.prow;
+        const float amp = cur.amp;
+        const int trow = cur.trow;
+        const uint32_t flags = cur.flags;
+        float *rg = ring + (b & 1) * RING;
+
+        if (flags & DESC_SKIP) {
+            // the reference's step() returned before stepping: no samples, state untouched
+            for (int i = tid; i < B; i += blockDim.x) aout[(size_t)b * B + i] = 0.f;
+            if (QN) {
+                const unsigned utid = lane_off();
+#pragma unroll
+                for (int r = 0; r < R; ++r) (b_qn + (size_t)b * p.m_pad)[r * rowlen + utid] = 0.f;
+            }
+            prefetch(next);
+            continue;
+        }
+        if (trow != XFER_KEEP) {
+            float tn[R], from[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float tr = trow >= 0 ? ntr[r] : 1e7f;
+                tn[r] = dead[r] ? 1.f : tr;
+                from[r] = scaled ? t[r] : 1.f;
+            }
+            rescale(from, tn);
+#pragma unroll
+            for (int v = 0; v < R; ++v) t[v] = tn[v];
+        }
+        float g_[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) g_[r] = frow >= 0 ? (scaled ? ngr[r] * t[r] : ngr[r]) : 0.f;
+        const bool impulse = (flags & DESC_IMPULSE) != 0;
+        const bool dense = frow >= 0 && !impulse;
+
+        if (scaled && !dense) {
+            // ================= block path =================
+            // sample 0, literal: d_0 = eps^2 d - e q + g T_0 ; q_0 = q + d_0   (nca = eps^2, ncb = -e)
+            const bool hit0 = frow >= 0 && (cur.tile_mask & 1u);
+            float p0 = 0.f;
+#pragma unroll
+            for (int v = 0; v < R; ++v) {
+                float a = nca[v] * d[v];
+                a = fmaf(ncb[v], q[v], a);
+                if (hit0) a = fmaf(g_[v], amp, a);
+                d[v] = a;
+                q[v] = q[v] + a;
+                p0 = (v == 0) ? q[v] : p0 + q[v];
+            }
+            if (QN) {
+                // sum_{k=0}^{B-1} q_k^2 = x0' G x0, x0 = state after sample 0 (the rest of the buffer is force-free)
+                const unsigned utid = lane_off();
+#pragma unroll
+                for (int v = 0; v < R; ++v) {
+                    float e = ng22[v] * d[v] * d[v];
+                    e = fmaf(ng12[v] * q[v], d[v], e);
+                    e = fmaf(ng11[v] * q[v], q[v], e);
+                    // v_sqrt_f32 / v_rcp_f32 (1 ulp each): the closed form itself is good to ~1e-5 only
+                    const float nrm = __builtin_amdgcn_sqrtf(fmaxf(e, 0.f));     // (it can round a tiny sum below zero)
+                    (b_qn + (size_t)b * p.m_pad)[v * rowlen + utid] = nrm * __builtin_amdgcn_rcpf(t[v]);
+                }
+            }
+            p0 = wave_sum(p0);
+            if (lane == 0) rg[GROUP * NG] = p0;
+
+            // ---- software pipeline over the U = NG * R slices of the buffer.  Slice u's 32 MFMAs take their
+            // B operands from registers (breg); between them run the coarse steps of slice u + 1 (which overwrite
+            // the staging area: its reads for slice u were issued before) and then the operand reads of slice u + 1.
+            float breg[32];
+            lap(cy_head);
+            wave_sync();                               // the previous buffer's staging reads are issued
+#pragma unroll
+            for (int n = 0; n < BN; ++n) coarse(0, n);
+            wave_sync();
+#pragma unroll
+            for (int s = 0; s < 16; ++s) breg[s] = bsrc[4 * s];
+            f4 acc0, acc1;
+            static_for<0, U>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                constexpr int r = u % R, grp = u / R;
+                constexpr int rn = (u + 1) % R;        // the slice whose states are prepared meanwhile
+                constexpr bool more = u + 1 < U;
+                if constexpr (r == 0) {
+                    acc0 = f4{0.f, 0.f, 0.f, 0.f};
+                    acc1 = f4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int s = 16; s < 32; ++s) breg[s] = bsrc[4 * s];
+                wave_sync();
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, 16>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    if constexpr (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s], breg[s], acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s], breg[s], acc0, 0, 0, 0);
+                    if constexpr (more) coarse(rn, s);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                if constexpr (more) wave_sync();
+                // last slice: the first-half operand registers are free -- the next buffer's inputs land in them
+                if constexpr (!more) prefetch(next);
+                static_for<16, 16>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    if constexpr (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s], breg[s], acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s], breg[s], acc0, 0, 0, 0);
+                    if constexpr (more && s < 24) {
+                        breg[2 * (s - 16)] = bsrc[8 * (s - 16)];
+                        breg[2 * (s - 16) + 1] = bsrc[8 * (s - 16) + 4];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                if constexpr (r == R - 1) {
+                    const f4 acc = acc0 + acc1;
+                    const unsigned l = lane_off() & 63u;       // (recomputed: not worth two registers across the pipeline)
+                    *reinterpret_cast<f4 *>(rg + GROUP * grp + 16 * (l & 15u) + 4 * (l >> 4)) = acc;
+                }
+            });
+        } else {
+            // ================= literal path: every sample stepped (velocity form), as K1 =================
+            const float *__restrict__ tprow = p_tprof + (size_t)(prow >= 0 ? prow : 0) * p.b_pad;
+            float qn[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) qn[r] = 0.f;
+            auto step1 = [&](float tk, bool forced) {
+                float pp = 0.f;
+#pragma unroll
+                for (int v = 0; v < R; ++v) {
+                    float a = nca[v] * d[v];
+                    a = fmaf(ncb[v], q[v], a);
+                    if (forced) a = fmaf(g_[v], tk, a);
+                    d[v] = a;
+                    q[v] = q[v] + a;
+                    if (scaled) pp = (v == 0) ? q[v] : pp + q[v];
+                    else pp = (v == 0) ? t[v] * q[v] : fmaf(t[v], q[v], pp);
+                    if (QN) qn[v] = fmaf(q[v], q[v], qn[v]);
+                }
+                return pp;
+            };
+            {
+                const float tk0 = dense ? tprow[0] : ((frow >= 0 && (cur.tile_mask & 1u)) ? amp : 0.f);
+                float p0 = step1(tk0, frow >= 0);
+                p0 = wave_sum(p0);
+                if (lane == 0) rg[GROUP * NG] = p0;
+            }
+            for (int c = 0; c < NG * BN; ++c) {
+                wave_sync();                           // the previous chunk's row reads are issued
+#pragma unroll 4                                       // (fully unrolled this path, not the pipeline, sets the kernel's register peak)
+                for (int k = 0; k < BJ; ++k) {
+                    const float tk = dense ? tprow[1 + c * BJ + k] : 0.f;
+                    const float pp = step1(tk, dense);
+                    stage[k * LIT_ROW + lane] = pp;
+                }
+                wave_sync();
+                float rs = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f4 v = lsrc[j];
+                    rs += v.x;
+                    rs += v.y;
+                    rs += v.z;
+                    rs += v.w;
+                }
+                rs += __shfl_xor(rs, 16, 64);
+                rs += __shfl_xor(rs, 32, 64);
+                if (lane < BJ) rg[c * BJ + lane] = rs;
+            }
+            if (QN) {
+                const unsigned utid = lane_off();
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float nrm = sqrtf(qn[r]);
+                    (b_qn + (size_t)b * p.m_pad)[r * rowlen + utid] = scaled ? nrm / t[r] : nrm;
+                }
+            }
+            prefetch(next);                            // (not hidden here: literal buffers are the slow path anyway)
+        }
+
+        // ---- the team's waves add their rings and store the buffer; one barrier per buffer (the ring
+        //      alternates by buffer parity, so a wave can be one buffer ahead of the slowest reader)
+        lap(cy_pipe);
+        __syncthreads();
+        lap(cy_bar);
+        {
+            // thread j adds the waves' ring entries 4j .. 4j+3 (samples 4j+1 .. 4j+4); thread 0 also sample 0
+            const float *r0 = lds + ST_FLOATS + (b & 1) * RING;
+            float *__restrict__ ao = aout + (size_t)b * B;
+            for (int j = tid; j < GROUP * NG / 4; j += blockDim.x) {
+                f4 acc = *reinterpret_cast<const f4 *>(r0 + 4 * j);
+                for (int w = 1; w < W; ++w) acc += *reinterpret_cast<const f4 *>(r0 + w * WAVE_FLOATS + 4 * j);
+                ao[4 * j + 1] = acc.x;
+                ao[4 * j + 2] = acc.y;
+                ao[4 * j + 3] = acc.z;
+                ao[4 * j + 4] = acc.w;
+            }
+            if (tid == 0) {
+                float acc = r0[GROUP * NG];
+                for (int w = 1; w < W; ++w) acc += r0[w * WAVE_FLOATS + GROUP * NG];
+                ao[0] = acc;
+            }
+        }
+        lap(cy_comb);
+    }
+
+    if (p_census && tid == 0) {
+        // where and when this workgroup ran, and the shader clock it held (diagnostics, PBSO_CENSUS=1)
+        p_census[(size_t)team.id * CENSUS_WORDS + 0] = census_t0;
+        p_census[(size_t)team.id * CENSUS_WORDS + 1] = __builtin_amdgcn_s_memrealtime();
+        p_census[(size_t)team.id * CENSUS_WORDS + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        p_census[(size_t)team.id * CENSUS_WORDS + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+        p_census[(size_t)team.id * CENSUS_WORDS + 4] = census_c0;
+        p_census[(size_t)team.id * CENSUS_WORDS + 5] = __builtin_amdgcn_s_memtime();
+        p_census[(size_t)team.id * CENSUS_WORDS + 6] = cy_head;
+        p_census[(size_t)team.id * CENSUS_WORDS + 7] = cy_pipe;
+        p_census[(size_t)team.id * CENSUS_WORDS + 8] = cy_bar;
+        p_census[(size_t)team.id * CENSUS_WORDS + 9] = cy_comb;
+    }
+    const unsigned utid_end = lane_off();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned k = r * rowlen + utid_end;
+        (p_sq + ubase)[k] = q[r];
+        (p_sd + ubase)[k] = d[r];
+        (p_ss + ubase)[k] = scaled ? t[r] : 1.f;
+    }
+}
+
+template <int R, int QNM>
+static int launch_one(const IirParams &p, int n_teams, int W, hipStream_t stream) {
+    const size_t lds = block_lds_bytes(W);
+    // R = 8 is the one-wave-per-SIMD build (512 registers: the 256 W-table operands go to AGPRs): teams of <= 4 waves
+    constexpr int MAXT = R == 8 ? 256 : 64 * MAX_WAVES_PER_BLOCK_TEAM;
+    if (64 * W > MAXT) return (int)hipErrorInvalidValue;
+    auto kern = iir_block_kernel<R, QNM, MAXT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int frames = p.frames;
+    const BlkDims dims = {p.nb, p.m_pad, p.b_pad, frames, (frames - 1) / GROUP, p.audio_stride, p.gq_plane, p.qn_nb, p.qn_b0};
+    hipLaunchKernelGGL(kern, dim3(n_teams), dim3(64 * W), lds, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows,
+                       p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.census, dims);
+    return (int)hipGetLastError();
+}
+
+int launch_iir_block(const IirParams &p, int n_teams, int R, int W, int qnm, hipStream_t s) {
+    if (n_teams <= 0) return 0;
+    if (W < 1 || W > MAX_WAVES_PER_BLOCK_TEAM) return (int)hipErrorInvalidValue;
+    if (p.frames != 1 + 2 * GROUP) return (int)hipErrorInvalidValue;      // the ring holds two groups (513 samples)
+    const bool qn = qnm != 0;
+    switch (R) {
+    case 1: return qn ? launch_one<1, 2>(p, n_teams, W, s) : launch_one<1, 0>(p, n_teams, W, s);
+    case 2: return qn ? launch_one<2, 2>(p, n_teams, W, s) : launch_one<2, 0>(p, n_teams, W, s);
+    case 4: return qn ? launch_one<4, 2>(p, n_teams, W, s) : launch_one<4, 0>(p, n_teams, W, s);
+    case 8: return qn ? launch_one<8, 2>(p, n_teams, W, s) : launch_one<8, 0>(p, n_teams, W, s);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+}  // namespace iir_block
+}  // namespace pbso

@@ -466,12 +466,12 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     flush();
     if (p_census && tid == 0) {
         // where and when this workgroup ran (placement / residency diagnostics)
-        p_census[(size_t)team.id * 6 + 0] = census_t0;
-        p_census[(size_t)team.id * 6 + 1] = __builtin_amdgcn_s_memrealtime();
-        p_census[(size_t)team.id * 6 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
-        p_census[(size_t)team.id * 6 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
-        p_census[(size_t)team.id * 6 + 4] = census_c0;                                    // shader clock at start
-        p_census[(size_t)team.id * 6 + 5] = __builtin_amdgcn_s_memtime();                 // ... and at the end
+        p_census[(size_t)team.id * CENSUS_WORDS + 0] = census_t0;
+        p_census[(size_t)team.id * CENSUS_WORDS + 1] = __builtin_amdgcn_s_memrealtime();
+        p_census[(size_t)team.id * CENSUS_WORDS + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        p_census[(size_t)team.id * CENSUS_WORDS + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+        p_census[(size_t)team.id * CENSUS_WORDS + 4] = census_c0;                                    // shader clock at start
+        p_census[(size_t)team.id * CENSUS_WORDS + 5] = __builtin_amdgcn_s_memtime();                 // ... and at the end
     }
 
 #pragma unroll

@@ -8,6 +8,7 @@ computes audio.
 """
 import collections
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -84,8 +85,13 @@ class ForceMessage:
 
 
 class Engine:
-    def __init__(self, device=0, form=capi.FORM_VELOCITY, qnorm=capi.QNORM_ALL, modes_per_lane=0,
+    def __init__(self, device=0, form=None, qnorm=capi.QNORM_ALL, modes_per_lane=0,
                  stream=None, frames_per_buffer=0):
+        if form is None:
+            # PBSO_FORM=block|velocity|direct lets a whole test / bench run pick the oscillator-bank kernel
+            form = {"block": capi.FORM_BLOCK, "velocity": capi.FORM_VELOCITY,
+                    "direct": capi.FORM_DIRECT}[os.environ.get("PBSO_FORM", "block")]
+        self.form = form
         self._l = capi.lib()
         d = capi.EngineDesc()
         d.abi_version = capi.ABI_VERSION
@@ -280,11 +286,11 @@ class Engine:
         return q1[:n], q2[:n]
 
     def census(self):
-        """per-workgroup (start, end [100 MHz ticks], HW_ID, XCC_ID, clock start/end) of the last launch (PBSO_CENSUS=1)."""
-        n = self.info()["n_teams"] * 6
+        """per-workgroup (start, end [100 MHz ticks], HW_ID, XCC_ID, clock start/end, block form: cycles in head / pipeline / barrier / combine) of the last launch (PBSO_CENSUS=1)."""
+        n = self.info()["n_teams"] * 12
         out = np.empty(n, dtype=np.uint64)
         self._chk(self._l.pbso_read_census(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), n))
-        return out.reshape(-1, 6)
+        return out.reshape(-1, 12)
 
     def audio_device_ptr(self):
         return self._l.pbso_audio_device_ptr(self._h)

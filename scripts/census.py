@@ -14,7 +14,8 @@ n_obj = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 nb = 86
 rng = np.random.default_rng(0)
-eng = Engine(qnorm=capi.QNORM_ALL)
+R = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+eng = Engine(qnorm=capi.QNORM_ALL, modes_per_lane=R)
 for i in range(n_obj):
     eng.add_object(synth.eigenvalues(M, 100 + i), synth.RHO, synth.ALPHA, synth.BETA)
 eng.finalize()
@@ -71,3 +72,9 @@ for kk in set(key.tolist()):
 for r in sorted(set(rank_in_cu.tolist())):
     m = rank_in_cu == r
     print(f"  {r}-th team dispatched to its CU: duration median {np.median(dur[m]):.0f} us")
+
+if c.shape[1] >= 10 and c[:, 6:10].any():
+    tot = c[:, 6:10].astype(np.float64).sum(axis=1)
+    for name, k in (("head", 6), ("pipeline", 7), ("barrier", 8), ("combine", 9)):
+        v = c[:, k].astype(np.float64)
+        print(f"block form, wave 0 of each team: {name:9s} median {np.median(v):.3e} cycles ({np.median(v / tot) * 100:.1f} % of the loop), per buffer {np.median(v) / nb:.0f}")

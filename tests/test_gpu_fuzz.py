@@ -131,5 +131,8 @@ def test_random_scripts_random_engine_shapes(seed, monkeypatch):
     cap = int(rng.choice([0, 2, 16, 16]))            # 0: the engine's own choice (one wave per CU for engines this small)
     if cap:
         monkeypatch.setenv("PBSO_TEAM_WAVES", str(cap))
-    kw = dict(modes_per_lane=int(rng.choice([0, 1, 2, 3, 4, 8])), qnorm=int(rng.choice([capi.QNORM_ALL, capi.QNORM_CLOSED])))
+    # both oscillator-bank kernels: the block state-space form (K1b, the default) and the per-sample form (K1)
+    form = int(rng.choice([capi.FORM_BLOCK, capi.FORM_BLOCK, capi.FORM_VELOCITY]))
+    mpl = [0, 1, 2, 4, 8] if form == capi.FORM_BLOCK else [0, 1, 2, 3, 4, 8]
+    kw = dict(form=form, modes_per_lane=int(rng.choice(mpl)), qnorm=int(rng.choice([capi.QNORM_ALL, capi.QNORM_CLOSED])))
     _run_seed(seed + 100000, [5, 64, 200, 1100, 2100], kw, projected_hits=True)

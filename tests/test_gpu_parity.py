@@ -68,17 +68,20 @@ def test_config2_512_modes_poisson_train(mpl, rotate, monkeypatch):
     assert len(evs) > 5
     evs.append(dict(t=0, obj=0, kind="use_transfer", use=False))
     objs = [ObjSpec(lam, shapes=shapes)]
-    got = run_engine(objs, evs, NB, modes_per_lane=mpl)
+    kw = dict(form=capi.FORM_VELOCITY) if mpl == 3 else {}      # three modes per lane exist in the per-sample kernel only
+    got = run_engine(objs, evs, NB, modes_per_lane=mpl, **kw)
     want = run_oracle(objs, evs, NB)
     mx, l2 = _check(got, want)
     assert got["info"]["modes_per_lane"] == mpl
     print(f"C2 R={mpl} rotate={rotate} max/peak={mx:.2e} relL2={l2:.2e}")
 
 
+@pytest.mark.parametrize("form", [capi.FORM_BLOCK, capi.FORM_VELOCITY])
 @pytest.mark.parametrize("mpl", [4, 8])
-def test_config5_shape_large_objects(mpl, monkeypatch):
+def test_config5_shape_large_objects(mpl, form, monkeypatch):
     """configs[4] object size: 4096 modes per object -> teams of 16 / 8 waves
-    (the 1024-thread build of the kernel), Gaussian + point forces."""
+    (the 1024-thread build of the per-sample kernel; the block form caps a team at 8 waves, 4 with
+    eight modes per lane, and cuts the object into several teams), Gaussian + point forces."""
     n_modes, nb = 4096, 10
     objs, evs = [], []
     rng = np.random.default_rng(55)
@@ -90,11 +93,13 @@ def test_config5_shape_large_objects(mpl, monkeypatch):
         evs.append(dict(t=0, obj=i, kind="use_transfer", use=False))
     want = run_oracle(objs, evs, nb)
     monkeypatch.setenv("PBSO_TEAM_WAVES", "16")      # whole objects as teams (what a full chip runs)
-    got = run_engine(objs, evs, nb, modes_per_lane=mpl)
+    got = run_engine(objs, evs, nb, modes_per_lane=mpl, form=form)
     _check(got, want)
-    assert got["info"]["waves_per_object"] == 4096 // (64 * mpl) and got["info"]["n_teams"] == 2
+    waves = 4096 // (64 * mpl)
+    cap = 16 if form == capi.FORM_VELOCITY else (4 if mpl == 8 else 8)
+    assert got["info"]["waves_per_object"] == min(waves, cap) and got["info"]["n_teams"] == 2 * max(1, waves // cap)
     monkeypatch.delenv("PBSO_TEAM_WAVES")            # a nearly empty chip: one wave per CU
-    got = run_engine(objs, evs, nb, modes_per_lane=mpl)
+    got = run_engine(objs, evs, nb, modes_per_lane=mpl, form=form)
     _check(got, want)
     assert got["info"]["waves_per_object"] == 1 and got["info"]["n_teams"] == 2 * 4096 // (64 * mpl)
 
@@ -390,7 +395,8 @@ def test_objects_split_over_several_teams():
     want = run_oracle(objs, evs, nb)
     ref = None
     for mpl, split in ((0, None), (1, [3, 4]), (3, None), (4, None), (8, [1, 6])):
-        got = run_engine(objs, evs, nb, modes_per_lane=mpl, split=split)
+        kw = dict(form=capi.FORM_VELOCITY) if mpl == 3 else {}      # three modes per lane: per-sample kernel only
+        got = run_engine(objs, evs, nb, modes_per_lane=mpl, split=split, **kw)
         assert got["info"]["n_teams"] > 3 or mpl == 8
         _check(got, want)
         for i in range(3):
