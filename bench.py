@@ -2,23 +2,32 @@
 """bench.py -- headline benchmark of the MI355X modal sound engine.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Workload (BASELINE.json configs[3], at N=1 on ONE GPU): 1024 objects x 512
-modes, a random impulse stream per object (Poisson, ~20 PointForce hits/s,
-vertex hits projected onto the mode shapes on the device), 86 buffers x 513
-samples (~1 s of audio) per step.  Weak scaling: every rank owns 1024 objects
-(objects are independent -- no data-path collective); with --gather the
-finished audio buffers of all ranks are all-gathered over RCCL inside the
-timed region, as a consumer of the whole mix would need.
+N > 1: one rank per GPU over torch.distributed (backend nccl = RCCL).  Either the driver launches the
+ranks (torch.distributed.run sets WORLD_SIZE) or this script starts them itself: with --gpus N > 1 and
+no WORLD_SIZE in the environment the parent process -- before it has touched the GPU in any way --
+runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child and exits with its
+code.  PBSO_BENCH_BACKEND=gloo lets several ranks share one GPU (smoke test of the N > 1 path on a
+1-GPU box; RCCL refuses two ranks on one device).
 
-One "step" = one pbso_step(86): host bookkeeping of ModalSolver::step for every
-(object, buffer), upload of the plan, projection, force combination, and the
-oscillator-bank kernel.  Prints ONE JSON line on rank 0.
+Workload (BASELINE.json configs[3]; at N = 1 all of it on ONE GPU): 1024 objects x 512 modes, a random
+impulse stream per object (Poisson, ~20 PointForce hits/s, vertex hits projected onto the mode shapes on
+the device), 86 buffers x 513 samples (~1 s of audio) per step.  Objects are independent, so they shard
+across ranks with no data-path collective; the finished audio buffers of all ranks are all-gathered over
+RCCL inside the timed region (--no-gather leaves that out).  The headline line is WEAK scaling (1024
+objects per GPU); for N > 1 the same run also measures the configuration as written (1024 objects split
+over the N ranks, balanced by the sum of modes) and reports it under "strong".
+
+One "step" = one pbso_step(86): host bookkeeping of ModalSolver::step for every (object, buffer), upload
+of the plan, projection, force combination, and the oscillator-bank kernel.  After the clock has stopped,
+8 objects of the first timed step are checked against the fp64 oracle (the run's own output, not a
+replay).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,24 +39,29 @@ sys.path.insert(0, ROOT)
 B = 513
 SAMPLE_RATE = 44100
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak (= fp32 MFMA dense peak), same guide
-FLOP_PER_MODE_SAMPLE = 10      # reference arithmetic incl. qnorm
+F32_PEAK_TFLOPS = 157.3        # fp32 vector peak = dense fp32 MFMA peak (same guide; 64 FLOP/clk/SIMD either way)
+FLOP_REF = 10                  # reference arithmetic per mode-sample incl. qnorm
+# what the block form executes per mode-sample: 2 MFMA products (a_j Q + b_j D = 4 flop) + the coarse
+# recurrence (4 FMA per mode per 16 samples = 0.5 flop); the per-sample form executes what the counters say
+FLOP_BLOCK = 4.5
+TOL_MAX, TOL_L2 = 5e-4, 1e-3   # stated fp32 tolerance vs the fp64 oracle
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--settle", type=int, default=30,
                     help="untimed steps run before the warm-up so that the shader clock has ramped (the first ~70 ms "
                          "after idle run 10 %% slower, profiles/r01_clock_ramp.txt); reported as settle_steps")
-    ap.add_argument("--objects", type=int, default=1024, help="objects per GPU")
+    ap.add_argument("--objects", type=int, default=1024, help="objects per GPU (weak scaling); the total for the strong leg")
     ap.add_argument("--modes", type=int, default=512)
     ap.add_argument("--buffers", type=int, default=86, help="audio buffers per step")
-    ap.add_argument("--form", choices=["block", "velocity", "direct"], default="block")
+    ap.add_argument("--form", choices=["block", "velocity", "direct"], default="block",
+                    help="block: state-space blocks on the f32 matrix pipe (K1b); velocity / direct: per-sample kernel (K1)")
     ap.add_argument("--qnorm", choices=["sample", "closed", "off"], default="sample",
-                    help="getQBufferNorm: per-sample accumulation (reference loop), closed form, or off")
+                    help="getQBufferNorm rows: on (the block form evaluates them in closed form), closed form, or off")
     ap.add_argument("--no-qnorm", action="store_true", help="same as --qnorm off")
     ap.add_argument("--modes-per-lane", type=int, default=0)
     ap.add_argument("--scenario", choices=["impulses", "scraping", "listener"], default="impulses",
@@ -55,58 +69,94 @@ def parse():
                          "AutoregressiveForce with one face hit per buffer (configs[4]); listener: impulses + FFAT maps "
                          "and a new listener position every buffer (configs[2])")
     ap.add_argument("--strong", action="store_true",
-                    help="strong scaling: --objects is the TOTAL, split evenly over the ranks (BASELINE configs[3] as written: "
-                         "1024 objects over 8 GPUs); default is weak scaling, --objects per GPU")
-    ap.add_argument("--gather", action="store_true", help="all-gather audio over RCCL inside the timed region")
+                    help="make the strong-scaling leg the headline: --objects is the TOTAL, split over the ranks")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the nested strong-scaling measurement")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the RCCL audio all-gather out of the timed region")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the first timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-objects", type=int, default=0, help="objects in the CPU baseline sample (0 = auto)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def build_inputs(args, rank):
-    """Deterministic per-rank inputs: eigenvalues, mode shapes, hit script."""
+# ----------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves, BEFORE anything in this process touches the GPU
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def rank_launch_command(n, argv):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + list(argv)
+
+
+def spawn_ranks(n, argv):
+    """Runs the N ranks as a child job and returns its exit code (the JSON line is rank 0's stdout)."""
+    env = dict(os.environ)
+    env["PBSO_BENCH_SPAWNED"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(rank_launch_command(n, argv), env=env).returncode
+
+
+# ----------------------------------------------------------------------------------------------------
+def build_inputs(args, global_ids, total_buffers):
+    """Deterministic inputs per GLOBAL object id: eigenvalues, mode shapes, hit script."""
     from openpbso_amd import synth
-    n_obj, M = args.objects, args.modes
-    total_buffers = (args.steps + args.warmup + args.settle) * args.buffers
-    lam = np.empty((n_obj, M))
-    shapes = []
-    scripts = []
-    for i in range(n_obj):
-        seed = synth.seed_for(4, rank * n_obj + i)
+    M = args.modes
+    lam = np.empty((len(global_ids), M))
+    shapes, scripts = [], []
+    for i, gid in enumerate(global_ids):
+        seed = synth.seed_for(4, gid)
         lam[i] = synth.eigenvalues(M, seed)
         shapes.append(synth.mode_shapes(M, seed))
-        hits = synth.poisson_hits(total_buffers, seed)
-        vns = synth.unit_normals(total_buffers, seed)
-        scripts.append((hits, vns))
+        scripts.append((synth.poisson_hits(total_buffers, seed), synth.unit_normals(total_buffers, seed)))
     return lam, shapes, scripts
 
 
-def measured_traffic(args):
-    """HBM bytes per launch from the PMC passes kept under profiles/ (same config only)."""
+def measured_traffic(args, objects):
+    """HBM bytes per launch from the PMC passes kept under profiles/ (same configuration only)."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name)))
+            c = t["config"]
+            qn = "off" if args.no_qnorm else args.qnorm
+            if (c["objects_per_gpu"], c["modes"], c["buffers_per_step"], c["qnorm"], c["form"]) == (
+                    objects, args.modes, args.buffers, qn, args.form):
+                return t["traffic_bytes_per_launch"], name
+        except Exception:
+            pass
+    return None, None
+
+
+def host_cores():
+    """threads this process may run on: the affinity mask, capped by a cgroup CPU quota if there is one"""
+    n = len(os.sched_getaffinity(0))
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        c = t["config"]
-        qn = "off" if args.no_qnorm else args.qnorm
-        if (c["objects_per_gpu"], c["modes"], c["buffers_per_step"], c["qnorm"], c["form"]) == (
-                args.objects, args.modes, args.buffers, qn, args.form):
-            return t["traffic_bytes_per_launch"]
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
     except Exception:
         pass
-    return None
+    return n
 
 
 def cpu_baseline(args, lam, shapes, scripts):
-    """The fp64 oracle (a port: the reference itself cannot be built here) timed on
-    this box's host cores on a bounded sample of the same workload."""
+    """The fp64 oracle (a port: the reference itself cannot be built here) timed on this box's host cores on a
+    bounded sample of the same workload: every thread builds and steps its own objects (first touch), one
+    warm-up run, median of five; the parallel efficiency against one object on one thread is reported."""
     from oracle import oracle_py as orc
     from openpbso_amd import synth
-    ncores = os.cpu_count() or 1
+    ncores = host_cores()
     try:
         lib = orc.lib(native=True)
     except Exception:
         lib = orc.lib()
-    n_obj = args.cpu_objects or min(args.objects, max(ncores, 8) * 2)
     nb, M = args.buffers, args.modes
+    # sample size: about 15 s of single-thread work (one object-second costs ~15-40 ms), at least two objects per thread
+    n_obj = args.cpu_objects or min(len(shapes), max(2 * ncores, 512))
     om = np.ascontiguousarray(lam[:n_obj])
     hit_data = np.zeros((n_obj, M))
     mask = np.zeros((n_obj, nb), dtype=np.uint8)
@@ -117,87 +167,94 @@ def cpu_baseline(args, lam, shapes, scripts):
         # one spatial vector per object (the CPU leg times stepping, not projection)
         hit_data[i] = orc.modal_force_vertex(shapes[i], max(int(hits[first]), 0), vns[first])
     dp = orc._dp
-    secs = lib.or_bench_run(n_obj, M, nb, ncores, dp(om), synth.RHO, synth.ALPHA, synth.BETA,
-                            dp(hit_data), mask.tobytes(), None, 0)
-    secs_ftz = lib.or_bench_run(n_obj, M, nb, ncores, dp(om), synth.RHO, synth.ALPHA, synth.BETA,
-                                dp(hit_data), mask.tobytes(), None, 1)
-    one = lib.or_bench_run(1, M, nb, 1, dp(om), synth.RHO, synth.ALPHA, synth.BETA,
-                           dp(hit_data), mask.tobytes(), None, 0)
+
+    def run(n, threads, ftz):
+        return lib.or_bench_run(n, M, nb, threads, dp(om), synth.RHO, synth.ALPHA, synth.BETA,
+                                dp(hit_data), mask.tobytes(), None, ftz)
+
+    def median_of(n, threads, ftz, reps=5):
+        run(n, threads, ftz)                       # warm-up: thread pool, page faults, clocks
+        return float(np.median([run(n, threads, ftz) for _ in range(reps)]))
+
+    one = median_of(1, 1, 0, reps=3)
+    secs = median_of(n_obj, ncores, 0)
+    secs_ftz = median_of(n_obj, ncores, 1, reps=3)
     samples = n_obj * nb * B
+    eff = (n_obj * one / min(ncores, n_obj)) / secs
     return {
         "value": samples / secs, "unit": "audio samples/s", "cores": ncores, "kind": "port",
         "realtime_x": (nb * B / SAMPLE_RATE) / secs,
         "value_flush_denormals": samples / secs_ftz,
         "single_thread_one_object": {"value": nb * B / one, "realtime_x": (nb * B / SAMPLE_RATE) / one},
-        "sample": f"{n_obj} objects x {M} modes x {nb} buffers (same generator/seeds as the GPU run), "
-                  f"fp64 oracle (reference-literal loop incl. qnorm), OpenMP over objects on {ncores} threads: "
-                  f"{secs:.2f} s with the default FP environment, {secs_ftz:.2f} s with FTZ/DAZ; "
-                  f"one object on one thread (the reference's threading model): {one:.3f} s",
+        "parallel_efficiency": eff, "suspect": bool(eff < 0.5),
+        "sample": f"{n_obj} objects x {M} modes x {nb} buffers (same generator/seeds as the GPU run; {n_obj * one:.1f} s of "
+                  f"single-thread work), fp64 oracle (reference-literal loop incl. qnorm), OpenMP static shares over {ncores} "
+                  f"threads (sched_getaffinity), every thread builds its own solvers; one warm-up + median of 5: {secs:.3f} s "
+                  f"with the default FP environment, {secs_ftz:.3f} s with FTZ/DAZ; one object on one thread (the reference's "
+                  f"threading model): {one:.3f} s; parallel efficiency {eff:.2f} (hardware threads, not cores, are counted)",
     }
 
 
-def main():
-    args = parse()
+def oracle_rows(args, lam, shapes, scripts, rows, n_steps):
+    """fp64 oracle audio of step n_steps - 1 (0-based) for the local objects `rows`, stepped from the start."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle_py as orc
+    from openpbso_amd import synth
+    nb = args.buffers
+
+    def one(i):
+        s = orc.Solver(lam[i], synth.RHO, synth.ALPHA, synth.BETA)
+        s.set_use_transfer(False)
+        hits, vns = scripts[i]
+        out = None
+        for k in range(n_steps):
+            bufs = []
+            for b in range(k * nb, (k + 1) * nb):
+                if hits[b] >= 0:
+                    s.enqueue_force(orc.modal_force_vertex(shapes[i], int(hits[b]), vns[b]))
+                snd = s.step()[0]
+                if k == n_steps - 1:
+                    bufs.append(snd.copy())
+            out = bufs
+        return np.concatenate(out)
+
+    with ThreadPoolExecutor(max_workers=min(len(rows), max(1, host_cores()))) as ex:
+        return np.array(list(ex.map(one, rows)))
+
+
+# ----------------------------------------------------------------------------------------------------
+def measure(args, ctx, global_ids, want_parity):
+    """One engine, settle + warm-up + K timed steps.  Returns the rank-local numbers (elapsed is the max over ranks)."""
     import torch
     import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
-    # one rank per GPU; PBSO_BENCH_BACKEND=gloo lets several ranks share one GPU (smoke test of the
-    # multi-rank path on a 1-GPU box: RCCL refuses two ranks on one device)
-    backend = os.environ.get("PBSO_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ      # under torch.distributed.run even for one rank
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-    if args.strong:
-        if args.objects % world:
-            raise SystemExit("--strong needs --objects divisible by the number of ranks")
-        args.objects //= world
-    if args.gpus != world and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    coll_dev = dev if backend == "nccl" else torch.device("cpu")
-
     from openpbso_amd import Engine, ForceMessage, capi, synth
     from openpbso_amd.distributed import gather_audio
 
-    lam, shapes, scripts = build_inputs(args, rank)
-    # a real (non-null) stream: handle 0 would make the engine create its own, and the RCCL gather
-    # orders itself after the CURRENT torch stream
-    run_stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(run_stream)
-    stream = run_stream.cuda_stream
-    eng = Engine(device=dev_index,
+    dev, world, rank, backend = ctx["dev"], ctx["world"], ctx["rank"], ctx["backend"]
+    n_obj = len(global_ids)
+    n_steps_all = args.settle + args.warmup + args.steps
+    total_buffers = n_steps_all * args.buffers
+    lam, shapes, scripts = build_inputs(args, global_ids, total_buffers)
+    stream = ctx["stream"].cuda_stream
+    eng = Engine(device=ctx["dev_index"],
                  form={"block": capi.FORM_BLOCK, "velocity": capi.FORM_VELOCITY, "direct": capi.FORM_DIRECT}[args.form],
                  qnorm={"sample": capi.QNORM_ALL, "closed": capi.QNORM_CLOSED, "off": capi.QNORM_OFF}[
                      "off" if args.no_qnorm else args.qnorm],
                  modes_per_lane=args.modes_per_lane, stream=stream)
-    for i in range(args.objects):
+    for i, gid in enumerate(global_ids):
         eng.add_object(lam[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
         if args.scenario == "listener":
-            eng.set_ffat_maps(i, synth.ffat_maps(lam[i], synth.seed_for(3, rank * args.objects + i)))
+            eng.set_ffat_maps(i, synth.ffat_maps(lam[i], synth.seed_for(3, gid)))
     eng.finalize()
     n_hits = 0
     feed_obj, feed_vid, feed_vn, feed_t, feed_bary = [], [], [], [], []
-    n_steps_all = args.settle + args.warmup + args.steps      # the clock-settle steps run the same script
-    total_buffers = n_steps_all * args.buffers
-    off = 0
-    for i in range(args.objects):
+    for i, gid in enumerate(global_ids):
         hits, vns = scripts[i]
         if args.scenario == "scraping":
             # tools/...:754-776 + :1127-1160: dummy start message, then one GetModalForceFace per frame
             eng.set_use_transfer(i, False)
-            rng = np.random.default_rng(synth.seed_for(5, rank * args.objects + i))
-            assert eng.enqueue_force(i, ForceMessage(forceType=capi.AUTOREGRESSIVE_FORCE, sustainedForceStart=True), off)
+            rng = np.random.default_rng(synth.seed_for(5, gid))
+            assert eng.enqueue_force(i, ForceMessage(forceType=capi.AUTOREGRESSIVE_FORCE, sustainedForceStart=True), 0)
             bary = rng.random((total_buffers, 3))
             fids = rng.integers(0, synth.N_VERTS, (total_buffers, 3))
             feed_obj.append(np.full(total_buffers - 1, i, dtype=np.int32))
@@ -210,7 +267,7 @@ def main():
         if args.scenario == "listener":
             path = synth.listener_path(total_buffers) * (1.0 + 0.001 * i)
             for b in range(total_buffers):
-                eng.compute_transfer(i, path[b], off + int(b))
+                eng.compute_transfer(i, path[b], int(b))
         else:
             eng.set_use_transfer(i, False)             # no FFAT maps in this config: unit transfer
         hb = np.nonzero(hits >= 0)[0]
@@ -234,25 +291,31 @@ def main():
         bounds = np.searchsorted(step_of, np.arange(n_steps_all + 1))
         for k in range(n_steps_all):
             a, b = bounds[k], bounds[k + 1]
-            feeds[k] = eng.hit_messages(fo[a:b], fv[a:b], fn[a:b], ft[a:b] + off, coords=None if fb is None else fb[a:b],
+            feeds[k] = eng.hit_messages(fo[a:b], fv[a:b], fn[a:b], ft[a:b], coords=None if fb is None else fb[a:b],
                                         force_type=capi.AUTOREGRESSIVE_FORCE if args.scenario == "scraping" else capi.POINT_FORCE)
 
     nb = args.buffers
-    # --gather: the finished buffers of all ranks are all-gathered over RCCL.  Audio and
-    # gather targets are double-buffered and the collective is asynchronous on RCCL's own stream, so the
-    # gather of step k runs beside the oscillator bank of step k+1; it is waited for only when its
-    # buffers are reused (and before the clock stops).
-    do_gather = args.gather and use_dist
+    # Gather: the finished buffers of all ranks are all-gathered over RCCL.  Audio and gather
+    # targets are double-buffered and the collective is asynchronous on RCCL's own stream, so the gather of
+    # step k runs beside the oscillator bank of step k+1; it is waited for only when its buffers are reused
+    # (and before the clock stops).  Ragged shards (strong leg) are padded to the largest one.
+    do_gather = ctx["use_dist"] and world > 1 and not args.no_gather
+    counts = ctx.get("counts")                       # objects per rank in this leg
+    cmax = max(counts) if counts else n_obj
     n_buf = 2 if do_gather else 1
-    audios = [torch.empty((args.objects, nb * B), dtype=torch.float32, device=dev) for _ in range(n_buf)]
-    audio = audios[0]
-    gathered = [torch.empty((world * args.objects, nb * B), dtype=torch.float32, device=dev) for _ in range(n_buf)] if do_gather else None
+    audios = [torch.zeros((cmax, nb * B), dtype=torch.float32, device=dev) for _ in range(n_buf)]
+    gathered = [torch.empty((world * cmax, nb * B), dtype=torch.float32, device=dev) for _ in range(n_buf)] if do_gather else None
     pending = [None] * n_buf
     enqueue_s = [0.0]
     n_calls = [0]
+    # parity: 8 rows of the FIRST TIMED step are copied aside on the engine's stream (1.4 MB device to device)
+    prng = np.random.default_rng(0x9B50)
+    rows = sorted(set([0, n_obj - 1] + prng.integers(0, n_obj, 6).tolist())) if n_obj > 1 else [0]
+    rows_t = torch.tensor(rows, dtype=torch.long, device=dev)
+    captured = [None]
 
-    def one_step(k=-1):
-        if k >= 0 and feeds[k] is not None:
+    def one_step(k, capture=False):
+        if feeds[k] is not None:
             te = time.perf_counter()
             taken = eng.enqueue_force_batch(*feeds[k])
             enqueue_s[0] += time.perf_counter() - te
@@ -263,6 +326,8 @@ def main():
             pending[slot].wait()
             pending[slot] = None
         eng.step(nb, into=audios[slot].data_ptr())
+        if capture:
+            captured[0] = audios[slot].index_select(0, rows_t)
         if do_gather:
             if backend == "nccl":
                 pending[slot] = dist.all_gather_into_tensor(gathered[slot], audios[slot], async_op=True)
@@ -276,89 +341,217 @@ def main():
                 pending[i] = None
 
     for k in range(args.settle + args.warmup):
-        one_step(k)
+        one_step(k, capture=(k == 0 and want_parity))     # (loads the copy kernel's code object outside the timed region)
     drain()
     torch.cuda.synchronize()
     info0 = eng.info()
-    if use_dist:
+    if ctx["use_dist"]:
         dist.barrier()
     torch.cuda.synchronize()
     enqueue_s[0] = 0.0
     t0 = time.perf_counter()
     for k in range(args.steps):
-        one_step(args.settle + args.warmup + k)
+        one_step(args.settle + args.warmup + k, capture=(k == 0 and want_parity))
     drain()
     torch.cuda.synchronize()
-    if use_dist:
+    if ctx["use_dist"]:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    if ctx["use_dist"]:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx["coll_dev"])
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     info1 = eng.info()
     assert all(torch.isfinite(a).all() for a in audios)
     if do_gather and backend == "nccl":
         last = (n_calls[0] - 1) % n_buf
-        assert torch.equal(gathered[last][rank * args.objects:(rank + 1) * args.objects], audios[last])
+        assert torch.equal(gathered[last][rank * cmax:rank * cmax + n_obj], audios[last][:n_obj])
+
+    res = {
+        "elapsed": elapsed, "n_local": n_obj, "n_hits": n_hits, "gather": bool(do_gather),
+        "kernel_ms": (info1["total_kernel_ms"] - info0["total_kernel_ms"]) / args.steps,
+        "device_ms": (info1["total_device_ms"] - info0["total_device_ms"]) / args.steps,
+        "plan_ms": (info1["total_host_plan_ms"] - info0["total_host_plan_ms"]) / args.steps,
+        "enqueue_ms": enqueue_s[0] / args.steps * 1e3, "info": info1, "form_run": info1.get("recurrence_form"),
+    }
+    if want_parity and args.scenario == "impulses":
+        tp = time.perf_counter()
+        got = captured[0].cpu().numpy().astype(np.float64)
+        want = oracle_rows(args, lam, shapes, scripts, rows, args.settle + args.warmup + 1)
+        peak = np.abs(want).max(axis=1)
+        mx = np.abs(got - want).max(axis=1) / peak
+        l2 = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
+        res["parity"] = {
+            "parity_checked_objects": len(rows), "objects": [int(global_ids[r]) for r in rows],
+            "step": "first timed step (buffers %d..%d of the run), this run's own output" % (
+                (args.settle + args.warmup) * nb, (args.settle + args.warmup + 1) * nb - 1),
+            "max_err": float(mx.max()), "rel_l2": float(l2.max()), "tol_max": TOL_MAX, "tol_l2": TOL_L2,
+            "oracle": "oracle/pbso_oracle.c (fp64 restatement), stepped from buffer 0", "seconds": time.perf_counter() - tp,
+            "pass": bool((mx <= TOL_MAX).all() and (l2 <= TOL_L2).all()),
+        }
+    res["_cpu_inputs"] = (lam, shapes, scripts)
+    eng.close()
+    return res
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # nothing above this line has initialised HIP (torch is not even imported yet)
+        sys.exit(spawn_ranks(args.gpus, argv))
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or leave WORLD_SIZE unset "
+                         f"and let bench.py start the ranks)")
+    # one rank per GPU; PBSO_BENCH_BACKEND=gloo lets several ranks share one GPU
+    backend = os.environ.get("PBSO_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ      # under torch.distributed.run even for one rank
+    rccl_ranks = None
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # (gloo prints its connection report on fd 1: keep stdout for the ONE JSON line)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+            one = torch.ones(1, dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(one)                      # the first collective: proves every rank is in the group
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
+        rccl_ranks = int(round(float(one.item())))
+        assert rccl_ranks == dist.get_world_size() == world
+    # a real (non-null) stream: handle 0 would make the engine create its own, and the RCCL gather
+    # orders itself after the CURRENT torch stream
+    run_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(run_stream)
+    ctx = dict(dev=dev, dev_index=dev_index, world=world, rank=rank, backend=backend, use_dist=use_dist,
+               coll_dev=coll_dev, stream=run_stream)
+
+    from openpbso_amd.distributed import shard_by_modes
+    # weak: every rank owns --objects objects (global ids rank * objects ...); strong: --objects in total,
+    # contiguous blocks balanced by the sum of modes
+    weak_ids = list(range(rank * args.objects, (rank + 1) * args.objects))
+    spans = [shard_by_modes([args.modes] * args.objects, world, r) for r in range(world)]
+    strong_ids = list(range(*spans[rank]))
+    order = ["strong", "weak"] if args.strong else ["weak", "strong"]
+    if world == 1:
+        order = ["weak"]                               # one rank: the two legs are the same run
+    elif args.no_strong:
+        order = order[:1]
+    legs = {}
+    for leg in order:
+        ids = weak_ids if leg == "weak" else strong_ids
+        ctx["counts"] = [args.objects] * world if leg == "weak" else [hi - lo for lo, hi in spans]
+        legs[leg] = measure(args, ctx, ids, want_parity=(not args.no_parity and leg == order[0] and rank == 0))
+    head = order[0]
+    m = legs[head]
 
     if rank == 0:
-        total_obj = world * args.objects
-        samples = total_obj * nb * B * args.steps
-        value = samples / elapsed
-        rt = (nb * B * args.steps / SAMPLE_RATE) / elapsed
-        # roofline of the dominant kernel (iir_bank): HIP events on the launch stream, this rank
-        k_ms = (info1["total_kernel_ms"] - info0["total_kernel_ms"]) / args.steps
-        d_ms = (info1["total_device_ms"] - info0["total_device_ms"]) / args.steps
-        plan_ms = (info1["total_host_plan_ms"] - info0["total_host_plan_ms"]) / args.steps
-        M = args.modes
-        mode_samples = args.objects * M * nb * B
-        flops = FLOP_PER_MODE_SAMPLE * mode_samples
-        # algorithmic bytes of one launch (SURVEY 8(d) formula with NB_l = nb; M = modes per object)
-        bytes_alg = args.objects * (M * (12 + 8 + 8 + (4 + 4 + 4) * nb) + nb * B * (4 + 4))
-        tf = flops / (k_ms * 1e-3) * 1e-12
+        nb, M = args.buffers, args.modes
+
+        def leg_numbers(leg, r):
+            total_obj = world * args.objects if leg == "weak" else args.objects
+            samples = total_obj * nb * B * args.steps
+            return {"value": samples / r["elapsed"], "realtime_x": (nb * B * args.steps / SAMPLE_RATE) / r["elapsed"],
+                    "ms_per_step": r["elapsed"] / args.steps * 1e3, "objects_total": total_obj,
+                    "objects_rank0": r["n_local"], "kernel_ms_rank0": r["kernel_ms"], "gather": r["gather"]}
+
+        hn = leg_numbers(head, m)
+        # roofline of the dominant kernel: HIP events on the launch stream, this rank
+        k_ms = m["kernel_ms"]
+        mode_samples = m["n_local"] * M * nb * B
+        block = m["form_run"] == 0
+        flop_exec = FLOP_BLOCK if block else FLOP_REF
+        tf_exec = flop_exec * mode_samples / (k_ms * 1e-3) * 1e-12
+        tf_ref = FLOP_REF * mode_samples / (k_ms * 1e-3) * 1e-12
+        # algorithmic bytes of one launch (SURVEY 8(d) formula with NB_l = nb; M = modes per object); the block
+        # form also reads its operand table once per launch (128 B per mode) and the coarse-step matrix (16 B)
+        bytes_alg = m["n_local"] * (M * (12 + 8 + 8 + (4 + 4 + 4) * nb + (144 if block else 0)) + nb * B * (4 + 4))
         gbs = bytes_alg / (k_ms * 1e-3) * 1e-9
+        traffic, traffic_src = measured_traffic(args, m["n_local"])
+        info = m["info"]
         out = {
             "metric": "audio samples/s & real-time x at N_obj x N_modes",
-            "value": value, "unit": "audio samples/s", "realtime_x": rt,
+            "value": hn["value"], "unit": "audio samples/s", "realtime_x": hn["realtime_x"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+            "ms_per_step": hn["ms_per_step"],
+            "higher_is_better": True, "scaling": head, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"{args.objects} objects x {M} modes per GPU, " + {
+                "workload": f"{m['n_local']} objects x {M} modes on rank 0 ({hn['objects_total']} in the job), " + {
                                 "impulses": "Poisson impulse stream (~20 PointForce hits/s/object, on-device vertex projection), unit transfer, ",
                                 "scraping": "sustained AutoregressiveForce scraping (one GetModalForceFace message per buffer, "
                                             "profiles generated on the device), unit transfer, ",
                                 "listener": "Poisson impulse stream + FFAT maps (16x16 cube faces) with a new listener position every buffer, ",
                             }[args.scenario] + f"{nb} buffers x 513 samples per step, "
-                            f"qnorm {'off' if args.no_qnorm else args.qnorm}, {args.form} recurrence form",
-                "scenario": args.scenario, "objects_per_gpu": args.objects, "modes": M, "buffers_per_step": nb, "frames_per_buffer": B,
-                "hits": n_hits, "modes_per_lane": info1["modes_per_lane"], "waves_per_object": info1["waves_per_object"],
-                "gather": bool(do_gather), "parallelism": f"object-sharded x{world}",
+                            f"qnorm {'off' if args.no_qnorm else args.qnorm}, {args.form} recurrence form"
+                            + (", RCCL all-gather of the audio buffers inside the timed region" if m["gather"] else ""),
+                "scenario": args.scenario, "objects_per_gpu": m["n_local"], "modes": M, "buffers_per_step": nb, "frames_per_buffer": B,
+                "hits": m["n_hits"], "modes_per_lane": info["modes_per_lane"], "waves_per_object": info["waves_per_object"],
+                "recurrence_form": args.form, "gather": m["gather"], "rccl_ranks": rccl_ranks, "backend": backend if use_dist else None,
+                "parallelism": f"object-sharded x{world}", "launched_by": "bench.py" if os.environ.get("PBSO_BENCH_SPAWNED") else
+                               ("torch.distributed.run" if use_dist else "single process"),
             },
             "roofline": {
-                "bound": "valu", "kernel": "iir_bank_kernel",
-                "bound_note": "fp32 vector-ALU issue (no dense contraction on this path, so neither hbm nor mfma binds); the peak "
-                              "used, 157.3 TFLOP/s, is also the dense fp32 MFMA peak of MI355X_MICROARCH.md, so frac is the "
-                              "same number under either label; the hbm fraction is in roofline.hbm",
-                "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS,
-                "flop_per_mode_sample": FLOP_PER_MODE_SAMPLE, "kernel_ms": k_ms,
+                "bound": "mfma" if block else "valu",
+                "kernel": "iir_block_kernel" if block else "iir_bank_kernel",
+                "bound_note": ("f32 matrix pipe: the per-sample sum over modes is a [16 x 2M].[2M x 16 blocks] product on "
+                               "v_mfma_f32_16x16x4_f32 (4 flop per mode-sample) + the coarse recurrence on the vector ALU "
+                               "(0.5 flop); on gfx950 the f32 MFMA and the f32 VALU do not co-execute "
+                               "(SQ_VALU_MFMA_COEXEC_CYCLES = 0, profiles/r02_pmc_summary.txt), so their cycles add against ONE "
+                               "157.3 TFLOP/s peak; frac counts the flops the kernel executes; reference_equivalent credits the "
+                               "reference's 10 flop per mode-sample") if block else
+                              ("fp32 vector-ALU issue; the peak used, 157.3 TFLOP/s, is also the dense fp32 MFMA peak"),
+                "achieved": tf_exec, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_exec / F32_PEAK_TFLOPS,
+                "flop_per_mode_sample": flop_exec, "kernel_ms": k_ms,
+                "reference_equivalent": {"flop_per_mode_sample": FLOP_REF, "achieved": tf_ref, "frac": tf_ref / F32_PEAK_TFLOPS},
                 "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": bytes_alg},
-                "traffic": measured_traffic(args),
-                "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+                "traffic": traffic,
+                "traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/{traffic_src})",
             },
-            "timing": {"device_pipeline_ms": d_ms, "host_plan_ms": plan_ms, "host_enqueue_ms": enqueue_s[0] / args.steps * 1e3},
+            "timing": {"device_pipeline_ms": m["device_ms"], "host_plan_ms": m["plan_ms"], "host_enqueue_ms": m["enqueue_ms"]},
         }
+        if "parity" in m:
+            out["parity"] = m["parity"]
+            out["parity_checked_objects"] = m["parity"]["parity_checked_objects"]
+            out["max_err"] = m["parity"]["max_err"]
+        for leg, r in legs.items():
+            if leg != head:
+                out[leg] = dict(leg_numbers(leg, r), scaling=leg,
+                                note="--objects objects (the configuration as written) split over the ranks by the sum of modes"
+                                if leg == "strong" else "--objects per GPU")
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(args, lam, shapes, scripts)
+                out["cpu_baseline"] = cpu_baseline(args, *m["_cpu_inputs"])
             except Exception as ex:   # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"error": repr(ex)}
-        print(json.dumps(out))
-    eng.close()
+        print(json.dumps(out), flush=True)
+        if "parity" in m and not m["parity"]["pass"]:
+            print("PARITY FAILED: " + json.dumps(m["parity"]), file=sys.stderr)
+            if use_dist:
+                dist.destroy_process_group()
+            sys.exit(3)
     if use_dist:
         dist.destroy_process_group()
 

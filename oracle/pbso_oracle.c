@@ -935,35 +935,54 @@ double or_bench_run(int n_obj, int n_modes, int n_buffers, int n_threads,
                     const double *omega2, double density, double alpha, double beta,
                     const double *hit_data, const unsigned char *hit_mask,
                     double *sound_out, int flush_denormals) {
+    /* Objects are dealt to the threads in contiguous static shares; every thread BUILDS its own
+     * solvers (first touch on its own NUMA node) and then steps them.  Only the stepping is timed:
+     * from the moment every thread has built its share until the last thread is done.           */
     or_solver **sv = (or_solver **)calloc((size_t)n_obj, sizeof(*sv));
-    for (int o = 0; o < n_obj; ++o) {
-        sv[o] = or_solver_new(n_modes);
-        or_solver_set_integrator(sv[o], or_integrator_build(
-            density, omega2 + (size_t)o * n_modes, n_modes, alpha, beta,
-            1. / (double)OR_SAMPLE_RATE, n_modes));
-        or_solver_set_use_transfer(sv[o], 0);
-    }
+    double t0 = 0, t1 = 0;
     (void)n_threads;
-    double t0 = now_s();
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+#pragma omp parallel num_threads(n_threads)
 #endif
-    for (int o = 0; o < n_obj; ++o) {
+    {
 #if defined(__x86_64__)
         if (flush_denormals) {
             _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_ON);
             _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_ON);
         }
 #endif
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int o = 0; o < n_obj; ++o) {
+            sv[o] = or_solver_new(n_modes);
+            or_solver_set_integrator(sv[o], or_integrator_build(
+                density, omega2 + (size_t)o * n_modes, n_modes, alpha, beta,
+                1. / (double)OR_SAMPLE_RATE, n_modes));
+            or_solver_set_use_transfer(sv[o], 0);
+        }   /* implicit barrier: everything is built */
+#ifdef _OPENMP
+#pragma omp single
+#endif
+        t0 = now_s();   /* implicit barrier after single */
         double sound[B];
         double *qn = (double *)malloc(sizeof(double) * (size_t)(n_modes > 0 ? n_modes : 1));
-        for (int b = 0; b < n_buffers; ++b) {
-            if (hit_mask[(size_t)o * n_buffers + b])
-                or_solver_enqueue_force(sv[o], hit_data + (size_t)o * n_modes, n_modes, NULL, 0, 0, 0);
-            or_solver_step(sv[o], sound, qn);        /* qnorm is part of step(), :262-273 */
-            if (sound_out)
-                memcpy(sound_out + ((size_t)o * n_buffers + b) * B, sound, sizeof(sound));
-        }
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int o = 0; o < n_obj; ++o) {
+            for (int b = 0; b < n_buffers; ++b) {
+                if (hit_mask[(size_t)o * n_buffers + b])
+                    or_solver_enqueue_force(sv[o], hit_data + (size_t)o * n_modes, n_modes, NULL, 0, 0, 0);
+                or_solver_step(sv[o], sound, qn);        /* qnorm is part of step(), :262-273 */
+                if (sound_out)
+                    memcpy(sound_out + ((size_t)o * n_buffers + b) * B, sound, sizeof(sound));
+            }
+        }   /* implicit barrier: the slowest thread is done */
+#ifdef _OPENMP
+#pragma omp single
+#endif
+        t1 = now_s();
         free(qn);
 #if defined(__x86_64__)
         if (flush_denormals) {
@@ -972,7 +991,6 @@ double or_bench_run(int n_obj, int n_modes, int n_buffers, int n_threads,
         }
 #endif
     }
-    double t1 = now_s();
     for (int o = 0; o < n_obj; ++o) or_solver_free(sv[o]);
     free(sv);
     return t1 - t0;

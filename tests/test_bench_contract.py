@@ -33,6 +33,39 @@ def test_committed_headline_line_has_the_contract_keys():
     assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
 
 
+def test_gpus_n_without_a_launcher_starts_the_ranks_before_touching_the_gpu(monkeypatch):
+    """python bench.py --gpus 2 with no WORLD_SIZE: the parent runs torch.distributed.run as a CHILD (no exec,
+    no torch import, hence no HIP initialisation in the parent) and exits with its code."""
+    sys.path.insert(0, ROOT)
+    import bench
+    calls = []
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        calls.append((cmd, env))
+        return Done()
+
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    torch_loaded_before = "torch" in sys.modules
+    try:
+        bench.main()
+        assert False, "main() must exit with the child's code"
+    except SystemExit as e:
+        assert e.code == 7
+    assert len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
+    assert env["PBSO_BENCH_SPAWNED"] == "1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert ("torch" in sys.modules) == torch_loaded_before        # the spawn path imports nothing that could touch the GPU
+    a = bench.parse(["--gpus", "2"])
+    assert not a.no_gather                                        # the RCCL gather is part of the N > 1 line by default
+
+
 def test_bench_defaults_are_the_single_gpu_headline(monkeypatch):
     sys.path.insert(0, ROOT)
     import bench

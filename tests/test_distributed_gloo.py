@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from openpbso_amd.distributed import gather_audio, shard_range
+from openpbso_amd.distributed import gather_audio, shard_by_modes, shard_range
 
 
 def test_shard_range_partitions_objects():
@@ -20,6 +20,26 @@ def test_shard_range_partitions_objects():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_shard_by_modes_balances_the_sum_of_modes():
+    """contiguous blocks balanced by sum of M, identical to shard_range for equal objects"""
+    for w in (1, 2, 3, 8):
+        for n in (1, 7, 1024):
+            spans = [shard_by_modes([512] * n, w, r) for r in range(w)]
+            assert spans == [shard_range(n, w, r) for r in range(w)] or max(hi - lo for lo, hi in spans) - min(
+                hi - lo for lo, hi in spans) <= 1
+            assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    rng = np.random.default_rng(5)
+    modes = rng.choice([64, 256, 512, 4096], 300).tolist()
+    for w in (2, 4, 8):
+        spans = [shard_by_modes(modes, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == len(modes) and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        loads = [sum(modes[lo:hi]) for lo, hi in spans]
+        assert max(loads) - min(loads) <= 2 * 4096            # within one largest object of each other
+        by_count = [sum(modes[slice(*shard_range(len(modes), w, r))]) for r in range(w)]
+        assert max(loads) <= max(by_count)                    # never worse than balancing the object count
+    assert [shard_by_modes([4096, 64, 64, 64], 2, r) for r in range(2)] == [(0, 1), (1, 4)]
 
 
 def _free_port():
