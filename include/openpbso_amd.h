@@ -166,6 +166,14 @@ int pbso_num_modes_audible(const double *omega_squared, int n_modes, double dens
 /* ModalMaterial<double>::Read (ModalMaterial.h:35-55): out = density,
  * youngsModulus, poissonRatio, alpha, beta                                    */
 int pbso_material_read(const char *path, double out[5]);
+/* <name>.tet.obj as the tool reads it (tools/real_time_modal_sound.cpp:508-509): igl::read_triangle_mesh
+ * (only `v` / `f` records; 1-based, negative and a/b/c indices; polygons become triangle fans) and
+ * igl::per_vertex_normals with libigl's default (area) weighting, each row normalised -- the tool normalises
+ * VN.row(vid) again at the hit (:607).  libigl is an un-vendored submodule of the reference: the weighting is
+ * its documented default, not pinned by code in the reference tree.  vertices [n_vertices][3], faces
+ * [n_faces][3] (0-based), vertex_normals [n_vertices][3] are malloc'ed: release with pbso_free.             */
+int pbso_obj_read(const char *path, int *n_vertices, int *n_faces, double **vertices, int **faces,
+                  double **vertex_normals);
 void pbso_free(void *p);
 
 /* uploads all objects to HBM; no pbso_add_object afterwards */
@@ -202,9 +210,13 @@ int pbso_enqueue_arprm(pbso_engine *e, int object_id, const double a[2], double 
  * every mode on the device, result offered to the 1-slot transfer queue.
  * 1 = enqueued, 0 = no maps / queue still full.                               */
 int pbso_compute_transfer(pbso_engine *e, int object_id, const double pos[3], int64_t not_before);
-/* ModalSolver::computeTransfer(pos, T *trans) (modal_solver.h:302-315),
- * batched over n_pos listener positions: out[n_pos][n_maps] doubles.          */
-int pbso_compute_transfer_batch(pbso_engine *e, int object_id, const double *pos, int n_pos, double *out);
+/* ModalSolver::computeTransfer(pos, T *trans) (modal_solver.h:302-315), batched over n_pos listener
+ * positions.  Like the reference it writes _ffat_maps->size() (= pbso_object_n_maps) entries per position:
+ * out[n_pos][out_cols] doubles, columns [0, n_maps) of every row are written, the others left alone;
+ * out_cols < n_maps is PBSO_ERR_INVALID.  1 = done, 0 = the object has no maps.                         */
+int pbso_compute_transfer_batch(pbso_engine *e, int object_id, const double *pos, int n_pos, double *out, int out_cols);
+/* _ffat_maps->size() of an object (modal_solver.h:312); 0 while readFFATMaps has not been called */
+int pbso_object_n_maps(pbso_engine *e, int object_id);
 /* ModalSolver::setUseTransfer (modal_solver.h:148-152) */
 int pbso_set_use_transfer(pbso_engine *e, int object_id, int use, int64_t not_before);
 /* ModalSolver::getLatestTransfer (modal_solver.h:145-147): n_modes doubles */

@@ -19,13 +19,15 @@
 // not in the image) a minimal built-in vector with the same accessors is used.
 #ifndef OPENPBSO_AMD_FACADE_H
 #define OPENPBSO_AMD_FACADE_H
+#include <atomic>
 #include <cassert>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
-#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -70,6 +72,34 @@ struct VecN {
     const T *data() const { return v; }
 };
 #endif
+
+// Single-producer / single-consumer ring, lock-free like the reference's moodycamel::ReaderWriterQueue
+// (modal_solver.h:105-109).  ReaderWriterQueue<M>(2) holds ceilToPow2(2 + 1) - 1 = 3 messages.  The audio
+// callback (PaModalCallback) only ever calls try_dequeue: no lock, no allocation, no system call.
+template <typename M, unsigned CAP = 3>
+class SpscRing {
+    M _slot[CAP + 1];
+    std::atomic<unsigned> _head{0};      // next slot to read  (written by the consumer only)
+    std::atomic<unsigned> _tail{0};      // next slot to write (written by the producer only)
+public:
+    bool try_enqueue(const M &m) {
+        const unsigned t = _tail.load(std::memory_order_relaxed), n = (t + 1) % (CAP + 1);
+        if (n == _head.load(std::memory_order_acquire)) return false;            // full
+        _slot[t] = m;
+        _tail.store(n, std::memory_order_release);
+        return true;
+    }
+    bool try_dequeue(M &m) {
+        const unsigned h = _head.load(std::memory_order_relaxed);
+        if (h == _tail.load(std::memory_order_acquire)) return false;            // empty
+        m = _slot[h];
+        _head.store((h + 1) % (CAP + 1), std::memory_order_release);
+        return true;
+    }
+    unsigned size_approx() const {
+        return (_tail.load(std::memory_order_acquire) + CAP + 1 - _head.load(std::memory_order_acquire)) % (CAP + 1);
+    }
+};
 }  // namespace pbso_facade
 
 // ---- forces.h ---------------------------------------------------------------
@@ -182,18 +212,19 @@ class ModalSolver {
     std::string _ffat_dir;
     bool _have_ffat_dir = false;
     std::shared_ptr<ModalIntegrator<T>> _integrator;
-    std::deque<SoundMessage<T, BUF_SIZE>> _queue_sound;      // ReaderWriterQueue(2): 3 usable slots
-    std::deque<DataMessage<T>> _queue_qnorm;                 // ReaderWriterQueue(2): 3 usable slots
-    std::mutex _queue_mutex;                                 // sim thread <-> audio/GUI thread
-    std::recursive_mutex _engine_mutex;                      // the C ABI wants one caller at a time
+    pbso_facade::SpscRing<SoundMessage<T, BUF_SIZE>> _queue_sound;   // sim thread -> audio callback, lock-free (:107)
+    pbso_facade::SpscRing<DataMessage<T>> _queue_qnorm;              // sim thread -> GUI thread, lock-free (:109)
+    std::recursive_mutex _engine_mutex;                      // the C ABI wants one caller at a time (never taken by the audio callback)
     TransMessage<T> _latest_transfer;
     std::vector<float> _audio32, _qnorm32;
     std::vector<double> _tmp;
 
+    // engine errors are the reference's assert / uncaught-exception paths: stop in EVERY build type
+    // (an assert alone would let an NDEBUG build carry on with a poisoned engine)
     void _require(int rc) const {
         if (rc < 0) {
             std::fprintf(stderr, "openpbso_amd: %s: %s\n", pbso_status_string(rc), pbso_last_error(_engine));
-            assert(false && "openpbso_amd engine error");
+            std::abort();
         }
     }
     typedef std::lock_guard<std::recursive_mutex> EngineLock;
@@ -244,12 +275,8 @@ public:
     }
     inline void setUseTransfer(const bool s) { EngineLock lk_(_engine_mutex); _finalize(); _require(pbso_set_use_transfer(_engine, _obj, s ? 1 : 0, 0)); }
     inline pbso_facade::VecX<T> getQBufferNorm() {
-        std::lock_guard<std::mutex> lk(_queue_mutex);
-        if (!_queue_qnorm.empty()) {
-            pbso_facade::VecX<T> r = _queue_qnorm.front().data;
-            _queue_qnorm.pop_front();
-            return r;
-        }
+        DataMessage<T> m;
+        if (_queue_qnorm.try_dequeue(m)) return m.data;
         pbso_facade::VecX<T> z;
         z.setZero(_N_modes);
         return z;
@@ -272,18 +299,10 @@ public:
         for (int i = 0; i < BUF_SIZE; ++i) mess.data(i) = (T)_audio32[i];
         _engine_mutex.unlock();          // the spin below must not block the GUI thread's enqueue calls
         struct Relock { std::recursive_mutex &m; ~Relock() { m.lock(); } } relock_{_engine_mutex};
-        {
-            std::lock_guard<std::mutex> lk(_queue_mutex);
-            if (_queue_qnorm.size() < 3) _queue_qnorm.push_back(qn);   // try_enqueue, may drop (:273)
-        }
+        (void)_queue_qnorm.try_enqueue(qn);                    // try_enqueue, may drop (:273)
         // enqueueSoundMessageNoFail (:275, :346-357): spin until the 3-slot queue has room --
         // this is the reference's real-time pacing
-        for (;;) {
-            {
-                std::lock_guard<std::mutex> lk(_queue_mutex);
-                if (_queue_sound.size() < 3) { _queue_sound.push_back(mess); break; }
-            }
-        }
+        while (!_queue_sound.try_enqueue(mess)) {}
     }
 
     bool computeTransfer(const pbso_facade::VecN<T, 3> &pos) {
@@ -291,6 +310,9 @@ public:
         _finalize();
         const double p[3] = {(double)pos(0), (double)pos(1), (double)pos(2)};
         int rc = pbso_compute_transfer(_engine, _obj, p, 0);
+        // a missing / empty FFAT directory gives an empty map (io.cpp:31-34, LoadAll): the reference then
+        // throws from _ffat_maps->at(ii) (modal_solver.h:294)
+        if (rc == PBSO_ERR_MISSING_MAP) throw std::out_of_range("map::at");
         _require(rc);
         return rc == 1;
     }
@@ -298,11 +320,14 @@ public:
         EngineLock lk_(_engine_mutex);
         _finalize();
         const double p[3] = {(double)pos(0), (double)pos(1), (double)pos(2)};
-        _tmp.resize(_N_modes > 0 ? _N_modes : 1);
-        int rc = pbso_compute_transfer_batch(_engine, _obj, p, 1, _tmp.data());
+        const int n_maps = pbso_object_n_maps(_engine, _obj);
+        _require(n_maps);
+        _tmp.resize(n_maps > 0 ? n_maps : 1);
+        int rc = pbso_compute_transfer_batch(_engine, _obj, p, 1, _tmp.data(), n_maps);
+        if (rc == PBSO_ERR_MISSING_MAP) throw std::out_of_range("map::at");        // modal_solver.h:309
         _require(rc);
         if (rc != 1) return false;
-        for (int i = 0; i < _N_modes; ++i) trans[i] = (T)_tmp[i];
+        for (int i = 0; i < n_maps; ++i) trans[i] = (T)_tmp[i];                    // _ffat_maps->size() entries (:308-312)
         return true;
     }
 
@@ -318,8 +343,10 @@ public:
         m.clear_all_forces = mess.clearAllForces;
         std::vector<double> d(mess.data.size());
         for (int i = 0; i < (int)d.size(); ++i) d[i] = (double)mess.data(i);
-        m.data_kind = PBSO_DATA_EXPLICIT;
-        m.data = d.data();
+        // "Clear force" (tools/real_time_modal_sound.cpp:745-747) sends a default-constructed message with
+        // clearAllForces = true and NO data: step() returns before looking at it (modal_solver.h:186-189)
+        m.data_kind = mess.clearAllForces ? PBSO_DATA_ZERO : PBSO_DATA_EXPLICIT;
+        m.data = d.empty() ? nullptr : d.data();
         m.n_data = (int)d.size();
         int rc = pbso_enqueue_force(_engine, _obj, &m, 0);
         _require(rc);
@@ -331,13 +358,8 @@ public:
             if (enqueueForceMessage(mess)) return true;
         return false;
     }
-    bool dequeueSoundMessage(SoundMessage<T, BUF_SIZE> &mess) {
-        std::lock_guard<std::mutex> lk(_queue_mutex);
-        if (_queue_sound.empty()) return false;
-        mess = _queue_sound.front();
-        _queue_sound.pop_front();
-        return true;
-    }
+    // called from the PortAudio callback: wait-free (one acquire load, one copy, one release store)
+    bool dequeueSoundMessage(SoundMessage<T, BUF_SIZE> &mess) { return _queue_sound.try_dequeue(mess); }
     bool enqueueArprmMessageNoFail(const AutoregressiveForceParam<T> &mess, const int maxIte = -1) {
         EngineLock lk_(_engine_mutex);
         (void)maxIte;

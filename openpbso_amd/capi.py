@@ -21,11 +21,11 @@ EXPORTS = [
     "pbso_abi_version", "pbso_status_string", "pbso_engine_create", "pbso_engine_destroy",
     "pbso_last_error", "pbso_add_object", "pbso_add_object_from_files", "pbso_object_set_ffat_maps",
     "pbso_object_read_ffat_maps", "pbso_fatcube_parse", "pbso_ffat_map_free", "pbso_finalize",
-    "pbso_enqueue_force", "pbso_enqueue_force_batch", "pbso_enqueue_arprm", "pbso_compute_transfer", "pbso_compute_transfer_batch",
+    "pbso_enqueue_force", "pbso_enqueue_force_batch", "pbso_enqueue_arprm", "pbso_compute_transfer", "pbso_compute_transfer_batch", "pbso_object_n_maps",
     "pbso_set_use_transfer", "pbso_get_latest_transfer", "pbso_step", "pbso_step_into", "pbso_sync",
     "pbso_read_audio", "pbso_read_emitted", "pbso_read_qnorm", "pbso_read_state",
     "pbso_audio_device_ptr", "pbso_pa_convert", "pbso_get_info",
-    "pbso_modes_read", "pbso_num_modes_audible", "pbso_material_read", "pbso_free", "pbso_read_census",
+    "pbso_modes_read", "pbso_num_modes_audible", "pbso_material_read", "pbso_free", "pbso_read_census", "pbso_obj_read",
 ]
 
 
@@ -104,7 +104,8 @@ def lib():
                                            C.POINTER(C.c_ubyte)]
     l.pbso_enqueue_arprm.argtypes = [vp, C.c_int, dp, C.c_double, C.c_double, C.c_int64]
     l.pbso_compute_transfer.argtypes = [vp, C.c_int, dp, C.c_int64]
-    l.pbso_compute_transfer_batch.argtypes = [vp, C.c_int, dp, C.c_int, dp]
+    l.pbso_compute_transfer_batch.argtypes = [vp, C.c_int, dp, C.c_int, dp, C.c_int]
+    l.pbso_object_n_maps.argtypes = [vp, C.c_int]
     l.pbso_set_use_transfer.argtypes = [vp, C.c_int, C.c_int, C.c_int64]
     l.pbso_get_latest_transfer.argtypes = [vp, C.c_int, dp]
     l.pbso_step.argtypes = [vp, C.c_int]
@@ -122,6 +123,7 @@ def lib():
     l.pbso_modes_read.argtypes = [C.c_char_p, ip, ip, C.POINTER(dp), C.POINTER(dp)]
     l.pbso_num_modes_audible.argtypes = [dp, C.c_int, C.c_double, C.c_double]
     l.pbso_material_read.argtypes = [C.c_char_p, dp]
+    l.pbso_obj_read.argtypes = [C.c_char_p, ip, ip, C.POINTER(dp), C.POINTER(ip), C.POINTER(dp)]
     l.pbso_read_census.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t]
     l.pbso_free.argtypes = [vp]
     l.pbso_free.restype = None

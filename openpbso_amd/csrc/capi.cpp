@@ -211,6 +211,31 @@ int pbso_modes_read(const char *path, int *n_dof, int *n_modes, double **omega_s
     }
 }
 
+int pbso_obj_read(const char *path, int *n_vertices, int *n_faces, double **vertices, int **faces, double **vertex_normals) {
+    if (!path || !n_vertices || !n_faces || !vertices || !faces || !vertex_normals) return PBSO_ERR_INVALID;
+    try {
+        std::vector<double> V, VN;
+        std::vector<int> F;
+        int rc = pbso::load_obj_file(path, V, F, VN);
+        if (rc != PBSO_OK) return rc;
+        double *a = (double *)std::malloc(sizeof(double) * std::max<size_t>(V.size(), 1));
+        int *b = (int *)std::malloc(sizeof(int) * std::max<size_t>(F.size(), 1));
+        double *c = (double *)std::malloc(sizeof(double) * std::max<size_t>(VN.size(), 1));
+        if (!a || !b || !c) { std::free(a); std::free(b); std::free(c); return PBSO_ERR_NOMEM; }
+        if (!V.empty()) std::memcpy(a, V.data(), sizeof(double) * V.size());
+        if (!F.empty()) std::memcpy(b, F.data(), sizeof(int) * F.size());
+        if (!VN.empty()) std::memcpy(c, VN.data(), sizeof(double) * VN.size());
+        *n_vertices = (int)(V.size() / 3);
+        *n_faces = (int)(F.size() / 3);
+        *vertices = a;
+        *faces = b;
+        *vertex_normals = c;
+        return PBSO_OK;
+    } catch (...) {
+        return PBSO_ERR_NOMEM;
+    }
+}
+
 int pbso_num_modes_audible(const double *omega_squared, int n_modes, double density, double audible_freq) {
     if (n_modes < 0 || (n_modes > 0 && !omega_squared)) return PBSO_ERR_INVALID;
     try {
@@ -272,10 +297,17 @@ int pbso_compute_transfer(pbso_engine *e, int obj, const double pos[3], int64_t 
     GUARD_END(e)
 }
 
-int pbso_compute_transfer_batch(pbso_engine *e, int obj, const double *pos, int n_pos, double *out) {
+int pbso_object_n_maps(pbso_engine *e, int obj) {
     NEED(e);
     GUARD_BEGIN
-    return e->impl->compute_transfer_batch(obj, pos, n_pos, out);
+    return e->impl->object_n_maps(obj);
+    GUARD_END(e)
+}
+
+int pbso_compute_transfer_batch(pbso_engine *e, int obj, const double *pos, int n_pos, double *out, int out_cols) {
+    NEED(e);
+    GUARD_BEGIN
+    return e->impl->compute_transfer_batch(obj, pos, n_pos, out, out_cols);
     GUARD_END(e)
 }
 

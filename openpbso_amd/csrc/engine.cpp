@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <condition_variable>
 #include <functional>
@@ -99,25 +100,43 @@ void PlanCtx::begin() {
 }
 
 // ---------------------------------------------------------------------------
+// Blocks replaced by a larger one are not freed on the spot: launches already queued on either engine
+// stream may still use them, and waiting for those would drain the whole device in the middle of a step --
+// the caller's own work (torch, an RCCL gather) included.  They are parked here and freed the next time
+// the engine is idle anyway (Engine::sync, destruction).
+namespace {
+std::mutex g_retired_mutex;
+std::vector<void *> g_retired;
+}  // namespace
+void free_retired_blocks() {
+    std::vector<void *> v;
+    {
+        std::lock_guard<std::mutex> lk(g_retired_mutex);
+        v.swap(g_retired);
+    }
+    if (v.empty()) return;
+    // the list is shared by the engines of a process (one per ModalSolver in the facade): another engine's
+    // launches may still use a block parked here, so this rare path waits for the whole device
+    (void)hipDeviceSynchronize();
+    for (void *q : v) (void)hipFree(q);
+}
 template <class T>
 hipError_t DevBuf<T>::ensure(size_t n, bool keep, hipStream_t s) {
     if (n <= cap) return hipSuccess;
-    // 25 % headroom: per-step demand (forced rows, slots) fluctuates by a few percent, and a
-    // regrowth drains the device
+    // 25 % headroom: per-step demand (forced rows, slots) fluctuates by a few percent
     size_t ncap = std::max(n + n / 4, cap + cap / 2);
     T *np = nullptr;
     hipError_t e = hipMalloc((void **)&np, ncap * sizeof(T));
     if (e != hipSuccess) return e;
     if (p) {
-        // in-flight work on either engine stream may still use the old block: drain the device
-        // (growth is rare: capacities only ever increase)
-        e = hipDeviceSynchronize();
-        if (e == hipSuccess && keep && cap) {
+        // `keep`: the contents move in stream order on s -- every writer and reader of a kept buffer is ordered
+        // after s (the preparation stream, or an event chain from it), so nobody sees the new block before the copy
+        if (keep && cap) {
             e = hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { (void)hipFree(np); return e; }
         }
-        if (e != hipSuccess) { (void)hipFree(np); return e; }
-        (void)hipFree(p);
+        std::lock_guard<std::mutex> lk(g_retired_mutex);
+        g_retired.push_back(p);
     }
     p = np;
     cap = ncap;
@@ -216,12 +235,18 @@ void ForceProfile::set_param(const double a_[2], double sigma_, double mu_) {   
 Engine::Engine(const pbso_engine_desc &d) : desc_(d) {}
 
 Engine::~Engine() {
+    if (std::getenv("PBSO_HOST_PROFILE") && tot_steps_ > 0)
+        std::fprintf(stderr, "pbso host profile, ms per step over %lld steps: wait-for-set %.3f | plan: fill %.3f objects %.3f merge %.3f | "
+                             "submit (uploads + launches) %.3f | step total %.3f\n", (long long)tot_steps_, hprof_[0] / tot_steps_,
+                     hprof_[1] / tot_steps_, hprof_[2] / tot_steps_, hprof_[3] / tot_steps_, hprof_[4] / tot_steps_, hprof_[5] / tot_steps_);
     delete pool_;
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (prep_stream_) (void)hipStreamSynchronize(prep_stream_);
+    free_retired_blocks();
     d_ca_.release(); d_cb_.release(); d_sq_.release(); d_sd_.release(); d_ss_.release(); d_c3_.release(); d_gq_.release();
     d_shapes_.release(); d_shape_off_.release(); d_n_modes_.release(); d_geom_.release();
     d_geom_off_.release(); d_psi_.release(); d_slots_.release(); d_xfer_.release();
+    d_pc_.release(); d_wtab_.release();
     d_arstate_.release(); d_board_.release(); d_teams_.release(); d_split_.release(); d_audio_parts_.release();
     d_audio_.release(); d_qnorm_.release(); d_grows_[0].release(); d_grows_[1].release(); d_census_.release();
     for (hipEvent_t ev : {ev_prep_done_[0], ev_prep_done_[1], ev_k1_done_[0], ev_k1_done_[1]})
@@ -697,6 +722,9 @@ int Engine::enqueue_force_impl(int obj, const pbso_force_msg &m, int64_t not_bef
     h.gaussian_width_us = m.gaussian_width_us;      // the Force object itself is built when the message is dequeued
     switch (m.data_kind) {
     case PBSO_DATA_EXPLICIT:
+        // a clearAllForces message returns from step() before any dimension check (modal_solver.h:186-189):
+        // the GUI sends it with an empty data vector (tools/real_time_modal_sound.cpp:745-747)
+        if (h.clear_all) { h.data_kind = PBSO_DATA_ZERO; break; }
         if (!m.data || m.n_data != o.n_modes)
             { *why = "dimension of force message incorrect"; return PBSO_ERR_INVALID; }   // assert :258
         h.data.assign(m.data, m.data + m.n_data);
@@ -1123,6 +1151,7 @@ int Engine::plan(int nb) {
     PlanSet &ps = set_[cur_set_];
     HIPTRY(ps.h_desc.ensure((size_t)N * nb));
     HIPTRY(ps.h_xfer_init.ensure(N));
+    const auto tp0 = std::chrono::steady_clock::now();
     const BufDesc dflt = {-1, -1, 0u, 0.f, XFER_KEEP, 0u, {0, 0}};
     std::fill(ps.h_desc.p, ps.h_desc.p + (size_t)N * nb, dflt);
     busy_.clear();
@@ -1143,8 +1172,10 @@ int Engine::plan(int nb) {
     size_t need_all = 0;
     for (int t = 0; t < T; ++t) {
         for (int k = lo[t]; k < lo[t + 1]; ++k)
-            for (const TimedEvent &ev : objs_[busy_[k]].pending)
-                if (ev.kind == TimedEvent::TRANSFER && ev.not_before < buffers_done_ + nb) ++need[t];
+            for (const TimedEvent &ev : objs_[busy_[k]].pending) {
+                if (ev.not_before >= buffers_done_ + nb) break;      // sorted by stamp (push_timed): the rest is later
+                if (ev.kind == TimedEvent::TRANSFER) ++need[t];
+            }
         need_all += need[t];
     }
     if ((int)need_all > xfer_cap_) {
@@ -1169,6 +1200,7 @@ int Engine::plan(int nb) {
             if (c.rc != PBSO_OK) return;
         }
     };
+    const auto tp1 = std::chrono::steady_clock::now();
     if (T > 1) {
         if (!pool_) {
             const char *pin = std::getenv("PBSO_PLAN_PIN");
@@ -1178,6 +1210,7 @@ int Engine::plan(int nb) {
     } else {
         job(0);
     }
+    const auto tp2 = std::chrono::steady_clock::now();
     for (int t = 0; t < T; ++t)
         if (ctx_[t].rc != PBSO_OK) return fail(ctx_[t].rc, ctx_[t].err);
 
@@ -1219,6 +1252,13 @@ int Engine::plan(int nb) {
         c.free_slots.insert(c.free_slots.end(), c.freed_this_plan.begin(), c.freed_this_plan.end());
         c.free_ar.insert(c.free_ar.end(), c.freed_ar.begin(), c.freed_ar.end());
     }
+    const auto tp3 = std::chrono::steady_clock::now();
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    hprof_[1] += ms(tp0, tp1);
+    hprof_[2] += ms(tp1, tp2);
+    hprof_[3] += ms(tp2, tp3);
     return PBSO_OK;
 }
 
@@ -1280,9 +1320,11 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     PlanSet &ps = set_[cur_set_];
     plan_b0_ = b0;
     plan_nb_total_ = nb_total;
+    const auto tw0 = std::chrono::steady_clock::now();
     HIPTRY(hipEventSynchronize(ev_set_[cur_set_]));      // this set's previous uploads are done
 
     const auto t0 = std::chrono::steady_clock::now();
+    hprof_[0] += std::chrono::duration<double, std::milli>(t0 - tw0).count();
     int rc = plan(nb);
     if (rc != PBSO_OK) return rc;
     // keep _latest_transfer / the transfer queue in their persistent rows after the launch
@@ -1447,6 +1489,8 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     ev_pending_.push_back(evq);
     buffers_done_ += nb;
     cur_set_ ^= 1;
+    hprof_[4] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - last_plan_ms_;
+    hprof_[5] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
     return PBSO_OK;
 }
 
@@ -1454,6 +1498,9 @@ int Engine::sync() {
     HIPTRY(hipSetDevice(desc_.device));      // the caller's thread may have another device current
     if (prep_stream_) HIPTRY(hipStreamSynchronize(prep_stream_));
     if (stream_) HIPTRY(hipStreamSynchronize(stream_));
+    for (hipStream_t cs : class_stream_)
+        if (cs) HIPTRY(hipStreamSynchronize(cs));
+    free_retired_blocks();                   // nothing of this engine is in flight any more
     return PBSO_OK;
 }
 
@@ -1522,7 +1569,12 @@ int Engine::get_latest_transfer(int obj, double *out) {
 }
 
 // ModalSolver::computeTransfer(pos, T *trans), modal_solver.h:302-315, batched
-int Engine::compute_transfer_batch(int obj, const double *pos, int n_pos, double *out) {
+int Engine::object_n_maps(int obj) {
+    if (!valid_obj(obj)) return fail(PBSO_ERR_INVALID, "object id");
+    return objs_[obj].have_maps ? objs_[obj].n_maps : 0;
+}
+
+int Engine::compute_transfer_batch(int obj, const double *pos, int n_pos, double *out, int out_cols) {
     HIPTRY(hipSetDevice(desc_.device));      // the caller's thread may have another device current
     if (!finalized_) return fail(PBSO_ERR_STATE, "compute_transfer_batch before finalize");
     if (!valid_obj(obj) || n_pos < 0 || (n_pos && (!pos || !out))) return fail(PBSO_ERR_INVALID, "arguments");
@@ -1530,6 +1582,7 @@ int Engine::compute_transfer_batch(int obj, const double *pos, int n_pos, double
     if (!o.have_maps) return 0;
     const int nmap = o.n_maps;
     if (nmap > o.n_modes) return fail(PBSO_ERR_INVALID, "more FFAT maps than audible modes is not supported");
+    if (out_cols < nmap) return fail(PBSO_ERR_INVALID, "compute_transfer_batch: out_cols is smaller than the object's map count (pbso_object_n_maps)");
     for (int m = 0; m < nmap; ++m)
         if (m >= (int)o.geom.size() || !o.geom[m].valid)
             return fail(PBSO_ERR_MISSING_MAP, "FFAT map ids are not 0..size-1 (std::map::at throws)");
@@ -1551,7 +1604,7 @@ int Engine::compute_transfer_batch(int obj, const double *pos, int n_pos, double
         if (le) e = (hipError_t)le;
     }
     if (e == hipSuccess)
-        e = hipMemcpy2DAsync(out, (size_t)nmap * sizeof(double), rows.p, (size_t)m_pad_ * sizeof(double),
+        e = hipMemcpy2DAsync(out, (size_t)out_cols * sizeof(double), rows.p, (size_t)m_pad_ * sizeof(double),
                              (size_t)nmap * sizeof(double), n_pos, hipMemcpyDeviceToHost, stream_);
     if (e == hipSuccess) e = hipStreamSynchronize(stream_);
     if (e != hipSuccess) rc = hip_fail(e, "compute_transfer_batch");

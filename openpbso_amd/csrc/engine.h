@@ -165,7 +165,8 @@ public:
     int enqueue_force_batch(int n, const int *objs, const pbso_force_msg *msgs, const int64_t *stamps, unsigned char *accepted);
     int enqueue_arprm(int obj, const double a[2], double sigma, double mu, int64_t not_before);
     int compute_transfer(int obj, const double pos[3], int64_t not_before);
-    int compute_transfer_batch(int obj, const double *pos, int n_pos, double *out);
+    int compute_transfer_batch(int obj, const double *pos, int n_pos, double *out, int out_cols);
+    int object_n_maps(int obj);
     int set_use_transfer(int obj, int use, int64_t not_before);
     int get_latest_transfer(int obj, double *out);
     int step(int n_buffers, void *d_audio);
@@ -298,6 +299,7 @@ private:
     int chunk_buffers_ = 128;                            // longer steps are cut into launches of this many buffers
     int plan_b0_ = 0, plan_nb_total_ = 0;                // where the chunk being planned sits in the step
     int64_t harvest_step_ = -1;
+    double hprof_[6] = {0, 0, 0, 0, 0, 0};               // PBSO_HOST_PROFILE=1: host milliseconds by stage, printed at destruction
     int64_t last_frows_ = 0, last_trows_ = 0;
 };
 
@@ -309,5 +311,6 @@ int load_material_file(const char *path, double out[5]);
 int parse_fatcube(const unsigned char *bytes, size_t n, pbso_ffat_map *out);
 int list_dir_files(const char *dir, const char *contains, std::vector<std::string> &names);
 int read_file_bytes(const char *path, std::vector<unsigned char> &out);
+int load_obj_file(const char *path, std::vector<double> &V, std::vector<int> &F, std::vector<double> &VN);
 
 }  // namespace pbso

@@ -85,8 +85,10 @@ int launch_iir_bank(const IirParams &p, int n_teams, int modes_per_lane, int wav
                     int form, int qnorm_mode, hipStream_t stream);
 }
 // per wave: one [TILE][LDS_ROW] transpose tile + a ring of (n_tiles + 1) tiles of row sums
+// (+ 5 rows: lanes 54..63 of the LAST wave read rows 27..31 behind its tile for bank spreading -- values unused --
+//  and with a one-wave team and few tiles the ring alone would not cover them)
 inline size_t iir_lds_bytes(int W, int n_tiles) {
-    return sizeof(float) * (size_t)W * (TILE * LDS_ROW + (size_t)(n_tiles + 1) * TILE);
+    return sizeof(float) * ((size_t)W * (TILE * LDS_ROW + (size_t)(n_tiles + 1) * TILE) + 5 * LDS_ROW);
 }
 constexpr int MAX_WAVES_PER_TEAM = 16;     // 1024 threads; larger objects are cut into several teams
 

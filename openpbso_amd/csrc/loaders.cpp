@@ -97,6 +97,77 @@ int list_dir_files(const char *dirname, const char *contains, std::vector<std::s
     return PBSO_OK;
 }
 
+// ---- <name>.tet.obj: igl::read_triangle_mesh + igl::per_vertex_normals, tools/real_time_modal_sound.cpp:508-509 ----
+// Only `v` and `f` records matter to the path.  Face indices are 1-based, may be negative (relative to the
+// vertices read so far) and may carry /vt/vn suffixes; polygons are cut into a triangle fan (what
+// read_triangle_mesh does through polygon_mesh_to_triangle_mesh).  Normals: libigl's default weighting is by
+// face area -- n_v = normalize(sum over incident faces of double-area x unit face normal) = normalize(sum of
+// the faces' edge cross products).  libigl is an un-vendored submodule of the reference (README pins a
+// modified 2.1.0), so this weighting is its documented default, not pinned by code under /root/reference.
+int load_obj_file(const char *path, std::vector<double> &V, std::vector<int> &F, std::vector<double> &VN) {
+    FILE *fp = std::fopen(path, "rb");
+    if (!fp) return PBSO_ERR_IO;
+    V.clear();
+    F.clear();
+    std::vector<char> buf(1 << 16);
+    std::vector<int> poly;
+    int rc = PBSO_OK;
+    while (std::fgets(buf.data(), (int)buf.size(), fp)) {
+        const char *p = buf.data();
+        while (*p == ' ' || *p == '\t') ++p;
+        if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+            char *end = nullptr;
+            const char *q = p + 1;
+            double x[3];
+            for (int j = 0; j < 3; ++j) {
+                x[j] = std::strtod(q, &end);
+                if (end == q) { rc = PBSO_ERR_IO; break; }
+                q = end;
+            }
+            if (rc != PBSO_OK) break;
+            V.insert(V.end(), x, x + 3);
+        } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+            poly.clear();
+            const char *q = p + 1;
+            const int nv = (int)(V.size() / 3);
+            for (;;) {
+                while (*q == ' ' || *q == '\t') ++q;
+                if (*q == 0 || *q == '\n' || *q == '\r' || *q == '#') break;
+                char *end = nullptr;
+                const long idx = std::strtol(q, &end, 10);
+                if (end == q) { rc = PBSO_ERR_IO; break; }
+                const long v = idx > 0 ? idx - 1 : nv + idx;             // negative: relative to the last vertex read
+                if (idx == 0 || v < 0 || v >= nv) { rc = PBSO_ERR_IO; break; }
+                poly.push_back((int)v);
+                q = end;
+                while (*q && *q != ' ' && *q != '\t' && *q != '\n' && *q != '\r') ++q;   // skip /vt/vn
+            }
+            if (rc != PBSO_OK) break;
+            if (poly.size() < 3) { rc = PBSO_ERR_IO; break; }
+            for (size_t k = 1; k + 1 < poly.size(); ++k) {
+                F.push_back(poly[0]);
+                F.push_back(poly[k]);
+                F.push_back(poly[k + 1]);
+            }
+        }
+    }
+    std::fclose(fp);
+    if (rc != PBSO_OK) return rc;
+    VN.assign(V.size(), 0.0);
+    for (size_t f = 0; f + 2 < F.size(); f += 3) {
+        const double *a = &V[3 * (size_t)F[f]], *b = &V[3 * (size_t)F[f + 1]], *c = &V[3 * (size_t)F[f + 2]];
+        const double u[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, w[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+        const double n[3] = {u[1] * w[2] - u[2] * w[1], u[2] * w[0] - u[0] * w[2], u[0] * w[1] - u[1] * w[0]};
+        for (int k = 0; k < 3; ++k)
+            for (int j = 0; j < 3; ++j) VN[3 * (size_t)F[f + k] + j] += n[j];
+    }
+    for (size_t v = 0; v + 2 < VN.size(); v += 3) {
+        const double len = std::sqrt(VN[v] * VN[v] + VN[v + 1] * VN[v + 1] + VN[v + 2] * VN[v + 2]);
+        if (len > 0) { VN[v] /= len; VN[v + 1] /= len; VN[v + 2] /= len; }      // a vertex of no face keeps (0, 0, 0)
+    }
+    return PBSO_OK;
+}
+
 // ---- proto3 wire reader -----------------------------------------------------
 namespace {
 struct Rd {

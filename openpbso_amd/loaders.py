@@ -57,3 +57,23 @@ def parse_fatcube(data: bytes):
     finally:
         capi.lib().pbso_ffat_map_free(C.byref(m))
     return out
+
+
+def read_obj(path):
+    """igl::read_triangle_mesh + igl::per_vertex_normals (tools/real_time_modal_sound.cpp:508-509) ->
+    (V [n][3], F [m][3] 0-based, VN [n][3] unit, area-weighted)."""
+    l = capi.lib()
+    nv, nf = C.c_int(0), C.c_int(0)
+    v, vn, f = C.POINTER(C.c_double)(), C.POINTER(C.c_double)(), C.POINTER(C.c_int)()
+    rc = l.pbso_obj_read(path.encode(), C.byref(nv), C.byref(nf), C.byref(v), C.byref(f), C.byref(vn))
+    if rc != capi.OK:
+        raise IOError(f"cannot read triangle mesh {path} (status {rc})")
+    try:
+        V = np.ctypeslib.as_array(v, shape=(max(3 * nv.value, 1),))[: 3 * nv.value].copy().reshape(-1, 3)
+        VN = np.ctypeslib.as_array(vn, shape=(max(3 * nv.value, 1),))[: 3 * nv.value].copy().reshape(-1, 3)
+        F = np.ctypeslib.as_array(f, shape=(max(3 * nf.value, 1),))[: 3 * nf.value].copy().reshape(-1, 3)
+    finally:
+        l.pbso_free(v)
+        l.pbso_free(f)
+        l.pbso_free(vn)
+    return V, F, VN

@@ -236,10 +236,17 @@ class Engine:
         p = np.ascontiguousarray(pos, dtype=np.float64)
         return bool(self._chk(self._l.pbso_compute_transfer(self._h, obj, _dp(p), not_before)))
 
-    def compute_transfer_batch(self, obj, pos, n_maps):
+    def n_maps(self, obj):
+        """_ffat_maps->size() (0 before readFFATMaps)"""
+        return self._chk(self._l.pbso_object_n_maps(self._h, obj))
+
+    def compute_transfer_batch(self, obj, pos, n_cols=None):
+        """computeTransfer(pos, T*) for many positions: [n_pos][n_cols]; columns beyond the object's map count stay 0"""
         p = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
-        out = np.empty((p.shape[0], n_maps))
-        rc = self._chk(self._l.pbso_compute_transfer_batch(self._h, obj, _dp(p), p.shape[0], _dp(out)))
+        if n_cols is None:
+            n_cols = self.n_maps(obj)
+        out = np.zeros((p.shape[0], n_cols))
+        rc = self._chk(self._l.pbso_compute_transfer_batch(self._h, obj, _dp(p), p.shape[0], _dp(out), n_cols))
         return bool(rc), out
 
     def set_use_transfer(self, obj, use, not_before=0):

@@ -644,6 +644,11 @@ int or_fatcube_parse(const unsigned char *bytes, size_t n, or_ffat_map *out) {
         else pb_skip(&r, wt);
     }
     if (r.err) rc = -1;
+    if (rc) {                        /* a rejected file leaves nothing behind (found by `make -C oracle asan`) */
+        free(out->psi);
+        out->psi = NULL;
+        out->n_psi = 0;
+    }
     return rc;
 }
 

@@ -7,6 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <stdexcept>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "openpbso_amd_facade.h"
@@ -49,7 +52,34 @@ static int PaModalCallback(void *outputBuffer, unsigned long framesPerBuffer, vo
     return 0;
 }
 
+// the lock-free sound / qnorm queue of the facade: capacity and FIFO order under a real producer / consumer pair
+static int ring_selftest() {
+    pbso_facade::SpscRing<int> r;
+    int x = -1;
+    if (r.try_dequeue(x)) return 10;
+    for (int i = 0; i < 3; ++i) if (!r.try_enqueue(i)) return 11;      // ReaderWriterQueue(2): 3 usable slots
+    if (r.try_enqueue(3)) return 12;                                   // the fourth try_enqueue fails (queue full)
+    if (r.size_approx() != 3) return 13;
+    for (int i = 0; i < 3; ++i) if (!r.try_dequeue(x) || x != i) return 14;
+    if (r.try_dequeue(x)) return 15;
+    const int n = 200000;
+    long long sum = 0;
+    bool ordered = true;
+    std::thread consumer([&]() {
+        int want = 0, v = 0;
+        while (want < n) {
+            if (r.try_dequeue(v)) { ordered = ordered && v == want; sum += v; ++want; }
+        }
+    });
+    for (int i = 0; i < n; ++i) while (!r.try_enqueue(i)) {}
+    consumer.join();
+    if (!ordered || sum != (long long)n * (n - 1) / 2) return 16;
+    std::printf("ring selftest ok\n");
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && std::string(argv[1]) == "--ring-selftest") return ring_selftest();
     const char *out_path = argc > 1 ? argv[1] : "facade_out.f32";
     const int n_modes = 96, n_verts = 8, n_buffers = 6;
     // deterministic "model": eigenvalues 200 Hz .. 9 kHz, mode shapes from a LCG
@@ -85,6 +115,38 @@ int main(int argc, char **argv) {
         solver->step();                              // simulation thread
         PaModalCallback(stereo.data(), FRAMES_PER_BUFFER, &pa);   // audio thread
         for (int i = 0; i < FRAMES_PER_BUFFER; ++i) mono.push_back(stereo[2 * i]);
+    }
+    // the GUI's "Clear force" button (tools/real_time_modal_sound.cpp:745-747): a default-constructed message,
+    // clearAllForces = true, NO data; that step() emits no buffer (modal_solver.h:186-189), the next one does
+    {
+        ForceMessage<double> clear;
+        clear.clearAllForces = true;
+        const bool ok = solver->enqueueForceMessageNoFail(clear, 4);
+        solver->step();
+        SoundMessage<double> none;
+        const bool sound = solver->dequeueSoundMessage(none);
+        std::printf("clear: enqueued=%d sound_after_clear=%d\n", (int)ok, (int)sound);
+        solver->step();
+        PaModalCallback(stereo.data(), FRAMES_PER_BUFFER, &pa);
+        for (int i = 0; i < FRAMES_PER_BUFFER; ++i) mono.push_back(stereo[2 * i]);
+    }
+    // a missing FFAT directory is an EMPTY map (io.cpp:31-34 + LoadAll): nothing happens until computeTransfer
+    // asks for _ffat_maps->at(0), which throws std::out_of_range (modal_solver.h:294)
+    {
+        std::unique_ptr<ModalSolver<double>> s2(new ModalSolver<double>(4));
+        std::vector<double> om(modes._omegaSquared.begin(), modes._omegaSquared.begin() + 4);
+        s2->setIntegrator(std::shared_ptr<ModalIntegrator<double>>(ModalIntegrator<double>::Build(2500.0, om, 6.0, 1e-7, 1. / SAMPLE_RATE, 4)));
+        s2->readFFATMaps("/nonexistent_ffat_dir_of_the_facade_test");
+        s2->step();                                   // fine: the unit transfer is in effect
+        bool threw = false;
+        try {
+            pbso_facade::VecN<double, 3> pos;
+            pos(0) = 1; pos(1) = 2; pos(2) = 3;
+            s2->computeTransfer(pos);
+        } catch (const std::out_of_range &) {
+            threw = true;
+        }
+        std::printf("missing_ffat_dir: out_of_range=%d\n", (int)threw);
     }
     pbso_facade::VecX<double> qn = solver->getQBufferNorm();
     const TransMessage<double> &tr = solver->getLatestTransfer();

@@ -85,63 +85,77 @@ def _oracle_maps(maps):
     return out
 
 
-def run_oracle(objs, events, n_buffers):
-    """same outputs in float64 from oracle/ (the reference's semantics)."""
-    n_obj = len(objs)
-    audio = np.zeros((n_obj, n_buffers * B))
-    emitted = np.ones((n_obj, n_buffers), dtype=bool)
-    qn, state, latest = {}, [], []
-    for oi, o in enumerate(objs):
-        s = orc.Solver(o.lam, o.rho, o.alpha, o.beta, n_modes=o.n_modes)
-        if o.maps is not None:
-            s.read_ffat_maps(_oracle_maps(o.maps))
-        evs = sorted([e for e in events if e["obj"] == oi], key=lambda e: e["t"])
-        # Model of the caller (GUI) thread for stamped scripts, the same on both sides of the comparison:
-        # force messages go straight to the 1023-slot queue; the other calls of an object form a FIFO
-        # in stamp order, and enqueueArprmMessageNoFail on a full 1-slot queue SPINS (modal_solver.h:
-        # 382-393) -- it, and the calls behind it, wait until a step() has drained the slot.
-        gui = []
-        ei = 0
-        for b in range(n_buffers):
-            while ei < len(evs) and evs[ei]["t"] <= b:
-                ev = evs[ei]
-                ei += 1
-                k = ev["kind"]
-                if k == "force":
-                    n = o.n_modes
-                    if ev["data"] is not None:
-                        data = np.asarray(ev["data"], dtype=np.float64)
-                    elif ev["vid"] is not None:
-                        data = orc.modal_force_vertex(o.shapes, ev["vid"], ev["vn"], n)
-                    elif ev["vids"] is not None:
-                        data = orc.modal_force_face(o.shapes, ev["vids"], ev["coords"], ev["vn"], n)
-                    else:
-                        data = np.zeros(n)
-                    f = orc.make_force(ev["force_type"], ev["width"])
-                    assert s.enqueue_force(data, f, ev["start"], ev["end"], ev["clear"])
+def _oracle_one(oi, o, events, n_buffers):
+    """one object through the oracle; returns (audio row, emitted row, {buffer: qnorm}, state, latest)"""
+    audio = np.zeros(n_buffers * B)
+    emitted = np.ones(n_buffers, dtype=bool)
+    qn = {}
+    s = orc.Solver(o.lam, o.rho, o.alpha, o.beta, n_modes=o.n_modes)
+    if o.maps is not None:
+        s.read_ffat_maps(_oracle_maps(o.maps))
+    evs = sorted([e for e in events if e["obj"] == oi], key=lambda e: e["t"])
+    # Model of the caller (GUI) thread for stamped scripts, the same on both sides of the comparison:
+    # force messages go straight to the 1023-slot queue; the other calls of an object form a FIFO
+    # in stamp order, and enqueueArprmMessageNoFail on a full 1-slot queue SPINS (modal_solver.h:
+    # 382-393) -- it, and the calls behind it, wait until a step() has drained the slot.
+    gui = []
+    ei = 0
+    for b in range(n_buffers):
+        while ei < len(evs) and evs[ei]["t"] <= b:
+            ev = evs[ei]
+            ei += 1
+            k = ev["kind"]
+            if k == "force":
+                n = o.n_modes
+                if ev["data"] is not None:
+                    data = np.asarray(ev["data"], dtype=np.float64)
+                elif ev["vid"] is not None:
+                    data = orc.modal_force_vertex(o.shapes, ev["vid"], ev["vn"], n)
+                elif ev["vids"] is not None:
+                    data = orc.modal_force_face(o.shapes, ev["vids"], ev["coords"], ev["vn"], n)
                 else:
-                    gui.append(ev)
-            while gui:
-                ev = gui[0]
-                k = ev["kind"]
-                if k == "arprm":
-                    if not s.enqueue_arprm(ev["a"], ev["sigma"], ev["mu"]):
-                        break                                   # spinning: nothing behind it happens yet
-                elif k == "listener":
-                    s.compute_transfer(ev["pos"])
-                elif k == "use_transfer":
-                    s.set_use_transfer(ev["use"])
-                gui.pop(0)
-            r = s.step()
-            if r is None:
-                emitted[oi, b] = False
+                    data = np.zeros(n)
+                f = orc.make_force(ev["force_type"], ev["width"])
+                assert s.enqueue_force(data, f, ev["start"], ev["end"], ev["clear"])
             else:
-                audio[oi, b * B:(b + 1) * B] = r[0]
-                qn[(oi, b)] = r[1].copy()
-        state.append(s.state())
-        latest.append(s.latest_transfer())
-        s.close()
-    return dict(audio=audio, emitted=emitted, qnorm=qn, state=state, latest=latest)
+                gui.append(ev)
+        while gui:
+            ev = gui[0]
+            k = ev["kind"]
+            if k == "arprm":
+                if not s.enqueue_arprm(ev["a"], ev["sigma"], ev["mu"]):
+                    break                                   # spinning: nothing behind it happens yet
+            elif k == "listener":
+                s.compute_transfer(ev["pos"])
+            elif k == "use_transfer":
+                s.set_use_transfer(ev["use"])
+            gui.pop(0)
+        r = s.step()
+        if r is None:
+            emitted[b] = False
+        else:
+            audio[b * B:(b + 1) * B] = r[0]
+            qn[b] = r[1].copy()
+    out = (audio, emitted, qn, s.state(), s.latest_transfer())
+    s.close()
+    return out
+
+
+def run_oracle(objs, events, n_buffers, only=None, threads=1):
+    """same outputs in float64 from oracle/ (the reference's semantics).  `only`: object ids to run
+    (rows of the result keep the order of `only`); threads > 1 runs objects side by side (they are
+    independent, and the oracle calls release the GIL)."""
+    ids = list(range(len(objs))) if only is None else list(only)
+    if threads > 1 and len(ids) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            res = list(ex.map(lambda oi: _oracle_one(oi, objs[oi], events, n_buffers), ids))
+    else:
+        res = [_oracle_one(oi, objs[oi], events, n_buffers) for oi in ids]
+    audio = np.array([r[0] for r in res]).reshape(len(ids), n_buffers * B)
+    emitted = np.array([r[1] for r in res]).reshape(len(ids), n_buffers)
+    qn = {(k, b): v for k, r in enumerate(res) for b, v in r[2].items()}
+    return dict(audio=audio, emitted=emitted, qnorm=qn, state=[r[3] for r in res], latest=[r[4] for r in res])
 
 
 def rel_errors(got, want):

@@ -54,3 +54,22 @@ def test_product_does_not_touch_oracle():
                 if re.search(r"oracle/|pbso_oracle|oracle_py|from oracle|import oracle", txt):
                     bad.append(os.path.join(base, f))
     assert not bad, bad
+
+
+def test_pa_convert_matches_the_portaudio_callback(capi):
+    """A9, PaModalCallback (tools/real_time_modal_sound.cpp:207-210): every frame is written twice
+    (interleaved stereo) as (float)(sound / 1E10).  Host-only entry point: no GPU needed."""
+    import ctypes as C
+
+    import numpy as np
+    lib = capi.lib()
+    rng = np.random.default_rng(9)
+    sound = np.concatenate([rng.standard_normal(513) * 1e10, [0.0, -0.0, 1e10, -3.5e9, 1e-30, 3.4e38, -3.4e38]]).astype(np.float32)
+    out = np.full(2 * sound.size + 2, 7.0, dtype=np.float32)           # two guard values behind the frames
+    lib.pbso_pa_convert(sound.ctypes.data_as(C.POINTER(C.c_float)), sound.size, out.ctypes.data_as(C.POINTER(C.c_float)))
+    want = (sound.astype(np.float64) / 1E10).astype(np.float32)
+    assert np.array_equal(out[0:-2:2], want) and np.array_equal(out[1:-2:2], want)      # L == R, bit for bit
+    assert np.array_equal(np.signbit(out[0:-2:2]), np.signbit(want))                   # -0.0 stays -0.0
+    assert out[-2] == 7.0 and out[-1] == 7.0                                           # exactly 2 * frames written
+    lib.pbso_pa_convert(sound.ctypes.data_as(C.POINTER(C.c_float)), 0, out.ctypes.data_as(C.POINTER(C.c_float)))   # zero frames: no write
+    assert np.array_equal(out[0:-2:2], want)

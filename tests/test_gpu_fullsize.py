@@ -1,0 +1,124 @@
+"""Parity at the sizes that are benchmarked (BASELINE.json configs[2..4] at FULL size, default engine
+settings: block form, the engine's own modes-per-lane / team policy, four teams per CU on the
+1024 x 512 shape).  The oracle steps every object of the small configurations and a sample of the
+1024-object one; `emitted` is compared for every object."""
+import os
+
+import numpy as np
+import pytest
+
+from openpbso_amd import Engine, ForceMessage, capi, synth
+from tests.scenarios import ObjSpec, force_ev, rel_errors, run_engine, run_oracle
+
+pytestmark = pytest.mark.gpu
+NB = 86
+TOL_MAX, TOL_L2 = 5e-4, 1e-3
+THREADS = max(1, min(8, len(os.sched_getaffinity(0))))
+
+
+def _assert_parity(got_audio, want_audio, what):
+    mx, l2 = rel_errors(got_audio, want_audio)
+    assert np.isfinite(got_audio).all()
+    assert (mx <= TOL_MAX).all(), f"{what}: max-abs/peak {mx.max():.3e} > {TOL_MAX}"
+    assert (l2 <= TOL_L2).all(), f"{what}: rel-L2 {l2.max():.3e} > {TOL_L2}"
+    return mx.max(), l2.max()
+
+
+def test_config3_64x256_moving_listener_full_size():
+    """configs[2]: 64 objects x 256 modes, 86 buffers, a new listener position EVERY buffer (per-buffer FFAT
+    re-interpolation, modal_solver.h:286-298; the scaled state is rescaled every buffer), Poisson hits."""
+    n_obj, M = 64, 256
+    objs, evs = [], []
+    for i in range(n_obj):
+        seed = synth.seed_for(3, i)
+        lam = synth.eigenvalues(M, seed)
+        objs.append(ObjSpec(lam, shapes=synth.mode_shapes(M, seed), maps=synth.ffat_maps(lam, seed)))
+        hits, vns = synth.poisson_hits(NB, seed), synth.unit_normals(NB, seed)
+        evs += [force_ev(int(b), i, vid=int(v), vn=vns[b]) for b, v in enumerate(hits) if v >= 0]
+        path = synth.listener_path(NB) * (1.0 + 0.001 * i)
+        evs += [dict(t=b, obj=i, kind="listener", pos=path[b]) for b in range(NB)]
+    got = run_engine(objs, evs, NB, qnorm=capi.QNORM_OFF)
+    assert got["info"]["recurrence_form"] == capi.FORM_BLOCK
+    want = run_oracle(objs, evs, NB, threads=THREADS)
+    assert np.array_equal(got["emitted"], want["emitted"])
+    mx, l2 = _assert_parity(got["audio"], want["audio"], "64x256 listener")
+    for a, w in zip(got["latest"], want["latest"]):
+        assert np.array_equal(a, w)                    # the fp64 FFAT lookup is bit-exact
+    print(f"C3 full size: max/peak {mx:.2e} relL2 {l2:.2e}")
+
+
+def test_config4_1024x512_impulse_stream_full_size():
+    """configs[3] on one GPU: 1024 objects x 512 modes x 86 buffers, Poisson PointForce stream with on-device
+    vertex projection -- the shape bench.py times (R = 4, two-wave teams, four teams per CU).  24 objects spread
+    over the id range go through the oracle; `emitted` is checked for all 1024."""
+    n_obj, M = 1024, 512
+    lams, shapes, scripts = [], [], []
+    with Engine(qnorm=capi.QNORM_ALL) as eng:
+        for i in range(n_obj):
+            seed = synth.seed_for(4, i)
+            lams.append(synth.eigenvalues(M, seed))
+            shapes.append(synth.mode_shapes(M, seed))
+            scripts.append((synth.poisson_hits(NB, seed), synth.unit_normals(NB, seed)))
+            eng.add_object(lams[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
+        eng.finalize()
+        fo, fv, fn, ft = [], [], [], []
+        for i in range(n_obj):
+            eng.set_use_transfer(i, False)
+            hits, vns = scripts[i]
+            hb = np.nonzero(hits >= 0)[0]
+            fo.append(np.full(hb.size, i, dtype=np.int32)); fv.append(hits[hb].astype(np.int32)); fn.append(vns[hb]); ft.append(hb)
+        fo, fv, fn, ft = (np.concatenate(x) for x in (fo, fv, fn, ft))
+        order = np.lexsort((fo, ft))
+        msgs = eng.hit_messages(fo[order], fv[order], fn[order], ft[order].astype(np.int64))
+        assert eng.enqueue_force_batch(*msgs) == fo.size
+        eng.step(NB)
+        audio = eng.audio().copy()
+        emitted = eng.emitted().copy()
+        info = eng.info()
+        rng = np.random.default_rng(4)
+        sample = sorted(set([0, 1, 511, 512, 1022, 1023] + rng.integers(0, n_obj, 18).tolist()))
+        qn_got = {(k, b): eng.qnorm(i, b).copy() for k, i in enumerate(sample) for b in (0, 40, 85)}
+    assert info["recurrence_form"] == capi.FORM_BLOCK and info["modes_per_lane"] == 4 and info["n_teams"] == 1024
+    assert emitted.all() and emitted.shape == (n_obj, NB)
+    objs = [ObjSpec(lams[i], shapes=shapes[i]) for i in sample]
+    evs = []
+    for k, i in enumerate(sample):
+        hits, vns = scripts[i]
+        evs += [force_ev(int(b), k, vid=int(v), vn=vns[b]) for b, v in enumerate(hits) if v >= 0]
+        evs.append(dict(t=0, obj=k, kind="use_transfer", use=False))
+    want = run_oracle(objs, evs, NB, threads=THREADS)
+    mx, l2 = _assert_parity(audio[sample], want["audio"], "1024x512 impulses")
+    for key, g in qn_got.items():
+        w = want["qnorm"][key]
+        assert np.abs(g[:M] - w).max() <= 2e-3 * np.abs(w).max(), key
+    print(f"C4 full size: {len(sample)} objects, max/peak {mx:.2e} relL2 {l2:.2e}")
+
+
+def test_config5_8x4096_sustained_scraping_full_size():
+    """configs[4]: 8 objects x 4096 modes, 86 buffers of sustained AutoregressiveForce scraping
+    (tools/real_time_modal_sound.cpp:754-776, 1127-1160): a sustainedForceStart message, then one
+    GetModalForceFace message per buffer (on-device face projection), one AR parameter update on the way
+    (modal_solver.h:226-236), a sustainedForceEnd near the end and free ringing after it.  Every buffer of
+    the contact is a dense-profile buffer (the block form steps those per sample); 4096 modes = teams cut
+    over several workgroups."""
+    n_obj, M = 8, 4096
+    objs, evs = [], []
+    for i in range(n_obj):
+        seed = synth.seed_for(5, i)
+        lam = synth.eigenvalues(M, seed)
+        objs.append(ObjSpec(lam, shapes=synth.mode_shapes(M, seed)))
+        rng = np.random.default_rng(seed)
+        vns = synth.unit_normals(NB, seed)
+        evs.append(dict(t=0, obj=i, kind="use_transfer", use=False))
+        evs.append(force_ev(0, i, force_type=2, start=True))           # dummy start message: data = 0
+        for b in range(1, 70):
+            bary = rng.random(3)
+            evs.append(force_ev(b, i, vids=rng.integers(0, synth.N_VERTS, 3), coords=bary / bary.sum(), vn=vns[b], force_type=2))
+        evs.append(dict(t=30, obj=i, kind="arprm", a=[0.6, 0.2], sigma=0.002, mu=0.1))
+        evs.append(force_ev(70, i, force_type=2, end=True))
+    got = run_engine(objs, evs, NB, qnorm=capi.QNORM_OFF)
+    assert got["info"]["recurrence_form"] == capi.FORM_BLOCK
+    want = run_oracle(objs, evs, NB, threads=THREADS)
+    assert np.array_equal(got["emitted"], want["emitted"])
+    mx, l2 = _assert_parity(got["audio"], want["audio"], "8x4096 scraping")
+    print(f"C5 full size: max/peak {mx:.2e} relL2 {l2:.2e}")

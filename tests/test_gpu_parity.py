@@ -534,7 +534,9 @@ def test_qnorm_off_gives_identical_audio():
 
 def test_error_paths_match_reference_asserts():
     from openpbso_amd import Engine, ForceMessage
+    from openpbso_amd import Engine
     from openpbso_amd.solver import PbsoError
+    from oracle import oracle_py as orc
     lam = synth.eigenvalues(32, 3)
     with Engine() as eng:
         eng.add_object(lam, synth.RHO, synth.ALPHA, synth.BETA)
@@ -553,7 +555,9 @@ def test_degenerate_objects_and_arguments():
     """An object with no audible mode at all (numModesAudible can return 0, ModeData.h:120-148), one
     with a single mode, invalid calls answered with a status instead of undefined behaviour."""
     from openpbso_amd import Engine
+    from openpbso_amd import Engine
     from openpbso_amd.solver import PbsoError
+    from oracle import oracle_py as orc
     lam1 = synth.eigenvalues(1, 5)
     with Engine() as eng:
         a = eng.add_object(np.zeros(0), synth.RHO, synth.ALPHA, synth.BETA)
@@ -613,7 +617,9 @@ def test_live_assert_of_the_reference_is_a_status_and_poisons_the_engine():
     reference's next step() dies on the assert at modal_solver.h:223.  The engine answers
     PBSO_ERR_ASSERT, and -- its queues consumed half-way -- refuses further steps."""
     from openpbso_amd import Engine
+    from openpbso_amd import Engine
     from openpbso_amd.solver import PbsoError
+    from oracle import oracle_py as orc
     lam = synth.eigenvalues(16, 4)
     with Engine() as eng:
         eng.add_object(lam, synth.RHO, synth.ALPHA, synth.BETA)
@@ -703,3 +709,30 @@ def test_batch_enqueue_on_several_threads(monkeypatch):
     t1, a1 = run("1")
     t4, a4 = run("4")
     assert t1 == t4 == n and np.abs(a1).max() > 0 and np.array_equal(a1, a4)
+
+
+def test_compute_transfer_batch_width_follows_the_map_count():
+    """computeTransfer(pos, T*) writes _ffat_maps->size() entries (modal_solver.h:308-312): with fewer maps than
+    modes the other columns are left alone, and an output narrower than the map count is refused instead of
+    being overrun."""
+    from openpbso_amd import Engine
+    from openpbso_amd.solver import PbsoError
+    from oracle import oracle_py as orc
+    n_modes, n_maps = 48, 20
+    lam = synth.eigenvalues(n_modes, 4242)
+    maps = synth.ffat_maps(lam, 4243, dim=4)[:n_maps]
+    pos = synth.listener_path(5)
+    with Engine() as eng:
+        oid = eng.add_object(lam, synth.RHO, synth.ALPHA, synth.BETA)
+        eng.set_ffat_maps(oid, maps)
+        eng.finalize()
+        assert eng.n_maps(oid) == n_maps
+        ok, got = eng.compute_transfer_batch(oid, pos)                   # sized from the engine's map count
+        assert ok and got.shape == (5, n_maps)
+        ok, wide = eng.compute_transfer_batch(oid, pos, n_modes)          # a caller sized for N_modes (the facade)
+        assert ok and np.array_equal(wide[:, :n_maps], got) and not wide[:, n_maps:].any()
+        with pytest.raises(PbsoError):
+            eng.compute_transfer_batch(oid, pos, n_maps - 1)
+    omaps = [orc.uniform_cube(m["mode_id"], m["k"], m["center"], m["cell_size"], 4, m["psi"]) for m in maps]
+    want = np.array([[abs(orc.ffat_get_map_val(om, p)) for om in omaps] for p in pos])
+    assert np.array_equal(got, want)

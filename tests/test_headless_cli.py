@@ -26,7 +26,8 @@ def make_data_dir(d, name="bowl", n_modes=40, n_verts=12, thr=9000.0):
     with open(d / f"{name}.tet.obj", "w") as f:
         for v in rng.standard_normal((n_verts, 3)):
             f.write("v %.6f %.6f %.6f\n" % tuple(v))
-        f.write("f 1 2 3\n")
+        for i in range(n_verts):                       # a triangle strip that touches every vertex
+            f.write("f %d %d %d\n" % (i + 1, (i + 1) % n_verts + 1, (i + 2) % n_verts + 1))
     with open(d / f"{name}_surf.modes", "wb") as f:
         f.write(np.array([3 * n_verts, n_modes], dtype=np.int32).tobytes())
         f.write(lam.tobytes())
@@ -53,16 +54,25 @@ def test_headless_directory_run_matches_oracle(tmp_path, oracle):
     d.mkdir()
     lam, shapes = make_data_dir(d)
     nb = 8
-    hits = [(0, 3, (0.2, -0.5, 1.0), "point"), (2, 7, (1.0, 0.0, 0.3), "gauss 400"), (5, 1, (0.0, 1.0, 0.0), "point")]
+    # the third hit carries no normal: the tool takes VN.row(vid) of the mesh (igl::per_vertex_normals, tools/...:509,607)
+    from openpbso_amd import loaders
+    V, F, VN = loaders.read_obj(str(d / "bowl.tet.obj"))
+    fn = np.cross(V[F[:, 1]] - V[F[:, 0]], V[F[:, 2]] - V[F[:, 0]])           # double-area x unit normal of every face
+    vn_np = np.zeros_like(V)
+    for k in range(3):
+        np.add.at(vn_np, F[:, k], fn)
+    vn_np /= np.linalg.norm(vn_np, axis=1, keepdims=True)
+    assert np.allclose(VN, vn_np, rtol=0, atol=1e-14) and V.shape == (12, 3) and F.shape == (12, 3)
+    hits = [(0, 3, (0.2, -0.5, 1.0), "point"), (2, 7, (1.0, 0.0, 0.3), "gauss 400"), (5, 1, None, "point")]
     (tmp_path / "hits.txt").write_text("# buffer vid nx ny nz type\n" + "".join(
-        f"{b} {v} {n[0]} {n[1]} {n[2]} {t}\n" for b, v, n, t in hits))
+        (f"{b} {v} {n[0]} {n[1]} {n[2]} {t}\n" if n is not None else f"{b} {v} - {t}\n") for b, v, n, t in hits))
     path = synth.listener_path(nb)
     (tmp_path / "listener.txt").write_text("".join(f"{b} {float(p[0])!r} {float(p[1])!r} {float(p[2])!r}\n" for b, p in enumerate(path)))
     r = subprocess.run([EXE, "-d", str(d), "--hits", str(tmp_path / "hits.txt"), "--listener", str(tmp_path / "listener.txt"),
                         "--buffers", str(nb), "--out", str(tmp_path / "o.wav"), "--raw", str(tmp_path / "o.raw")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert "object name: bowl" in r.stdout
+    assert "object name: bowl" in r.stdout and "mesh: 12 vertices, 12 triangles" in r.stdout
     got = np.fromfile(tmp_path / "o.raw", dtype=np.float32).astype(np.float64)
 
     # ---- the same directory through the oracle's loaders
@@ -90,7 +100,7 @@ def test_headless_directory_run_matches_oracle(tmp_path, oracle):
         s.compute_transfer(path[bb])
         for hb, v, n, t in hits:
             if hb == bb:
-                vn = np.array(n) / np.linalg.norm(n)
+                vn = np.array(n) / np.linalg.norm(n) if n is not None else vn_np[v]
                 f = oracle.make_force(oracle.GAUSSIAN, 400.0) if t.startswith("gauss") else oracle.make_force(oracle.POINT)
                 s.enqueue_force(oracle.modal_force_vertex(md, v, vn, n_aud), f)
         want.append(s.step()[0])

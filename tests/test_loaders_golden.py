@@ -165,3 +165,57 @@ def test_golden_audio_fixture_matches_oracle(oracle):
     out = [s.step() for _ in range(4)]
     assert np.array_equal(np.concatenate([o[0] for o in out]), z["sound"])
     assert np.array_equal(np.array([o[1] for o in out]), z["qnorm"])
+
+
+def test_obj_reader_and_area_weighted_vertex_normals(loaders, tmp_path):
+    """<name>.tet.obj as tools/real_time_modal_sound.cpp:508-509 reads it: v / f records only, 1-based,
+    negative and a/b/c face indices, polygons as triangle fans; per-vertex normals weighted by face area
+    (libigl's default; the weighting itself is unpinned: libigl is not in the reference tree)."""
+    # a unit cube: quads, mixed index forms, a comment, texture / normal records that must be ignored
+    obj = """# cube
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+vt 0.5 0.5
+vn 0 0 1
+v 0 0 1
+v 1 0 1
+v 1 1 1
+v 0 1 1
+f 1 4 3 2
+f 5/1 6/1 7/1 8/1
+f 1//1 2//1 6//1 5//1
+f -7 -6 -2 -3
+f 3 4 8 7
+g side
+f 4/1/1 1/1/1 5/1/1 8/1/1
+"""
+    p = tmp_path / "cube.obj"
+    p.write_text(obj)
+    V, F, VN = loaders.read_obj(str(p))
+    assert V.shape == (8, 3) and F.shape == (12, 3) and F.min() == 0 and F.max() == 7
+    assert np.array_equal(F[0], [0, 3, 2]) and np.array_equal(F[1], [0, 2, 1])            # fan of the first quad
+    assert np.array_equal(F[6], [1, 2, 6]) and np.array_equal(F[7], [1, 6, 5])            # -7 -6 -2 -3 with 8 vertices read
+    fn = np.cross(V[F[:, 1]] - V[F[:, 0]], V[F[:, 2]] - V[F[:, 0]])
+    want = np.zeros_like(V)
+    for k in range(3):
+        np.add.at(want, F[:, k], fn)
+    want /= np.linalg.norm(want, axis=1, keepdims=True)
+    assert np.allclose(VN, want, rtol=0, atol=1e-15)
+    # outward faces of a cube: every vertex normal points away from the centre, and is a unit vector
+    assert (np.einsum("ij,ij->i", VN, V - 0.5) > 0).all() and np.allclose(np.linalg.norm(VN, axis=1), 1.0)
+    # area weighting: a sliver triangle barely turns the normal of a vertex it shares with a big one
+    (tmp_path / "w.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1e-3\nf 1 2 3\nf 1 4 2\n")
+    _, _, vn2 = loaders.read_obj(str(tmp_path / "w.obj"))
+    assert vn2[0][2] > 0.999 and abs(vn2[0][1]) < 2e-3
+    # a vertex that no face uses keeps a zero normal; malformed files are rejected
+    (tmp_path / "lone.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 5 5 5\nf 1 2 3\n")
+    assert np.array_equal(loaders.read_obj(str(tmp_path / "lone.obj"))[2][3], [0, 0, 0])
+    for bad in ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 4\n", "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 0 1 2\n",
+                "v 0 0 0\nv 1 0 0\nf 1 2\n", "v 0 0\n", "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 -4\n"):
+        (tmp_path / "bad.obj").write_text(bad)
+        with pytest.raises(IOError):
+            loaders.read_obj(str(tmp_path / "bad.obj"))
+    with pytest.raises(IOError):
+        loaders.read_obj(str(tmp_path / "missing.obj"))

@@ -8,6 +8,8 @@
 // PaModalCallback would have played (:207-210, sound / 1e10) as a mono float32 WAV.
 //
 //   --hits FILE      lines: <buffer> <vertex_id> <nx> <ny> <nz> [point|gauss <width_us>|ar]
+//                    or:    <buffer> <vertex_id> - [point|gauss <width_us>|ar]   (normal = VN.row(vid) of the mesh:
+//                    igl::per_vertex_normals of the .obj, tools/...:509,607 -- needs -m / -d)
 //   --listener FILE  lines: <buffer> <x> <y> <z>          (computeTransfer at that buffer)
 //   --buffers N      number of 513-sample buffers (default 86 ~ 1 s)
 //   --out FILE       output WAV (default out.wav);  --raw FILE also dumps the fp32 sound values
@@ -45,16 +47,6 @@ static std::string guess_name(const std::string &dir) {
     closedir(d);
     if (found.empty()) die("no *.tet.obj in " + dir);
     return found.substr(0, found.find_first_of("."));
-}
-
-static int count_obj_vertices(const std::string &path) {
-    std::ifstream f(path);
-    if (!f) return -1;
-    std::string line;
-    int n = 0;
-    while (std::getline(f, line))
-        if (line.size() > 1 && line[0] == 'v' && (line[1] == ' ' || line[1] == '\t')) ++n;
-    return n;
 }
 
 static void write_wav_f32(const std::string &path, const std::vector<float> &mono, int rate) {
@@ -116,9 +108,23 @@ int main(int argc, char **argv) {
     check(e, pbso_modes_read(modes.c_str(), &n_dof, &n_modes, &om, &md), "modes_read");
     pbso_free(om);
     pbso_free(md);
+    // igl::read_triangle_mesh(obj_file, V, F); igl::per_vertex_normals(V, F, VN);   tools/...:508-509
+    std::vector<double> VN;
     if (!mesh.empty()) {
-        const int nv = count_obj_vertices(mesh);
-        if (nv >= 0 && nv * 3 != n_dof) die("DOFs mismatch: .obj has " + std::to_string(nv) + " vertices, modes have nDOF " + std::to_string(n_dof));
+        int nv = 0, nf = 0;
+        double *V = nullptr, *vn = nullptr;
+        int *F = nullptr;
+        const int orc = pbso_obj_read(mesh.c_str(), &nv, &nf, &V, &F, &vn);
+        if (orc == PBSO_OK) {
+            if (nv * 3 != n_dof) die("DOFs mismatch: .obj has " + std::to_string(nv) + " vertices, modes have nDOF " + std::to_string(n_dof));
+            VN.assign(vn, vn + 3 * (size_t)nv);
+            std::printf("mesh: %d vertices, %d triangles\n", nv, nf);
+            pbso_free(V);
+            pbso_free(F);
+            pbso_free(vn);
+        } else if (d.empty()) {
+            die("cannot read mesh " + mesh);
+        }
     }
     std::printf("modes: %d of %d audible, nDOF %d\n", n_aud, n_modes, n_dof);
     check(e, pbso_finalize(e), "finalize");
@@ -145,8 +151,16 @@ int main(int argc, char **argv) {
         while (std::getline(f, line)) {
             if (line.empty() || line[0] == '#') continue;
             std::istringstream iss(line);
-            long b; int vid; double n[3]; std::string type = "point";
-            if (!(iss >> b >> vid >> n[0] >> n[1] >> n[2])) die("bad hit line: " + line);
+            long b; int vid; double n[3]; std::string type = "point", tok;
+            if (!(iss >> b >> vid >> tok)) die("bad hit line: " + line);
+            if (tok == "-") {                                // the tool's own path: vn = VN.row(vid), tools/...:607
+                if (VN.empty()) die("hit without a normal needs the mesh (-m / -d)");
+                if (vid < 0 || 3 * (size_t)vid + 2 >= VN.size()) die("vertex id out of range: " + line);
+                for (int j = 0; j < 3; ++j) n[j] = VN[3 * (size_t)vid + j];
+            } else {
+                n[0] = std::atof(tok.c_str());
+                if (!(iss >> n[1] >> n[2])) die("bad hit line: " + line);
+            }
             iss >> type;
             pbso_force_msg m;
             std::memset(&m, 0, sizeof(m));
