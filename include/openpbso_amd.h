@@ -270,6 +270,10 @@ typedef struct pbso_engine_info {
                                * 16 waves of modes are stepped by several) */
     int recurrence_form;      /* the form that runs (PBSO_FORM_BLOCK falls back to VELOCITY when
                                * frames_per_buffer != 513) */
+    int64_t total_block_launches;     /* oscillator-bank launches on the block kernel (K1b) ...            */
+    int64_t total_sample_launches;    /* ... and on the per-sample kernel (K1): every launch of the per-sample
+                                       * forms, and launches of the block form in which more than half of the
+                                       * (object, buffer) pairs carry a dense force profile (sustained contact) */
 } pbso_engine_info;
 int pbso_get_info(pbso_engine *e, pbso_engine_info *out);
 /* diagnostics (engine created with env PBSO_CENSUS=1): for every object's

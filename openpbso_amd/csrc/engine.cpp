@@ -300,6 +300,7 @@ int Engine::init() {
     form_ = desc_.recurrence_form;
     // the block form tiles a buffer as 1 + 2 * 16 * 16 samples (the reference's 513); other lengths step per sample
     if (form_ == PBSO_FORM_BLOCK && B_ != 1 + 2 * BLOCK_J * BLOCK_N) form_ = PBSO_FORM_VELOCITY;
+    if (const char *v = std::getenv("PBSO_DENSE_LAUNCHES")) dense_to_k1_ = std::string(v) != "block";
     if (const char *v = std::getenv("PBSO_BLOCK_TEAM_WAVES")) block_team_waves_ = std::min(MAX_WAVES_PER_BLOCK_TEAM, std::max(1, std::atoi(v)));
     if (desc_.qnorm_mode < PBSO_QNORM_OFF || desc_.qnorm_mode > PBSO_QNORM_CLOSED)
         return fail(PBSO_ERR_INVALID, "qnorm_mode");
@@ -1455,6 +1456,14 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     // stream); an engine that needs several rounds of workgroups runs its classes one after the other
     // (512 x 512 + 4096 x 64: 3.1 ms in sequence, 3.7 ms side by side -- teams of different size fragment
     // the CUs' LDS and wave slots).
+    // Block form: a launch in which most (object, buffer) pairs carry a dense force profile -- sustained
+    // scraping, forces.h:107-128 -- has nothing for the matrix pipe to do (every sample is forced) and runs on the
+    // per-sample kernel K1, whose inner loop is built for exactly that; state layout, teams and scaled-state
+    // rules are shared, so the two kernels hand over at any launch boundary.  (Audio then is bit-identical
+    // across different cuts of a step only while both cuts pick the same kernel; always within tolerance.)
+    // PBSO_DENSE_LAUNCHES=block keeps every launch on the block kernel (bit-identical audio for any cut of a step).
+    const bool dense_heavy = form_ == PBSO_FORM_BLOCK && dense_to_k1_ && (long long)n_prows_ * 2 > (long long)N * nb;
+    (dense_heavy || form_ != PBSO_FORM_BLOCK ? tot_sample_launches_ : tot_block_launches_) += 1;
     bool used[N_CLASS_STREAMS] = {false, false, false};
     const bool fork = classes_.size() > 1 && ev_fork_ && total_team_waves_ <= 4096;
     if (fork) HIPTRY(hipEventRecord(ev_fork_, sk));
@@ -1470,7 +1479,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
             }
         }
         kp.teams = d_teams_.p + c.first;
-        if (form_ == PBSO_FORM_BLOCK)
+        if (form_ == PBSO_FORM_BLOCK && !dense_heavy)
             LAUNCHTRY(iir_block::launch_iir_block(kp, c.count, R_, c.W, desc_.qnorm_mode, s));
         else
             LAUNCHTRY(iir_scalar::launch_iir_bank(kp, c.count, R_, c.W, form_ == PBSO_FORM_DIRECT ? 1 : 0, desc_.qnorm_mode, s));
@@ -1623,6 +1632,8 @@ int Engine::info(pbso_engine_info *out) {
     out->n_teams = n_teams_;
     out->lds_bytes_per_workgroup = !finalized_ ? 0 : form_ == PBSO_FORM_BLOCK ? (int)block_lds_bytes(W_) : (int)iir_lds_bytes(W_, n_tiles_);
     out->recurrence_form = form_;
+    out->total_block_launches = tot_block_launches_;
+    out->total_sample_launches = tot_sample_launches_;
     out->buffers_done = buffers_done_;
     out->last_step_host_plan_ms = last_plan_ms_;
     out->last_step_forced_rows = last_frows_;

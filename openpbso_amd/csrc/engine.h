@@ -213,7 +213,7 @@ private:
     std::vector<EvQuad> ev_free_, ev_pending_;           // one quad per step, harvested in info()
     int harvest_timing();
     double tot_kernel_ms_ = 0, tot_device_ms_ = 0, tot_plan_ms_ = 0, last_kernel_ms_ = 0, last_device_ms_ = 0;
-    int64_t tot_steps_ = 0;
+    int64_t tot_steps_ = 0, tot_block_launches_ = 0, tot_sample_launches_ = 0;
     std::string err_;
     std::vector<Object> objs_;
     int64_t buffers_done_ = 0;
@@ -232,6 +232,7 @@ private:
     DevBuf<float> d_gq_;                                 // closed-form qnorm: G11, 2 G12, G22 planes
     DevBuf<float> d_pc_, d_wtab_;                        // block form: P = A^16 planes and the MFMA W table (kernels_block.hip)
     int form_ = PBSO_FORM_BLOCK;                         // the form that runs (block falls back to velocity for odd buffer lengths)
+    bool dense_to_k1_ = true;                            // PBSO_DENSE_LAUNCHES=block: dense-heavy launches stay on the block kernel
     int block_team_waves_ = 0;                           // PBSO_BLOCK_TEAM_WAVES: waves per team of the block form (0 = policy)
     DevBuf<double> d_shapes_;
     DevBuf<long long> d_shape_off_;
