@@ -480,7 +480,8 @@ def main():
         # roofline of the dominant kernel: HIP events on the launch stream, this rank
         k_ms = m["kernel_ms"]
         mode_samples = m["n_local"] * M * nb * B
-        block = m["form_run"] == 0
+        # (a block-form engine runs launches that are mostly dense-profile buffers on the per-sample kernel)
+        block = m["form_run"] == 0 and m["info"]["total_block_launches"] >= m["info"]["total_sample_launches"]
         flop_exec = FLOP_BLOCK if block else FLOP_REF
         tf_exec = flop_exec * mode_samples / (k_ms * 1e-3) * 1e-12
         tf_ref = FLOP_REF * mode_samples / (k_ms * 1e-3) * 1e-12

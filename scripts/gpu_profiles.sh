@@ -1,30 +1,33 @@
 #!/bin/bash
-# Collects the round's evidence under gpurun_out/ (copied to profiles/ afterwards):
-# rocprofv3 kernel-trace stats of the default bench command, PMC passes (own runs,
-# no trace domains besides kernel-trace), the workgroup census, and bench JSON lines.
+# Collects the round's evidence under gpurun_out/final/ (copied to profiles/ afterwards by
+# scripts/collect_profiles.py): rocprofv3 kernel-trace stats of the default bench command, PMC passes
+# (own runs, no trace domains besides kernel-trace), the workgroup census, and bench JSON lines.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out/final
 export TMPDIR=/tmp
 R=$PWD
-echo "== env =="; (rocminfo | grep -E "Marketing Name|gfx9" | sort | uniq -c | head -4; lscpu | grep -E "Model name|^CPU\(s\)"; free -g | head -2) > gpurun_out/final/env.txt 2>&1; cat gpurun_out/final/env.txt
-echo "== bench default (with cpu baseline) =="; timeout 900 python bench.py > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err; echo rc=$?; cat gpurun_out/final/bench_default.json
-for q in closed off; do timeout 600 python bench.py --no-cpu-baseline --qnorm $q > gpurun_out/final/bench_qnorm_$q.json 2>/dev/null; done
+echo "== env =="; (rocminfo | grep -E "Marketing Name|gfx9" | sort | uniq -c | head -4; lscpu | grep -E "Model name|^CPU\(s\)"; echo "cgroup cpu.max: $(cat /sys/fs/cgroup/cpu.max 2>/dev/null)"; free -g | head -2) > gpurun_out/final/env.txt 2>&1; cat gpurun_out/final/env.txt
+echo "== bench default (driver flags, with cpu baseline and parity) =="; timeout 900 python bench.py > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err; echo rc=$?; cut -c1-400 gpurun_out/final/bench_default.json
+timeout 600 python bench.py --no-cpu-baseline --qnorm off > gpurun_out/final/bench_qnorm_off.json 2>/dev/null
+timeout 600 python bench.py --no-cpu-baseline --form velocity > gpurun_out/final/bench_velocity.json 2>/dev/null
+timeout 600 python bench.py --no-cpu-baseline --form velocity --qnorm closed > gpurun_out/final/bench_velocity_qnorm_closed.json 2>/dev/null
 timeout 600 python bench.py --no-cpu-baseline --form direct > gpurun_out/final/bench_direct.json 2>/dev/null
 echo "== rocprofv3 kernel trace + stats of the default command =="
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/rocprof_stats -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/final/rocprof_stats.log 2>&1); echo rc=$?
 f=$(find gpurun_out/final/rocprof_stats -name "*kernel_stats.csv" | head -1); head -8 "$f" | cut -c1-260
-pmc() { name=$1; shift; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/final/pmc_$name -- python3 $R/bench.py --steps 3 --warmup 1 --settle 0 --no-cpu-baseline > $R/gpurun_out/final/pmc_$name.log 2>&1); echo "pmc $name rc=$?"; }
-pmc sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU
-pmc sq2 SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE
-pmc sq3 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32
-pmc sq4 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FLOPS_FP32 SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_INSTS_LDS_STORE SQ_INSTS_LDS_LOAD SQ_ACTIVE_INST_VALU2 SQ_IFETCH
+python scripts/trace_gaps.py gpurun_out/final/rocprof_stats > gpurun_out/final/trace_gaps.txt 2>&1; tail -8 gpurun_out/final/trace_gaps.txt
+pmc() { name=$1; shift; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/final/pmc_$name -- python3 $R/bench.py --steps 3 --warmup 1 --settle 0 --no-cpu-baseline --no-parity > $R/gpurun_out/final/pmc_$name.log 2>&1); echo "pmc $name rc=$?"; }
+pmc m1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA
+pmc m2 SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE
+pmc m3 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_LDS SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_CYCLES
+pmc m4 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_LDS_STORE SQ_INSTS_LDS_LOAD SQ_INSTS_SMEM SQ_IFETCH
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 python - <<'PY' > gpurun_out/final/pmc_summary.txt
 import csv, glob, collections
-print("per-dispatch averages for pbso kernels (rocprofv3 --pmc, bench.py --steps 3 --warmup 1)")
-for name in ("sq1", "sq2", "sq3", "sq4", "fetch", "write"):
+print("per-dispatch averages for pbso kernels (rocprofv3 --pmc, bench.py --steps 3 --warmup 1 --settle 0)")
+for name in ("m1", "m2", "m3", "m4", "fetch", "write"):
     fs = glob.glob(f"gpurun_out/final/pmc_{name}/**/*counter_collection.csv", recursive=True)
     if not fs: continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
@@ -34,10 +37,7 @@ for name in ("sq1", "sq2", "sq3", "sq4", "fetch", "write"):
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
     for k in agg:
         for c, v in sorted(agg[k].items()):
-            print(f"{name:6s} {k:50s} {c:24s} {v / cnt[(k, c)]:.6g}  (n={cnt[(k, c)]})")
+            print(f"{name:6s} {k:50s} {c:28s} {v / cnt[(k, c)]:.6g}  (n={cnt[(k, c)]})")
 PY
-cat gpurun_out/final/pmc_summary.txt
-echo "== census =="; PBSO_CENSUS=1 timeout 300 python scripts/census.py 1024 2>&1 | grep -v amdgpu.ids > gpurun_out/final/census.txt; cat gpurun_out/final/census.txt
-echo "== issue-rate microbenchmarks =="
-for n in 3 4 5; do ./openpbso_amd/microbench${n}_gfx950 > gpurun_out/final/microbench$n.txt 2>&1; done
-cat gpurun_out/final/microbench4.txt gpurun_out/final/microbench5.txt
+grep -E "iir_block" gpurun_out/final/pmc_summary.txt
+echo "== census =="; PBSO_CENSUS=1 timeout 300 python scripts/census.py 1024 2>&1 | grep -v amdgpu.ids > gpurun_out/final/census.txt; tail -8 gpurun_out/final/census.txt

@@ -11,7 +11,7 @@ for r in csv.DictReader(open(f)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-60:]))
 rows.sort()
 t0 = rows[0][0]
-k1 = [r for r in rows if "iir_bank" in r[2]]
+k1 = [r for r in rows if "iir_bank" in r[2] or "iir_block" in r[2]]
 print("all kernels in the last two steps:")
 if len(k1) >= 3:
     lo = k1[-3][1]
