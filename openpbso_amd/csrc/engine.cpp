@@ -91,7 +91,7 @@ private:
 
 void PlanCtx::begin() {
     row_ptr.clear(); slot_idx.clear(); row_obj.clear(); stage_slot.clear(); chain_ptr.clear();
-    tprof.clear(); prof_entries.clear(); prof_rows.clear(); stage.clear(); proj.clear(); ffat.clear();
+    tprof.clear(); prof_entries.clear(); prof_rows.clear(); stage.clear(); proj.clear(); proj_direct.clear(); ffat.clear();
     forced.clear(); freed_this_plan.clear(); freed_ar.clear();
     n_frows = n_prows = n_xfer = 0;
     chain_obj = -1;
@@ -160,6 +160,23 @@ hipError_t PinBuf<T>::ensure(size_t n) {
     cap = ncap;
     return hipSuccess;
 }
+// grows and keeps the first `keep` elements (the plan's fixed front part is written in place before the
+// variable part is known)
+template <class T>
+hipError_t PinBuf<T>::ensure_keep(size_t n, size_t keep) {
+    if (n <= cap) return hipSuccess;
+    size_t ncap = std::max(n + n / 4, cap + cap / 2);
+    T *np = nullptr;
+    hipError_t e = hipHostMalloc((void **)&np, ncap * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    if (p) {
+        if (keep) std::memcpy(np, p, std::min(keep, cap) * sizeof(T));
+        (void)hipHostFree(p);
+    }
+    p = np;
+    cap = ncap;
+    return hipSuccess;
+}
 template <class T>
 void PinBuf<T>::release() {
     if (p) (void)hipHostFree(p);
@@ -168,14 +185,7 @@ void PinBuf<T>::release() {
 }
 
 void Engine::PlanSet::release() {
-    h_desc.release(); d_desc.release(); h_row_ptr.release(); d_row_ptr.release();
-    h_slot_idx.release(); d_slot_idx.release(); h_row_obj.release(); d_row_obj.release();
-    h_tprof.release(); d_tprof.release(); h_stage.release(); d_stage.release();
-    h_stage_slot.release(); d_stage_slot.release(); h_proj.release(); d_proj.release();
-    h_ffat.release(); d_ffat.release(); h_copy.release(); d_copy.release();
-    h_xfer_init.release(); d_xfer_init.release();
-    h_prof_entries.release(); d_prof_entries.release(); h_prof_rows.release(); d_prof_rows.release();
-    h_chain_ptr.release(); d_chain_ptr.release();
+    h_arena.release(); d_arena.release(); d_tprof.release();
 }
 
 // ---------------------------------------------------------------------------
@@ -851,7 +861,7 @@ int Engine::set_use_transfer(int obj, int use, int64_t not_before) {
 }
 
 void Engine::release(PlanCtx &c, ActiveForce &af) {
-    c.freed_this_plan.push_back(af.slot);
+    if (af.slot >= 0) c.freed_this_plan.push_back(af.slot);      // (negative: an on-the-fly projection, no pool row)
     if (af.ar_state >= 0) c.freed_ar.push_back(af.ar_state);
     af.ar_state = -1;
 }
@@ -870,7 +880,7 @@ int Engine::alloc_slot(PlanCtx &c) {
 int Engine::plan_object(PlanCtx &c, int oi, int b, int nb, int64_t t) {
     Object &o = objs_[oi];
     const int N = (int)objs_.size();
-    BufDesc &d = set_[cur_set_].h_desc.p[(size_t)oi * nb + b];
+    BufDesc &d = plan_desc_[(size_t)oi * nb + b];
 
     // GUI-thread calls stamped for this buffer or earlier
     while (!o.pending.empty() && o.pending.front().not_before <= t) {
@@ -906,8 +916,12 @@ int Engine::plan_object(PlanCtx &c, int oi, int b, int nb, int64_t t) {
             emitted_[(size_t)oi * plan_nb_total_ + plan_b0_ + b] = 0;
             return PBSO_OK;
         }
-        // the message's modal data becomes one immutable row of the slot pool
-        const int slot = alloc_slot(c);
+        // the message's modal data becomes one immutable row of the slot pool -- except for the hit of a plain
+        // PointForce (forces.h:81-90: alive for exactly one buffer), whose projection the combine kernel
+        // evaluates on the fly: slot -(event + 1) refers to the event, no pool row is written or read back
+        const bool direct = device_profiles_ && mess.force_type == PBSO_POINT_FORCE && !mess.sustained_start && !mess.sustained_end &&
+                            !o.sustained && (mess.data_kind == PBSO_DATA_VERTEX || mess.data_kind == PBSO_DATA_FACE);
+        const int slot = direct ? -((int)c.proj_direct.size() + 1) : alloc_slot(c);
         if (mess.data_kind == PBSO_DATA_EXPLICIT || mess.data_kind == PBSO_DATA_ZERO) {
             const size_t off = c.stage.size();
             c.stage.resize(off + m_pad_, 0.0);
@@ -924,7 +938,7 @@ int Engine::plan_object(PlanCtx &c, int oi, int b, int nb, int64_t t) {
                 pe.coords[j] = mess.coords[j];
                 pe.vn[j] = mess.vn[j];
             }
-            c.proj.push_back(pe);
+            (direct ? c.proj_direct : c.proj).push_back(pe);
         }
         ActiveForce af;
         af.slot = slot;
@@ -956,7 +970,7 @@ int Engine::plan_object(PlanCtx &c, int oi, int b, int nb, int64_t t) {
             o.sustained = false;
             slot_used = true;   // freed through the list (or below)
         }
-        if (!slot_used) c.freed_this_plan.push_back(slot);
+        if (!slot_used && slot >= 0) c.freed_this_plan.push_back(slot);
     }
 
     // :206-240 time profile and spatial sum
@@ -1012,8 +1026,15 @@ int Engine::plan_object(PlanCtx &c, int oi, int b, int nb, int64_t t) {
                     release(c, af);                                            // erase
                 } else {
                     c.slot_idx.push_back(af.slot);
-                    if (w != r) o.active[w] = std::move(af);
-                    ++w;
+                    if (af.force.type == PBSO_POINT_FORCE) {
+                        // a PointForce adds its one sample and is erased by the NEXT step()'s Add (forces.h:84-85,
+                        // modal_solver.h:212-215); nothing can observe it in between, so it leaves the list now
+                        // and an object with no other live force needs no bookkeeping for the next buffer
+                        release(c, af);
+                    } else {
+                        if (w != r) o.active[w] = std::move(af);
+                        ++w;
+                    }
                 }
             }
             o.active.resize(w);
@@ -1150,15 +1171,19 @@ int Engine::plan_object_span(PlanCtx &c, int oi, int nb) {
 int Engine::plan(int nb) {
     const int N = (int)objs_.size();
     PlanSet &ps = set_[cur_set_];
-    HIPTRY(ps.h_desc.ensure((size_t)N * nb));
-    HIPTRY(ps.h_xfer_init.ensure(N));
+    // one pinned arena per plan set, uploaded with ONE copy: [descriptors | xfer_init | everything the planner emits]
+    ps.off_xfer_init = arena_align((size_t)N * nb * sizeof(BufDesc));
+    ps.front_bytes = ps.off_xfer_init + arena_align((size_t)N * sizeof(int));
+    HIPTRY(ps.h_arena.ensure_keep(std::max(ps.front_bytes, ps.last_bytes), 0));
+    plan_desc_ = reinterpret_cast<BufDesc *>(ps.h_arena.p);
+    int *h_xfer_init = reinterpret_cast<int *>(ps.h_arena.p + ps.off_xfer_init);
     const auto tp0 = std::chrono::steady_clock::now();
     const BufDesc dflt = {-1, -1, 0u, 0.f, XFER_KEEP, 0u, {0, 0}};
-    std::fill(ps.h_desc.p, ps.h_desc.p + (size_t)N * nb, dflt);
+    std::fill(plan_desc_, plan_desc_ + (size_t)N * nb, dflt);
     busy_.clear();
     for (int i = 0; i < N; ++i) {
         const Object &o = objs_[i];
-        ps.h_xfer_init.p[i] = o.latest_row;
+        h_xfer_init[i] = o.latest_row;
         if (!o.force_q.empty() || !o.active.empty() || !o.pending.empty() || o.trans_full ||
             o.sustained || (!o.use_transfer && o.latest_row != XFER_UNIT))
             busy_.push_back(i);
@@ -1218,7 +1243,7 @@ int Engine::plan(int nb) {
     // merge in object order: the numbering is the one a single context would have produced
     row_ptr_.assign(1, 0);
     slot_idx_.clear(); row_obj_.clear(); tprof_.clear(); stage_.clear(); stage_slot_.clear();
-    proj_.clear(); ffat_.clear(); prof_entries_.clear(); prof_rows_.clear(); chain_ptr_.clear();
+    proj_.clear(); proj_direct_.clear(); ffat_.clear(); prof_entries_.clear(); prof_rows_.clear(); chain_ptr_.clear();
     n_frows_ = 0;
     n_prows_ = 0;
     for (int t = 0; t < T; ++t) {
@@ -1232,7 +1257,10 @@ int Engine::plan(int nb) {
             }
         }
         for (int e : c.row_ptr) row_ptr_.push_back(base_s + e);
-        slot_idx_.insert(slot_idx_.end(), c.slot_idx.begin(), c.slot_idx.end());
+        const int base_d = (int)proj_direct_.size();
+        if (base_d == 0) slot_idx_.insert(slot_idx_.end(), c.slot_idx.begin(), c.slot_idx.end());
+        else for (int e : c.slot_idx) slot_idx_.push_back(e >= 0 ? e : e - base_d);     // on-the-fly projections: global event index
+        proj_direct_.insert(proj_direct_.end(), c.proj_direct.begin(), c.proj_direct.end());
         row_obj_.insert(row_obj_.end(), c.row_obj.begin(), c.row_obj.end());
         tprof_.insert(tprof_.end(), c.tprof.begin(), c.tprof.end());
         prof_entries_.insert(prof_entries_.end(), c.prof_entries.begin(), c.prof_entries.end());
@@ -1264,17 +1292,6 @@ int Engine::plan(int nb) {
 }
 
 // ---------------------------------------------------------------------------
-template <class T>
-static hipError_t upload(PinBuf<T> &h, DevBuf<T> &d, const T *src, size_t n, hipStream_t s) {
-    if (!n) return hipSuccess;
-    hipError_t e = h.ensure(n);
-    if (e != hipSuccess) return e;
-    e = d.ensure(n, false, s);
-    if (e != hipSuccess) return e;
-    std::memcpy(h.p, src, n * sizeof(T));
-    return hipMemcpyAsync(d.p, h.p, n * sizeof(T), hipMemcpyHostToDevice, s);
-}
-
 // One step = nb buffers for every object.  Long steps are cut into launches of at most
 // chunk_buffers_ buffers so that the host plans chunk c+1 while the device runs chunk c (the same
 // overlap consecutive steps have); results do not depend on the cut (state, force lists and queues
@@ -1376,60 +1393,85 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     //      bank that last read them (two steps ago) has finished
     HIPTRY(hipStreamWaitEvent(sp, ev_k1_done_[cur_set_], 0));
     HIPTRY(hipEventRecord(evq.p0, sp));
-    HIPTRY(ps.d_desc.ensure((size_t)N * nb, false, sp));
-    HIPTRY(hipMemcpyAsync(ps.d_desc.p, ps.h_desc.p, (size_t)N * nb * sizeof(BufDesc), hipMemcpyHostToDevice, sp));
-    HIPTRY(ps.d_xfer_init.ensure(N, false, sp));
-    HIPTRY(hipMemcpyAsync(ps.d_xfer_init.p, ps.h_xfer_init.p, (size_t)N * sizeof(int), hipMemcpyHostToDevice, sp));
-    HIPTRY(upload(ps.h_row_ptr, ps.d_row_ptr, row_ptr_.data(), row_ptr_.size(), sp));
-    HIPTRY(upload(ps.h_slot_idx, ps.d_slot_idx, slot_idx_.data(), slot_idx_.size(), sp));
-    HIPTRY(upload(ps.h_row_obj, ps.d_row_obj, row_obj_.data(), row_obj_.size(), sp));
+    // ---- ONE upload: everything the planner produced sits behind the descriptors in the set's pinned arena.
+    // (Twelve separate copies cost the host 0.1 ms of API calls per step, and the small ones went through
+    // blit kernels that cannot start while the oscillator bank fills the register file.)
+    std::vector<int> cp;
+    const int n_cl = (int)copy_latest.size() / 2, n_cq = (int)copy_queued.size() / 2;
+    {
+        // layout: [src...] then [dst...]
+        cp.resize((size_t)2 * (n_cl + n_cq));
+        for (int i = 0; i < n_cl; ++i) { cp[i] = copy_latest[2 * i]; cp[n_cl + n_cq + i] = copy_latest[2 * i + 1]; }
+        for (int i = 0; i < n_cq; ++i) { cp[n_cl + i] = copy_queued[2 * i]; cp[n_cl + n_cq + n_cl + i] = copy_queued[2 * i + 1]; }
+    }
+    size_t off = ps.front_bytes;
+    auto place = [&](size_t bytes) { const size_t o = off; off += arena_align(bytes); return o; };
+    const size_t o_row_ptr = place(row_ptr_.size() * sizeof(int)), o_slot_idx = place(slot_idx_.size() * sizeof(int));
+    const size_t o_row_obj = place(row_obj_.size() * sizeof(int));
+    const size_t o_pent = place(device_profiles_ ? prof_entries_.size() * sizeof(ProfEntry) : 0);
+    const size_t o_prow = place(device_profiles_ ? prof_rows_.size() * sizeof(ProfRow) : 0);
+    const size_t o_chain = place(device_profiles_ ? chain_ptr_.size() * sizeof(int) : 0);
+    const size_t o_tprof = place(device_profiles_ ? 0 : tprof_.size() * sizeof(float));
+    const size_t o_stage = place(stage_.size() * sizeof(double)), o_stage_slot = place(stage_slot_.size() * sizeof(int));
+    const size_t o_proj = place(proj_.size() * sizeof(ProjectEvent)), o_projd = place(proj_direct_.size() * sizeof(ProjectEvent));
+    const size_t o_ffat = place(ffat_.size() * sizeof(FfatEvent)), o_copy = place(cp.size() * sizeof(int));
+    HIPTRY(ps.h_arena.ensure_keep(off, ps.front_bytes));
+    ps.last_bytes = off;
+    unsigned char *ha = ps.h_arena.p;
+    auto put = [&](size_t o, const void *src, size_t bytes) { if (bytes) std::memcpy(ha + o, src, bytes); };
+    put(o_row_ptr, row_ptr_.data(), row_ptr_.size() * sizeof(int));
+    put(o_slot_idx, slot_idx_.data(), slot_idx_.size() * sizeof(int));
+    put(o_row_obj, row_obj_.data(), row_obj_.size() * sizeof(int));
     if (device_profiles_) {
+        put(o_pent, prof_entries_.data(), prof_entries_.size() * sizeof(ProfEntry));
+        put(o_prow, prof_rows_.data(), prof_rows_.size() * sizeof(ProfRow));
+        put(o_chain, chain_ptr_.data(), chain_ptr_.size() * sizeof(int));
         HIPTRY(ps.d_tprof.ensure(std::max<size_t>(1, (size_t)n_prows_) * b_pad_, false, sp));
-        HIPTRY(upload(ps.h_prof_entries, ps.d_prof_entries, prof_entries_.data(), prof_entries_.size(), sp));
-        HIPTRY(upload(ps.h_prof_rows, ps.d_prof_rows, prof_rows_.data(), prof_rows_.size(), sp));
-        HIPTRY(upload(ps.h_chain_ptr, ps.d_chain_ptr, chain_ptr_.data(), chain_ptr_.size(), sp));
         HIPTRY(d_arstate_.ensure(std::max<size_t>(1, n_ar_states_.load()), true, sp));
     } else {
-        HIPTRY(upload(ps.h_tprof, ps.d_tprof, tprof_.data(), tprof_.size(), sp));
+        put(o_tprof, tprof_.data(), tprof_.size() * sizeof(float));
     }
-    HIPTRY(upload(ps.h_stage, ps.d_stage, stage_.data(), stage_.size(), sp));
-    HIPTRY(upload(ps.h_stage_slot, ps.d_stage_slot, stage_slot_.data(), stage_slot_.size(), sp));
-    HIPTRY(upload(ps.h_proj, ps.d_proj, proj_.data(), proj_.size(), sp));
-    HIPTRY(upload(ps.h_ffat, ps.d_ffat, ffat_.data(), ffat_.size(), sp));
-    std::vector<int> copies(copy_latest);
-    copies.insert(copies.end(), copy_queued.begin(), copy_queued.end());
-    // layout: [src,dst] pairs -> split into src[] and dst[] arrays
-    std::vector<int> cp(copies.size());
-    const int n_cl = (int)copy_latest.size() / 2, n_cq = (int)copy_queued.size() / 2;
-    for (int i = 0; i < n_cl + n_cq; ++i) {
-        cp[i] = copies[2 * i];
-        cp[n_cl + n_cq + i] = copies[2 * i + 1];
-    }
-    HIPTRY(upload(ps.h_copy, ps.d_copy, cp.data(), cp.size(), sp));
-    HIPTRY(hipEventRecord(ev_set_[cur_set_], sp));          // this set's pinned buffers are reusable
+    put(o_stage, stage_.data(), stage_.size() * sizeof(double));
+    put(o_stage_slot, stage_slot_.data(), stage_slot_.size() * sizeof(int));
+    put(o_proj, proj_.data(), proj_.size() * sizeof(ProjectEvent));
+    put(o_projd, proj_direct_.data(), proj_direct_.size() * sizeof(ProjectEvent));
+    put(o_ffat, ffat_.data(), ffat_.size() * sizeof(FfatEvent));
+    put(o_copy, cp.data(), cp.size() * sizeof(int));
+    HIPTRY(ps.d_arena.ensure(off, false, sp));
+    HIPTRY(hipMemcpyAsync(ps.d_arena.p, ha, off, hipMemcpyHostToDevice, sp));
+    HIPTRY(hipEventRecord(ev_set_[cur_set_], sp));          // this set's pinned arena is reusable
+    unsigned char *da = ps.d_arena.p;
+    const BufDesc *d_desc = reinterpret_cast<const BufDesc *>(da);
+    const int *d_xfer_init = reinterpret_cast<const int *>(da + ps.off_xfer_init);
+    const int *d_row_ptr = reinterpret_cast<const int *>(da + o_row_ptr), *d_slot_idx = reinterpret_cast<const int *>(da + o_slot_idx);
+    const int *d_row_obj = reinterpret_cast<const int *>(da + o_row_obj), *d_chain = reinterpret_cast<const int *>(da + o_chain);
+    const ProfEntry *d_pent = reinterpret_cast<const ProfEntry *>(da + o_pent);
+    const ProfRow *d_prow = reinterpret_cast<const ProfRow *>(da + o_prow);
+    const float *d_tprof = device_profiles_ ? ps.d_tprof.p : reinterpret_cast<const float *>(da + o_tprof);
+    const double *d_stage = reinterpret_cast<const double *>(da + o_stage);
+    const int *d_stage_slot = reinterpret_cast<const int *>(da + o_stage_slot), *d_copy = reinterpret_cast<const int *>(da + o_copy);
+    const ProjectEvent *d_proj = reinterpret_cast<const ProjectEvent *>(da + o_proj), *d_projd = reinterpret_cast<const ProjectEvent *>(da + o_projd);
+    const FfatEvent *d_ffat = reinterpret_cast<const FfatEvent *>(da + o_ffat);
 
     // K2 -> time-profile rows ; K3 / scatter -> data slots ; K4 -> transfer rows ; combine -> g rows
     if (device_profiles_)
-        LAUNCHTRY(launch_force_profiles(ps.d_chain_ptr.p, n_chains, ps.d_prof_rows.p, ps.d_prof_entries.p,
-                                        d_arstate_.p, ps.d_tprof.p, B_, b_pad_, sp));
-    LAUNCHTRY(launch_scatter_rows(ps.d_stage.p, ps.d_stage_slot.p, (int)stage_slot_.size(), d_slots_.p, m_pad_, sp));
-    LAUNCHTRY(launch_modal_project(ps.d_proj.p, (int)proj_.size(), d_shapes_.p, d_shape_off_.p, d_n_modes_.p,
-                                   d_slots_.p, m_pad_, sp));
-    LAUNCHTRY(launch_ffat_lookup(ps.d_ffat.p, (int)ffat_.size(), d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p,
-                                 d_xfer_.p, m_pad_, sp));
-    LAUNCHTRY(launch_force_combine(ps.d_row_ptr.p, ps.d_slot_idx.p, ps.d_row_obj.p, n_frows, d_slots_.p, d_c3_.p,
-                                   grows.p, m_pad_, sp));
+        LAUNCHTRY(launch_force_profiles(d_chain, n_chains, d_prow, d_pent, d_arstate_.p, ps.d_tprof.p, B_, b_pad_, sp));
+    LAUNCHTRY(launch_scatter_rows(d_stage, d_stage_slot, (int)stage_slot_.size(), d_slots_.p, m_pad_, sp));
+    LAUNCHTRY(launch_modal_project(d_proj, (int)proj_.size(), d_shapes_.p, d_shape_off_.p, d_n_modes_.p, d_slots_.p, m_pad_, sp));
+    LAUNCHTRY(launch_ffat_lookup(d_ffat, (int)ffat_.size(), d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p, d_xfer_.p, m_pad_, sp));
+    LAUNCHTRY(launch_force_combine(d_row_ptr, d_slot_idx, d_row_obj, n_frows, d_slots_.p, d_c3_.p, grows.p, d_projd, d_shapes_.p,
+                                   d_shape_off_.p, d_n_modes_.p, m_pad_, sp));
     HIPTRY(hipEventRecord(ev_prep_done_[cur_set_], sp));
 
     // ---- compute stream: K1 after its preparation (and, stream order, after the previous K1)
     HIPTRY(hipStreamWaitEvent(sk, ev_prep_done_[cur_set_], 0));
     IirParams kp;
     kp.ca = d_ca_.p; kp.cb = d_cb_.p; kp.sq = d_sq_.p; kp.sd = d_sd_.p; kp.ss = d_ss_.p;
-    kp.desc = ps.d_desc.p;
+    kp.desc = d_desc;
     kp.grows = grows.p;
-    kp.tprof = ps.d_tprof.p;
+    kp.tprof = d_tprof;
     kp.xfer_rows = d_xfer_.p;
-    kp.xfer_init = ps.d_xfer_init.p;
+    kp.xfer_init = d_xfer_init;
     kp.audio = audio + (size_t)b0 * B_;
     kp.qnorm = qn ? d_qnorm_.p : nullptr;
     kp.qn_nb = nb_total;
@@ -1491,8 +1533,8 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     }
     HIPTRY(hipEventRecord(evq.k1, sk));
     // _latest_transfer = trans (modal_solver.h:251), then re-park a still-queued transfer
-    LAUNCHTRY(launch_copy_rows(ps.d_copy.p, ps.d_copy.p + (n_cl + n_cq), n_cl, d_xfer_.p, m_pad_, sk));
-    LAUNCHTRY(launch_copy_rows(ps.d_copy.p + n_cl, ps.d_copy.p + (n_cl + n_cq) + n_cl, n_cq, d_xfer_.p, m_pad_, sk));
+    LAUNCHTRY(launch_copy_rows(d_copy, d_copy + (n_cl + n_cq), n_cl, d_xfer_.p, m_pad_, sk));
+    LAUNCHTRY(launch_copy_rows(d_copy + n_cl, d_copy + (n_cl + n_cq) + n_cl, n_cq, d_xfer_.p, m_pad_, sk));
     HIPTRY(hipEventRecord(evq.p1, sk));
     HIPTRY(hipEventRecord(ev_k1_done_[cur_set_], sk));
     ev_pending_.push_back(evq);

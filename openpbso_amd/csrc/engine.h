@@ -35,8 +35,10 @@ struct PinBuf {
     T *p = nullptr;
     size_t cap = 0;
     hipError_t ensure(size_t n);
+    hipError_t ensure_keep(size_t n, size_t keep);
     void release();
 };
+inline size_t arena_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // ---- forces.h: time profile of one force (Point / Gaussian / AR(2)) ---------
 struct ForceProfile {
@@ -140,7 +142,7 @@ struct PlanCtx {
     std::vector<ProfEntry> prof_entries;
     std::vector<ProfRow> prof_rows;
     std::vector<double> stage;
-    std::vector<ProjectEvent> proj;
+    std::vector<ProjectEvent> proj, proj_direct;
     std::vector<FfatEvent> ffat;
     std::vector<BufDesc *> forced;                       // descriptors holding context-local frow / prow numbers
     std::vector<int> free_slots, freed_this_plan, free_ar, freed_ar;     // this context's share of the slot / AR-state pools
@@ -253,21 +255,12 @@ private:
     std::atomic<size_t> n_slots_{0};
 
     // per-launch plan, double-buffered (host pinned + device copies)
+    // per-launch plan, double-buffered: one pinned arena and its device copy ([BufDesc table | xfer_init | lists])
     struct PlanSet {
-        PinBuf<BufDesc> h_desc;     DevBuf<BufDesc> d_desc;
-        PinBuf<int> h_row_ptr;      DevBuf<int> d_row_ptr;
-        PinBuf<int> h_slot_idx;     DevBuf<int> d_slot_idx;
-        PinBuf<int> h_row_obj;      DevBuf<int> d_row_obj;
-        PinBuf<float> h_tprof;      DevBuf<float> d_tprof;
-        PinBuf<double> h_stage;     DevBuf<double> d_stage;
-        PinBuf<int> h_stage_slot;   DevBuf<int> d_stage_slot;
-        PinBuf<ProjectEvent> h_proj; DevBuf<ProjectEvent> d_proj;
-        PinBuf<FfatEvent> h_ffat;   DevBuf<FfatEvent> d_ffat;
-        PinBuf<int> h_copy;         DevBuf<int> d_copy;
-        PinBuf<int> h_xfer_init;    DevBuf<int> d_xfer_init;
-        PinBuf<ProfEntry> h_prof_entries; DevBuf<ProfEntry> d_prof_entries;
-        PinBuf<ProfRow> h_prof_rows;      DevBuf<ProfRow> d_prof_rows;
-        PinBuf<int> h_chain_ptr;          DevBuf<int> d_chain_ptr;
+        PinBuf<unsigned char> h_arena;
+        DevBuf<unsigned char> d_arena;
+        DevBuf<float> d_tprof;                           // device-generated force profile rows (K2)
+        size_t off_xfer_init = 0, front_bytes = 0, last_bytes = 0;
         void release();
     } set_[2];
     DevBuf<float> d_grows_[2];                           // g rows, one arena per plan set
@@ -283,7 +276,8 @@ private:
     std::atomic<size_t> n_ar_states_{0};
     DevBuf<ArState> d_arstate_;
     std::vector<double> stage_;
-    std::vector<ProjectEvent> proj_;
+    std::vector<ProjectEvent> proj_, proj_direct_;         // projections into pool rows / evaluated on the fly by the combine kernel
+    BufDesc *plan_desc_ = nullptr;                       // the descriptor table being planned (front of the set's arena)
     std::vector<FfatEvent> ffat_;
     std::vector<unsigned char> emitted_;
     // planner threads (PBSO_PLAN_THREADS, default 1): ctx_[t] plans a contiguous share of the busy objects.

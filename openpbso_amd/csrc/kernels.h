@@ -119,8 +119,10 @@ int launch_modal_project(const ProjectEvent *events, int n_events, const double 
                          int m_pad, hipStream_t stream);
 int launch_scatter_rows(const double *src, const int *dst_slot, int n_rows, double *slots,
                         int m_pad, hipStream_t stream);
+// slot_idx >= 0: a row of the slot pool; < 0: event -(idx + 1) of `direct`, projected on the fly
 int launch_force_combine(const int *row_ptr, const int *slot_idx, const int *row_obj, int n_rows,
-                         const double *slots, const double *c3, float *grows, int m_pad,
+                         const double *slots, const double *c3, float *grows, const ProjectEvent *direct,
+                         const double *shapes, const long long *shape_off, const int *n_modes, int m_pad,
                          hipStream_t stream);
 
 // ---- K2: force time profiles on the device (forces.h:81-137)

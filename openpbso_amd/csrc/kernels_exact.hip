@@ -21,6 +21,23 @@ namespace pbso {
 // (the reference is mode-major, ModeData.h:24) so that the three (or nine) rows
 // a hit touches are contiguous over modes: coalesced 8-B loads.
 // grid = (ceil(m_pad / 256), n_events)
+// GetModalForceVertex / GetModalForceFace for one mode (tools/real_time_modal_sound.cpp:276-280, 244-251),
+// the reference's operation order (this file is built without FMA contraction)
+__device__ __forceinline__ double project_one(const ProjectEvent &ev, const double *__restrict__ U, int m_pad, int m) {
+    if (ev.kind == 1) {                           // vertex
+        const double *u = U + (size_t)(ev.vids[0] * 3) * m_pad + m;
+        return ev.vn[0] * u[0] + ev.vn[1] * u[m_pad] + ev.vn[2] * u[2 * (size_t)m_pad];
+    }
+    double acc = 0.0;                             // face
+    for (int jj = 0; jj < 3; ++jj) {
+        const double *u = U + (size_t)(ev.vids[jj] * 3) * m_pad + m;
+        acc += ev.vn[0] * u[0] * ev.coords[jj]
+             + ev.vn[1] * u[m_pad] * ev.coords[jj]
+             + ev.vn[2] * u[2 * (size_t)m_pad] * ev.coords[jj];
+    }
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void modal_project_kernel(
     const ProjectEvent *__restrict__ events, const double *__restrict__ shapes,
     const long long *__restrict__ shape_off, const int *__restrict__ n_modes,
@@ -29,22 +46,7 @@ __global__ __launch_bounds__(256) void modal_project_kernel(
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= m_pad) return;
     double out = 0.0;
-    if (m < n_modes[ev.obj]) {
-        const double *U = shapes + shape_off[ev.obj];
-        if (ev.kind == 1) {                       // vertex, tools/...:276-280
-            const double *u = U + (size_t)(ev.vids[0] * 3) * m_pad + m;
-            out = ev.vn[0] * u[0] + ev.vn[1] * u[m_pad] + ev.vn[2] * u[2 * (size_t)m_pad];
-        } else {                                  // face, tools/...:244-251
-            double acc = 0.0;
-            for (int jj = 0; jj < 3; ++jj) {
-                const double *u = U + (size_t)(ev.vids[jj] * 3) * m_pad + m;
-                acc += ev.vn[0] * u[0] * ev.coords[jj]
-                     + ev.vn[1] * u[m_pad] * ev.coords[jj]
-                     + ev.vn[2] * u[2 * (size_t)m_pad] * ev.coords[jj];
-            }
-            out = acc;
-        }
-    }
+    if (m < n_modes[ev.obj]) out = project_one(ev, shapes + shape_off[ev.obj], m_pad, m);
     slots[(size_t)ev.slot * m_pad + m] = out;
 }
 
@@ -78,25 +80,39 @@ int launch_scatter_rows(const double *src, const int *dst_slot, int n_rows, doub
 // ---------------------------------------------------------------------------
 // one forced (object, buffer) row: S = 0 + data_0 + data_1 + ... in list order
 // (setZero then += , modal_solver.h:209,218), then g = (float)(c3 * S).
+// A negative slot index -(e + 1) stands for projection event e evaluated here (the hit of a PointForce lives
+// for one buffer: writing its row to the pool only to read it back once costs a kernel and 170 MB of traffic).
 __global__ __launch_bounds__(256) void force_combine_kernel(
     const int *__restrict__ row_ptr, const int *__restrict__ slot_idx,
     const int *__restrict__ row_obj, const double *__restrict__ slots,
-    const double *__restrict__ c3, float *__restrict__ grows, int m_pad) {
+    const double *__restrict__ c3, float *__restrict__ grows, const ProjectEvent *__restrict__ direct,
+    const double *__restrict__ shapes, const long long *__restrict__ shape_off, const int *__restrict__ n_modes,
+    int m_pad) {
     const int row = blockIdx.y;
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= m_pad) return;
+    const int obj = row_obj[row];
     double S = 0.0;
-    for (int j = row_ptr[row]; j < row_ptr[row + 1]; ++j) S += slots[(size_t)slot_idx[j] * m_pad + m];
-    grows[(size_t)row * m_pad + m] = (float)(c3[(size_t)row_obj[row] * m_pad + m] * S);
+    for (int j = row_ptr[row]; j < row_ptr[row + 1]; ++j) {
+        const int si = slot_idx[j];
+        if (si >= 0) {
+            S += slots[(size_t)si * m_pad + m];
+        } else {
+            const ProjectEvent ev = direct[-si - 1];
+            S += m < n_modes[obj] ? project_one(ev, shapes + shape_off[obj], m_pad, m) : 0.0;
+        }
+    }
+    grows[(size_t)row * m_pad + m] = (float)(c3[(size_t)obj * m_pad + m] * S);
 }
 
 int launch_force_combine(const int *row_ptr, const int *slot_idx, const int *row_obj, int n_rows,
-                         const double *slots, const double *c3, float *grows, int m_pad,
+                         const double *slots, const double *c3, float *grows, const ProjectEvent *direct,
+                         const double *shapes, const long long *shape_off, const int *n_modes, int m_pad,
                          hipStream_t stream) {
     if (n_rows <= 0) return 0;
     dim3 grid((m_pad + 255) / 256, n_rows);
     hipLaunchKernelGGL(force_combine_kernel, grid, dim3(256), 0, stream, row_ptr, slot_idx, row_obj,
-                       slots, c3, grows, m_pad);
+                       slots, c3, grows, direct, shapes, shape_off, n_modes, m_pad);
     return (int)hipGetLastError();
 }
 
