@@ -906,7 +906,41 @@ int Engine::plan_object(PlanCtx &c, int oi, int b, int nb, int64_t t) {
     }
 
     // :184 dequeue at most one force message
-    if (!o.force_q.empty() && o.force_q.front().not_before <= t) {
+    const bool due_msg = !o.force_q.empty() && o.force_q.front().not_before <= t;
+    bool plain_hit = false;
+    if (due_msg && device_profiles_ && o.active.empty() && !o.sustained) {
+        const HostForceMsg &m0 = o.force_q.front();
+        plain_hit = m0.force_type == PBSO_POINT_FORCE && !m0.clear_all && !m0.sustained_start && !m0.sustained_end &&
+                    (m0.data_kind == PBSO_DATA_VERTEX || m0.data_kind == PBSO_DATA_FACE);
+    }
+    if (plain_hit) {
+        const HostForceMsg &m0 = o.force_q.front();
+        {
+            // The common case in one go -- the hit of a plain PointForce on an object with no live force: what the
+            // general path below does for it (active list of one, Force::Add -> 1 at sample 0, erased next step,
+            // modal_solver.h:195-221, forces.h:81-90) comes to one impulse row whose spatial vector is the
+            // projection of this hit, evaluated by the combine kernel.
+            ProjectEvent pe;
+            pe.obj = oi;
+            pe.kind = m0.data_kind;
+            pe.slot = -1;
+            for (int j = 0; j < 3; ++j) {
+                pe.vids[j] = m0.vids[j];
+                pe.coords[j] = m0.coords[j];
+                pe.vn[j] = m0.vn[j];
+            }
+            c.slot_idx.push_back(-((int)c.proj_direct.size() + 1));
+            c.proj_direct.push_back(pe);
+            o.force_q.pop_front();
+            d.frow = c.n_frows++;
+            c.forced.push_back(&d);
+            c.row_obj.push_back(oi);
+            c.row_ptr.push_back((int)c.slot_idx.size());
+            d.flags |= DESC_IMPULSE;
+            d.tile_mask = 1u;
+            d.amp = 1.f;
+        }
+    } else if (due_msg) {
         HostForceMsg mess = std::move(o.force_q.front());
         o.force_q.pop_front();
         if (mess.clear_all) {                                           // :186-189
