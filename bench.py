@@ -58,7 +58,7 @@ def parse(argv=None):
     ap.add_argument("--objects", type=int, default=1024, help="objects per GPU (weak scaling); the total for the strong leg")
     ap.add_argument("--modes", type=int, default=512)
     ap.add_argument("--buffers", type=int, default=86, help="audio buffers per step")
-    ap.add_argument("--form", choices=["block", "velocity", "direct"], default="block",
+    ap.add_argument("--form", choices=["block", "block_bf16", "velocity", "direct"], default="block",
                     help="block: state-space blocks on the f32 matrix pipe (K1b); velocity / direct: per-sample kernel (K1)")
     ap.add_argument("--qnorm", choices=["sample", "closed", "off"], default="sample",
                     help="getQBufferNorm rows: on (the block form evaluates them in closed form), closed form, or off")
@@ -237,7 +237,8 @@ def measure(args, ctx, global_ids, want_parity):
     lam, shapes, scripts = build_inputs(args, global_ids, total_buffers)
     stream = ctx["stream"].cuda_stream
     eng = Engine(device=ctx["dev_index"],
-                 form={"block": capi.FORM_BLOCK, "velocity": capi.FORM_VELOCITY, "direct": capi.FORM_DIRECT}[args.form],
+                 form={"block": capi.FORM_BLOCK, "block_bf16": capi.FORM_BLOCK_BF16, "velocity": capi.FORM_VELOCITY,
+                       "direct": capi.FORM_DIRECT}[args.form],
                  qnorm={"sample": capi.QNORM_ALL, "closed": capi.QNORM_CLOSED, "off": capi.QNORM_OFF}[
                      "off" if args.no_qnorm else args.qnorm],
                  modes_per_lane=args.modes_per_lane, stream=stream)
@@ -481,7 +482,7 @@ def main():
         k_ms = m["kernel_ms"]
         mode_samples = m["n_local"] * M * nb * B
         # (a block-form engine runs launches that are mostly dense-profile buffers on the per-sample kernel)
-        block = m["form_run"] == 0 and m["info"]["total_block_launches"] >= m["info"]["total_sample_launches"]
+        block = m["form_run"] in (0, 3) and m["info"]["total_block_launches"] >= m["info"]["total_sample_launches"]
         flop_exec = FLOP_BLOCK if block else FLOP_REF
         tf_exec = flop_exec * mode_samples / (k_ms * 1e-3) * 1e-12
         tf_ref = FLOP_REF * mode_samples / (k_ms * 1e-3) * 1e-12

@@ -75,7 +75,12 @@ enum pbso_recurrence_form {
                                  sample as PBSO_FORM_VELOCITY does.  Needs frames_per_buffer = 513 (else the
                                  engine runs PBSO_FORM_VELOCITY); qnorm is evaluated in closed form.            */
     PBSO_FORM_VELOCITY = 1,   /* per-sample recurrence, state (q, q-q_prev), coefficients (eps^2, 1-c1-c2): fp32-safe */
-    PBSO_FORM_DIRECT = 2      /* per-sample, the reference's literal q = c1 q1 + c2 q2 + c3 Q in fp32 */
+    PBSO_FORM_DIRECT = 2,     /* per-sample, the reference's literal q = c1 q1 + c2 q2 + c3 Q in fp32 */
+    PBSO_FORM_BLOCK_BF16 = 3  /* the block form with the OUTPUT projection (which has no feedback) evaluated as a
+                                 split-bf16 product: every f32 operand x = hi + lo (two bf16, 16 significant bits),
+                                 W.X ~ Whi.Xhi + Whi.Xlo + Wlo.Xhi on v_mfma_f32_16x16x32_bf16 (16x the f32 MFMA rate,
+                                 f32 accumulation).  The state recurrence stays exact f32.  Error 1.5e-5 ... 3e-5 of
+                                 the peak (PBSO_FORM_BLOCK: 7e-6; stated tolerance 5e-4).                               */
 };
 
 enum pbso_qnorm_mode {

@@ -13,7 +13,7 @@ OK = 0
 ERR_INVALID, ERR_HIP, ERR_STATE, ERR_IO, ERR_MISSING_MAP, ERR_ASSERT, ERR_NOMEM = -1, -2, -3, -4, -5, -6, -7
 POINT_FORCE, GAUSSIAN_FORCE, AUTOREGRESSIVE_FORCE = 0, 1, 2
 DATA_EXPLICIT, DATA_VERTEX, DATA_FACE, DATA_ZERO = 0, 1, 2, 3
-FORM_BLOCK, FORM_VELOCITY, FORM_DIRECT = 0, 1, 2
+FORM_BLOCK, FORM_VELOCITY, FORM_DIRECT, FORM_BLOCK_BF16 = 0, 1, 2, 3
 QNORM_OFF, QNORM_ALL, QNORM_CLOSED = 0, 1, 2
 
 # every symbol include/openpbso_amd.h declares

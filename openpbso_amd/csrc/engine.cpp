@@ -304,12 +304,12 @@ int Engine::init() {
         return fail(PBSO_ERR_INVALID, "frames_per_buffer must be a multiple of the 27-sample tile (at most 32 tiles); the reference uses 513");
     n_tiles_ = B_ / TILE;
     b_pad_ = (B_ + 15) / 16 * 16;
-    if (desc_.recurrence_form != PBSO_FORM_BLOCK && desc_.recurrence_form != PBSO_FORM_VELOCITY &&
+    if (desc_.recurrence_form != PBSO_FORM_BLOCK && desc_.recurrence_form != PBSO_FORM_BLOCK_BF16 && desc_.recurrence_form != PBSO_FORM_VELOCITY &&
         desc_.recurrence_form != PBSO_FORM_DIRECT)
         return fail(PBSO_ERR_INVALID, "recurrence_form");
     form_ = desc_.recurrence_form;
     // the block form tiles a buffer as 1 + 2 * 16 * 16 samples (the reference's 513); other lengths step per sample
-    if (form_ == PBSO_FORM_BLOCK && B_ != 1 + 2 * BLOCK_J * BLOCK_N) form_ = PBSO_FORM_VELOCITY;
+    if (is_block() && B_ != 1 + 2 * BLOCK_J * BLOCK_N) form_ = PBSO_FORM_VELOCITY;
     if (const char *v = std::getenv("PBSO_DENSE_LAUNCHES")) dense_to_k1_ = std::string(v) != "block";
     if (const char *v = std::getenv("PBSO_BLOCK_TEAM_WAVES")) block_team_waves_ = std::min(MAX_WAVES_PER_BLOCK_TEAM, std::max(1, std::atoi(v)));
     if (desc_.qnorm_mode < PBSO_QNORM_OFF || desc_.qnorm_mode > PBSO_QNORM_CLOSED)
@@ -453,7 +453,7 @@ int Engine::finalize() {
     // SIMD (4096 on the chip, profiles/r01_microbench.txt).
     int R = desc_.modes_per_lane;
     if (R != 0 && R != 1 && R != 2 && R != 3 && R != 4 && R != 8) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,3,4,8");
-    const bool block = form_ == PBSO_FORM_BLOCK;
+    const bool block = is_block();
     if (block && R == 3) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,4,8 in the block form");
     auto waves_of = [&](const Object &o, int r) { return std::max(1, (o.n_modes + 64 * r - 1) / (64 * r)); };
     auto total_waves = [&](int r) {
@@ -638,6 +638,44 @@ int Engine::finalize() {
                 pc[2 * nm + k] = (float)p10;
                 pc[3 * nm + k] = (float)p11;
             }
+        }
+        if (form_ == PBSO_FORM_BLOCK_BF16) {
+            // Split-bf16 operand table: per group of 16 columns 8 rows of 64 dwords, rows 0..3 the hi parts, 4..7 the
+            // lo parts; lane l = 16 kq + (j - 1), dword dd <-> mode 16 G + 4 kq + dd: low half a_j, high half b_j (the k
+            // order of v_mfma_f32_16x16x32_bf16: k = 8 kq + 2 dd + comp).  hi = bf16(x) round-to-nearest-even,
+            // lo = bf16(x - hi).
+            auto bf16_rne = [](float x) -> uint32_t {
+                uint32_t u;
+                std::memcpy(&u, &x, 4);
+                if ((u & 0x7F800000u) == 0x7F800000u) return u >> 16;                 // inf / nan
+                return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+            };
+            auto split = [&](double x, uint32_t &hi, uint32_t &lo) {
+                const float xf = (float)x;
+                hi = bf16_rne(xf);
+                const uint32_t hb = hi << 16;
+                float hf;
+                std::memcpy(&hf, &hb, 4);
+                lo = bf16_rne(xf - hf);
+            };
+            std::vector<float> wf(wt);                                               // the f32 table just built
+            std::vector<uint32_t> w16(wt.size(), 0u);
+            for (size_t G = 0; G < nm / 16; ++G)
+                for (int l = 0; l < 64; ++l) {
+                    const int j = l & 15, kq = l >> 4;
+                    for (int dd = 0; dd < 4; ++dd) {
+                        const size_t col = 16 * G + 4 * kq + dd;                      // flat column index (object * m_pad + column)
+                        // f32 table: row col / 2, lane 16 * (2 * (col & 1) + comp) + j
+                        const float a = wf[(col / 2) * 64 + 16 * (2 * (col & 1) + 0) + j];
+                        const float b = wf[(col / 2) * 64 + 16 * (2 * (col & 1) + 1) + j];
+                        uint32_t ah, al, bh, bl;
+                        split(a, ah, al);
+                        split(b, bh, bl);
+                        w16[(8 * G + dd) * 64 + l] = ah | (bh << 16);
+                        w16[(8 * G + 4 + dd) * 64 + l] = al | (bl << 16);
+                    }
+                }
+            std::memcpy(wt.data(), w16.data(), wt.size() * sizeof(float));
         }
         HIPTRY(d_pc_.ensure(4 * nm));
         HIPTRY(hipMemcpy(d_pc_.p, pc.data(), 4 * nm * sizeof(float), hipMemcpyHostToDevice));
@@ -1538,8 +1576,8 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     // rules are shared, so the two kernels hand over at any launch boundary.  (Audio then is bit-identical
     // across different cuts of a step only while both cuts pick the same kernel; always within tolerance.)
     // PBSO_DENSE_LAUNCHES=block keeps every launch on the block kernel (bit-identical audio for any cut of a step).
-    const bool dense_heavy = form_ == PBSO_FORM_BLOCK && dense_to_k1_ && (long long)n_prows_ * 2 > (long long)N * nb;
-    (dense_heavy || form_ != PBSO_FORM_BLOCK ? tot_sample_launches_ : tot_block_launches_) += 1;
+    const bool dense_heavy = is_block() && dense_to_k1_ && (long long)n_prows_ * 2 > (long long)N * nb;
+    (dense_heavy || !is_block() ? tot_sample_launches_ : tot_block_launches_) += 1;
     bool used[N_CLASS_STREAMS] = {false, false, false};
     const bool fork = classes_.size() > 1 && ev_fork_ && total_team_waves_ <= 4096;
     if (fork) HIPTRY(hipEventRecord(ev_fork_, sk));
@@ -1555,8 +1593,8 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
             }
         }
         kp.teams = d_teams_.p + c.first;
-        if (form_ == PBSO_FORM_BLOCK && !dense_heavy)
-            LAUNCHTRY(iir_block::launch_iir_block(kp, c.count, R_, c.W, desc_.qnorm_mode, s));
+        if (is_block() && !dense_heavy)
+            LAUNCHTRY(iir_block::launch_iir_block(kp, c.count, R_, c.W, desc_.qnorm_mode, form_ == PBSO_FORM_BLOCK_BF16 ? 1 : 0, s));
         else
             LAUNCHTRY(iir_scalar::launch_iir_bank(kp, c.count, R_, c.W, form_ == PBSO_FORM_DIRECT ? 1 : 0, desc_.qnorm_mode, s));
     }
@@ -1706,7 +1744,7 @@ int Engine::info(pbso_engine_info *out) {
     out->modes_per_lane = R_;
     out->waves_per_object = W_;
     out->n_teams = n_teams_;
-    out->lds_bytes_per_workgroup = !finalized_ ? 0 : form_ == PBSO_FORM_BLOCK ? (int)block_lds_bytes(W_) : (int)iir_lds_bytes(W_, n_tiles_);
+    out->lds_bytes_per_workgroup = !finalized_ ? 0 : is_block() ? (int)block_lds_bytes(W_) : (int)iir_lds_bytes(W_, n_tiles_);
     out->recurrence_form = form_;
     out->total_block_launches = tot_block_launches_;
     out->total_sample_launches = tot_sample_launches_;

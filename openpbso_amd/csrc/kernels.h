@@ -95,13 +95,15 @@ constexpr int MAX_WAVES_PER_TEAM = 16;     // 1024 threads; larger objects are c
 // ---- K1b: block state-space form of the oscillator bank on the f32 matrix pipe (kernels_block.hip)
 constexpr int BLOCK_J = 16;                // samples per block = rows of v_mfma_f32_16x16x4_f32
 constexpr int BLOCK_N = 16;                // blocks per group = its columns; a buffer is 1 + n_groups * 256 samples
-constexpr int BLOCK_STAGE_FLOATS = 2080;   // per wave: block-start states of one slice, [16 blocks][64 lanes][Q, D] + 2 per row
+constexpr int BLOCK_STAGE_FLOATS = 2304;   // (split-bf16 projection: two planes of [16 blocks][72 dwords])
+constexpr int BLOCK_STAGE_FLOATS_F32 = 2080;   // per wave: block-start states of one slice, [16 blocks][64 lanes][Q, D] + 2 per row
 constexpr int BLOCK_RING_FLOATS = 516;     // per wave and buffer parity: the wave's partial sums of one buffer
 constexpr int MAX_WAVES_PER_BLOCK_TEAM = 8;
 inline size_t block_lds_bytes(int W) { return sizeof(float) * (size_t)W * (BLOCK_STAGE_FLOATS + 2 * BLOCK_RING_FLOATS); }
 namespace iir_block {
 // modes_per_lane in {1,2,4}; qnorm_mode 0 off, otherwise closed form (+ per-sample in literal buffers)
-int launch_iir_block(const IirParams &p, int n_teams, int modes_per_lane, int waves_per_team, int qnorm_mode,
+// proj: 0 = f32 MFMA projection, 1 = split-bf16 projection (wtab holds the split table)
+int launch_iir_block(const IirParams &p, int n_teams, int modes_per_lane, int waves_per_team, int qnorm_mode, int proj,
                      hipStream_t stream);
 }
 

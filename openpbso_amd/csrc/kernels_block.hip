@@ -51,7 +51,12 @@ constexpr int ST_ROW = 130;
 constexpr int LIT_ROW = 68;                        // literal path: [16 samples][64 lanes] tile, 16-B aligned rows
 constexpr int ST_FLOATS = BLOCK_STAGE_FLOATS;
 constexpr int RING = BLOCK_RING_FLOATS;            // per wave and parity: samples 1..512 at [0..511], sample 0 at [512]
-static_assert(BN * ST_ROW <= ST_FLOATS && BJ * LIT_ROW <= ST_FLOATS, "staging area");
+// split-bf16 projection (PROJ == 1): staging planes "hi" and "lo", [16 blocks][64 lanes] dwords = (Q, D) as two
+// bf16; the row stride of 72 dwords makes the ds_read_b128 of (4 modes of block n) conflict-free in all four
+// 16-lane groups
+constexpr int H_ROW = 72;
+constexpr int H_PLANE = BN * H_ROW;
+static_assert(BN * ST_ROW <= ST_FLOATS && BJ * LIT_ROW <= ST_FLOATS && 2 * H_PLANE <= ST_FLOATS, "staging area");
 
 struct BlkDims {
     int nb, m_pad, b_pad, frames, n_groups;
@@ -61,6 +66,10 @@ struct BlkDims {
 };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
 
 // sum over the 64 lanes without LDS traffic: four DPP adds inside every row of 16, then the four row sums
 __device__ __forceinline__ float wave_sum(float v) {
@@ -86,7 +95,7 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-template <int R, int QNM, int MAXT>
+template <int R, int QNM, int PROJ, int MAXT>
 __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     const float *__restrict__ p_ca, const float *__restrict__ p_cb, float *__restrict__ p_sq,
     float *__restrict__ p_sd, float *__restrict__ p_ss, const BufDesc *__restrict__ p_desc,
@@ -124,27 +133,39 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     float *ring = stage + ST_FLOATS;                   // [2][RING]
 
     // per-mode registers for the whole launch: scaled state, coarse step P - I / P, transfer weight
-    float q[R], d[R], e11[R], p12[R], p21[R], p22[R], t[R];
+    // state x = (Q, D) and the coarse-step matrix as register PAIRS: c1 = (P11 - 1, P21), c2 = (P12, P22)
+    f2 x2[R], c1[R], c2[R];
+    float t[R];
     bool dead[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const unsigned k = r * rowlen + utid;
-        q[r] = (p_sq + ubase)[k];
-        d[r] = (p_sd + ubase)[k];
-        e11[r] = (p_pc + ubase)[k];
-        p12[r] = (p_pc + p.plane + ubase)[k];
-        p21[r] = (p_pc + 2 * p.plane + ubase)[k];
-        p22[r] = (p_pc + 3 * p.plane + ubase)[k];
+        x2[r].x = (p_sq + ubase)[k];
+        x2[r].y = (p_sd + ubase)[k];
+        c1[r].x = (p_pc + ubase)[k];
+        c2[r].x = (p_pc + p.plane + ubase)[k];
+        c1[r].y = (p_pc + 2 * p.plane + ubase)[k];
+        c2[r].y = (p_pc + 3 * p.plane + ubase)[k];
         dead[r] = b_ca[k] == 0.f && b_cb[k] == 0.f;
     }
     // W table: one VGPR per pair of columns, [pair][64 lanes]; this wave's slice r covers the pairs
     // (team.col0 + r * rowlen + 64 * wave) / 2 + s, s = 0..31
-    float wreg[R][32];
+    // (PROJ == 1: the same 32 dwords are eight MFMA operands of four registers each -- hi and lo parts of four groups
+    //  of 16 modes -- and are kept as quads from the start, so that the allocator never has to re-pack them)
+    float wreg[PROJ == 0 ? R : 1][32];
+    u4 wq[PROJ == 1 ? R : 1][8];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const float *__restrict__ wsrc = p_wtab + ((ubase + r * rowlen + 64 * wave) / 2) * 64;
+        if constexpr (PROJ == 0) {
 #pragma unroll
-        for (int s = 0; s < 32; ++s) wreg[r][s] = wsrc[s * 64 + lane];
+            for (int s = 0; s < 32; ++s) wreg[r][s] = wsrc[s * 64 + lane];
+        } else {
+            const unsigned *__restrict__ wu = reinterpret_cast<const unsigned *>(wsrc);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                wq[r][i] = u4{wu[(4 * i + 0) * 64 + lane], wu[(4 * i + 1) * 64 + lane], wu[(4 * i + 2) * 64 + lane], wu[(4 * i + 3) * 64 + lane]};
+        }
     }
 
     // ---- scaled state (as K1): registers hold Q = t q, D = t d while every weight of the wave is usable
@@ -164,15 +185,15 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const float f = tn[r] / from[r];
-                    q[r] = q[r] * f;
-                    d[r] = d[r] * f;
+                    x2[r].x = x2[r].x * f;
+                    x2[r].y = x2[r].y * f;
                 }
             }
         } else if (!__all(unit)) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                q[r] = q[r] / from[r];
-                d[r] = d[r] / from[r];
+                x2[r].x = x2[r].x / from[r];
+                x2[r].y = x2[r].y / from[r];
             }
         }
         scaled = ok;
@@ -245,11 +266,11 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
 
     // one coarse step of slice r: park the block-start state of block n, then x <- P x
     auto coarse = [&](int r, int n) {
-        wdst[n * (ST_ROW / 2)] = f2{q[r], d[r]};
-        const float qa = fmaf(e11[r], q[r], q[r]);
-        const float da = p21[r] * q[r];
-        q[r] = fmaf(p12[r], d[r], qa);
-        d[r] = fmaf(p22[r], d[r], da);
+        wdst[n * (ST_ROW / 2)] = f2{x2[r].x, x2[r].y};
+        const float qa = fmaf(c1[r].x, x2[r].x, x2[r].x);
+        const float da = c1[r].y * x2[r].x;
+        x2[r].x = fmaf(c2[r].x, x2[r].y, qa);
+        x2[r].y = fmaf(c2[r].y, x2[r].y, da);
     };
 
     // diagnostics (PBSO_CENSUS=1): where wave 0's shader cycles go
@@ -267,6 +288,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     for (int b = 0; b < p.nb; ++b) {
         const BufDesc cur = next;
         next = dsc[b + 1 < p.nb ? b + 1 : b];
+
         const int frow = cur.frow;
         const int prow = cur.prow;
         const float amp = cur.amp;
@@ -310,21 +332,21 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
             float p0 = 0.f;
 #pragma unroll
             for (int v = 0; v < R; ++v) {
-                float a = nca[v] * d[v];
-                a = fmaf(ncb[v], q[v], a);
+                float a = nca[v] * x2[v].y;
+                a = fmaf(ncb[v], x2[v].x, a);
                 if (hit0) a = fmaf(g_[v], amp, a);
-                d[v] = a;
-                q[v] = q[v] + a;
-                p0 = (v == 0) ? q[v] : p0 + q[v];
+                x2[v].y = a;
+                x2[v].x = x2[v].x + a;
+                p0 = (v == 0) ? x2[v].x : p0 + x2[v].x;
             }
             if (QN) {
                 // sum_{k=0}^{B-1} q_k^2 = x0' G x0, x0 = state after sample 0 (the rest of the buffer is force-free)
                 const unsigned utid = lane_off();
 #pragma unroll
                 for (int v = 0; v < R; ++v) {
-                    float e = ng22[v] * d[v] * d[v];
-                    e = fmaf(ng12[v] * q[v], d[v], e);
-                    e = fmaf(ng11[v] * q[v], q[v], e);
+                    float e = ng22[v] * x2[v].y * x2[v].y;
+                    e = fmaf(ng12[v] * x2[v].x, x2[v].y, e);
+                    e = fmaf(ng11[v] * x2[v].x, x2[v].x, e);
                     // v_sqrt_f32 / v_rcp_f32 (1 ulp each): the closed form itself is good to ~1e-5 only
                     const float nrm = __builtin_amdgcn_sqrtf(fmaxf(e, 0.f));     // (it can round a tiny sum below zero)
                     (b_qn + (size_t)b * p.m_pad)[v * rowlen + utid] = nrm * __builtin_amdgcn_rcpf(t[v]);
@@ -333,6 +355,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
             p0 = wave_sum(p0);
             if (lane == 0) rg[GROUP * NG] = p0;
 
+            if constexpr (PROJ == 0) {
             // ---- software pipeline over the U = NG * R slices of the buffer.  Slice u's 32 MFMAs take their
             // B operands from registers (breg); between them run the coarse steps of slice u + 1 (which overwrite
             // the staging area: its reads for slice u were issued before) and then the operand reads of slice u + 1.
@@ -384,6 +407,89 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                     *reinterpret_cast<f4 *>(rg + GROUP * grp + 16 * (l & 15u) + 4 * (l >> 4)) = acc;
                 }
             });
+            } else {
+                // ---- split-bf16 projection.  The lane that owns a mode parks every block-start state twice: hi =
+                // bf16(x) (v_cvt_pk_bf16_f32 rounds to nearest even; (Q, D) share a dword) and lo = bf16(x - hi); the
+                // projection of 16 modes x 16 blocks is three v_mfma_f32_16x16x32_bf16 (Whi.Xhi + Whi.Xlo + Wlo.Xhi,
+                // f32 accumulation), 48 matrix cycles instead of 256.  The recurrence itself (coarse steps) is
+                // unchanged f32.
+                unsigned *hdst = reinterpret_cast<unsigned *>(stage) + lane;
+                const u4 *hsrc = reinterpret_cast<const u4 *>(reinterpret_cast<const unsigned *>(stage) + (lane & 15) * H_ROW + 4 * (lane >> 4));
+                // one coarse step of slice r: park block n's start state (hi and lo parts), then x <- P x
+                // (packed f32 math on the pair (q, d): with two waves per SIMD the vector ALU is issue-bound -- ~4 cycles per
+                //  instruction whatever it is -- so a v_pk_fma_f32 that advances both components is worth two plain ones)
+                auto coarse16 = [&](int r, int n) {
+                    const f2 x = x2[r];
+                    const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+                    const f2 xh = {__builtin_bit_cast(float, hp << 16), __builtin_bit_cast(float, hp & 0xFFFF0000u)};
+                    const unsigned lp = __builtin_bit_cast(unsigned, __builtin_convertvector(x - xh, bf16x2));
+                    hdst[n * H_ROW] = hp;
+                    hdst[H_PLANE + n * H_ROW] = lp;
+                    // t = ((P11 - 1) q + P12 d, P21 q + P22 d);  q' = q + t.x (the small term last), d' = t.y
+                    // (plain f32 ops here: the packed form of the step below -- two v_pk instructions -- makes the
+                    //  allocator spill 130 registers in the R = 4 build of this pipeline)
+                    const float qa = fmaf(c1[r].x, x.x, x.x);
+                    const float da = c1[r].y * x.x;
+                    x2[r].x = fmaf(c2[r].x, x.y, qa);
+                    x2[r].y = fmaf(c2[r].y, x.y, da);
+                };
+                // Software pipeline as above: a slice's 8 operand reads (4 groups of 16 modes x hi / lo) sit in
+                // registers; its 12 MFMAs ride on the coarse steps 4..15 of the NEXT slice (the matrix pipe co-executes
+                // with the vector ALU for bf16), whose steps 0..3 cover the LDS latency of the reads.
+                u4 breg[8];
+                wave_sync();
+#pragma unroll
+                for (int n = 0; n < BN; ++n) coarse16(0, n);
+                wave_sync();
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    breg[2 * g] = hsrc[4 * g];
+                    breg[2 * g + 1] = hsrc[H_PLANE / 4 + 4 * g];
+                }
+                f4 acc0, acc1;
+                static_for<0, U>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    constexpr int r = u % R, grp = u / R;
+                    constexpr int rn = (u + 1) % R;
+                    constexpr bool more = u + 1 < U;
+                    if constexpr (r == 0) {
+                        acc0 = f4{0.f, 0.f, 0.f, 0.f};
+                        acc1 = f4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    wave_sync();                       // this slice's operand reads are issued: the staging area is free
+                    __builtin_amdgcn_sched_barrier(0);
+                    static_for<0, BN>([&](auto nc) {
+                        constexpr int n = decltype(nc)::value;
+                        if constexpr (more) coarse16(rn, n);
+                        if constexpr (n >= 4) {
+                            constexpr int k = n - 4, g = k / 3, which = k % 3;      // group g: Whi.Xhi, Whi.Xlo, Wlo.Xhi
+                            const u4 wh = wq[r][2 * g], wl = wq[r][2 * g + 1];
+                            if constexpr (which == 0)
+                                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wh), __builtin_bit_cast(bf16x8, breg[2 * g]), acc0, 0, 0, 0);
+                            else if constexpr (which == 1)
+                                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wh), __builtin_bit_cast(bf16x8, breg[2 * g + 1]), acc1, 0, 0, 0);
+                            else
+                                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wl), __builtin_bit_cast(bf16x8, breg[2 * g]), acc0, 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    if constexpr (more) {
+                        wave_sync();
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            breg[2 * g] = hsrc[4 * g];
+                            breg[2 * g + 1] = hsrc[H_PLANE / 4 + 4 * g];
+                        }
+                    } else {
+                        prefetch(next);                // behind it: ring write, barrier, combine
+                    }
+                    if constexpr (r == R - 1) {
+                        const f4 acc = acc0 + acc1;
+                        const unsigned l = lane_off() & 63u;
+                        *reinterpret_cast<f4 *>(rg + GROUP * grp + 16 * (l & 15u) + 4 * (l >> 4)) = acc;
+                    }
+                });
+            }
         } else {
             // ================= literal path: every sample stepped (velocity form), as K1 =================
             const float *__restrict__ tprow = p_tprof + (size_t)(prow >= 0 ? prow : 0) * p.b_pad;
@@ -394,14 +500,14 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 float pp = 0.f;
 #pragma unroll
                 for (int v = 0; v < R; ++v) {
-                    float a = nca[v] * d[v];
-                    a = fmaf(ncb[v], q[v], a);
+                    float a = nca[v] * x2[v].y;
+                    a = fmaf(ncb[v], x2[v].x, a);
                     if (forced) a = fmaf(g_[v], tk, a);
-                    d[v] = a;
-                    q[v] = q[v] + a;
-                    if (scaled) pp = (v == 0) ? q[v] : pp + q[v];
-                    else pp = (v == 0) ? t[v] * q[v] : fmaf(t[v], q[v], pp);
-                    if (QN) qn[v] = fmaf(q[v], q[v], qn[v]);
+                    x2[v].y = a;
+                    x2[v].x = x2[v].x + a;
+                    if (scaled) pp = (v == 0) ? x2[v].x : pp + x2[v].x;
+                    else pp = (v == 0) ? t[v] * x2[v].x : fmaf(t[v], x2[v].x, pp);
+                    if (QN) qn[v] = fmaf(x2[v].x, x2[v].x, qn[v]);
                 }
                 return pp;
             };
@@ -487,19 +593,19 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const unsigned k = r * rowlen + utid_end;
-        (p_sq + ubase)[k] = q[r];
-        (p_sd + ubase)[k] = d[r];
+        (p_sq + ubase)[k] = x2[r].x;
+        (p_sd + ubase)[k] = x2[r].y;
         (p_ss + ubase)[k] = scaled ? t[r] : 1.f;
     }
 }
 
-template <int R, int QNM>
+template <int R, int QNM, int PROJ>
 static int launch_one(const IirParams &p, int n_teams, int W, hipStream_t stream) {
     const size_t lds = block_lds_bytes(W);
     // R = 8 is the one-wave-per-SIMD build (512 registers: the 256 W-table operands go to AGPRs): teams of <= 4 waves
     constexpr int MAXT = R == 8 ? 256 : 64 * MAX_WAVES_PER_BLOCK_TEAM;
     if (64 * W > MAXT) return (int)hipErrorInvalidValue;
-    auto kern = iir_block_kernel<R, QNM, MAXT>;
+    auto kern = iir_block_kernel<R, QNM, PROJ, MAXT>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -512,16 +618,22 @@ static int launch_one(const IirParams &p, int n_teams, int W, hipStream_t stream
     return (int)hipGetLastError();
 }
 
-int launch_iir_block(const IirParams &p, int n_teams, int R, int W, int qnm, hipStream_t s) {
+template <int R>
+static int launch_r(const IirParams &p, int n_teams, int W, bool qn, int proj, hipStream_t s) {
+    if (proj) return qn ? launch_one<R, 2, 1>(p, n_teams, W, s) : launch_one<R, 0, 1>(p, n_teams, W, s);
+    return qn ? launch_one<R, 2, 0>(p, n_teams, W, s) : launch_one<R, 0, 0>(p, n_teams, W, s);
+}
+
+int launch_iir_block(const IirParams &p, int n_teams, int R, int W, int qnm, int proj, hipStream_t s) {
     if (n_teams <= 0) return 0;
     if (W < 1 || W > MAX_WAVES_PER_BLOCK_TEAM) return (int)hipErrorInvalidValue;
     if (p.frames != 1 + 2 * GROUP) return (int)hipErrorInvalidValue;      // the ring holds two groups (513 samples)
     const bool qn = qnm != 0;
     switch (R) {
-    case 1: return qn ? launch_one<1, 2>(p, n_teams, W, s) : launch_one<1, 0>(p, n_teams, W, s);
-    case 2: return qn ? launch_one<2, 2>(p, n_teams, W, s) : launch_one<2, 0>(p, n_teams, W, s);
-    case 4: return qn ? launch_one<4, 2>(p, n_teams, W, s) : launch_one<4, 0>(p, n_teams, W, s);
-    case 8: return qn ? launch_one<8, 2>(p, n_teams, W, s) : launch_one<8, 0>(p, n_teams, W, s);
+    case 1: return launch_r<1>(p, n_teams, W, qn, proj, s);
+    case 2: return launch_r<2>(p, n_teams, W, qn, proj, s);
+    case 4: return launch_r<4>(p, n_teams, W, qn, proj, s);
+    case 8: return launch_r<8>(p, n_teams, W, qn, proj, s);
     }
     return (int)hipErrorInvalidValue;
 }

@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 NB = 86
 TOL_MAX, TOL_L2 = 5e-4, 1e-3
 THREADS = max(1, min(8, len(os.sched_getaffinity(0))))
+BLOCK_FORMS = (capi.FORM_BLOCK, capi.FORM_BLOCK_BF16)      # the default form of Engine() (PBSO_FORM) must be one of the block forms here
 
 
 def _assert_parity(got_audio, want_audio, what):
@@ -38,7 +39,7 @@ def test_config3_64x256_moving_listener_full_size():
         path = synth.listener_path(NB) * (1.0 + 0.001 * i)
         evs += [dict(t=b, obj=i, kind="listener", pos=path[b]) for b in range(NB)]
     got = run_engine(objs, evs, NB, qnorm=capi.QNORM_OFF)
-    assert got["info"]["recurrence_form"] == capi.FORM_BLOCK
+    assert got["info"]["recurrence_form"] in BLOCK_FORMS
     want = run_oracle(objs, evs, NB, threads=THREADS)
     assert np.array_equal(got["emitted"], want["emitted"])
     mx, l2 = _assert_parity(got["audio"], want["audio"], "64x256 listener")
@@ -78,7 +79,7 @@ def test_config4_1024x512_impulse_stream_full_size():
         rng = np.random.default_rng(4)
         sample = sorted(set([0, 1, 511, 512, 1022, 1023] + rng.integers(0, n_obj, 18).tolist()))
         qn_got = {(k, b): eng.qnorm(i, b).copy() for k, i in enumerate(sample) for b in (0, 40, 85)}
-    assert info["recurrence_form"] == capi.FORM_BLOCK and info["modes_per_lane"] == 4 and info["n_teams"] == 1024
+    assert info["recurrence_form"] in BLOCK_FORMS and info["modes_per_lane"] == 4 and info["n_teams"] == 1024
     assert emitted.all() and emitted.shape == (n_obj, NB)
     objs = [ObjSpec(lams[i], shapes=shapes[i]) for i in sample]
     evs = []
@@ -120,7 +121,7 @@ def test_config5_8x4096_sustained_scraping_full_size():
     # kernel; buffers 60..85 hold ten dense ones -> block kernel, per-sample stepping inside it for those ten,
     # starting from the state the other kernel left
     got = run_engine(objs, evs, NB, qnorm=capi.QNORM_OFF, split=[60, 26])
-    assert got["info"]["recurrence_form"] == capi.FORM_BLOCK
+    assert got["info"]["recurrence_form"] in BLOCK_FORMS
     assert got["info"]["total_sample_launches"] == 1 and got["info"]["total_block_launches"] == 1
     want = run_oracle(objs, evs, NB, threads=THREADS)
     assert np.array_equal(got["emitted"], want["emitted"])
