@@ -44,6 +44,12 @@ FLOP_REF = 10                  # reference arithmetic per mode-sample incl. qnor
 # what the block form executes per mode-sample: 2 MFMA products (a_j Q + b_j D = 4 flop) + the coarse
 # recurrence (4 FMA per mode per 16 samples = 0.5 flop); the per-sample form executes what the counters say
 FLOP_BLOCK = 4.5
+# split-bf16 projection: the same contraction as three bf16 products (12 bf16 flop per mode-sample on the matrix pipe)
+# + the coarse recurrence and the hi/lo split on the vector ALU: 11 VALU instructions per mode and block of 16 samples
+# (profiles/r02_pmc_summary_bf16.txt: 1431 wave-instructions per wave-buffer of 256 modes x 513 samples at R = 4, incl. the buffer head)
+FLOP_BF16_MFMA = 12.0
+VALU_OPS_BF16 = 1431 * 64 / (256 * 513.0)      # = 0.70 lane-operations per mode-sample
+BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 TOL_MAX, TOL_L2 = 5e-4, 1e-3   # stated fp32 tolerance vs the fp64 oracle
 
 
@@ -58,8 +64,12 @@ def parse(argv=None):
     ap.add_argument("--objects", type=int, default=1024, help="objects per GPU (weak scaling); the total for the strong leg")
     ap.add_argument("--modes", type=int, default=512)
     ap.add_argument("--buffers", type=int, default=86, help="audio buffers per step")
-    ap.add_argument("--form", choices=["block", "block_bf16", "velocity", "direct"], default="block",
-                    help="block: state-space blocks on the f32 matrix pipe (K1b); velocity / direct: per-sample kernel (K1)")
+    ap.add_argument("--form", choices=["block_bf16", "block", "velocity", "direct"], default="block_bf16",
+                    help="block_bf16: block state-space form, output projection as a split-bf16 MFMA product (default); block: the same "
+                         "with an exact f32 MFMA projection; velocity / direct: per-sample kernel (K1)")
+    ap.add_argument("--plan-threads", type=int, default=1,
+                    help="host planner threads (PBSO_PLAN_THREADS, pinned next to the caller's core); 1 (default): the caller's "
+                         "thread alone -- helpers cut the planning time 2.4x but did not move the step on the measured boxes")
     ap.add_argument("--qnorm", choices=["sample", "closed", "off"], default="sample",
                     help="getQBufferNorm rows: on (the block form evaluates them in closed form), closed form, or off")
     ap.add_argument("--no-qnorm", action="store_true", help="same as --qnorm off")
@@ -403,6 +413,12 @@ def main():
         # nothing above this line has initialised HIP (torch is not even imported yet)
         sys.exit(spawn_ranks(args.gpus, argv))
 
+    # host planner threads (per-thread planning contexts merged in object order; the helpers are pinned into the
+    # caller's core complex: unpinned they wander over the two sockets of these hosts and lose).  With N ranks on
+    # one node every rank gets its share of the cores.
+    os.environ.setdefault("PBSO_PLAN_THREADS", str(args.plan_threads))
+    os.environ.setdefault("PBSO_PLAN_PIN", "1" if int(os.environ["PBSO_PLAN_THREADS"]) > 1 else "0")
+
     import torch
     import torch.distributed as dist
 
@@ -483,7 +499,9 @@ def main():
         mode_samples = m["n_local"] * M * nb * B
         # (a block-form engine runs launches that are mostly dense-profile buffers on the per-sample kernel)
         block = m["form_run"] in (0, 3) and m["info"]["total_block_launches"] >= m["info"]["total_sample_launches"]
-        flop_exec = FLOP_BLOCK if block else FLOP_REF
+        bf16 = block and m["form_run"] == 3
+        # bf16 form: the vector ALU binds (instruction issue); one VALU instruction = 64 lanes x 2 flop-equivalents
+        flop_exec = 2 * VALU_OPS_BF16 if bf16 else (FLOP_BLOCK if block else FLOP_REF)
         tf_exec = flop_exec * mode_samples / (k_ms * 1e-3) * 1e-12
         tf_ref = FLOP_REF * mode_samples / (k_ms * 1e-3) * 1e-12
         # algorithmic bytes of one launch (SURVEY 8(d) formula with NB_l = nb; M = modes per object); the block
@@ -511,13 +529,21 @@ def main():
                 "scenario": args.scenario, "objects_per_gpu": m["n_local"], "modes": M, "buffers_per_step": nb, "frames_per_buffer": B,
                 "hits": m["n_hits"], "modes_per_lane": info["modes_per_lane"], "waves_per_object": info["waves_per_object"],
                 "recurrence_form": args.form, "gather": m["gather"], "rccl_ranks": rccl_ranks, "backend": backend if use_dist else None,
-                "parallelism": f"object-sharded x{world}", "launched_by": "bench.py" if os.environ.get("PBSO_BENCH_SPAWNED") else
+                "host_planner_threads": int(os.environ["PBSO_PLAN_THREADS"]), "parallelism": f"object-sharded x{world}", "launched_by": "bench.py" if os.environ.get("PBSO_BENCH_SPAWNED") else
                                ("torch.distributed.run" if use_dist else "single process"),
             },
             "roofline": {
-                "bound": "mfma" if block else "valu",
+                "bound": "valu" if bf16 or not block else "mfma",
                 "kernel": "iir_block_kernel" if block else "iir_bank_kernel",
-                "bound_note": ("f32 matrix pipe: the per-sample sum over modes is a [16 x 2M].[2M x 16 blocks] product on "
+                "bound_note": ("vector-ALU instruction issue: the output projection runs as a split-bf16 product on "
+                               "v_mfma_f32_16x16x32_bf16 (12 bf16 flop per mode-sample = " + ("%.0f" % (FLOP_BF16_MFMA * mode_samples / (k_ms * 1e-3) * 1e-12)) +
+                               " TFLOP/s, " + ("%.2f" % (FLOP_BF16_MFMA * mode_samples / (k_ms * 1e-3) * 1e-12 / BF16_PEAK_TFLOPS)) + " of the dense bf16 peak: not the "
+                               "limiter) and co-executes with the vector ALU, which carries the f32 coarse recurrence and the hi / lo "
+                               "split of every block-start state: 1431 VALU instructions per wave and buffer (PMC, profiles/r02_pmc_summary_bf16.txt); "
+                               "achieved / frac count every VALU instruction as 64 lanes x 2 flop against the 157.3 TFLOP/s f32 vector "
+                               "peak, i.e. issue-slot utilisation (two waves per SIMD issue one instruction per ~4 cycles, PMC); "
+                               "reference_equivalent credits the reference's 10 flop per mode-sample") if bf16 else
+                              ("f32 matrix pipe: the per-sample sum over modes is a [16 x 2M].[2M x 16 blocks] product on "
                                "v_mfma_f32_16x16x4_f32 (4 flop per mode-sample) + the coarse recurrence on the vector ALU "
                                "(0.5 flop); on gfx950 the f32 MFMA and the f32 VALU do not co-execute "
                                "(SQ_VALU_MFMA_COEXEC_CYCLES = 0, profiles/r02_pmc_summary.txt), so their cycles add against ONE "

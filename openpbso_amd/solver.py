@@ -90,7 +90,7 @@ class Engine:
         if form is None:
             # PBSO_FORM=block|velocity|direct lets a whole test / bench run pick the oscillator-bank kernel
             form = {"block": capi.FORM_BLOCK, "velocity": capi.FORM_VELOCITY, "direct": capi.FORM_DIRECT,
-                    "block_bf16": capi.FORM_BLOCK_BF16}[os.environ.get("PBSO_FORM", "block")]
+                    "block_bf16": capi.FORM_BLOCK_BF16}[os.environ.get("PBSO_FORM", "block_bf16")]
         self.form = form
         self._l = capi.lib()
         d = capi.EngineDesc()

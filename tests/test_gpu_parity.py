@@ -68,7 +68,8 @@ def test_config2_512_modes_poisson_train(mpl, rotate, monkeypatch):
     assert len(evs) > 5
     evs.append(dict(t=0, obj=0, kind="use_transfer", use=False))
     objs = [ObjSpec(lam, shapes=shapes)]
-    kw = dict(form=capi.FORM_VELOCITY) if mpl == 3 else {}      # three modes per lane exist in the per-sample kernel only
+    # three modes per lane exist in the per-sample kernel only; the f32 projection of the block kernel takes rotate = "1"
+    kw = dict(form=capi.FORM_VELOCITY) if mpl == 3 else (dict(form=capi.FORM_BLOCK) if rotate == "1" else {})
     got = run_engine(objs, evs, NB, modes_per_lane=mpl, **kw)
     want = run_oracle(objs, evs, NB)
     mx, l2 = _check(got, want)
