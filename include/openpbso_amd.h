@@ -220,6 +220,15 @@ int pbso_compute_transfer(pbso_engine *e, int object_id, const double pos[3], in
  * out[n_pos][out_cols] doubles, columns [0, n_maps) of every row are written, the others left alone;
  * out_cols < n_maps is PBSO_ERR_INVALID.  1 = done, 0 = the object has no maps.                         */
 int pbso_compute_transfer_batch(pbso_engine *e, int object_id, const double *pos, int n_pos, double *out, int out_cols);
+/* Multi-listener output (the reference evaluates the transfer for many positions, modal_solver.h:302-315,
+ * tools/...:916-927, but mixes one listener): after pbso_listeners_enable(obj) every pbso_step keeps the block-start
+ * states of that object (block forms only), and pbso_mix_listeners returns the LAST step's audio of the object as heard
+ * at each of n_listeners positions -- out[n_listeners][n_buffers * 513] floats, host memory -- i.e. what n_listeners
+ * ModalSolvers fed the same forces and computeTransfer(pos_l) would emit.  The per-sample dot q . transfer_l becomes an
+ * [L x 16 samples x 2M] . [2M x 16 blocks] contraction on the f32 matrix pipe.  PBSO_ERR_STATE if the last step holds a
+ * buffer of the object with a dense force profile (Gaussian / AR: stepped per sample, no block states).            */
+int pbso_listeners_enable(pbso_engine *e, int object_id);
+int pbso_mix_listeners(pbso_engine *e, int object_id, const double *pos, int n_listeners, float *out, size_t n_out);
 /* _ffat_maps->size() of an object (modal_solver.h:312); 0 while readFFATMaps has not been called */
 int pbso_object_n_maps(pbso_engine *e, int object_id);
 /* ModalSolver::setUseTransfer (modal_solver.h:148-152) */

@@ -21,7 +21,7 @@ EXPORTS = [
     "pbso_abi_version", "pbso_status_string", "pbso_engine_create", "pbso_engine_destroy",
     "pbso_last_error", "pbso_add_object", "pbso_add_object_from_files", "pbso_object_set_ffat_maps",
     "pbso_object_read_ffat_maps", "pbso_fatcube_parse", "pbso_ffat_map_free", "pbso_finalize",
-    "pbso_enqueue_force", "pbso_enqueue_force_batch", "pbso_enqueue_arprm", "pbso_compute_transfer", "pbso_compute_transfer_batch", "pbso_object_n_maps",
+    "pbso_enqueue_force", "pbso_enqueue_force_batch", "pbso_enqueue_arprm", "pbso_compute_transfer", "pbso_compute_transfer_batch", "pbso_object_n_maps", "pbso_listeners_enable", "pbso_mix_listeners",
     "pbso_set_use_transfer", "pbso_get_latest_transfer", "pbso_step", "pbso_step_into", "pbso_sync",
     "pbso_read_audio", "pbso_read_emitted", "pbso_read_qnorm", "pbso_read_state",
     "pbso_audio_device_ptr", "pbso_pa_convert", "pbso_get_info",
@@ -106,6 +106,8 @@ def lib():
     l.pbso_compute_transfer.argtypes = [vp, C.c_int, dp, C.c_int64]
     l.pbso_compute_transfer_batch.argtypes = [vp, C.c_int, dp, C.c_int, dp, C.c_int]
     l.pbso_object_n_maps.argtypes = [vp, C.c_int]
+    l.pbso_listeners_enable.argtypes = [vp, C.c_int]
+    l.pbso_mix_listeners.argtypes = [vp, C.c_int, dp, C.c_int, C.POINTER(C.c_float), C.c_size_t]
     l.pbso_set_use_transfer.argtypes = [vp, C.c_int, C.c_int, C.c_int64]
     l.pbso_get_latest_transfer.argtypes = [vp, C.c_int, dp]
     l.pbso_step.argtypes = [vp, C.c_int]

@@ -297,6 +297,20 @@ int pbso_compute_transfer(pbso_engine *e, int obj, const double pos[3], int64_t 
     GUARD_END(e)
 }
 
+int pbso_listeners_enable(pbso_engine *e, int obj) {
+    NEED(e);
+    GUARD_BEGIN
+    return e->impl->listeners_enable(obj);
+    GUARD_END(e)
+}
+
+int pbso_mix_listeners(pbso_engine *e, int obj, const double *pos, int n_listeners, float *out, size_t n_out) {
+    NEED(e);
+    GUARD_BEGIN
+    return e->impl->mix_listeners(obj, pos, n_listeners, out, n_out);
+    GUARD_END(e)
+}
+
 int pbso_object_n_maps(pbso_engine *e, int obj) {
     NEED(e);
     GUARD_BEGIN

@@ -256,7 +256,7 @@ Engine::~Engine() {
     d_ca_.release(); d_cb_.release(); d_sq_.release(); d_sd_.release(); d_ss_.release(); d_c3_.release(); d_gq_.release();
     d_shapes_.release(); d_shape_off_.release(); d_n_modes_.release(); d_geom_.release();
     d_geom_off_.release(); d_psi_.release(); d_slots_.release(); d_xfer_.release();
-    d_pc_.release(); d_wtab_.release();
+    d_pc_.release(); d_wtab_.release(); d_dump_row_.release(); d_xdump_.release(); d_xscale_.release(); d_wtab32_.release();
     d_arstate_.release(); d_board_.release(); d_teams_.release(); d_split_.release(); d_audio_parts_.release();
     d_audio_.release(); d_qnorm_.release(); d_grows_[0].release(); d_grows_[1].release(); d_census_.release();
     for (hipEvent_t ev : {ev_prep_done_[0], ev_prep_done_[1], ev_k1_done_[0], ev_k1_done_[1]})
@@ -1381,7 +1381,20 @@ int Engine::step(int nb, void *d_audio_user) {
         HIPTRY(d_audio_.ensure((size_t)N * nb * B_, false, stream_));
         audio = d_audio_.p;
     }
-    if (desc_.qnorm_mode != PBSO_QNORM_OFF) HIPTRY(d_qnorm_.ensure((size_t)N * nb * m_pad_, false, stream_));
+    if (desc_.qnorm_mode != PBSO_QNORM_OFF || n_dump_ > 0) HIPTRY(d_qnorm_.ensure((size_t)N * nb * m_pad_, false, stream_));
+    if (n_dump_ > 0) {
+        // block-start states of the objects a multi-listener mix was asked for (pbso_listeners_enable)
+        HIPTRY(d_xdump_.ensure((size_t)n_dump_ * nb * 32 * m_pad_ * 2, false, stream_));
+        HIPTRY(d_xscale_.ensure((size_t)n_dump_ * nb * m_pad_, false, stream_));
+        if (dump_rows_dirty_) {
+            HIPTRY(d_dump_row_.ensure(N, false, stream_));
+            HIPTRY(hipMemcpyAsync(d_dump_row_.p, dump_row_.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, stream_));
+            HIPTRY(hipStreamSynchronize(stream_));           // (dump_row_ is pageable host memory)
+            dump_rows_dirty_ = false;
+        }
+        dump_nb_ = nb;
+        std::fill(dump_valid_.begin(), dump_valid_.end(), 1);
+    }
     if (n_part_rows_) HIPTRY(d_audio_parts_.ensure((size_t)n_part_rows_ * nb * B_, false, stream_));
     emitted_.assign((size_t)N * nb, 1);
     const int64_t step_id = tot_steps_;
@@ -1488,6 +1501,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     const size_t o_proj = place(proj_.size() * sizeof(ProjectEvent)), o_projd = place(proj_direct_.size() * sizeof(ProjectEvent));
     const size_t o_ffat = place(ffat_.size() * sizeof(FfatEvent)), o_copy = place(cp.size() * sizeof(int));
     HIPTRY(ps.h_arena.ensure_keep(off, ps.front_bytes));
+    plan_desc_ = reinterpret_cast<BufDesc *>(ps.h_arena.p);      // (the arena may have moved)
     ps.last_bytes = off;
     unsigned char *ha = ps.h_arena.p;
     auto put = [&](size_t o, const void *src, size_t bytes) { if (bytes) std::memcpy(ha + o, src, bytes); };
@@ -1545,7 +1559,10 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.xfer_rows = d_xfer_.p;
     kp.xfer_init = d_xfer_init;
     kp.audio = audio + (size_t)b0 * B_;
-    kp.qnorm = qn ? d_qnorm_.p : nullptr;
+    kp.qnorm = (qn || n_dump_ > 0) ? d_qnorm_.p : nullptr;
+    kp.xdump = n_dump_ > 0 ? d_xdump_.p : nullptr;
+    kp.xscale = d_xscale_.p;
+    kp.dump_row = d_dump_row_.p;
     kp.qn_nb = nb_total;
     kp.qn_b0 = b0;
     kp.gq = d_gq_.p;
@@ -1578,6 +1595,15 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     // PBSO_DENSE_LAUNCHES=block keeps every launch on the block kernel (bit-identical audio for any cut of a step).
     const bool dense_heavy = is_block() && dense_to_k1_ && (long long)n_prows_ * 2 > (long long)N * nb;
     (dense_heavy || !is_block() ? tot_sample_launches_ : tot_block_launches_) += 1;
+    if (n_dump_ > 0) {
+        // the mix needs block states: a launch on the per-sample kernel leaves none, a dense-profile buffer neither
+        for (int i = 0; i < N; ++i) {
+            if (dump_row_[i] < 0) continue;
+            if (dense_heavy || !is_block()) { dump_valid_[i] = 0; continue; }
+            for (int b = 0; b < nb; ++b)
+                if (plan_desc_[(size_t)i * nb + b].prow >= 0) { dump_valid_[i] = 0; break; }
+        }
+    }
     bool used[N_CLASS_STREAMS] = {false, false, false};
     const bool fork = classes_.size() > 1 && ev_fork_ && total_team_waves_ <= 4096;
     if (fork) HIPTRY(hipEventRecord(ev_fork_, sk));
@@ -1692,6 +1718,94 @@ int Engine::get_latest_transfer(int obj, double *out) {
 }
 
 // ModalSolver::computeTransfer(pos, T *trans), modal_solver.h:302-315, batched
+// Multi-listener output: from the next step on the block kernel keeps this object's block-start states.
+int Engine::listeners_enable(int obj) {
+    if (!finalized_) return fail(PBSO_ERR_STATE, "listeners_enable before finalize");
+    if (!valid_obj(obj)) return fail(PBSO_ERR_INVALID, "object id");
+    if (!is_block()) return fail(PBSO_ERR_STATE, "the multi-listener mix needs one of the block forms (frames_per_buffer = 513)");
+    if (dump_row_.empty()) { dump_row_.assign(objs_.size(), -1); dump_valid_.assign(objs_.size(), 0); }
+    if (dump_row_[obj] >= 0) return PBSO_OK;
+    const Object &o = objs_[obj];
+    // this object's f32 operand table (the engine's own table may hold the split-bf16 form)
+    std::vector<float> wt((size_t)m_pad_ / 2 * 64, 0.f);
+    for (int m = 0; m < o.n_modes; ++m) {
+        const double eps2 = -o.c2[m], e = (1.0 - o.c1[m]) - o.c2[m];
+        const double a00 = 1.0 - e, a01 = eps2, a10 = -e, a11 = eps2;
+        double p00 = 1, p01 = 0, p10 = 0, p11 = 1;
+        float *w = wt.data() + (size_t)(m / 2) * 64 + 16 * (2 * (m & 1));
+        for (int j = 1; j <= BLOCK_J; ++j) {
+            const double n00 = a00 * p00 + a01 * p10, n01 = a00 * p01 + a01 * p11;
+            const double n10 = a10 * p00 + a11 * p10, n11 = a10 * p01 + a11 * p11;
+            p00 = n00; p01 = n01; p10 = n10; p11 = n11;
+            w[j - 1] = (float)p00;
+            w[16 + j - 1] = (float)p01;
+        }
+    }
+    HIPTRY(hipSetDevice(desc_.device));
+    int rc = sync();
+    if (rc) return rc;
+    HIPTRY(d_wtab32_.ensure((size_t)(n_dump_ + 1) * wt.size(), true, stream_));
+    HIPTRY(hipMemcpyAsync(d_wtab32_.p + (size_t)n_dump_ * wt.size(), wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+    HIPTRY(hipStreamSynchronize(stream_));
+    dump_row_[obj] = n_dump_++;
+    dump_rows_dirty_ = true;
+    return PBSO_OK;
+}
+
+// out[n_listeners][last_nb * frames]: the last step's audio of `obj` as heard at each position
+int Engine::mix_listeners(int obj, const double *pos, int n_listeners, float *out, size_t n_out) {
+    HIPTRY(hipSetDevice(desc_.device));
+    if (!finalized_) return fail(PBSO_ERR_STATE, "mix_listeners before finalize");
+    if (!valid_obj(obj) || n_listeners <= 0 || !pos || !out) return fail(PBSO_ERR_INVALID, "mix_listeners arguments");
+    if (dump_row_.empty() || dump_row_[obj] < 0) return fail(PBSO_ERR_STATE, "pbso_listeners_enable was not called for this object");
+    if (dump_nb_ <= 0 || dump_nb_ != last_nb_) return fail(PBSO_ERR_STATE, "no step since pbso_listeners_enable");
+    if (!dump_valid_[obj])
+        return fail(PBSO_ERR_STATE, "the last step has buffers of this object without block states (dense force profile or per-sample launch)");
+    if (n_out != (size_t)n_listeners * last_nb_ * B_) return fail(PBSO_ERR_INVALID, "mix_listeners output size");
+    Object &o = objs_[obj];
+    DevBuf<double> rows;
+    DevBuf<float> dout;
+    int rc = PBSO_OK;
+    hipError_t e = rows.ensure((size_t)n_listeners * m_pad_, false, stream_);
+    if (e == hipSuccess) e = dout.ensure(n_out, false, stream_);
+    if (e == hipSuccess && o.have_maps && o.n_maps > 0) {
+        // ModalSolver::computeTransfer(pos, T*) per listener (modal_solver.h:302-315)
+        if (o.n_maps < o.n_modes) { rows.release(); dout.release(); return fail(PBSO_ERR_MISSING_MAP, "FFAT maps do not cover the audible modes"); }
+        std::vector<FfatEvent> evs(n_listeners);
+        for (int i = 0; i < n_listeners; ++i) {
+            evs[i].obj = obj;
+            evs[i].row = i;
+            for (int j = 0; j < 3; ++j) evs[i].pos[j] = pos[3 * i + j];
+        }
+        DevBuf<FfatEvent> dev;
+        e = dev.ensure(n_listeners, false, stream_);
+        if (e == hipSuccess) e = hipMemcpyAsync(dev.p, evs.data(), n_listeners * sizeof(FfatEvent), hipMemcpyHostToDevice, stream_);
+        if (e == hipSuccess) {
+            int le = launch_ffat_lookup(dev.p, n_listeners, d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p, rows.p, m_pad_, stream_);
+            if (le) e = (hipError_t)le;
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+        dev.release();
+    } else if (e == hipSuccess) {
+        std::vector<double> unit((size_t)n_listeners * m_pad_, 1E7);          // no maps: TransMessage::setToUnit (modal_solver.h:89-92)
+        e = hipMemcpyAsync(rows.p, unit.data(), unit.size() * sizeof(double), hipMemcpyHostToDevice, stream_);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+    }
+    if (e == hipSuccess) {
+        const size_t row = (size_t)dump_row_[obj];
+        int le = iir_block::launch_listener_mix(d_xdump_.p + row * last_nb_ * 32 * m_pad_ * 2, d_xscale_.p + row * last_nb_ * m_pad_,
+                                                d_wtab32_.p + row * ((size_t)m_pad_ / 2 * 64), rows.p, dout.p, last_nb_, m_pad_, o.n_modes,
+                                                n_listeners, (long long)last_nb_ * B_, stream_);
+        if (le) e = (hipError_t)le;
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout.p, n_out * sizeof(float), hipMemcpyDeviceToHost, stream_);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+    if (e != hipSuccess) rc = hip_fail(e, "mix_listeners");
+    rows.release();
+    dout.release();
+    return rc;
+}
+
 int Engine::object_n_maps(int obj) {
     if (!valid_obj(obj)) return fail(PBSO_ERR_INVALID, "object id");
     return objs_[obj].have_maps ? objs_[obj].n_maps : 0;

@@ -168,6 +168,8 @@ public:
     int enqueue_arprm(int obj, const double a[2], double sigma, double mu, int64_t not_before);
     int compute_transfer(int obj, const double pos[3], int64_t not_before);
     int compute_transfer_batch(int obj, const double *pos, int n_pos, double *out, int out_cols);
+    int listeners_enable(int obj);
+    int mix_listeners(int obj, const double *pos, int n_listeners, float *out, size_t n_out);
     int object_n_maps(int obj);
     int set_use_transfer(int obj, int use, int64_t not_before);
     int get_latest_transfer(int obj, double *out);
@@ -232,6 +234,14 @@ private:
     int n_teams_ = 0, n_split_ = 0, n_part_rows_ = 0;
     long long total_team_waves_ = 0;
     DevBuf<float> d_gq_;                                 // closed-form qnorm: G11, 2 G12, G22 planes
+    // multi-listener mix: objects that keep their block-start states (row per object), the f32 (a_j, b_j) tables of
+    // those objects, and whether the last step's states are usable (block launches only, no dense-profile buffer)
+    std::vector<int> dump_row_;
+    std::vector<char> dump_valid_;
+    int n_dump_ = 0, dump_nb_ = 0;
+    bool dump_rows_dirty_ = false;
+    DevBuf<int> d_dump_row_;
+    DevBuf<float> d_xdump_, d_xscale_, d_wtab32_;
     DevBuf<float> d_pc_, d_wtab_;                        // block form: P = A^16 planes and the MFMA W table (kernels_block.hip)
     bool is_block() const { return form_ == PBSO_FORM_BLOCK || form_ == PBSO_FORM_BLOCK_BF16; }
     int form_ = PBSO_FORM_BLOCK;                         // the form that runs (block falls back to velocity for odd buffer lengths)

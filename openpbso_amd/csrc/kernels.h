@@ -75,6 +75,10 @@ struct IirParams {
     const float *pc;             // planes P11 - 1, P12, P21, P22 of P = A^16 in the (q, q - q_prev) basis, each [n_obj][m_pad] (stride gq_plane)
     const float *wtab;           // [n_obj * m_pad / 2][64]: MFMA A operand per pair of columns (a_j, b_j of both modes, j = 1..16)
     int frames;                  // samples per buffer
+    // multi-listener mix: objects with dump_row[obj] >= 0 keep their block-start states (nullptr: nobody does)
+    float *xdump;                // [n_dump][qn_nb][32][m_pad] pairs (Q, D), scaled as the registers hold them
+    float *xscale;               // [n_dump][qn_nb][m_pad] the scale (transfer weight) of that buffer; 0: stepped per sample
+    const int *dump_row;         // [n_obj]
 };
 
 // launches the oscillator bank for n_teams teams of waves_per_team waves; returns hipError_t as int.
@@ -105,6 +109,12 @@ namespace iir_block {
 // proj: 0 = f32 MFMA projection, 1 = split-bf16 projection (wtab holds the split table)
 int launch_iir_block(const IirParams &p, int n_teams, int modes_per_lane, int waves_per_team, int qnorm_mode, int proj,
                      hipStream_t stream);
+}
+namespace iir_block {
+// multi-listener mix of ONE object from the states a dump launch kept: xdump / xscale are that object's rows,
+// wtab32 its f32 (a_j, b_j) table [m_pad / 2][64], trows [n_listeners][m_pad] transfer values, out [n_listeners][out_stride]
+int launch_listener_mix(const float *xdump, const float *xscale, const float *wtab32, const double *trows, float *out,
+                        int nb, int m_pad, int n_modes, int n_listeners, long long out_stride, hipStream_t stream);
 }
 
 // ---- exact fp64 helper kernels (kernels_exact.hip, built with -ffp-contract=off)

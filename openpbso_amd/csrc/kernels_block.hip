@@ -95,7 +95,9 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-template <int R, int QNM, int PROJ, int MAXT>
+// DUMP: objects with a dump row (multi-listener mix, pbso_listeners_enable) also write every block-start state
+// (scaled, as the registers hold it) and the scale of the buffer to memory; other builds carry no trace of it.
+template <int R, int QNM, int PROJ, bool DUMP, int MAXT>
 __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     const float *__restrict__ p_ca, const float *__restrict__ p_cb, float *__restrict__ p_sq,
     float *__restrict__ p_sd, float *__restrict__ p_ss, const BufDesc *__restrict__ p_desc,
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     const int *__restrict__ p_xfer_init, float *__restrict__ p_audio, float *__restrict__ p_qnorm,
     const float *__restrict__ p_gq, const float *__restrict__ p_pc, const float *__restrict__ p_wtab,
     const TeamDesc *__restrict__ p_teams, float *__restrict__ p_audio_parts, unsigned long long *__restrict__ p_census,
-    const BlkDims p) {
+    float *__restrict__ p_xdump, float *__restrict__ p_xscale, const int *__restrict__ p_dump_row, const BlkDims p) {
     constexpr bool QN = QNM != 0;
     constexpr int NG = 2;                              // groups per buffer (513 = 1 + 2 * 256; checked at launch)
     constexpr int U = NG * R;                          // slices per buffer: (group, r)
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
+
     // Inputs of a buffer that come from memory -- per-sample coefficients (sample 0 and literal buffers),
     // qnorm matrices, the force gain row, the new transfer row -- are fetched while the previous buffer's
     // last slice runs on the matrix pipe, so that a buffer never starts with a round trip to L2 / HBM.
@@ -238,6 +241,24 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
         unsigned v = utid;
         asm volatile("" : "+v"(v));
         return v;
+    };
+    // DUMP: xdump[row][qn_nb][32 blocks][m_pad] pairs (Q, D), xscale[row][qn_nb][m_pad] (0 marks a buffer that was
+    // stepped per sample: no block states)
+    const int dump_row = DUMP ? p_dump_row[obj] : -1;
+    int dump_b = 0;                                    // buffer (within the step) the pipeline is working on
+    auto dump_state = [&](int r, int blk) {
+        if (DUMP && dump_row >= 0) {
+            f2 *dst = reinterpret_cast<f2 *>(p_xdump) + (((size_t)dump_row * p.qn_nb + dump_b) * 32 + blk) * p.m_pad + team.col0;
+            dst[r * rowlen + lane_off()] = x2[r];
+        }
+    };
+    auto dump_scale = [&](bool block_buffer) {
+        if (DUMP && dump_row >= 0) {
+            float *dst = p_xscale + ((size_t)dump_row * p.qn_nb + dump_b) * p.m_pad + team.col0;
+            const unsigned utid = lane_off();
+#pragma unroll
+            for (int r = 0; r < R; ++r) dst[r * rowlen + utid] = block_buffer ? t[r] : 0.f;
+        }
     };
     auto prefetch = [&](const BufDesc &nd) {
         const unsigned utid = lane_off();
@@ -265,7 +286,8 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     };
 
     // one coarse step of slice r: park the block-start state of block n, then x <- P x
-    auto coarse = [&](int r, int n) {
+    auto coarse = [&](int r, int n, int blk) {
+        dump_state(r, blk);
         wdst[n * (ST_ROW / 2)] = f2{x2[r].x, x2[r].y};
         const float qa = fmaf(c1[r].x, x2[r].x, x2[r].x);
         const float da = c1[r].y * x2[r].x;
@@ -295,8 +317,10 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
         const int trow = cur.trow;
         const uint32_t flags = cur.flags;
         float *rg = ring + (b & 1) * RING;
+        dump_b = p.qn_b0 + b;
 
         if (flags & DESC_SKIP) {
+            dump_scale(false);
             // the reference's step() returned before stepping: no samples, state untouched
             for (int i = tid; i < B; i += blockDim.x) aout[(size_t)b * B + i] = 0.f;
             if (QN) {
@@ -325,6 +349,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
         const bool impulse = (flags & DESC_IMPULSE) != 0;
         const bool dense = frow >= 0 && !impulse;
 
+        dump_scale(scaled && !dense);
         if (scaled && !dense) {
             // ================= block path =================
             // sample 0, literal: d_0 = eps^2 d - e q + g T_0 ; q_0 = q + d_0   (nca = eps^2, ncb = -e)
@@ -363,7 +388,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
             lap(cy_head);
             wave_sync();                               // the previous buffer's staging reads are issued
 #pragma unroll
-            for (int n = 0; n < BN; ++n) coarse(0, n);
+            for (int n = 0; n < BN; ++n) coarse(0, n, n);
             wave_sync();
 #pragma unroll
             for (int s = 0; s < 16; ++s) breg[s] = bsrc[4 * s];
@@ -385,7 +410,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                     constexpr int s = decltype(sc)::value;
                     if constexpr (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s], breg[s], acc1, 0, 0, 0);
                     else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s], breg[s], acc0, 0, 0, 0);
-                    if constexpr (more) coarse(rn, s);
+                    if constexpr (more) coarse(rn, s, BN * ((u + 1) / R) + s);
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 if constexpr (more) wave_sync();
@@ -418,7 +443,8 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 // one coarse step of slice r: park block n's start state (hi and lo parts), then x <- P x
                 // (packed f32 math on the pair (q, d): with two waves per SIMD the vector ALU is issue-bound -- ~4 cycles per
                 //  instruction whatever it is -- so a v_pk_fma_f32 that advances both components is worth two plain ones)
-                auto coarse16 = [&](int r, int n) {
+                auto coarse16 = [&](int r, int n, int blk) {
+                    dump_state(r, blk);
                     const f2 x = x2[r];
                     const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
                     const f2 xh = {__builtin_bit_cast(float, hp << 16), __builtin_bit_cast(float, hp & 0xFFFF0000u)};
@@ -439,7 +465,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 u4 breg[8];
                 wave_sync();
 #pragma unroll
-                for (int n = 0; n < BN; ++n) coarse16(0, n);
+                for (int n = 0; n < BN; ++n) coarse16(0, n, n);
                 wave_sync();
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -460,7 +486,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                     __builtin_amdgcn_sched_barrier(0);
                     static_for<0, BN>([&](auto nc) {
                         constexpr int n = decltype(nc)::value;
-                        if constexpr (more) coarse16(rn, n);
+                        if constexpr (more) coarse16(rn, n, BN * ((u + 1) / R) + n);
                         if constexpr (n >= 4) {
                             constexpr int k = n - 4, g = k / 3, which = k % 3;      // group g: Whi.Xhi, Whi.Xlo, Wlo.Xhi
                             const u4 wh = wq[r][2 * g], wl = wq[r][2 * g + 1];
@@ -599,13 +625,13 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     }
 }
 
-template <int R, int QNM, int PROJ>
+template <int R, int QNM, int PROJ, bool DUMP>
 static int launch_one(const IirParams &p, int n_teams, int W, hipStream_t stream) {
     const size_t lds = block_lds_bytes(W);
     // R = 8 is the one-wave-per-SIMD build (512 registers: the 256 W-table operands go to AGPRs): teams of <= 4 waves
     constexpr int MAXT = R == 8 ? 256 : 64 * MAX_WAVES_PER_BLOCK_TEAM;
     if (64 * W > MAXT) return (int)hipErrorInvalidValue;
-    auto kern = iir_block_kernel<R, QNM, PROJ, MAXT>;
+    auto kern = iir_block_kernel<R, QNM, PROJ, DUMP, MAXT>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -614,14 +640,17 @@ static int launch_one(const IirParams &p, int n_teams, int W, hipStream_t stream
     const int frames = p.frames;
     const BlkDims dims = {p.nb, p.m_pad, p.b_pad, frames, (frames - 1) / GROUP, p.audio_stride, p.gq_plane, p.qn_nb, p.qn_b0};
     hipLaunchKernelGGL(kern, dim3(n_teams), dim3(64 * W), lds, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows,
-                       p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.census, dims);
+                       p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.census, p.xdump, p.xscale, p.dump_row, dims);
     return (int)hipGetLastError();
 }
 
 template <int R>
 static int launch_r(const IirParams &p, int n_teams, int W, bool qn, int proj, hipStream_t s) {
-    if (proj) return qn ? launch_one<R, 2, 1>(p, n_teams, W, s) : launch_one<R, 0, 1>(p, n_teams, W, s);
-    return qn ? launch_one<R, 2, 0>(p, n_teams, W, s) : launch_one<R, 0, 0>(p, n_teams, W, s);
+    if (p.xdump) {          // some object keeps its block-start states (multi-listener mix): qnorm rows always on in that build
+        return proj ? launch_one<R, 2, 1, true>(p, n_teams, W, s) : launch_one<R, 2, 0, true>(p, n_teams, W, s);
+    }
+    if (proj) return qn ? launch_one<R, 2, 1, false>(p, n_teams, W, s) : launch_one<R, 0, 1, false>(p, n_teams, W, s);
+    return qn ? launch_one<R, 2, 0, false>(p, n_teams, W, s) : launch_one<R, 0, 0, false>(p, n_teams, W, s);
 }
 
 int launch_iir_block(const IirParams &p, int n_teams, int R, int W, int qnm, int proj, hipStream_t s) {
@@ -636,6 +665,84 @@ int launch_iir_block(const IirParams &p, int n_teams, int R, int W, int qnm, int
     case 8: return launch_r<8>(p, n_teams, W, qn, proj, s);
     }
     return (int)hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Multi-listener output mix: the sound of ONE object at L listener positions from the block-start
+// states a DUMP launch kept.  For listener l the per-sample dot q . transfer_l (modal_solver.h:267-269, with the
+// transfer of computeTransfer(pos, T*), :302-315) is  Y_l[16 samples][16 blocks] = sum over modes of
+// (T_l[m] / scale[m]) . W[16][(m, comp)] . X[(m, comp)][16 blocks]:  the B operand (states) is shared by all
+// listeners, the A operand is the object's (a_j, b_j) table times the listener's weight -- an
+// [L x 16 samples x 2M] . [2M x 16 blocks] contraction on v_mfma_f32_16x16x4_f32 per group of 256 samples.
+// One wave per (buffer, group); listeners in tiles of 8 accumulators.
+constexpr int MIX_TILE = 8;
+__global__ __launch_bounds__(64) void listener_mix_kernel(
+    const float *__restrict__ xdump, const float *__restrict__ xscale, const float *__restrict__ wtab32,
+    const double *__restrict__ trows, float *__restrict__ out, int nb, int m_pad, int n_modes, int n_listeners,
+    long long out_stride) {
+    __shared__ __attribute__((aligned(16))) float st[BN * ST_ROW];         // [16 blocks][64 modes][Q, D], stride 130
+    __shared__ float tls[MIX_TILE][64];                                    // listener weight / scale of the 64 modes
+    const int lane = threadIdx.x;
+    const int grp = blockIdx.x, b = blockIdx.y;
+    const f2 *xs = reinterpret_cast<const f2 *>(xdump) + ((size_t)b * 32 + grp * BN) * m_pad;
+    const float *sc = xscale + (size_t)b * m_pad;
+    const float *bsrc = st + (lane & 15) * ST_ROW + 2 * (lane >> 5) + ((lane >> 4) & 1);
+    for (int l0 = 0; l0 < n_listeners; l0 += MIX_TILE) {
+        f4 acc[MIX_TILE];
+        float y0[MIX_TILE];
+#pragma unroll
+        for (int l = 0; l < MIX_TILE; ++l) {
+            acc[l] = f4{0.f, 0.f, 0.f, 0.f};
+            y0[l] = 0.f;
+        }
+        for (int slab = 0; slab < m_pad / 64; ++slab) {
+            const int m = slab * 64 + lane;
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < BN; ++n) *reinterpret_cast<f2 *>(st + n * ST_ROW + 2 * lane) = xs[(size_t)n * m_pad + m];
+            const float s = sc[m];
+#pragma unroll
+            for (int l = 0; l < MIX_TILE; ++l) {
+                const bool on = l0 + l < n_listeners && m < n_modes;
+                tls[l][lane] = on ? (float)trows[(size_t)(l0 + l) * m_pad + m] / s : 0.f;     // scale 0 (per-sample buffer): NaN, on purpose
+            }
+            __syncthreads();
+            if (grp == 0) {                            // sample 0 of the buffer = the Q component of block 0's start state
+                const float q0 = st[2 * lane];
+#pragma unroll
+                for (int l = 0; l < MIX_TILE; ++l) y0[l] = fmaf(tls[l][lane], q0, y0[l]);
+            }
+            for (int pr = 0; pr < 32; ++pr) {
+                const float bop = bsrc[4 * pr];
+                const float wv = wtab32[((size_t)slab * 32 + pr) * 64 + lane];
+#pragma unroll
+                for (int l = 0; l < MIX_TILE; ++l)
+                    acc[l] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv * tls[l][2 * pr + (lane >> 5)], bop, acc[l], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < MIX_TILE; ++l) {
+            if (l0 + l >= n_listeners) break;
+            float *o = out + (size_t)(l0 + l) * out_stride + (size_t)b * (1 + 2 * GROUP);
+            float *og = o + 1 + GROUP * grp + 16 * (lane & 15) + 4 * (lane >> 4);
+            og[0] = acc[l].x;
+            og[1] = acc[l].y;
+            og[2] = acc[l].z;
+            og[3] = acc[l].w;
+            if (grp == 0) {
+                const float tot = wave_sum(y0[l]);
+                if (lane == 0) o[0] = tot;
+            }
+        }
+    }
+}
+
+int launch_listener_mix(const float *xdump, const float *xscale, const float *wtab32, const double *trows, float *out,
+                        int nb, int m_pad, int n_modes, int n_listeners, long long out_stride, hipStream_t stream) {
+    if (nb <= 0 || n_listeners <= 0) return 0;
+    hipLaunchKernelGGL(listener_mix_kernel, dim3(2, nb), dim3(64), 0, stream, xdump, xscale, wtab32, trows, out, nb, m_pad,
+                       n_modes, n_listeners, out_stride);
+    return (int)hipGetLastError();
 }
 
 }  // namespace iir_block

@@ -236,6 +236,17 @@ class Engine:
         p = np.ascontiguousarray(pos, dtype=np.float64)
         return bool(self._chk(self._l.pbso_compute_transfer(self._h, obj, _dp(p), not_before)))
 
+    def listeners_enable(self, obj):
+        """from the next step on, keep this object's block-start states for mix_listeners"""
+        self._chk(self._l.pbso_listeners_enable(self._h, obj))
+
+    def mix_listeners(self, obj, pos):
+        """the last step's audio of `obj` at every listener position: [n_listeners][n_buffers * 513] float32"""
+        p = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+        out = np.empty((p.shape[0], self._last_nb * self.B), dtype=np.float32)
+        self._chk(self._l.pbso_mix_listeners(self._h, obj, _dp(p), p.shape[0], out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+        return out
+
     def n_maps(self, obj):
         """_ffat_maps->size() (0 before readFFATMaps)"""
         return self._chk(self._l.pbso_object_n_maps(self._h, obj))

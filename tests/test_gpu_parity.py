@@ -748,3 +748,64 @@ def test_compute_transfer_batch_width_follows_the_map_count():
     omaps = [orc.uniform_cube(m["mode_id"], m["k"], m["center"], m["cell_size"], 4, m["psi"]) for m in maps]
     want = np.array([[abs(orc.ffat_get_map_val(om, p)) for om in omaps] for p in pos])
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("form", [capi.FORM_BLOCK, capi.FORM_BLOCK_BF16])
+def test_multi_listener_mix_matches_independent_solvers(form):
+    """SURVEY N4, multi-listener OUTPUT: pbso_mix_listeners returns one object's last step as heard at L positions --
+    what L ModalSolvers fed the same force messages and computeTransfer(pos_l) (modal_solver.h:286-315) would emit.
+    L = 11 (two accumulator tiles), 200 modes (padding columns), a second object beside it, launches cut at 3 buffers,
+    and the listener path of the engine's own single-listener output as one of the positions."""
+    from openpbso_amd import Engine
+    from openpbso_amd.solver import PbsoError
+    from oracle import oracle_py as orc
+    n_modes, nb, L = 200, 7, 11
+    lam = synth.eigenvalues(n_modes, 31337)
+    maps = synth.ffat_maps(lam, 31338, dim=6, cell_size=0.01)
+    rng = np.random.default_rng(8)
+    pos = rng.standard_normal((L, 3))
+    pos = 0.3 * pos / np.linalg.norm(pos, axis=1, keepdims=True) * (1.0 + rng.random((L, 1)))     # outside the 0.03 half-size cube
+    hits = {0: rng.standard_normal(n_modes) * 1e-3, 2: rng.standard_normal(n_modes) * 1e-3, 5: rng.standard_normal(n_modes) * 1e-3}
+    with Engine(form=form) as eng:
+        oid = eng.add_object(lam, synth.RHO, synth.ALPHA, synth.BETA)
+        eng.set_ffat_maps(oid, maps)
+        other = eng.add_object(synth.eigenvalues(70, 5), synth.RHO, synth.ALPHA, synth.BETA)
+        eng.finalize()
+        with pytest.raises(PbsoError):
+            eng.mix_listeners(oid, pos)                        # not enabled yet
+        eng.listeners_enable(oid)
+        eng.set_use_transfer(other, False)
+        eng.compute_transfer(oid, pos[3], 0)                   # the engine's own (single) listener = position 3
+        for b, dvec in hits.items():
+            assert eng.enqueue_force(oid, ForceMessage(data=dvec), b)
+        assert eng.enqueue_force(other, ForceMessage(data=np.ones(70) * 1e-3), 1)
+        import os
+        os.environ["PBSO_CHUNK_BUFFERS"] = "3"
+        try:
+            eng.step(nb)
+        finally:
+            os.environ.pop("PBSO_CHUNK_BUFFERS", None)
+        single = eng.audio()[oid].astype(np.float64)
+        mix = eng.mix_listeners(oid, pos).astype(np.float64)
+        assert mix.shape == (L, nb * 513)
+        # a Gaussian force (dense profile) in the next step: no block states for that step -> refused, not garbage
+        assert eng.enqueue_force(oid, ForceMessage(data=hits[0], forceType=capi.GAUSSIAN_FORCE, gaussianWidth=800.0), nb)
+        eng.step(2)
+        with pytest.raises(PbsoError):
+            eng.mix_listeners(oid, pos)
+    omaps = [orc.uniform_cube(m["mode_id"], m["k"], m["center"], m["cell_size"], 6, m["psi"]) for m in maps]
+    for l in range(L):
+        s = orc.Solver(lam, synth.RHO, synth.ALPHA, synth.BETA)
+        s.read_ffat_maps(omaps)
+        s.compute_transfer(pos[l])
+        want = []
+        for b in range(nb):
+            if b in hits:
+                s.enqueue_force(hits[b])
+            want.append(s.step()[0])
+        want = np.concatenate(want)
+        err = np.abs(mix[l] - want).max() / np.abs(want).max()
+        assert err <= 5e-4, (l, err)
+        if l == 3:
+            assert np.abs(single - want).max() <= 5e-4 * np.abs(want).max()
+            assert np.abs(mix[l] - single).max() <= 1e-4 * np.abs(want).max()
