@@ -15,7 +15,9 @@ names = {
     "bench_default.json": "bench_default.json", "bench_qnorm_closed.json": "bench_qnorm_closed.json",
     "bench_qnorm_off.json": "bench_qnorm_off.json", "bench_direct.json": "bench_direct.json",
     "bench_velocity.json": "bench_velocity.json", "bench_velocity_qnorm_closed.json": "bench_velocity_qnorm_closed.json",
-    "trace_gaps.txt": "trace_gaps.txt",
+    "trace_gaps.txt": "trace_gaps.txt", "bench_block_f32.json": "bench_block_f32.json",
+    "pmc_summary_block.txt": "pmc_summary_block_f32.txt", "pmc_summary_block_bf16.txt": "pmc_summary_bf16.txt",
+    "census_block_f32.txt": "census_1024x512_block_f32.txt",
     "bench_c2_1x512.json": "bench_c2_1x512.json", "bench_c3_64x256_listener.json": "bench_c3_64x256_listener.json",
     "bench_c5_8x4096_scraping.json": "bench_c5_8x4096_scraping.json",
     "bench_c5_8x4096_scraping_hostprof.json": "bench_c5_8x4096_scraping_hostprofiles.json",
@@ -48,7 +50,7 @@ t = {
 }
 t["traffic_bytes_per_launch"] = int((f * t["fetch_correction"] + w) * 1024)
 json.dump(t, open(f"{dst}/{rnd}_pmc_traffic.json", "w"), indent=1)
-for n in ("bench_default", "bench_qnorm_off", "bench_velocity", "bench_velocity_qnorm_closed", "bench_direct", "bench_c2_1x512", "bench_c3_64x256_listener",
+for n in ("bench_default", "bench_qnorm_off", "bench_block_f32", "bench_velocity", "bench_velocity_qnorm_closed", "bench_direct", "bench_c2_1x512", "bench_c3_64x256_listener",
           "bench_c5_8x4096_scraping"):
     try:
         d = json.load(open(f"{dst}/{rnd}_{n}.json"))
