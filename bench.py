@@ -67,9 +67,10 @@ def parse(argv=None):
     ap.add_argument("--form", choices=["block_bf16", "block", "velocity", "direct"], default="block_bf16",
                     help="block_bf16: block state-space form, output projection as a split-bf16 MFMA product (default); block: the same "
                          "with an exact f32 MFMA projection; velocity / direct: per-sample kernel (K1)")
-    ap.add_argument("--plan-threads", type=int, default=1,
-                    help="host planner threads (PBSO_PLAN_THREADS, pinned next to the caller's core); 1 (default): the caller's "
-                         "thread alone -- helpers cut the planning time 2.4x but did not move the step on the measured boxes")
+    ap.add_argument("--plan-threads", type=int, default=2,
+                    help="host planner threads (PBSO_PLAN_THREADS; the helper is pinned into the caller's core complex).  With the "
+                         "split-bf16 kernel one host thread (0.42 ms planning + 0.17 ms feeding + 0.15 ms launches per step) is as "
+                         "long as the device's step; a second planner thread (0.26 ms) gives the margin that keeps the run device-bound")
     ap.add_argument("--qnorm", choices=["sample", "closed", "off"], default="sample",
                     help="getQBufferNorm rows: on (the block form evaluates them in closed form), closed form, or off")
     ap.add_argument("--no-qnorm", action="store_true", help="same as --qnorm off")

@@ -245,6 +245,8 @@ void ForceProfile::set_param(const double a_[2], double sigma_, double mu_) {   
 Engine::Engine(const pbso_engine_desc &d) : desc_(d) {}
 
 Engine::~Engine() {
+    for (Object &o : objs_)
+        while (!o.force_q.empty()) { std::free(o.force_q.front().ext); o.force_q.pop_front(); }
     if (std::getenv("PBSO_HOST_PROFILE") && tot_steps_ > 0)
         std::fprintf(stderr, "pbso host profile, ms per step over %lld steps: wait-for-set %.3f | plan: fill %.3f objects %.3f merge %.3f | "
                              "submit (uploads + launches) %.3f | step total %.3f\n", (long long)tot_steps_, hprof_[0] / tot_steps_,
@@ -455,6 +457,7 @@ int Engine::finalize() {
     if (R != 0 && R != 1 && R != 2 && R != 3 && R != 4 && R != 8) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,3,4,8");
     const bool block = is_block();
     if (block && R == 3) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,4,8 in the block form");
+
     auto waves_of = [&](const Object &o, int r) { return std::max(1, (o.n_modes + 64 * r - 1) / (64 * r)); };
     auto total_waves = [&](int r) {
         long long w = 0;
@@ -768,7 +771,16 @@ int Engine::enqueue_force_impl(int obj, const pbso_force_msg &m, int64_t not_bef
     h.clear_all = m.clear_all_forces != 0;
     h.data_kind = m.data_kind;
     h.not_before = not_before;
-    h.gaussian_width_us = m.gaussian_width_us;      // the Force object itself is built when the message is dequeued
+    // (the Force object itself is built when the message is dequeued)
+    const bool need_ext = m.data_kind == PBSO_DATA_FACE || m.gaussian_width_us != 0.0 ||
+                          (m.data_kind == PBSO_DATA_EXPLICIT && !h.clear_all);
+    auto make_ext = [&](int n_data) {
+        MsgExt *x = (MsgExt *)std::malloc(sizeof(MsgExt) + sizeof(double) * (size_t)(n_data > 0 ? n_data - 1 : 0));
+        x->coords[0] = m.coords[0]; x->coords[1] = m.coords[1]; x->coords[2] = m.coords[2];
+        x->gaussian_width_us = m.gaussian_width_us;
+        x->n_data = n_data;
+        return x;
+    };
     switch (m.data_kind) {
     case PBSO_DATA_EXPLICIT:
         // a clearAllForces message returns from step() before any dimension check (modal_solver.h:186-189):
@@ -776,7 +788,8 @@ int Engine::enqueue_force_impl(int obj, const pbso_force_msg &m, int64_t not_bef
         if (h.clear_all) { h.data_kind = PBSO_DATA_ZERO; break; }
         if (!m.data || m.n_data != o.n_modes)
             { *why = "dimension of force message incorrect"; return PBSO_ERR_INVALID; }   // assert :258
-        h.data.assign(m.data, m.data + m.n_data);
+        h.ext = make_ext(m.n_data);
+        if (m.n_data) std::memcpy(h.ext->data, m.data, sizeof(double) * (size_t)m.n_data);
         break;
     case PBSO_DATA_VERTEX:
     case PBSO_DATA_FACE: {
@@ -787,7 +800,6 @@ int Engine::enqueue_force_impl(int obj, const pbso_force_msg &m, int64_t not_bef
             if (m.vids[j] < 0 || m.vids[j] >= nv) { *why = "vertex id out of range"; return PBSO_ERR_INVALID; }
         for (int j = 0; j < 3; ++j) {
             h.vids[j] = m.vids[j];
-            h.coords[j] = m.coords[j];
             h.vn[j] = m.vn[j];
         }
         break;
@@ -797,7 +809,8 @@ int Engine::enqueue_force_impl(int obj, const pbso_force_msg &m, int64_t not_bef
     default:
         { *why = "data_kind"; return PBSO_ERR_INVALID; }
     }
-    if (o.force_q.size() >= 1023) return 0;      // ReaderWriterQueue(512): ceilToPow2(513)-1 usable slots
+    if (o.force_q.size() >= 1023) { std::free(h.ext); return 0; }      // ReaderWriterQueue(512): ceilToPow2(513)-1 usable slots
+    if (need_ext && !h.ext) h.ext = make_ext(0);
     // keep arrival order monotone: a message cannot overtake an earlier one (FIFO)
     if (!o.force_q.empty()) h.not_before = std::max(h.not_before, o.force_q.back().not_before);
     o.force_q.push_back(std::move(h));
@@ -964,11 +977,12 @@ int Engine::plan_object(PlanCtx &c, int oi, int b, int nb, int64_t t) {
             pe.slot = -1;
             for (int j = 0; j < 3; ++j) {
                 pe.vids[j] = m0.vids[j];
-                pe.coords[j] = m0.coords[j];
+                pe.coords[j] = m0.coord(j);
                 pe.vn[j] = m0.vn[j];
             }
             c.slot_idx.push_back(-((int)c.proj_direct.size() + 1));
             c.proj_direct.push_back(pe);
+            std::free(m0.ext);
             o.force_q.pop_front();
             d.frow = c.n_frows++;
             c.forced.push_back(&d);
@@ -979,8 +993,9 @@ int Engine::plan_object(PlanCtx &c, int oi, int b, int nb, int64_t t) {
             d.amp = 1.f;
         }
     } else if (due_msg) {
-        HostForceMsg mess = std::move(o.force_q.front());
+        const HostForceMsg mess = o.force_q.front();
         o.force_q.pop_front();
+        struct FreeExt { MsgExt *p; ~FreeExt() { std::free(p); } } free_ext{mess.ext};
         if (mess.clear_all) {                                           // :186-189
             for (ActiveForce &af : o.active) release(c, af);
             o.active.clear();
@@ -998,7 +1013,7 @@ int Engine::plan_object(PlanCtx &c, int oi, int b, int nb, int64_t t) {
             const size_t off = c.stage.size();
             c.stage.resize(off + m_pad_, 0.0);
             if (mess.data_kind == PBSO_DATA_EXPLICIT)
-                std::copy(mess.data.begin(), mess.data.end(), c.stage.begin() + off);
+                std::copy(mess.ext->data, mess.ext->data + mess.ext->n_data, c.stage.begin() + off);
             c.stage_slot.push_back(slot);
         } else {
             ProjectEvent pe;
@@ -1007,7 +1022,7 @@ int Engine::plan_object(PlanCtx &c, int oi, int b, int nb, int64_t t) {
             pe.slot = slot;
             for (int j = 0; j < 3; ++j) {
                 pe.vids[j] = mess.vids[j];
-                pe.coords[j] = mess.coords[j];
+                pe.coords[j] = mess.coord(j);
                 pe.vn[j] = mess.vn[j];
             }
             (direct ? c.proj_direct : c.proj).push_back(pe);
@@ -1015,7 +1030,7 @@ int Engine::plan_object(PlanCtx &c, int oi, int b, int nb, int64_t t) {
         ActiveForce af;
         af.slot = slot;
         af.force_type = mess.force_type;
-        af.force = ForceProfile::make(mess.force_type, mess.gaussian_width_us, rate_);   // fresh Force, tools/...:281-294
+        af.force = ForceProfile::make(mess.force_type, mess.gaussian_width_us(), rate_);   // fresh Force, tools/...:281-294
         bool slot_used = false;
         if (mess.sustained_start) {                                     // :190-194
             for (ActiveForce &x : o.active) release(c, x);

@@ -57,16 +57,27 @@ struct ForceProfile {
     void set_param(const double a_[2], double sigma_, double mu_);   // forces.h:130-137
 };
 
-struct HostForceMsg {                                    // ForceMessage, modal_solver.h:27-77
-    int force_type = PBSO_POINT_FORCE;
-    bool sustained_start = false, sustained_end = false, clear_all = false;
-    int data_kind = PBSO_DATA_ZERO;
-    std::vector<double> data;
-    int vids[3] = {0, 0, 0};
-    double coords[3] = {0, 0, 0}, vn[3] = {0, 0, 0};
-    double gaussian_width_us = 0;                        // GaussianForce(width); a queued message carries a pristine Force
-    int64_t not_before = 0;
+// ForceMessage, modal_solver.h:27-77, as it waits in an object's queue: ONE cache line.  (A scene's queues hold a
+// step's worth of messages -- megabytes that enqueue writes and the planner reads back: the 120-byte message
+// with a std::vector inside cost two lines each way.)  What only some messages carry -- barycentric coordinates of
+// a face hit, the Gaussian width, explicit modal data -- lives in a heap block owned by the message.
+struct MsgExt {
+    double coords[3];
+    double gaussian_width_us;                            // GaussianForce(width); a queued message carries a pristine Force
+    int n_data;
+    double data[1];                                      // n_data doubles (ForceMessage::data as the GUI built it)
 };
+struct alignas(64) HostForceMsg {
+    int64_t not_before = 0;
+    double vn[3] = {0, 0, 0};
+    int vids[3] = {0, 0, 0};
+    int8_t force_type = PBSO_POINT_FORCE, data_kind = PBSO_DATA_ZERO;
+    bool sustained_start = false, sustained_end = false, clear_all = false;
+    MsgExt *ext = nullptr;                               // owned; nullptr for a plain vertex hit
+    double coord(int j) const { return ext ? ext->coords[j] : 0.0; }
+    double gaussian_width_us() const { return ext ? ext->gaussian_width_us : 0.0; }
+};
+static_assert(sizeof(HostForceMsg) == 64, "one cache line per queued message");
 
 // _queue_force (modal_solver.h:105): FIFO of at most 1023 messages.  A ring that grows by doubling and
 // never shrinks: no allocation per message (a node-based queue filled by the caller's thread and drained
