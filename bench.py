@@ -50,6 +50,7 @@ FLOP_BLOCK = 4.5
 FLOP_BF16_MFMA = 12.0
 VALU_OPS_BF16 = 1431 * 64 / (256 * 513.0)      # = 0.70 lane-operations per mode-sample
 BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+XGMI_LINK_GBPS = 153.0         # one xGMI link (point to point; 7 per GPU): the figure the task statement and the guide quote
 TOL_MAX, TOL_L2 = 5e-4, 1e-3   # stated fp32 tolerance vs the fp64 oracle
 
 
@@ -83,6 +84,7 @@ def parse(argv=None):
                     help="make the strong-scaling leg the headline: --objects is the TOTAL, split over the ranks")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the nested strong-scaling measurement")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the RCCL audio all-gather out of the timed region")
+    ap.add_argument("--no-gather-cost", action="store_true", help="N > 1: skip the extra leg that times the same run without the all-gather")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the first timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-objects", type=int, default=0, help="objects in the CPU baseline sample (0 = auto)")
@@ -311,7 +313,7 @@ def measure(args, ctx, global_ids, want_parity):
     # targets are double-buffered and the collective is asynchronous on RCCL's own stream, so the gather of
     # step k runs beside the oscillator bank of step k+1; it is waited for only when its buffers are reused
     # (and before the clock stops).  Ragged shards (strong leg) are padded to the largest one.
-    do_gather = ctx["use_dist"] and world > 1 and not args.no_gather
+    do_gather = ctx["use_dist"] and world > 1 and not args.no_gather and not ctx.get("leg_without_gather")
     counts = ctx.get("counts")                       # objects per rank in this leg
     cmax = max(counts) if counts else n_obj
     n_buf = 2 if do_gather else 1
@@ -483,6 +485,13 @@ def main():
         legs[leg] = measure(args, ctx, ids, want_parity=(not args.no_parity and leg == order[0] and rank == 0))
     head = order[0]
     m = legs[head]
+    # what the collective costs: the head leg once more with the all-gather left out (reported beside it, never as `value`)
+    bare = None
+    if m["gather"] and not args.no_gather_cost:
+        ctx["leg_without_gather"] = True
+        ctx["counts"] = [args.objects] * world if head == "weak" else [hi - lo for lo, hi in spans]
+        bare = measure(args, ctx, weak_ids if head == "weak" else strong_ids, want_parity=False)
+        ctx["leg_without_gather"] = False
 
     if rank == 0:
         nb, M = args.buffers, args.modes
@@ -542,7 +551,9 @@ def main():
                                "limiter) and co-executes with the vector ALU, which carries the f32 coarse recurrence and the hi / lo "
                                "split of every block-start state: 1431 VALU instructions per wave and buffer (PMC, profiles/r02_pmc_summary_bf16.txt); "
                                "achieved / frac count every VALU instruction as 64 lanes x 2 flop against the 157.3 TFLOP/s f32 vector "
-                               "peak, i.e. issue-slot utilisation (two waves per SIMD issue one instruction per ~4 cycles, PMC); "
+                               "peak (32 lanes per cycle and SIMD), i.e. issue-slot utilisation with every instruction counted as one slot; half of the "
+                               "step's ~10 instructions (v_cvt_pk_bf16_f32, v_pk_add_f32, v_lshlrev_b32) issue at half rate on gfx950 and "
+                               "one wave issues at most one instruction per 4 cycles (profiles/r02_valu_issue.txt), so the slots in use are ~1.4x frac; "
                                "reference_equivalent credits the reference's 10 flop per mode-sample") if bf16 else
                               ("f32 matrix pipe: the per-sample sum over modes is a [16 x 2M].[2M x 16 blocks] product on "
                                "v_mfma_f32_16x16x4_f32 (4 flop per mode-sample) + the coarse recurrence on the vector ALU "
@@ -565,6 +576,22 @@ def main():
             out["parity"] = m["parity"]
             out["parity_checked_objects"] = m["parity"]["parity_checked_objects"]
             out["max_err"] = m["parity"]["max_err"]
+        if bare is not None:
+            bn = leg_numbers(head, bare)
+            per_rank = max(ctx["counts"]) * nb * B * 4
+            exposed = hn["ms_per_step"] - bn["ms_per_step"]
+            out["gather_cost"] = {
+                "bytes_sent_per_rank": per_rank, "bytes_received_per_rank": per_rank * (world - 1),
+                "ms_per_step_with_gather": hn["ms_per_step"], "ms_per_step_without_gather": bn["ms_per_step"],
+                "value_without_gather": bn["value"], "realtime_x_without_gather": bn["realtime_x"],
+                "exposed_ms": exposed,
+                "inbound_GBps_if_gather_bound": per_rank * (world - 1) / (hn["ms_per_step"] * 1e-3) * 1e-9,
+                "xgmi_inbound_peak_GBps": XGMI_LINK_GBPS * min(world - 1, 7),
+                "note": "every rank produces bytes_sent_per_rank of audio per step and receives the other ranks' buffers; the "
+                        "all-gather is asynchronous and double-buffered (it runs beside the next step's oscillator bank), so a "
+                        "step costs max(compute, gather); at these sizes the links, not the kernels, set the step time "
+                        "whenever bytes_received_per_rank / xgmi_inbound_peak exceeds ms_per_step_without_gather",
+            }
         for leg, r in legs.items():
             if leg != head:
                 out[leg] = dict(leg_numbers(leg, r), scaling=leg,

@@ -1,0 +1,33 @@
+"""bench.py --gpus 2 on ONE GPU: the ranks are started by bench.py itself (a torch.distributed.run child), share the
+GPU under PBSO_BENCH_BACKEND=gloo, and the line carries the gather, its cost leg and the strong (configs[3] as
+written) leg.  The data path is the one N GPUs run; only the collective's transport differs (gloo through the host)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_print_one_line_with_gather_and_strong_leg():
+    env = dict(os.environ, PBSO_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--objects", "96", "--steps", "3", "--warmup", "1",
+                        "--settle", "2", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                     # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["gather"] is True and d["config"]["rccl_ranks"] == 2
+    assert d["config"]["launched_by"] == "bench.py" and d["config"]["objects_per_gpu"] == 96
+    assert d["parity"]["pass"] and d["parity_checked_objects"] == 8
+    g = d["gather_cost"]
+    assert g["bytes_sent_per_rank"] == 96 * 86 * 513 * 4 and g["bytes_received_per_rank"] == g["bytes_sent_per_rank"]
+    assert g["ms_per_step_without_gather"] > 0 and g["value_without_gather"] > 0
+    s = d["strong"]
+    assert s["scaling"] == "strong" and s["objects_total"] == 96 and s["objects_rank0"] == 48 and s["gather"] is True
+    # whole-job value: both ranks' objects over the slowest rank's time
+    assert abs(d["value"] - 2 * 96 * 86 * 513 * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]
