@@ -325,6 +325,12 @@ int Engine::init() {
     if (ndev <= 0) return fail(PBSO_ERR_HIP, "no HIP device: this engine has no CPU fallback");
     if (desc_.device < 0 || desc_.device >= ndev) return fail(PBSO_ERR_INVALID, "device ordinal out of range");
     HIPTRY(hipSetDevice(desc_.device));
+    {
+        // sizes of the chip (or of the partition this ordinal is: a CPX / NPS slice has fewer CUs)
+        hipDeviceProp_t prop;
+        HIPTRY(hipGetDeviceProperties(&prop, desc_.device));
+        n_cus_ = std::max(1, prop.multiProcessorCount);
+    }
     if (desc_.stream) {
         stream_ = (hipStream_t)desc_.stream;
     } else {
@@ -470,7 +476,7 @@ int Engine::finalize() {
         // The fewest modes per lane that fit the chip at two waves per SIMD; more objects run in rounds.
         R = 4;
         for (int r : {1, 2, 4})
-            if (total_waves(r) <= 2048) { R = r; break; }
+            if (total_waves(r) <= 8LL * n_cus_) { R = r; break; }
     }
     if (R == 0) {
         // the fewest modes per lane whose waves are all resident at once (16 waves per CU is what the
@@ -480,11 +486,11 @@ int Engine::finalize() {
         // wave-sample (5 R + 2.2); R = 8 needs more registers than 4 waves per SIMD leave.
         R = 0;
         for (int r : {1, 2, 3, 4})
-            if (total_waves(r) <= 4096) { R = r; break; }
+            if (total_waves(r) <= 16LL * n_cus_) { R = r; break; }
         if (R == 0) {
             double best = 0;
             for (int r : {1, 2, 3, 4}) {
-                const double cost = (double)((total_waves(r) + 4095) / 4096) * (5.0 * r + 2.2);
+                const double cost = (double)((total_waves(r) + 16LL * n_cus_ - 1) / (16LL * n_cus_)) * (5.0 * r + 2.2);
                 if (R == 0 || cost < best) { R = r; best = cost; }
             }
         }
@@ -502,7 +508,7 @@ int Engine::finalize() {
         // real time with 2-wave teams, 1 x 512 modes 778 -> 822 x with 1-wave teams): spread the waves
         // evenly over the 256 CUs.
         const int team_max = block ? (R == 8 ? 4 : MAX_WAVES_PER_BLOCK_TEAM) : MAX_WAVES_PER_TEAM;
-        int team_cap = (int)std::min<long long>(team_max, std::max<long long>(1, (total_waves(R) + 255) / 256));
+        int team_cap = (int)std::min<long long>(team_max, std::max<long long>(1, (total_waves(R) + n_cus_ - 1) / n_cus_));
         if (const char *v = std::getenv("PBSO_TEAM_WAVES")) team_cap = std::min(team_max, std::max(1, std::atoi(v)));
         if (block && block_team_waves_ > 0) team_cap = block_team_waves_;
         std::vector<std::vector<TeamDesc>> by_w(MAX_WAVES_PER_TEAM + 1);
@@ -930,7 +936,6 @@ int Engine::alloc_slot(PlanCtx &c) {
 // One object, one buffer: ModalSolver::step lines 184-256.
 int Engine::plan_object(PlanCtx &c, int oi, int b, int nb, int64_t t) {
     Object &o = objs_[oi];
-    const int N = (int)objs_.size();
     BufDesc &d = plan_desc_[(size_t)oi * nb + b];
 
     // GUI-thread calls stamped for this buffer or earlier
@@ -1590,7 +1595,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.nb = nb; kp.n_tiles = n_tiles_; kp.m_pad = m_pad_; kp.b_pad = b_pad_;
     kp.audio_stride = (long long)nb_total * B_;
     // the per-CU progress feedback only pays when several teams compete for every SIMD
-    kp.rotate_prio = (rotate_prio_ == 2 && total_team_waves_ < 3072) ? 1 : rotate_prio_;
+    kp.rotate_prio = (rotate_prio_ == 2 && total_team_waves_ < 12LL * n_cus_) ? 1 : rotate_prio_;
     kp.board = d_board_.p;
     kp.launch_seq = ++launch_seq_;
     kp.pc = d_pc_.p;
@@ -1620,7 +1625,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         }
     }
     bool used[N_CLASS_STREAMS] = {false, false, false};
-    const bool fork = classes_.size() > 1 && ev_fork_ && total_team_waves_ <= 4096;
+    const bool fork = classes_.size() > 1 && ev_fork_ && total_team_waves_ <= 16LL * n_cus_;
     if (fork) HIPTRY(hipEventRecord(ev_fork_, sk));
     for (size_t ci = 0; ci < classes_.size(); ++ci) {
         const SizeClass &c = classes_[ci];

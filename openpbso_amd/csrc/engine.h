@@ -243,6 +243,7 @@ private:
     DevBuf<SplitObj> d_split_;                           // objects stepped by more than one team
     DevBuf<float> d_audio_parts_;                        // [n_part_rows_][nb * B] their partial sample sums
     int n_teams_ = 0, n_split_ = 0, n_part_rows_ = 0;
+    int n_cus_ = 256;                                     // hipDeviceProp_t::multiProcessorCount of the engine's device
     long long total_team_waves_ = 0;
     DevBuf<float> d_gq_;                                 // closed-form qnorm: G11, 2 G12, G22 planes
     // multi-listener mix: objects that keep their block-start states (row per object), the f32 (a_j, b_j) tables of

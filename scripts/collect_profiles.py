@@ -24,7 +24,7 @@ names = {
     "census.txt": "census_1024x512.txt", "env.txt": "env.txt", "pmc_summary.txt": "pmc_summary.txt",
     "microbench3.txt": "microbench3_vgpr_banks.txt", "microbench4.txt": "microbench4_body_real_cycles.txt",
     "microbench5.txt": "microbench5_mfma_coissue.txt", "realtime_latency.txt": "realtime_latency.txt",
-    "hud_sphere.txt": "hud_sphere_batch_transfer.txt",
+    "hud_sphere.txt": "hud_sphere_batch_transfer.txt", "bench_2ranks_one_gpu_gloo.json": "bench_2ranks_one_gpu_gloo.json",
 }
 for a, b in names.items():
     if os.path.exists(os.path.join(src, a)):

@@ -13,4 +13,6 @@ PY
 run c2_1x512 --objects 1 --modes 512 --steps 40 --warmup 2
 run c3_64x256_listener --objects 64 --modes 256 --scenario listener --steps 40 --warmup 2
 run c5_8x4096_scraping --objects 8 --modes 4096 --scenario scraping --steps 40 --warmup 2
+# the N > 1 path on one GPU: two ranks started by bench.py, gloo through the host instead of RCCL (transport only)
+PBSO_BENCH_BACKEND=gloo run 2ranks_one_gpu_gloo --gpus 2 --steps 20 --warmup 2
 PBSO_DEVICE_PROFILES=0 run c5_8x4096_scraping_hostprof --objects 8 --modes 4096 --scenario scraping --steps 6 --warmup 2
