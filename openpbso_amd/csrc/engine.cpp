@@ -1565,22 +1565,16 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     LAUNCHTRY(launch_scatter_rows(d_stage, d_stage_slot, (int)stage_slot_.size(), d_slots_.p, m_pad_, sp));
     LAUNCHTRY(launch_modal_project(d_proj, (int)proj_.size(), d_shapes_.p, d_shape_off_.p, d_n_modes_.p, d_slots_.p, m_pad_, sp));
     LAUNCHTRY(launch_ffat_lookup(d_ffat, (int)ffat_.size(), d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p, d_xfer_.p, m_pad_, sp));
-    // A block-form launch that fills the register file (two 256-register waves on every SIMD) lets nothing run
-    // beside it: the combine then waits for the bank's last workgroup wherever it is queued, and behind the bank
-    // in the bank's own stream it starts a kernel boundary after it instead of an event hand-over later.
-    const bool dense_heavy = is_block() && dense_to_k1_ && (long long)n_prows_ * 2 > (long long)N * nb;
-    static const bool inline_ok = !(std::getenv("PBSO_INLINE_COMBINE") && std::atoi(std::getenv("PBSO_INLINE_COMBINE")) == 0);
-    const bool inline_combine = inline_ok && is_block() && !dense_heavy && R_ >= 4 && total_team_waves_ >= 8LL * n_cus_;
-    if (!inline_combine)
-        LAUNCHTRY(launch_force_combine(d_row_ptr, d_slot_idx, d_row_obj, n_frows, d_slots_.p, d_c3_.p, grows.p, d_projd, d_shapes_.p,
-                                       d_shape_off_.p, d_n_modes_.p, m_pad_, sp));
+    // (the combine stays on the preparation stream even when the bank fills the register file: its workgroups
+    //  move in as the bank's retire, so most of it is done when the last one leaves -- queued behind the bank in
+    //  the bank's own stream it would start only then: 0.785 instead of 0.735 ms per step at 1024 x 512)
+    LAUNCHTRY(launch_force_combine(d_row_ptr, d_slot_idx, d_row_obj, n_frows, d_slots_.p, d_c3_.p, grows.p, d_projd, d_shapes_.p,
+                                   d_shape_off_.p, d_n_modes_.p, m_pad_, sp));
     HIPTRY(hipEventRecord(ev_prep_done_[cur_set_], sp));
 
     // ---- compute stream: K1 after its preparation (and, stream order, after the previous K1)
     HIPTRY(hipStreamWaitEvent(sk, ev_prep_done_[cur_set_], 0));
-    if (inline_combine)
-        LAUNCHTRY(launch_force_combine(d_row_ptr, d_slot_idx, d_row_obj, n_frows, d_slots_.p, d_c3_.p, grows.p, d_projd, d_shapes_.p,
-                                       d_shape_off_.p, d_n_modes_.p, m_pad_, sk));
+    const bool dense_heavy = is_block() && dense_to_k1_ && (long long)n_prows_ * 2 > (long long)N * nb;
     IirParams kp;
     kp.ca = d_ca_.p; kp.cb = d_cb_.p; kp.sq = d_sq_.p; kp.sd = d_sd_.p; kp.ss = d_ss_.p;
     kp.desc = d_desc;
