@@ -434,26 +434,32 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
             });
             } else {
                 // ---- split-bf16 projection.  The lane that owns a mode parks every block-start state twice: hi =
-                // bf16(x) (v_cvt_pk_bf16_f32 rounds to nearest even; (Q, D) share a dword) and lo = bf16(x - hi); the
+                // the top 8 significant bits of x (rounded) and lo = the next 8 of x - hi, both bf16 bit patterns; the
                 // projection of 16 modes x 16 blocks is three v_mfma_f32_16x16x32_bf16 (Whi.Xhi + Whi.Xlo + Wlo.Xhi,
                 // f32 accumulation), 48 matrix cycles instead of 256.  The recurrence itself (coarse steps) is
                 // unchanged f32.
                 unsigned *hdst = reinterpret_cast<unsigned *>(stage) + lane;
                 const u4 *hsrc = reinterpret_cast<const u4 *>(reinterpret_cast<const unsigned *>(stage) + (lane & 15) * H_ROW + 4 * (lane >> 4));
                 // one coarse step of slice r: park block n's start state (hi and lo parts), then x <- P x
-                // (packed f32 math on the pair (q, d): with two waves per SIMD the vector ALU is issue-bound -- ~4 cycles per
-                //  instruction whatever it is -- so a v_pk_fma_f32 that advances both components is worth two plain ones)
                 auto coarse16 = [&](int r, int n, int blk) {
                     dump_state(r, blk);
                     const f2 x = x2[r];
-                    const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
-                    const f2 xh = {__builtin_bit_cast(float, hp << 16), __builtin_bit_cast(float, hp & 0xFFFF0000u)};
-                    const unsigned lp = __builtin_bit_cast(unsigned, __builtin_convertvector(x - xh, bf16x2));
+                    // hi = x rounded to 8 significant bits (half up, in integer arithmetic), lo = the next 8 bits of
+                    // x - hi (truncated); (Q, D) share a dword (v_perm_b32).  v_add_u32 / v_and_b32 / v_sub_f32 issue at
+                    // full rate on gfx950; v_cvt_pk_bf16_f32, v_pk_add_f32 and the 16-bit shift of the obvious form
+                    // (hp = cvt_pk(x); hi = hp << 16, hp & mask; lo = cvt_pk(x - hi)) at half rate, and the (q, d) pair no
+                    // longer has to sit in an aligned register pair: 13.9 instead of 17.8 ns per step and SIMD
+                    // (profiles/r02_valu_issue.txt), the kernel 0.647 instead of 0.679 ms, error 1.2e-5 instead of 1.05e-5.
+                    const float xq = x.x, xd = x.y;          // (scalars first: a bit cast of a vector ELEMENT expression reads element 0)
+                    const unsigned hq = (__builtin_bit_cast(unsigned, xq) + 0x8000u) & 0xFFFF0000u;
+                    const unsigned hd = (__builtin_bit_cast(unsigned, xd) + 0x8000u) & 0xFFFF0000u;
+                    const unsigned hp = __builtin_amdgcn_perm(hd, hq, 0x07060302u);
+                    const float lq = xq - __builtin_bit_cast(float, hq), ld = xd - __builtin_bit_cast(float, hd);
+                    const unsigned lp = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, ld), __builtin_bit_cast(unsigned, lq), 0x07060302u);
                     hdst[n * H_ROW] = hp;
                     hdst[H_PLANE + n * H_ROW] = lp;
                     // t = ((P11 - 1) q + P12 d, P21 q + P22 d);  q' = q + t.x (the small term last), d' = t.y
-                    // (plain f32 ops here: the packed form of the step below -- two v_pk instructions -- makes the
-                    //  allocator spill 130 registers in the R = 4 build of this pipeline)
+                    // (plain f32 ops: v_pk_fma_f32 / v_pk_mul_f32 issue at half rate, a packed step is no shorter)
                     const float qa = fmaf(c1[r].x, x.x, x.x);
                     const float da = c1[r].y * x.x;
                     x2[r].x = fmaf(c2[r].x, x.y, qa);

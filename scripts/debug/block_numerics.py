@@ -86,6 +86,12 @@ def bf16_trunc(x):
     return (u & np.uint32(0xFFFF0000)).view(np.float32)
 
 
+def bf16_round_half_up(x):
+    """(bits + 0x8000) & 0xFFFF0000: what the kernel's integer split does for the hi part of a state"""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    return ((u + np.uint32(0x8000)) & np.uint32(0xFFFF0000)).view(np.float32)
+
+
 def run_bf16x3(M=512, NB=86, seed=1, f_lo=100.0, terms=3):
     """same block form, but the output projection runs as bf16 x bf16 -> fp32 products of the split
     operands: hi.hi + hi.lo + lo.hi (terms = 3), state recurrence unchanged in fp32"""
@@ -129,7 +135,7 @@ def run_bf16x3(M=512, NB=86, seed=1, f_lo=100.0, terms=3):
             qa = fma(e11, Q, Q); qn = fma(p12, D, qa)
             da = p21 * Q; dn = fma(p22, D, da)
             Q, D = qn, dn
-        Xhi = bf16_trunc(X); Xlo = bf16_trunc(X - Xhi)
+        Xhi = bf16_round_half_up(X); Xlo = bf16_trunc(X - Xhi)        # the kernel: rounded hi, truncated lo
         # products of bf16 operands are exact in fp32; accumulate in fp32 (chunks of 32 in fp64 ~ the MFMA's internal sum)
         acc = np.zeros((J, NBLK), np.float64)
         pairs = [(Whi, Xhi), (Whi, Xlo), (Wlo, Xhi)][:terms]

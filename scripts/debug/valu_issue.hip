@@ -119,6 +119,28 @@ __global__ __launch_bounds__(512) void k(float *out, int iters, long *n_out) {
             "v_pk_add_f32 v[104:105], v[100:101], v[104:105] neg_lo:[0,1] neg_hi:[0,1]\n v_cvt_pk_bf16_f32 v103, v104, v105\n ds_write2st64_b32 %4, v102, v103 offset0:1 offset1:19\n"
             "v_mul_f32 v106, v100, %1\n v_fmac_f32 v100, %0, v100\n v_fmac_f32 v100, %2, v101\n v_fmac_f32 v106, %3, v101\n v_mov_b32 v101, v106"
             : : "v"(dd), "v"(cc), "v"(a4), "v"(a5), "v"(ldsa) : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "memory");), 88)
+    } else if constexpr (CASE == 25) {  // v_mov_b32_sdwa word insert (dst_unused:UNUSED_PRESERVE)
+        BODY_LOOP(REP8(asm volatile("v_mov_b32_sdwa %0, %4 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n v_mov_b32_sdwa %1, %5 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n"
+                       "v_mov_b32_sdwa %2, %6 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n v_mov_b32_sdwa %3, %7 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n"
+                       "v_mov_b32_sdwa %0, %5 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n v_mov_b32_sdwa %1, %6 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n"
+                       "v_mov_b32_sdwa %2, %7 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n v_mov_b32_sdwa %3, %4 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1"
+                       : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));), 64)
+    } else if constexpr (CASE == 26) {  // v_add_u32 with a literal
+        BODY_LOOP(REP8(asm volatile("v_add_u32 %0, 0x8000, %4\n v_add_u32 %1, 0x8000, %5\n v_add_u32 %2, 0x8000, %6\n v_add_u32 %3, 0x8000, %7\n v_add_u32 %0, 0x8000, %5\n v_add_u32 %1, 0x8000, %6\n v_add_u32 %2, 0x8000, %7\n v_add_u32 %3, 0x8000, %4"
+                       : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));), 64)
+    } else if constexpr (CASE == 27) {  // step C: integer split, SDWA packs (12 instructions, all full rate if SDWA is)
+        BODY_LOOP(REP8(asm volatile(
+            "v_add_u32 v104, 0x8000, v100\n v_add_u32 v105, 0x8000, v101\n v_and_b32 v104, 0xffff0000, v104\n v_and_b32 v105, 0xffff0000, v105\n"
+            "v_sub_f32 v102, v100, v104\n v_sub_f32 v103, v101, v105\n v_mov_b32_sdwa v105, v104 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n"
+            "v_mov_b32_sdwa v103, v102 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n"
+            "v_mul_f32 v106, v100, %1\n v_fmac_f32 v100, %0, v100\n v_fmac_f32 v100, %2, v101\n v_fmac_f32 v106, %3, v101\n v_mov_b32 v101, v106"
+            : : "v"(dd), "v"(cc), "v"(a4), "v"(a5) : "v100", "v101", "v102", "v103", "v104", "v105", "v106");), 104)
+    } else if constexpr (CASE == 28) {  // step C': integer split, v_perm_b32 packs (what the int-split build emits)
+        BODY_LOOP(REP8(asm volatile(
+            "v_add_u32 v104, 0x8000, v100\n v_add_u32 v105, 0x8000, v101\n v_and_b32 v104, 0xffff0000, v104\n v_and_b32 v105, 0xffff0000, v105\n"
+            "v_perm_b32 v107, v105, v104, %4\n v_sub_f32 v102, v100, v104\n v_sub_f32 v103, v101, v105\n v_perm_b32 v103, v103, v102, %4\n"
+            "v_mul_f32 v106, v100, %1\n v_fmac_f32 v100, %0, v100\n v_fmac_f32 v100, %2, v101\n v_fmac_f32 v106, %3, v101\n v_mov_b32 v101, v106"
+            : : "v"(dd), "v"(cc), "v"(a4), "v"(a5), "v"(sel) : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107");), 104)
     } else if constexpr (CASE == 10) {  // v_fmac_f32 (VOP2) 8 independent
         BODY_LOOP(REP8(asm volatile("v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n"
                        "v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %8, %9\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %8, %9"
@@ -185,5 +207,9 @@ int main() {
     run<22>("step B (mask/perm/sub/perm, 10 instr)", out, n_dev);
     run<23>("step A + ds_write2st64 (11 instr)", out, n_dev);
     run<24>("current step + ds_write2st64 (11 instr)", out, n_dev);
+    run<25>("v_mov_b32_sdwa word insert", out, n_dev);
+    run<26>("v_add_u32 literal", out, n_dev);
+    run<27>("step C (int split, SDWA packs, 13 instr)", out, n_dev);
+    run<28>("step C' (int split, perm packs, 13 instr)", out, n_dev);
     return 0;
 }
