@@ -256,7 +256,7 @@ Engine::~Engine() {
     if (prep_stream_) (void)hipStreamSynchronize(prep_stream_);
     free_retired_blocks();
     d_ca_.release(); d_cb_.release(); d_sq_.release(); d_sd_.release(); d_ss_.release(); d_c3_.release(); d_gq_.release();
-    d_shapes_.release(); d_shape_off_.release(); d_n_modes_.release(); d_geom_.release();
+    d_shapes_.release(); d_shape_off_.release(); d_g32_.release(); d_g32_off_.release(); d_n_modes_.release(); d_geom_.release();
     d_geom_off_.release(); d_psi_.release(); d_slots_.release(); d_xfer_.release();
     d_pc_.release(); d_wtab_.release(); d_dump_row_.release(); d_xdump_.release(); d_xscale_.release(); d_wtab32_.release();
     d_arstate_.release(); d_board_.release(); d_teams_.release(); d_split_.release(); d_audio_parts_.release();
@@ -362,6 +362,7 @@ int Engine::init() {
     if (const char *v = std::getenv("PBSO_CENSUS")) census_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_ROTATE_PRIO")) rotate_prio_ = std::min(2, std::max(0, std::atoi(v)));
     if (const char *v = std::getenv("PBSO_DEVICE_PROFILES")) device_profiles_ = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PBSO_DIRECT_HITS")) direct_hits_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_CHUNK_BUFFERS")) chunk_buffers_ = std::max(1, std::atoi(v));
     return PBSO_OK;
 }
@@ -702,17 +703,28 @@ int Engine::finalize() {
         }
         HIPTRY(d_shape_off_.ensure(N));
         HIPTRY(hipMemcpy(d_shape_off_.p, off.data(), N * sizeof(long long), hipMemcpyHostToDevice));
+        std::vector<long long> row_off(N, 0);
+        for (int i = 0; i < N; ++i) row_off[i] = off[i] / m_pad_;
+        HIPTRY(d_g32_off_.ensure(N));
+        HIPTRY(hipMemcpy(d_g32_off_.p, row_off.data(), N * sizeof(long long), hipMemcpyHostToDevice));
+        HIPTRY(d_g32_.ensure(std::max<size_t>(total, 1)));
         if (total) {
             HIPTRY(d_shapes_.ensure(total));
             std::vector<double> vm;
+            std::vector<float> vg;
             for (int i = 0; i < N; ++i) {
                 Object &o = objs_[i];
                 if (!o.n_dof) continue;
                 vm.assign((size_t)o.n_dof * m_pad_, 0.0);
+                vg.assign((size_t)o.n_dof * m_pad_, 0.f);
                 for (int m = 0; m < o.n_modes; ++m)
-                    for (int dof = 0; dof < o.n_dof; ++dof)
-                        vm[(size_t)dof * m_pad_ + m] = o.shapes[(size_t)m * o.n_dof + dof];
+                    for (int dof = 0; dof < o.n_dof; ++dof) {
+                        const double u = o.shapes[(size_t)m * o.n_dof + dof];
+                        vm[(size_t)dof * m_pad_ + m] = u;
+                        vg[(size_t)dof * m_pad_ + m] = (float)(o.c3[m] * u);
+                    }
                 HIPTRY(hipMemcpy(d_shapes_.p + off[i], vm.data(), vm.size() * sizeof(double), hipMemcpyHostToDevice));
+                HIPTRY(hipMemcpy(d_g32_.p + off[i], vg.data(), vg.size() * sizeof(float), hipMemcpyHostToDevice));
                 std::vector<double>().swap(o.shapes);
             }
         }
@@ -969,7 +981,20 @@ int Engine::plan_object(PlanCtx &c, int oi, int b, int nb, int64_t t) {
         plain_hit = m0.force_type == PBSO_POINT_FORCE && !m0.clear_all && !m0.sustained_start && !m0.sustained_end &&
                     (m0.data_kind == PBSO_DATA_VERTEX || m0.data_kind == PBSO_DATA_FACE);
     }
-    if (plain_hit) {
+    if (plain_hit && direct_hits_ && o.force_q.front().data_kind == PBSO_DATA_VERTEX && 3 * o.force_q.front().vids[0] + 2 < o.n_dof) {
+        // ... and when the hit is at a vertex, not even a row: the oscillator bank dots the hit's normal with three rows
+        // of the object's (float)(c3 * shape) table itself (DESC_DIRECT).  No work for any preparation kernel.
+        const HostForceMsg &m0 = o.force_q.front();
+        const float vn[3] = {(float)m0.vn[0], (float)m0.vn[1], (float)m0.vn[2]};
+        d.frow = 3 * m0.vids[0];
+        std::memcpy(&d.prow, &vn[0], 4);
+        std::memcpy(&d.tile_mask, &vn[1], 4);
+        std::memcpy(&d.pad[0], &vn[2], 4);
+        d.flags |= DESC_IMPULSE | DESC_DIRECT;
+        d.amp = 1.f;
+        std::free(m0.ext);
+        o.force_q.pop_front();
+    } else if (plain_hit) {
         const HostForceMsg &m0 = o.force_q.front();
         {
             // The common case in one go -- the hit of a plain PointForce on an object with no live force: what the
@@ -1579,6 +1604,8 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.ca = d_ca_.p; kp.cb = d_cb_.p; kp.sq = d_sq_.p; kp.sd = d_sd_.p; kp.ss = d_ss_.p;
     kp.desc = d_desc;
     kp.grows = grows.p;
+    kp.g32 = d_g32_.p;
+    kp.g32_off = d_g32_off_.p;
     kp.tprof = d_tprof;
     kp.xfer_rows = d_xfer_.p;
     kp.xfer_init = d_xfer_init;
@@ -1624,7 +1651,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
             if (dump_row_[i] < 0) continue;
             if (dense_heavy || !is_block()) { dump_valid_[i] = 0; continue; }
             for (int b = 0; b < nb; ++b)
-                if (plan_desc_[(size_t)i * nb + b].prow >= 0) { dump_valid_[i] = 0; break; }
+                if (!(plan_desc_[(size_t)i * nb + b].flags & DESC_DIRECT) && plan_desc_[(size_t)i * nb + b].prow >= 0) { dump_valid_[i] = 0; break; }
         }
     }
     bool used[N_CLASS_STREAMS] = {false, false, false};
@@ -1881,7 +1908,7 @@ int Engine::info(pbso_engine_info *out) {
     out->modes_per_lane = R_;
     out->waves_per_object = W_;
     out->n_teams = n_teams_;
-    out->lds_bytes_per_workgroup = !finalized_ ? 0 : is_block() ? (int)block_lds_bytes(W_) : (int)iir_lds_bytes(W_, n_tiles_);
+    out->lds_bytes_per_workgroup = !finalized_ ? 0 : is_block() ? (int)block_lds_bytes(W_, R_) : (int)iir_lds_bytes(W_, n_tiles_);
     out->recurrence_form = form_;
     out->total_block_launches = tot_block_launches_;
     out->total_sample_launches = tot_sample_launches_;

@@ -261,6 +261,11 @@ private:
     int block_team_waves_ = 0;                           // PBSO_BLOCK_TEAM_WAVES: waves per team of the block form (0 = policy)
     DevBuf<double> d_shapes_;
     DevBuf<long long> d_shape_off_;
+    // (float)(c3[m] * shape[dof][m]), [dof][m_pad] per object (rows as d_shapes_: d_g32_off_ = d_shape_off_ / m_pad): the
+    // oscillator bank takes the spatial vector of a plain PointForce vertex hit from three of its rows (DESC_DIRECT)
+    DevBuf<float> d_g32_;
+    DevBuf<long long> d_g32_off_;
+    bool direct_hits_ = true;                            // PBSO_DIRECT_HITS=0: such hits go through the combine kernel
     DevBuf<int> d_n_modes_;
     DevBuf<FfatGeom> d_geom_;
     DevBuf<long long> d_geom_off_;

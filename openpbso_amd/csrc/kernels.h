@@ -23,6 +23,10 @@ constexpr int XFER_UNIT = -2;          // TransMessage::setToUnit, 1e7 (modal_so
 
 constexpr uint32_t DESC_SKIP = 1u;     // step() returned early (modal_solver.h:186-189)
 constexpr uint32_t DESC_IMPULSE = 2u;  // time profile is amp * delta[0] (PointForce): no profile row
+// DESC_IMPULSE whose spatial vector the oscillator bank evaluates itself (the hit of a plain PointForce at a vertex,
+// tools/real_time_modal_sound.cpp:276-280): frow = row 3 * vertex of the object's g32 table, the three floats
+// behind amp's neighbours (prow, tile_mask, pad[0]) are the hit's normal.  No g row, no combine work for it.
+constexpr uint32_t DESC_DIRECT = 4u;
 
 // what ModalSolver::step's bookkeeping (modal_solver.h:184-256) decided for one
 // (object, buffer); written by the host planner, read with scalar loads.
@@ -55,6 +59,8 @@ struct IirParams {
     float *ss;                   // [n_obj][m_pad] scale carried by the stored state (1 = unscaled; kernels_iir.hip)
     const BufDesc *desc;         // [n_obj][nb]
     const float *grows;          // [n_frows][m_pad]  g = (float)(c3 * S)
+    const float *g32;            // [sum of n_dof][m_pad]  (float)(c3[m] * shape[dof][m]): DESC_DIRECT hits take their g from three of its rows
+    const long long *g32_off;    // [n_obj] first row of an object's table
     const float *tprof;          // [n_prows][b_pad]  dense force time profiles
     const double *xfer_rows;     // [n_rows][m_pad]   FFAT transfer rows (fp64)
     const int *xfer_init;        // [n_obj] row (or XFER_UNIT) in effect when the launch starts
@@ -103,7 +109,8 @@ constexpr int BLOCK_STAGE_FLOATS = 2304;   // (split-bf16 projection: two planes
 constexpr int BLOCK_STAGE_FLOATS_F32 = 2080;   // per wave: block-start states of one slice, [16 blocks][64 lanes][Q, D] + 2 per row
 constexpr int BLOCK_RING_FLOATS = 516;     // per wave and buffer parity: the wave's partial sums of one buffer
 constexpr int MAX_WAVES_PER_BLOCK_TEAM = 8;
-inline size_t block_lds_bytes(int W) { return sizeof(float) * (size_t)W * (BLOCK_STAGE_FLOATS + 2 * BLOCK_RING_FLOATS); }
+// per wave: the staging area, two rings, and the landing area of a direct hit's three g32 rows ([3][R][64] floats)
+inline size_t block_lds_bytes(int W, int R) { return sizeof(float) * (size_t)W * (BLOCK_STAGE_FLOATS + 2 * BLOCK_RING_FLOATS + 3 * R * 64); }
 namespace iir_block {
 // modes_per_lane in {1,2,4}; qnorm_mode 0 off, otherwise closed form (+ per-sample in literal buffers)
 // proj: 0 = f32 MFMA projection, 1 = split-bf16 projection (wtab holds the split table)

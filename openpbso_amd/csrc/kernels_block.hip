@@ -101,7 +101,8 @@ template <int R, int QNM, int PROJ, bool DUMP, int MAXT>
 __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     const float *__restrict__ p_ca, const float *__restrict__ p_cb, float *__restrict__ p_sq,
     float *__restrict__ p_sd, float *__restrict__ p_ss, const BufDesc *__restrict__ p_desc,
-    const float *__restrict__ p_grows, const float *__restrict__ p_tprof, const double *__restrict__ p_xfer_rows,
+    const float *__restrict__ p_grows, const float *__restrict__ p_g32, const long long *__restrict__ p_g32_off,
+    const float *__restrict__ p_tprof, const double *__restrict__ p_xfer_rows,
     const int *__restrict__ p_xfer_init, float *__restrict__ p_audio, float *__restrict__ p_qnorm,
     const float *__restrict__ p_gq, const float *__restrict__ p_pc, const float *__restrict__ p_wtab,
     const TeamDesc *__restrict__ p_teams, float *__restrict__ p_audio_parts, unsigned long long *__restrict__ p_census,
@@ -234,6 +235,10 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     // qnorm matrices, the force gain row, the new transfer row -- are fetched while the previous buffer's
     // last slice runs on the matrix pipe, so that a buffer never starts with a round trip to L2 / HBM.
     float nca[R], ncb[R], ng11[R], ng12[R], ng22[R], ngr[R];
+    const float *__restrict__ g32_obj = p_g32 + (size_t)p_g32_off[obj] * p.m_pad + team.col0;
+    // landing area of a DESC_DIRECT hit's three table rows: [3][R][64] floats per wave, behind the waves' staging areas;
+    // filled by LDS-DMA loads (no registers between the prefetch and the buffer's head)
+    float *gland = lds + blockDim.x / 64 * WAVE_FLOATS + wave * (3 * R * 64);
     float ntr[R];
     // (lane offsets used inside the buffer loop are laundered through an empty asm: otherwise LICM hoists one
     //  64-bit address per array and slice out of the loop and keeps 16 R VGPRs alive for the whole kernel)
@@ -274,9 +279,21 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
             }
         }
         if (nd.frow >= 0) {
-            const float *__restrict__ gsrc = p_grows + (size_t)nd.frow * p.m_pad + team.col0;
+            if (nd.flags & DESC_DIRECT) {
+                // the hit of a plain PointForce: three rows of the object's (float)(c3 * shape) table, dotted with the normal at the buffer's head
+                const float *__restrict__ gsrc = g32_obj + (size_t)nd.frow * p.m_pad;
 #pragma unroll
-            for (int r = 0; r < R; ++r) ngr[r] = gsrc[r * rowlen + utid];
+                for (int k = 0; k < 3; ++k) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + (size_t)k * p.m_pad + r * rowlen + utid),
+                                                         (__attribute__((address_space(3))) void *)(gland + (k * R + r) * 64), 4, 0, 0);
+                }
+            } else {
+                const float *__restrict__ gsrc = p_grows + (size_t)nd.frow * p.m_pad + team.col0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) ngr[r] = gsrc[r * rowlen + utid];
+            }
         }
         if (nd.trow >= 0) {
             const double *__restrict__ tsrc = p_xfer_rows + (size_t)nd.trow * p.m_pad + team.col0;
@@ -312,7 +329,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
         next = dsc[b + 1 < p.nb ? b + 1 : b];
 
         const int frow = cur.frow;
-        const int prow = cur.prow;
+        const int prow = (cur.flags & DESC_DIRECT) ? -1 : cur.prow;     // (a direct hit keeps its normal there)
         const float amp = cur.amp;
         const int trow = cur.trow;
         const uint32_t flags = cur.flags;
@@ -345,7 +362,16 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
         }
         float g_[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) g_[r] = frow >= 0 ? (scaled ? ngr[r] * t[r] : ngr[r]) : 0.f;
+        for (int r = 0; r < R; ++r) {
+            float gv = ngr[r];
+            if (flags & DESC_DIRECT) {
+                const float *gl = gland + r * 64 + lane;         // (the loads were issued a buffer ago; the wait below is the head's anyway)
+                gv = __builtin_bit_cast(float, cur.prow) * gl[0];
+                gv = fmaf(__builtin_bit_cast(float, cur.tile_mask), gl[R * 64], gv);
+                gv = fmaf(__builtin_bit_cast(float, cur.pad[0]), gl[2 * R * 64], gv);
+            }
+            g_[r] = frow >= 0 ? (scaled ? gv * t[r] : gv) : 0.f;
+        }
         const bool impulse = (flags & DESC_IMPULSE) != 0;
         const bool dense = frow >= 0 && !impulse;
 
@@ -353,7 +379,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
         if (scaled && !dense) {
             // ================= block path =================
             // sample 0, literal: d_0 = eps^2 d - e q + g T_0 ; q_0 = q + d_0   (nca = eps^2, ncb = -e)
-            const bool hit0 = frow >= 0 && (cur.tile_mask & 1u);
+            const bool hit0 = frow >= 0 && ((flags & DESC_DIRECT) || (cur.tile_mask & 1u));
             float p0 = 0.f;
 #pragma unroll
             for (int v = 0; v < R; ++v) {
@@ -544,7 +570,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 return pp;
             };
             {
-                const float tk0 = dense ? tprow[0] : ((frow >= 0 && (cur.tile_mask & 1u)) ? amp : 0.f);
+                const float tk0 = dense ? tprow[0] : ((frow >= 0 && ((flags & DESC_DIRECT) || (cur.tile_mask & 1u))) ? amp : 0.f);
                 float p0 = step1(tk0, frow >= 0);
                 p0 = wave_sum(p0);
                 if (lane == 0) rg[GROUP * NG] = p0;
@@ -633,7 +659,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
 
 template <int R, int QNM, int PROJ, bool DUMP>
 static int launch_one(const IirParams &p, int n_teams, int W, hipStream_t stream) {
-    const size_t lds = block_lds_bytes(W);
+    const size_t lds = block_lds_bytes(W, R);
     // R = 8 is the one-wave-per-SIMD build (512 registers: the 256 W-table operands go to AGPRs): teams of <= 4 waves
     constexpr int MAXT = R == 8 ? 256 : 64 * MAX_WAVES_PER_BLOCK_TEAM;
     if (64 * W > MAXT) return (int)hipErrorInvalidValue;
@@ -645,7 +671,7 @@ static int launch_one(const IirParams &p, int n_teams, int W, hipStream_t stream
     }
     const int frames = p.frames;
     const BlkDims dims = {p.nb, p.m_pad, p.b_pad, frames, (frames - 1) / GROUP, p.audio_stride, p.gq_plane, p.qn_nb, p.qn_b0};
-    hipLaunchKernelGGL(kern, dim3(n_teams), dim3(64 * W), lds, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows,
+    hipLaunchKernelGGL(kern, dim3(n_teams), dim3(64 * W), lds, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows, p.g32, p.g32_off,
                        p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.census, p.xdump, p.xscale, p.dump_row, dims);
     return (int)hipGetLastError();
 }

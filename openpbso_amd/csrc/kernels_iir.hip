@@ -141,6 +141,7 @@ template <int R, int FORM, int QNM, int MAXT>
 __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     const float *__restrict__ p_ca, const float *__restrict__ p_cb, float *__restrict__ p_sq,
     float *__restrict__ p_sd, float *__restrict__ p_ss, const BufDesc *__restrict__ p_desc, const float *__restrict__ p_grows,
+    const float *__restrict__ p_g32, const long long *__restrict__ p_g32_off,
     const float *__restrict__ p_tprof, const double *__restrict__ p_xfer_rows,
     const int *__restrict__ p_xfer_init, float *__restrict__ p_audio, float *__restrict__ p_qnorm,
     const float *__restrict__ p_gq, const TeamDesc *__restrict__ p_teams, float *__restrict__ p_audio_parts, unsigned *__restrict__ p_board,
@@ -333,11 +334,13 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
         const BufDesc cur = next;
         next = dsc[b + 1 < p.nb ? b + 1 : b];
         const int frow = cur.frow;
-        const int prow = cur.prow;
-        const uint32_t mask = cur.tile_mask;
+        const uint32_t flags = cur.flags;
+        // DESC_DIRECT (the hit of a plain PointForce the bank projects itself): prow / tile_mask / pad[0] hold the normal
+        const bool direct = (flags & DESC_DIRECT) != 0;
+        const int prow = direct ? -1 : cur.prow;
+        const uint32_t mask = direct ? 1u : cur.tile_mask;
         const float amp = cur.amp;
         const int trow = cur.trow;
-        const uint32_t flags = cur.flags;
 
         if (flags & DESC_SKIP) {
             // the reference's step() returned before stepping: no samples, state untouched
@@ -363,9 +366,15 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
             for (int v = 0; v < R; ++v) t[v] = tn[v];
         }
         if (frow >= 0) {
+            const float *__restrict__ gsrc = direct ? p_g32 + ((size_t)p_g32_off[obj] + frow) * p.m_pad : p_grows + (size_t)frow * p.m_pad;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const float gr = p_grows[(size_t)frow * p.m_pad + col + r * rowlen];
+                float gr = gsrc[col + r * rowlen];
+                if (direct) {
+                    gr = __builtin_bit_cast(float, cur.prow) * gr;
+                    gr = fmaf(__builtin_bit_cast(float, cur.tile_mask), (gsrc + p.m_pad)[col + r * rowlen], gr);
+                    gr = fmaf(__builtin_bit_cast(float, cur.pad[0]), (gsrc + 2 * (size_t)p.m_pad)[col + r * rowlen], gr);
+                }
                 g_[r] = (scaled ? gr * t[r] : gr);
             }
         }
@@ -493,7 +502,7 @@ static int launch_one(const IirParams &p, int n_obj, int W, hipStream_t stream) 
     }
     const IirDims dims = {p.nb, p.n_tiles, p.m_pad, p.b_pad, p.audio_stride, p.rotate_prio, p.gq_plane, p.qn_nb, p.qn_b0, p.launch_seq};
     hipLaunchKernelGGL(kern, dim3(n_obj), dim3(64 * W), lds, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc,
-                       p.grows, p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.teams, p.audio_parts, p.board, p.census, dims);
+                       p.grows, p.g32, p.g32_off, p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.teams, p.audio_parts, p.board, p.census, dims);
     return (int)hipGetLastError();
 }
 

@@ -459,10 +459,15 @@ def test_ffat_lookup_bit_exact_batch():
     assert np.array_equal(got, want)
 
 
-def test_projection_bit_exact_through_state():
+@pytest.mark.parametrize("direct_hits", ["0", "1"])
+def test_projection_bit_exact_through_state(monkeypatch, direct_hits):
     """GetModalForceVertex/Face on the device are fp64 in the reference's
     operation order: an explicit-data message built by the oracle's projection
-    must give bit-identical audio to the on-device projection."""
+    must give bit-identical audio to the on-device projection (K3 / the combine kernel).
+    With PBSO_DIRECT_HITS=1 (default) the plain vertex hit takes its vector from the oscillator
+    bank's own (float)(c3 * shape) table -- three f32 products instead of the rounded fp64 dot: equal to
+    f32 rounding (the face hit, and any hit on an object with live forces, still is the fp64 path)."""
+    monkeypatch.setenv("PBSO_DIRECT_HITS", direct_hits)
     from oracle import oracle_py as orc
     n_modes = 200
     seed = 44
@@ -476,7 +481,11 @@ def test_projection_bit_exact_through_state():
             force_ev(2, 0, data=orc.modal_force_face(shapes, [3, 99, 250], bary, vn[1]))]
     a = run_engine(objs, dev, 4)["audio"]
     b = run_engine(objs, host, 4)["audio"]
-    assert np.array_equal(a, b)
+    if direct_hits == "0":
+        assert np.array_equal(a, b)
+    else:
+        assert not np.array_equal(a, b)                              # (the table path did run)
+        assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max()         # f32 rounding of three products, through 4 buffers of recurrence
 
 
 def test_size_independent_properties_full_size_object():
