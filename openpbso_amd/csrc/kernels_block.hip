@@ -278,27 +278,36 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 ng22[r] = (b_gq + 2 * p.plane)[k];
             }
         }
-        if (nd.frow >= 0) {
-            if (nd.flags & DESC_DIRECT) {
-                // the hit of a plain PointForce: three rows of the object's (float)(c3 * shape) table, dotted with the normal at the buffer's head
-                const float *__restrict__ gsrc = g32_obj + (size_t)nd.frow * p.m_pad;
+        if (nd.frow >= 0 && !(nd.flags & DESC_DIRECT)) {
+            const float *__restrict__ gsrc = p_grows + (size_t)nd.frow * p.m_pad + team.col0;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + (size_t)k * p.m_pad + r * rowlen + utid),
-                                                         (__attribute__((address_space(3))) void *)(gland + (k * R + r) * 64), 4, 0, 0);
-                }
-            } else {
-                const float *__restrict__ gsrc = p_grows + (size_t)nd.frow * p.m_pad + team.col0;
-#pragma unroll
-                for (int r = 0; r < R; ++r) ngr[r] = gsrc[r * rowlen + utid];
-            }
+            for (int r = 0; r < R; ++r) ngr[r] = gsrc[r * rowlen + utid];
         }
         if (nd.trow >= 0) {
             const double *__restrict__ tsrc = p_xfer_rows + (size_t)nd.trow * p.m_pad + team.col0;
 #pragma unroll
             for (int r = 0; r < R; ++r) ntr[r] = (float)tsrc[r * rowlen + utid];     // (fp64 rows: the FFAT kernel is bit-exact with the oracle)
+        }
+    };
+
+    // The hit of a plain PointForce (DESC_DIRECT): three rows of the object's (float)(c3 * shape) table go straight to
+    // the landing area by LDS-DMA -- issued a whole buffer ahead, right after the head has read the previous hit's
+    // rows, so that even a cold (HBM) row is there when the next head dots it with the normal; no registers in between.
+    // (Inline asm: through the builtin the compiler, which cannot tell the landing area from the staging area, waits
+    //  for the DMA before the pipeline's first operand read.)
+    const unsigned gland_addr = (unsigned)(size_t)gland;
+    auto prefetch_direct = [&](const BufDesc &nd) {
+        if (nd.frow >= 0 && (nd.flags & DESC_DIRECT)) {
+            const unsigned voff = 4u * lane_off();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float *__restrict__ row = g32_obj + (size_t)(nd.frow + k) * p.m_pad + r * rowlen;      // uniform
+                    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2"
+                                 :: "s"(gland_addr + (unsigned)((k * R + r) * 256)), "v"(voff), "s"(row) : "memory", "m0");
+                }
+            }
         }
     };
 
@@ -323,6 +332,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     };
     BufDesc next = dsc[0];
     prefetch(next);
+    prefetch_direct(next);
     if (p_census) cy_mark = __builtin_amdgcn_s_memtime();
     for (int b = 0; b < p.nb; ++b) {
         const BufDesc cur = next;
@@ -346,6 +356,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 for (int r = 0; r < R; ++r) (b_qn + (size_t)b * p.m_pad)[r * rowlen + utid] = 0.f;
             }
             prefetch(next);
+            prefetch_direct(next);
             continue;
         }
         if (trow != XFER_KEEP) {
@@ -365,13 +376,15 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
         for (int r = 0; r < R; ++r) {
             float gv = ngr[r];
             if (flags & DESC_DIRECT) {
-                const float *gl = gland + r * 64 + lane;         // (the loads were issued a buffer ago; the wait below is the head's anyway)
+                __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): the DMA was issued a buffer ago (normally long done)
+                const float *gl = gland + r * 64 + lane;
                 gv = __builtin_bit_cast(float, cur.prow) * gl[0];
                 gv = fmaf(__builtin_bit_cast(float, cur.tile_mask), gl[R * 64], gv);
                 gv = fmaf(__builtin_bit_cast(float, cur.pad[0]), gl[2 * R * 64], gv);
             }
             g_[r] = frow >= 0 ? (scaled ? gv * t[r] : gv) : 0.f;
         }
+        prefetch_direct(next);                             // (the landing area is free again: the dot above has read it)
         const bool impulse = (flags & DESC_IMPULSE) != 0;
         const bool dense = frow >= 0 && !impulse;
 
