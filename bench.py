@@ -83,6 +83,7 @@ def parse(argv=None):
     ap.add_argument("--strong", action="store_true",
                     help="make the strong-scaling leg the headline: --objects is the TOTAL, split over the ranks")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the nested strong-scaling measurement")
+    ap.add_argument("--time-every", type=int, default=4, help="HIP-event pairs around every n-th oscillator-bank launch (PBSO_TIMING_EVERY)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the RCCL audio all-gather out of the timed region")
     ap.add_argument("--no-gather-cost", action="store_true", help="N > 1: skip the extra leg that times the same run without the all-gather")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the first timed step")
@@ -384,8 +385,10 @@ def measure(args, ctx, global_ids, want_parity):
 
     res = {
         "elapsed": elapsed, "n_local": n_obj, "n_hits": n_hits, "gather": bool(do_gather),
-        "kernel_ms": (info1["total_kernel_ms"] - info0["total_kernel_ms"]) / args.steps,
-        "device_ms": (info1["total_device_ms"] - info0["total_device_ms"]) / args.steps,
+        # HIP events bracket every PBSO_TIMING_EVERY-th launch of the timed region (one launch per step here)
+        "kernel_samples": info1["total_timed_launches"] - info0["total_timed_launches"],
+        "kernel_ms": (info1["total_kernel_ms"] - info0["total_kernel_ms"]) / max(1, info1["total_timed_launches"] - info0["total_timed_launches"]),
+        "device_ms": (info1["total_device_ms"] - info0["total_device_ms"]) / max(1, info1["total_timed_launches"] - info0["total_timed_launches"]),
         "plan_ms": (info1["total_host_plan_ms"] - info0["total_host_plan_ms"]) / args.steps,
         "enqueue_ms": enqueue_s[0] / args.steps * 1e3, "info": info1, "form_run": info1.get("recurrence_form"),
     }
@@ -421,6 +424,9 @@ def main():
     # one node every rank gets its share of the cores.
     os.environ.setdefault("PBSO_PLAN_THREADS", str(args.plan_threads))
     os.environ.setdefault("PBSO_PLAN_PIN", "1" if int(os.environ["PBSO_PLAN_THREADS"]) > 1 else "0")
+    # kernel durations for the roofline: HIP events around every 4th launch (around every launch they cost the stream
+    # ~15 us per step; rocprofv3's average over ALL launches of the same command is in profiles/)
+    os.environ.setdefault("PBSO_TIMING_EVERY", str(args.time_every if args.steps >= 4 * args.time_every else 1))
 
     import torch
     import torch.distributed as dist
@@ -564,6 +570,8 @@ def main():
                               ("fp32 vector-ALU issue; the peak used, 157.3 TFLOP/s, is also the dense fp32 MFMA peak"),
                 "achieved": tf_exec, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_exec / F32_PEAK_TFLOPS,
                 "flop_per_mode_sample": flop_exec, "kernel_ms": k_ms,
+                "kernel_ms_source": "HIP events on the launch stream around every %s-th launch of the timed region: %d launches" % (
+                    os.environ["PBSO_TIMING_EVERY"], m["kernel_samples"]),
                 "reference_equivalent": {"flop_per_mode_sample": FLOP_REF, "achieved": tf_ref, "frac": tf_ref / F32_PEAK_TFLOPS},
                 "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": bytes_alg},

@@ -288,6 +288,9 @@ typedef struct pbso_engine_info {
     int64_t total_sample_launches;    /* ... and on the per-sample kernel (K1): every launch of the per-sample
                                        * forms, and launches of the block form in which more than half of the
                                        * (object, buffer) pairs carry a dense force profile (sustained contact) */
+    int64_t total_timed_launches;     /* launches whose HIP-event times are in total_kernel_ms / total_device_ms: all of
+                                       * them, or every n-th with env PBSO_TIMING_EVERY=n (an event pair costs the
+                                       * stream ~8 us per launch; 0 = none)                                           */
 } pbso_engine_info;
 int pbso_get_info(pbso_engine *e, pbso_engine_info *out);
 /* diagnostics (engine created with env PBSO_CENSUS=1): for every object's

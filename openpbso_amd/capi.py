@@ -66,7 +66,8 @@ class EngineInfo(C.Structure):
                 ("last_step_transfer_rows", C.c_int64),
                 ("total_kernel_ms", C.c_double), ("total_device_ms", C.c_double),
                 ("total_host_plan_ms", C.c_double), ("total_steps", C.c_int64), ("n_teams", C.c_int),
-                ("recurrence_form", C.c_int), ("total_block_launches", C.c_int64), ("total_sample_launches", C.c_int64)]
+                ("recurrence_form", C.c_int), ("total_block_launches", C.c_int64), ("total_sample_launches", C.c_int64),
+                ("total_timed_launches", C.c_int64)]
 
 
 _lib = None

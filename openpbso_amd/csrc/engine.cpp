@@ -363,6 +363,7 @@ int Engine::init() {
     if (const char *v = std::getenv("PBSO_ROTATE_PRIO")) rotate_prio_ = std::min(2, std::max(0, std::atoi(v)));
     if (const char *v = std::getenv("PBSO_DEVICE_PROFILES")) device_profiles_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_DIRECT_HITS")) direct_hits_ = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PBSO_TIMING_EVERY")) timing_every_ = std::max(0, std::atoi(v));
     if (const char *v = std::getenv("PBSO_CHUNK_BUFFERS")) chunk_buffers_ = std::max(1, std::atoi(v));
     return PBSO_OK;
 }
@@ -1519,10 +1520,12 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         HIPTRY(hipEventCreate(&evq.p1));
     }
     evq.step_id = step_id;
+    // (two timing events before and three after the bank cost the stream ~15 us per launch -- 2 % of a 0.7 ms step)
+    const bool timed = timing_every_ > 0 && (launch_seq_ % (unsigned)timing_every_) == 0;
     // ---- preparation stream: this set's device buffers are free once the oscillator
     //      bank that last read them (two steps ago) has finished
     HIPTRY(hipStreamWaitEvent(sp, ev_k1_done_[cur_set_], 0));
-    HIPTRY(hipEventRecord(evq.p0, sp));
+    if (timed) HIPTRY(hipEventRecord(evq.p0, sp));
     // ---- ONE upload: everything the planner produced sits behind the descriptors in the set's pinned arena.
     // (Twelve separate copies cost the host 0.1 ms of API calls per step, and the small ones went through
     // blit kernels that cannot start while the oscillator bank fills the register file.)
@@ -1632,7 +1635,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.pc = d_pc_.p;
     kp.wtab = d_wtab_.p;
     kp.frames = B_;
-    HIPTRY(hipEventRecord(evq.k0, sk));
+    if (timed) HIPTRY(hipEventRecord(evq.k0, sk));
     kp.audio_parts = n_part_rows_ ? d_audio_parts_.p + (size_t)b0 * B_ : nullptr;
     // Side by side only while everything is resident at once (largest teams first, on the engine's
     // stream); an engine that needs several rounds of workgroups runs its classes one after the other
@@ -1679,13 +1682,14 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         HIPTRY(hipEventRecord(ev_join_[j], class_stream_[j]));
         HIPTRY(hipStreamWaitEvent(sk, ev_join_[j], 0));
     }
-    HIPTRY(hipEventRecord(evq.k1, sk));
+    if (timed) HIPTRY(hipEventRecord(evq.k1, sk));
     // _latest_transfer = trans (modal_solver.h:251), then re-park a still-queued transfer
     LAUNCHTRY(launch_copy_rows(d_copy, d_copy + (n_cl + n_cq), n_cl, d_xfer_.p, m_pad_, sk));
     LAUNCHTRY(launch_copy_rows(d_copy + n_cl, d_copy + (n_cl + n_cq) + n_cl, n_cq, d_xfer_.p, m_pad_, sk));
-    HIPTRY(hipEventRecord(evq.p1, sk));
+    if (timed) HIPTRY(hipEventRecord(evq.p1, sk));
     HIPTRY(hipEventRecord(ev_k1_done_[cur_set_], sk));
-    ev_pending_.push_back(evq);
+    if (timed) ev_pending_.push_back(evq);
+    else ev_free_.push_back(evq);
     buffers_done_ += nb;
     cur_set_ ^= 1;
     hprof_[4] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - last_plan_ms_;
@@ -1922,6 +1926,7 @@ int Engine::info(pbso_engine_info *out) {
     out->last_step_device_ms = last_device_ms_;
     out->total_kernel_ms = tot_kernel_ms_;
     out->total_device_ms = tot_device_ms_;
+    out->total_timed_launches = tot_timed_launches_;
     out->total_host_plan_ms = tot_plan_ms_;
     out->total_steps = tot_steps_;
     return PBSO_OK;
@@ -1942,6 +1947,7 @@ int Engine::harvest_timing() {
         }
         last_kernel_ms_ += ms;
         tot_kernel_ms_ += ms;
+        tot_timed_launches_ += 1;
         last_device_ms_ += ms2;
         tot_device_ms_ += ms2;
         ev_free_.push_back(q);

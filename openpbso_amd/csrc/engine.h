@@ -228,7 +228,8 @@ private:
     std::vector<EvQuad> ev_free_, ev_pending_;           // one quad per step, harvested in info()
     int harvest_timing();
     double tot_kernel_ms_ = 0, tot_device_ms_ = 0, tot_plan_ms_ = 0, last_kernel_ms_ = 0, last_device_ms_ = 0;
-    int64_t tot_steps_ = 0, tot_block_launches_ = 0, tot_sample_launches_ = 0;
+    int64_t tot_steps_ = 0, tot_block_launches_ = 0, tot_sample_launches_ = 0, tot_timed_launches_ = 0;
+    int timing_every_ = 1;                               // PBSO_TIMING_EVERY=n: HIP-event pairs around every n-th launch only (0: none)
     std::string err_;
     std::vector<Object> objs_;
     int64_t buffers_done_ = 0;
