@@ -63,6 +63,7 @@ struct BlkDims {
     long long audio_stride;
     long long plane;             // elements between the planes of p_gq / p_pc
     int qn_nb, qn_b0;
+    int rotate;                  // != 0: the teams of a CU take turns at the highest wave priority, one buffer each
 };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     const int *__restrict__ p_xfer_init, float *__restrict__ p_audio, float *__restrict__ p_qnorm,
     const float *__restrict__ p_gq, const float *__restrict__ p_pc, const float *__restrict__ p_wtab,
     const TeamDesc *__restrict__ p_teams, float *__restrict__ p_audio_parts, unsigned long long *__restrict__ p_census,
-    float *__restrict__ p_xdump, float *__restrict__ p_xscale, const int *__restrict__ p_dump_row, const BlkDims p) {
+    float *__restrict__ p_xdump, float *__restrict__ p_xscale, const int *__restrict__ p_dump_row, unsigned *__restrict__ p_board,
+    const BlkDims p) {
     constexpr bool QN = QNM != 0;
     constexpr int NG = 2;                              // groups per buffer (513 = 1 + 2 * 256; checked at launch)
     constexpr int U = NG * R;                          // slices per buffer: (group, r)
@@ -334,9 +336,30 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     prefetch(next);
     prefetch_direct(next);
     if (p_census) cy_mark = __builtin_amdgcn_s_memtime();
+    // The arbiters of a CU (instruction issue, LDS) serve equal-priority waves oldest first: left alone, the team that
+    // was dispatched to a CU first finishes at 84 % of the kernel and the other three share the rest at the efficiency
+    // of three (scripts/census.py).  Every team takes the order in which it arrived on its CU (an atomic counter per
+    // CU; never reset: only the order matters) and the four rotate through the wave priorities, one buffer each.
+    // A scheduling hint only: results do not depend on it.
+    int prio_rank = 0;
+    if (p.rotate) {
+        unsigned *word = p_board + 2048 + (((__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u) << 8) | ((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 8) & 0xFFu));
+        if (tid == 0) ring[0] = __builtin_bit_cast(float, atomicAdd(word, 1u));
+        __syncthreads();
+        prio_rank = (int)(__builtin_bit_cast(unsigned, lds[ST_FLOATS]) & 3u);       // wave 0's ring[0]
+        __syncthreads();
+    }
     for (int b = 0; b < p.nb; ++b) {
         const BufDesc cur = next;
         next = dsc[b + 1 < p.nb ? b + 1 : b];
+        if (p.rotate) {
+            switch ((prio_rank + b) & 3) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        }
 
         const int frow = cur.frow;
         const int prow = (cur.flags & DESC_DIRECT) ? -1 : cur.prow;     // (a direct hit keeps its normal there)
@@ -683,9 +706,9 @@ static int launch_one(const IirParams &p, int n_teams, int W, hipStream_t stream
         if (e != hipSuccess) return (int)e;
     }
     const int frames = p.frames;
-    const BlkDims dims = {p.nb, p.m_pad, p.b_pad, frames, (frames - 1) / GROUP, p.audio_stride, p.gq_plane, p.qn_nb, p.qn_b0};
+    const BlkDims dims = {p.nb, p.m_pad, p.b_pad, frames, (frames - 1) / GROUP, p.audio_stride, p.gq_plane, p.qn_nb, p.qn_b0, p.rotate_prio};
     hipLaunchKernelGGL(kern, dim3(n_teams), dim3(64 * W), lds, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows, p.g32, p.g32_off,
-                       p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.census, p.xdump, p.xscale, p.dump_row, dims);
+                       p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.census, p.xdump, p.xscale, p.dump_row, p.board, dims);
     return (int)hipGetLastError();
 }
 
