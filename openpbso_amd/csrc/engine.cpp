@@ -680,8 +680,8 @@ int Engine::finalize() {
                         const float a = wf[(col / 2) * 64 + 16 * (2 * (col & 1) + 0) + j];
                         const float b = wf[(col / 2) * 64 + 16 * (2 * (col & 1) + 1) + j];
                         uint32_t ah, al, bh, bl;
-                        split(a, ah, al);
-                        split(b, bh, bl);
+                        split((double)a * TRUNC_SPLIT_GAIN, ah, al);
+                        split((double)b * TRUNC_SPLIT_GAIN, bh, bl);
                         w16[(8 * G + dd) * 64 + l] = ah | (bh << 16);
                         w16[(8 * G + 4 + dd) * 64 + l] = al | (bl << 16);
                     }

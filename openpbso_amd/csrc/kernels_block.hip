@@ -506,15 +506,16 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 auto coarse16 = [&](int r, int n, int blk) {
                     dump_state(r, blk);
                     const f2 x = x2[r];
-                    // hi = x rounded to 8 significant bits (half up, in integer arithmetic), lo = the next 8 bits of
-                    // x - hi (truncated); (Q, D) share a dword (v_perm_b32).  v_add_u32 / v_and_b32 / v_sub_f32 issue at
-                    // full rate on gfx950; v_cvt_pk_bf16_f32, v_pk_add_f32 and the 16-bit shift of the obvious form
-                    // (hp = cvt_pk(x); hi = hp << 16, hp & mask; lo = cvt_pk(x - hi)) at half rate, and the (q, d) pair no
-                    // longer has to sit in an aligned register pair: 13.9 instead of 17.8 ns per step and SIMD
-                    // (profiles/r02_valu_issue.txt), the kernel 0.647 instead of 0.679 ms, error 1.2e-5 instead of 1.05e-5.
+                    // hi = the top 8 significant bits of x, lo = the next 8 (of x - hi), both TRUNCATED: a mask, a subtraction
+                    // and a v_perm_b32 that packs (Q, D) into one dword, per part.  v_and_b32 / v_sub_f32 issue at full rate
+                    // on gfx950; v_cvt_pk_bf16_f32, v_pk_add_f32 and the 16-bit shift of the obvious form (hp = cvt_pk(x);
+                    // hi = hp << 16, hp & mask; lo = cvt_pk(x - hi)) at half rate (profiles/r02_valu_issue.txt), and the (q, d)
+                    // pair no longer has to sit in an aligned register pair.  Truncating twice loses (7.2 +- 6.4)e-6 of every
+                    // value, whatever its distribution (2^-16 . 2/3 . E[1/mantissa]): the mean is folded into the operand
+                    // table by the host (TRUNC_SPLIT_GAIN), the spread is below the f32 recurrence's own rounding.
                     const float xq = x.x, xd = x.y;          // (scalars first: a bit cast of a vector ELEMENT expression reads element 0)
-                    const unsigned hq = (__builtin_bit_cast(unsigned, xq) + 0x8000u) & 0xFFFF0000u;
-                    const unsigned hd = (__builtin_bit_cast(unsigned, xd) + 0x8000u) & 0xFFFF0000u;
+                    const unsigned hq = __builtin_bit_cast(unsigned, xq) & 0xFFFF0000u;
+                    const unsigned hd = __builtin_bit_cast(unsigned, xd) & 0xFFFF0000u;
                     const unsigned hp = __builtin_amdgcn_perm(hd, hq, 0x07060302u);
                     const float lq = xq - __builtin_bit_cast(float, hq), ld = xd - __builtin_bit_cast(float, hd);
                     const unsigned lp = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, ld), __builtin_bit_cast(unsigned, lq), 0x07060302u);
@@ -531,6 +532,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 // registers; its 12 MFMAs ride on the coarse steps 4..15 of the NEXT slice (the matrix pipe co-executes
                 // with the vector ALU for bf16), whose steps 0..3 cover the LDS latency of the reads.
                 u4 breg[8];
+                lap(cy_head);
                 wave_sync();
 #pragma unroll
                 for (int n = 0; n < BN; ++n) coarse16(0, n, n);

@@ -117,6 +117,7 @@ def run_bf16x3(M=512, NB=86, seed=1, f_lo=100.0, terms=3):
         W[j] = Ap[:, 0, :]
     P = Ap
     Wf = W.astype(f32).reshape(J, 2 * M)
+    Wf = (Wf.astype(np.float64) * (1.0 + 7.2e-6)).astype(f32)     # TRUNC_SPLIT_GAIN (kernels.h)
     Whi = bf16_trunc(Wf); Wlo = bf16_trunc(Wf - Whi)
     e11 = (P[:, 0, 0] - 1).astype(f32); p12 = P[:, 0, 1].astype(f32); p21 = P[:, 1, 0].astype(f32); p22 = P[:, 1, 1].astype(f32)
     ca = (-c2).astype(f32); cb = (-e).astype(f32); g = c3.astype(f32); tf = t.astype(f32)
@@ -135,7 +136,7 @@ def run_bf16x3(M=512, NB=86, seed=1, f_lo=100.0, terms=3):
             qa = fma(e11, Q, Q); qn = fma(p12, D, qa)
             da = p21 * Q; dn = fma(p22, D, da)
             Q, D = qn, dn
-        Xhi = bf16_round_half_up(X); Xlo = bf16_trunc(X - Xhi)        # the kernel: rounded hi, truncated lo
+        Xhi = bf16_trunc(X); Xlo = bf16_trunc(X - Xhi)        # the kernel: both parts truncated, the mean loss folded into W
         # products of bf16 operands are exact in fp32; accumulate in fp32 (chunks of 32 in fp64 ~ the MFMA's internal sum)
         acc = np.zeros((J, NBLK), np.float64)
         pairs = [(Whi, Xhi), (Whi, Xlo), (Wlo, Xhi)][:terms]
