@@ -48,7 +48,7 @@ FLOP_BLOCK = 4.5
 # + the coarse recurrence and the hi/lo split on the vector ALU: 11 VALU instructions per mode and block of 16 samples
 # (profiles/r02_pmc_summary_bf16.txt: 1431 wave-instructions per wave-buffer of 256 modes x 513 samples at R = 4, incl. the buffer head)
 FLOP_BF16_MFMA = 12.0
-VALU_OPS_BF16 = 1431 * 64 / (256 * 513.0)      # = 0.70 lane-operations per mode-sample
+VALU_OPS_BF16 = 1510 * 64 / (256 * 513.0)      # = 0.74 lane-operations per mode-sample (SQ_INSTS_VALU - SQ_INSTS_MFMA per wave and buffer)
 BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 XGMI_LINK_GBPS = 153.0         # one xGMI link (point to point; 7 per GPU): the figure the task statement and the guide quote
 TOL_MAX, TOL_L2 = 5e-4, 1e-3   # stated fp32 tolerance vs the fp64 oracle
@@ -555,11 +555,11 @@ def main():
                                "v_mfma_f32_16x16x32_bf16 (12 bf16 flop per mode-sample = " + ("%.0f" % (FLOP_BF16_MFMA * mode_samples / (k_ms * 1e-3) * 1e-12)) +
                                " TFLOP/s, " + ("%.2f" % (FLOP_BF16_MFMA * mode_samples / (k_ms * 1e-3) * 1e-12 / BF16_PEAK_TFLOPS)) + " of the dense bf16 peak: not the "
                                "limiter) and co-executes with the vector ALU, which carries the f32 coarse recurrence and the hi / lo "
-                               "split of every block-start state: 1431 VALU instructions per wave and buffer (PMC, profiles/r02_pmc_summary_bf16.txt); "
+                               "split of every block-start state: 1510 VALU instructions per wave and buffer (PMC, profiles/r02_pmc_summary_bf16.txt); "
                                "achieved / frac count every VALU instruction as 64 lanes x 2 flop against the 157.3 TFLOP/s f32 vector "
-                               "peak (32 lanes per cycle and SIMD), i.e. issue-slot utilisation with every instruction counted as one slot; half of the "
-                               "step's ~10 instructions (v_cvt_pk_bf16_f32, v_pk_add_f32, v_lshlrev_b32) issue at half rate on gfx950 and "
-                               "one wave issues at most one instruction per 4 cycles (profiles/r02_valu_issue.txt), so the slots in use are ~1.4x frac; "
+                               "peak (32 lanes per cycle and SIMD), i.e. issue-slot utilisation; the kernel is bound by what ONE wave can issue -- at most "
+                               "one instruction of any kind per 4 cycles (profiles/r02_valu_issue.txt), and the register file holds two waves per SIMD: "
+                               "~3000 instructions per wave and buffer (vector, LDS, scalar, MFMA) in 15.7 K cycles (profiles/r02_census_1024x512.txt); "
                                "reference_equivalent credits the reference's 10 flop per mode-sample") if bf16 else
                               ("f32 matrix pipe: the per-sample sum over modes is a [16 x 2M].[2M x 16 blocks] product on "
                                "v_mfma_f32_16x16x4_f32 (4 flop per mode-sample) + the coarse recurrence on the vector ALU "
