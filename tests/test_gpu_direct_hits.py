@@ -1,0 +1,75 @@
+"""DESC_DIRECT: the hit of a plain PointForce at a vertex of an object with no live force is projected by the oscillator
+bank itself (three rows of the per-object (float)(c3 * shape) table, dotted with the hit's normal) -- no force row, no
+work for the preparation kernels.  Every bank kernel against the oracle, the rows the planner emits, and the messages
+that must NOT take the shortcut (tools/real_time_modal_sound.cpp:236-295 for the projections, modal_solver.h:195-221)."""
+import numpy as np
+import pytest
+
+from openpbso_amd import capi, synth
+from tests.scenarios import ObjSpec, force_ev, rel_errors, run_engine, run_oracle
+
+pytestmark = pytest.mark.gpu
+NB = 24
+
+
+def _scene(n_obj=6, n_modes=300, seed=5):
+    objs, evs = [], []
+    rng = np.random.default_rng(seed)
+    for i in range(n_obj):
+        s = synth.seed_for(7, i)
+        objs.append(ObjSpec(synth.eigenvalues(n_modes, s), shapes=synth.mode_shapes(n_modes, s)))
+        n_verts = objs[-1].shapes.shape[1] // 3
+        vns = synth.unit_normals(NB, s)
+        for b in range(NB):
+            if rng.random() < 0.45:
+                evs.append(force_ev(b, i, vid=int(rng.integers(0, n_verts)), vn=vns[b]))
+        evs.append(dict(t=0, obj=i, kind="use_transfer", use=False))
+    return objs, evs
+
+
+@pytest.mark.parametrize("form,mpl", [(capi.FORM_BLOCK_BF16, 0), (capi.FORM_BLOCK_BF16, 4), (capi.FORM_BLOCK, 2), (capi.FORM_BLOCK, 8),
+                                      (capi.FORM_VELOCITY, 0), (capi.FORM_VELOCITY, 3), (capi.FORM_DIRECT, 1)])
+def test_vertex_hits_through_the_bank_match_the_oracle(form, mpl):
+    objs, evs = _scene()
+    want = run_oracle(objs, evs, NB)
+    got = run_engine(objs, evs, NB, form=form, modes_per_lane=mpl, split=[10, 14])
+    assert np.array_equal(got["emitted"], want["emitted"])
+    mx, l2 = rel_errors(got["audio"], want["audio"])
+    tol = (2e-2, 3e-2) if form == capi.FORM_DIRECT else (5e-4, 1e-3)
+    assert (mx <= tol[0]).all() and (l2 <= tol[1]).all(), (mx.max(), l2.max())
+    assert got["info"]["last_step_forced_rows"] == 0          # no force row was built: the bank did the projection
+
+
+def test_switch_off_sends_them_through_the_fp64_kernels(monkeypatch):
+    objs, evs = _scene(n_obj=3)
+    a = run_engine(objs, evs, NB)
+    monkeypatch.setenv("PBSO_DIRECT_HITS", "0")
+    b = run_engine(objs, evs, NB)
+    assert a["info"]["last_step_forced_rows"] == 0 and b["info"]["last_step_forced_rows"] > 0
+    assert np.abs(a["audio"] - b["audio"]).max() <= 1e-5 * np.abs(b["audio"]).max()      # f32 table vs rounded fp64 dot, 24 buffers on
+
+
+def test_messages_that_keep_the_general_path():
+    """a face hit, a hit while a Gaussian force is alive, a hit on a sustained object and a hit in the same buffer as a
+    clear: none of them is a DESC_DIRECT descriptor, all must match the oracle"""
+    n_modes = 200
+    s = synth.seed_for(7, 40)
+    shapes = synth.mode_shapes(n_modes, s)
+    objs = [ObjSpec(synth.eigenvalues(n_modes, synth.seed_for(7, 40 + i)), shapes=shapes) for i in range(4)]
+    vn = synth.unit_normals(8, s)
+    rng = np.random.default_rng(3)
+    evs = [
+        force_ev(1, 0, vids=[3, 9, 20], coords=np.array([0.1, 0.6, 0.3]), vn=vn[0]),                   # face hit
+        force_ev(0, 1, data=rng.standard_normal(n_modes) * 1e-3, force_type=1, width=900.0),          # Gaussian spanning buffers
+        force_ev(1, 1, vid=5, vn=vn[1]),                                                                # ... and a hit meanwhile
+        force_ev(0, 2, data=rng.standard_normal(n_modes) * 1e-3, force_type=2, start=True),           # sustained AR
+        force_ev(2, 2, vid=7, vn=vn[2]),                                                                # hit on the sustained object: data swap
+        force_ev(4, 2, force_type=2, end=True),
+        force_ev(6, 2, vid=8, vn=vn[3]),                                                                # idle again: direct
+        force_ev(2, 3, vid=2, vn=vn[4]), force_ev(3, 3, clear=True), force_ev(4, 3, vid=4, vn=vn[5]),
+    ] + [dict(t=0, obj=i, kind="use_transfer", use=False) for i in range(4)]
+    want = run_oracle(objs, evs, 10)
+    got = run_engine(objs, evs, 10)
+    assert np.array_equal(got["emitted"], want["emitted"])
+    mx, l2 = rel_errors(got["audio"], want["audio"])
+    assert (mx <= 5e-4).all() and (l2 <= 1e-3).all(), (mx, l2)
