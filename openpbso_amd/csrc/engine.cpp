@@ -756,6 +756,7 @@ int Engine::finalize() {
         }
         HIPTRY(d_geom_off_.ensure(N));
         HIPTRY(hipMemcpy(d_geom_off_.p, goff.data(), N * sizeof(long long), hipMemcpyHostToDevice));
+        geom_off_h_ = goff;
         if (!geom.empty()) {
             HIPTRY(d_geom_.ensure(geom.size()));
             HIPTRY(hipMemcpy(d_geom_.p, geom.data(), geom.size() * sizeof(FfatGeom), hipMemcpyHostToDevice));
@@ -1878,29 +1879,41 @@ int Engine::compute_transfer_batch(int obj, const double *pos, int n_pos, double
         if (m >= (int)o.geom.size() || !o.geom[m].valid)
             return fail(PBSO_ERR_MISSING_MAP, "FFAT map ids are not 0..size-1 (std::map::at throws)");
     if (!n_pos) return 1;
-    DevBuf<double> rows;
-    DevBuf<FfatEvent> dev;
-    std::vector<FfatEvent> evs(n_pos);
-    for (int i = 0; i < n_pos; ++i) {
-        evs[i].obj = obj;
-        evs[i].row = i;
-        for (int j = 0; j < 3; ++j) evs[i].pos[j] = pos[3 * i + j];
-    }
+    // Positions go up once; the lookups run in chunks (one workgroup per mode and 1024 positions, the mode's map
+    // staged in LDS) into two row buffers, and the copy of chunk c to the caller's memory (the copy stream) runs beside
+    // the kernel of chunk c + 1.
+    const int CH = 16384;
+    const int n_chunks = (n_pos + CH - 1) / CH;
+    DevBuf<double> rows, dpos;
+    hipEvent_t ev_k[2] = {nullptr, nullptr};
     int rc = PBSO_OK;
-    hipError_t e = rows.ensure((size_t)n_pos * m_pad_, false, stream_);
-    if (e == hipSuccess) e = dev.ensure(n_pos, false, stream_);
-    if (e == hipSuccess) e = hipMemcpyAsync(dev.p, evs.data(), n_pos * sizeof(FfatEvent), hipMemcpyHostToDevice, stream_);
-    if (e == hipSuccess) {
-        int le = launch_ffat_lookup(dev.p, n_pos, d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p, rows.p, m_pad_, stream_);
-        if (le) e = (hipError_t)le;
+    hipError_t e = rows.ensure((size_t)2 * std::min(n_pos, CH) * m_pad_, false, stream_);
+    if (e == hipSuccess) e = dpos.ensure((size_t)3 * n_pos, false, stream_);
+    if (e == hipSuccess) e = hipMemcpyAsync(dpos.p, pos, (size_t)3 * n_pos * sizeof(double), hipMemcpyHostToDevice, stream_);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ev_k[i], hipEventDisableTiming);
+    const FfatGeom *g0 = d_geom_.p + geom_off_h_[obj];
+    auto launch_chunk = [&](int c) -> hipError_t {
+        const int p0 = c * CH, n = std::min(CH, n_pos - p0);
+        int le = launch_ffat_batch(dpos.p + 3 * (size_t)p0, n, g0, nmap, d_psi_.p, rows.p + (size_t)(c & 1) * CH * m_pad_, m_pad_, stream_);
+        if (le) return (hipError_t)le;
+        return hipEventRecord(ev_k[c & 1], stream_);
+    };
+    if (e == hipSuccess) e = launch_chunk(0);
+    for (int c = 0; c < n_chunks && e == hipSuccess; ++c) {
+        if (c + 1 < n_chunks) e = launch_chunk(c + 1);          // (its row buffer was copied out two chunks ago: the copy below is synchronous)
+        const int p0 = c * CH, n = std::min(CH, n_pos - p0);
+        if (e == hipSuccess) e = hipStreamWaitEvent(prep_stream_, ev_k[c & 1], 0);
+        if (e == hipSuccess)
+            e = hipMemcpy2DAsync(out + (size_t)p0 * out_cols, (size_t)out_cols * sizeof(double), rows.p + (size_t)(c & 1) * CH * m_pad_,
+                                 (size_t)m_pad_ * sizeof(double), (size_t)nmap * sizeof(double), n, hipMemcpyDeviceToHost, prep_stream_);
+        if (e == hipSuccess) e = hipStreamSynchronize(prep_stream_);
     }
-    if (e == hipSuccess)
-        e = hipMemcpy2DAsync(out, (size_t)out_cols * sizeof(double), rows.p, (size_t)m_pad_ * sizeof(double),
-                             (size_t)nmap * sizeof(double), n_pos, hipMemcpyDeviceToHost, stream_);
     if (e == hipSuccess) e = hipStreamSynchronize(stream_);
     if (e != hipSuccess) rc = hip_fail(e, "compute_transfer_batch");
+    for (hipEvent_t ev : ev_k)
+        if (ev) (void)hipEventDestroy(ev);
     rows.release();
-    dev.release();
+    dpos.release();
     return rc == PBSO_OK ? 1 : rc;
 }
 

@@ -262,6 +262,7 @@ private:
     int block_team_waves_ = 0;                           // PBSO_BLOCK_TEAM_WAVES: waves per team of the block form (0 = policy)
     DevBuf<double> d_shapes_;
     DevBuf<long long> d_shape_off_;
+    std::vector<long long> geom_off_h_;                  // host copy of d_geom_off_ (first FfatGeom of every object)
     // (float)(c3[m] * shape[dof][m]), [dof][m_pad] per object (rows as d_shapes_: d_g32_off_ = d_shape_off_ / m_pad): the
     // oscillator bank takes the spatial vector of a plain PointForce vertex hit from three of its rows (DESC_DIRECT)
     DevBuf<float> d_g32_;

@@ -195,6 +195,10 @@ struct FfatEvent {
 int launch_ffat_lookup(const FfatEvent *events, int n_events, const FfatGeom *geom,
                        const long long *geom_off, const int *n_modes, const double *psi,
                        double *rows, int m_pad, hipStream_t stream);
+// the same lookups for n_pos positions of ONE object (geom_of_object = its first FfatGeom), Psi staged in LDS per mode;
+// writes rows[p][0 .. n_maps)
+int launch_ffat_batch(const double *pos, int n_pos, const FfatGeom *geom_of_object, int n_maps, const double *psi,
+                      double *rows, int m_pad, hipStream_t stream);
 // audio[obj][i] = sum over the object's teams, in team order (deterministic)
 struct SplitObj { int obj, first_row, n_rows, pad; };
 int launch_sum_parts(const SplitObj *split, int n_split, const float *parts, float *audio, long long stride,

@@ -445,6 +445,42 @@ int launch_ffat_lookup(const FfatEvent *events, int n_events, const FfatGeom *ge
     return (int)hipGetLastError();
 }
 
+// K4, many positions of ONE object (computeTransfer(pos, T*), modal_solver.h:302-315; the HUD sphere of the tool,
+// tools/real_time_modal_sound.cpp:916-927).  One workgroup per (mode, chunk of positions): the mode's map -- all six
+// faces of Psi -- is staged in LDS once and every bilinear interpolation of the chunk gathers from there; the mode's
+// geometry is workgroup-uniform (scalar loads).  The per-event kernel above reads 300 bytes of geometry per lookup and
+// gathers Psi from L2 / HBM, which a 1024-mode object overflows (12 MB of maps against 4 MB of L2 per XCD).
+// Same arithmetic (ffat_get_map_val), bit-exact with the oracle.  Maps that do not fit the LDS window are read in place.
+constexpr int FFAT_LDS_DOUBLES = 7168;             // 56 KB: a 32 x 32-cell cube map is 6144 doubles
+constexpr int FFAT_POS_PER_BLOCK = 1024;
+__global__ __launch_bounds__(256) void ffat_batch_kernel(const double *__restrict__ pos, int n_pos, const FfatGeom *__restrict__ geom,
+                                                         const double *__restrict__ psi, double *__restrict__ rows, int m_pad) {
+    extern __shared__ __attribute__((aligned(16))) double lpsi[];
+    const int m = blockIdx.x;
+    const FfatGeom &g = geom[m];
+    const bool staged = g.valid && g.n_psi <= FFAT_LDS_DOUBLES;
+    if (staged)
+        for (int i = threadIdx.x; i < g.n_psi; i += blockDim.x) lpsi[i] = psi[g.psi_off + i];
+    __syncthreads();
+    const double *src = staged ? lpsi : psi + g.psi_off;
+    const int p0 = blockIdx.y * FFAT_POS_PER_BLOCK;
+    const int p1 = p0 + FFAT_POS_PER_BLOCK < n_pos ? p0 + FFAT_POS_PER_BLOCK : n_pos;
+    for (int p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+        const double P[3] = {pos[3 * (size_t)p], pos[3 * (size_t)p + 1], pos[3 * (size_t)p + 2]};
+        // computeTransfer wraps GetMapVal in another std::abs (modal_solver.h:312)
+        rows[(size_t)p * m_pad + m] = g.valid ? fabs(ffat_get_map_val(g, src, P)) : 0.0;
+    }
+}
+
+int launch_ffat_batch(const double *pos, int n_pos, const FfatGeom *geom_of_object, int n_maps, const double *psi,
+                      double *rows, int m_pad, hipStream_t stream) {
+    if (n_pos <= 0 || n_maps <= 0) return 0;
+    dim3 grid(n_maps, (n_pos + FFAT_POS_PER_BLOCK - 1) / FFAT_POS_PER_BLOCK);
+    hipLaunchKernelGGL(ffat_batch_kernel, grid, dim3(256), FFAT_LDS_DOUBLES * sizeof(double), stream, pos, n_pos, geom_of_object,
+                       psi, rows, m_pad);
+    return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // Objects stepped by several teams: add the teams' partial sample sums, team 0 first.
 __global__ __launch_bounds__(256) void sum_parts_kernel(const SplitObj *__restrict__ split,

@@ -251,12 +251,16 @@ class Engine:
         """_ffat_maps->size() (0 before readFFATMaps)"""
         return self._chk(self._l.pbso_object_n_maps(self._h, obj))
 
-    def compute_transfer_batch(self, obj, pos, n_cols=None):
-        """computeTransfer(pos, T*) for many positions: [n_pos][n_cols]; columns beyond the object's map count stay 0"""
+    def compute_transfer_batch(self, obj, pos, n_cols=None, out=None):
+        """computeTransfer(pos, T*) for many positions: [n_pos][n_cols]; columns beyond the object's map count stay 0.
+        out: a C-contiguous float64 array [n_pos][n_cols] to fill (a caller that asks every frame keeps one: a fresh
+        84 MB array costs more in page faults than the lookups and the copy together)"""
         p = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
         if n_cols is None:
-            n_cols = self.n_maps(obj)
-        out = np.zeros((p.shape[0], n_cols))
+            n_cols = self.n_maps(obj) if out is None else out.shape[1]
+        if out is None:
+            out = np.zeros((p.shape[0], n_cols))
+        assert out.dtype == np.float64 and out.flags.c_contiguous and out.shape == (p.shape[0], n_cols)
         rc = self._chk(self._l.pbso_compute_transfer_batch(self._h, obj, _dp(p), p.shape[0], _dp(out), n_cols))
         return bool(rc), out
 

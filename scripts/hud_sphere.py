@@ -23,14 +23,20 @@ for n_modes in (64, 256, 1024):
     eng.add_object(lam, synth.RHO, synth.ALPHA, synth.BETA)
     eng.set_ffat_maps(0, maps)
     eng.finalize()
-    ts = []
+    ts, tf = [], []
+    keep = np.zeros((n_pos, n_modes))
     for _ in range(12):
         t0 = time.perf_counter()
-        ok, out = eng.compute_transfer_batch(0, pos, n_modes)
+        ok, out = eng.compute_transfer_batch(0, pos, n_modes, out=keep)
         ts.append(time.perf_counter() - t0)
-    assert ok and np.isfinite(out).all() and (out > 0).all()
+    for _ in range(4):
+        t0 = time.perf_counter()
+        ok2, fresh = eng.compute_transfer_batch(0, pos, n_modes)           # a new array per call: its first touch is in the time
+        tf.append(time.perf_counter() - t0)
+    assert ok and ok2 and np.isfinite(out).all() and (out > 0).all() and np.array_equal(out, fresh)
     t = np.median(ts[2:])
     look = n_pos * n_modes
     print(f"modes={n_modes:5d}: {n_pos} positions -> {look / 1e6:.2f} M lookups, result {out.nbytes / 1e6:.1f} MB: "
-          f"median {t * 1e3:.2f} ms per call = {look / t / 1e9:.2f} G lookups/s incl. D2H ({out.nbytes / t / 1e9:.1f} GB/s of results)")
+          f"median {t * 1e3:.2f} ms per call = {look / t / 1e9:.2f} G lookups/s incl. D2H ({out.nbytes / t / 1e9:.1f} GB/s of results); "
+          f"into a fresh array {np.median(tf) * 1e3:.2f} ms")
     eng.close()

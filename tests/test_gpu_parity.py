@@ -818,3 +818,29 @@ def test_multi_listener_mix_matches_independent_solvers(form):
         if l == 3:
             assert np.abs(single - want).max() <= 5e-4 * np.abs(want).max()
             assert np.abs(mix[l] - single).max() <= 1e-4 * np.abs(want).max()
+
+
+def test_compute_transfer_batch_chunks_large_maps_and_reused_output():
+    """the batched lookup stages a mode's map in LDS (56 KB window): a map too large for it is read in place, a call with
+    more positions than one chunk (16 384) is cut, and a caller-owned output array is filled in place -- all three against
+    the per-listener path (K4's per-event kernel, the one a step uses), bit for bit"""
+    from openpbso_amd import Engine
+    n_modes = 6
+    lam = synth.eigenvalues(n_modes, 35)
+    rng = np.random.default_rng(35)
+    for dim, n_pos in ((8, 20000), (40, 300)):           # 40 x 40 cells x 6 faces = 9600 doubles > the LDS window
+        maps = synth.ffat_maps(lam, 35, dim=dim)
+        v = rng.standard_normal((n_pos, 3))
+        pos = 0.4 * v / np.linalg.norm(v, axis=1, keepdims=True) * (1.0 + rng.random((n_pos, 1)))
+        with Engine() as eng:
+            oid = eng.add_object(lam, synth.RHO, synth.ALPHA, synth.BETA)
+            eng.set_ffat_maps(oid, maps)
+            eng.finalize()
+            keep = np.full((n_pos, n_modes), -1.0)
+            ok, got = eng.compute_transfer_batch(oid, pos, out=keep)
+            assert ok and got is keep and (keep > 0).all()
+            # the per-listener path: computeTransfer(pos) stamped per buffer, read back as _latest_transfer
+            for i in (0, 1, n_pos // 2, n_pos - 1):
+                eng.compute_transfer(oid, pos[i], 0)
+                eng.step(1)
+                assert np.array_equal(eng.latest_transfer(oid), keep[i])
