@@ -314,7 +314,9 @@ def measure(args, ctx, global_ids, want_parity):
     # targets are double-buffered and the collective is asynchronous on RCCL's own stream, so the gather of
     # step k runs beside the oscillator bank of step k+1; it is waited for only when its buffers are reused
     # (and before the clock stops).  Ragged shards (strong leg) are padded to the largest one.
-    do_gather = ctx["use_dist"] and world > 1 and not args.no_gather and not ctx.get("leg_without_gather")
+    # (PBSO_BENCH_GATHER_SELF=1: a one-rank group gathers too -- the RCCL code path on a one-GPU box, tests/test_gpu_bench_ranks.py)
+    do_gather = (ctx["use_dist"] and (world > 1 or os.environ.get("PBSO_BENCH_GATHER_SELF") == "1") and not args.no_gather
+                 and not ctx.get("leg_without_gather"))
     counts = ctx.get("counts")                       # objects per rank in this leg
     cmax = max(counts) if counts else n_obj
     n_buf = 2 if do_gather else 1

@@ -31,3 +31,23 @@ def test_two_ranks_on_one_gpu_print_one_line_with_gather_and_strong_leg():
     assert s["scaling"] == "strong" and s["objects_total"] == 96 and s["objects_rank0"] == 48 and s["gather"] is True
     # whole-job value: both ranks' objects over the slowest rank's time
     assert abs(d["value"] - 2 * 96 * 86 * 513 * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+def test_one_rank_under_torchrun_runs_the_rccl_gather_path():
+    """the launcher the driver uses for N > 1 (python -m torch.distributed.run ... bench.py --gpus N), with N = 1 and
+    PBSO_BENCH_GATHER_SELF=1: backend nccl (= RCCL), init with device_id, the asynchronous double-buffered
+    all_gather_into_tensor beside the next step's oscillator bank, the equality check of the gathered rows"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PBSO_BENCH_GATHER_SELF="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PBSO_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--objects", "256", "--steps", "8",
+                        "--warmup", "2", "--settle", "4", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["gather"] is True and d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 1
+    assert d["config"]["launched_by"] == "torch.distributed.run" and d["parity"]["pass"]
+    assert d["gather_cost"]["bytes_sent_per_rank"] == 256 * 86 * 513 * 4 and d["gather_cost"]["bytes_received_per_rank"] == 0
