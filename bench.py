@@ -319,9 +319,15 @@ def measure(args, ctx, global_ids, want_parity):
                  and not ctx.get("leg_without_gather"))
     counts = ctx.get("counts")                       # objects per rank in this leg
     cmax = max(counts) if counts else n_obj
+    # leg "mix": the consumer wants ONE mixed stream: every rank sums its objects' buffers and the ranks
+    # all-reduce that row (nb * 513 floats) instead of gathering every object's audio
+    do_mix = bool(do_gather and ctx.get("leg_mix"))
     n_buf = 2 if do_gather else 1
     audios = [torch.zeros((cmax, nb * B), dtype=torch.float32, device=dev) for _ in range(n_buf)]
-    gathered = [torch.empty((world * cmax, nb * B), dtype=torch.float32, device=dev) for _ in range(n_buf)] if do_gather else None
+    gathered = ([torch.empty((world * cmax, nb * B), dtype=torch.float32, device=dev) for _ in range(n_buf)]
+                if do_gather and not do_mix else None)
+    mixes = [torch.zeros(nb * B, dtype=torch.float32, device=dev) for _ in range(n_buf)] if do_mix else None
+    ones_obj = torch.ones(n_obj, dtype=torch.float32, device=dev) if do_mix else None
     pending = [None] * n_buf
     enqueue_s = [0.0]
     n_calls = [0]
@@ -345,7 +351,15 @@ def measure(args, ctx, global_ids, want_parity):
         eng.step(nb, into=audios[slot].data_ptr())
         if capture:
             captured[0] = audios[slot].index_select(0, rows_t)
-        if do_gather:
+        if do_mix:
+            torch.mv(audios[slot][:n_obj].t(), ones_obj, out=mixes[slot])          # sum over the rank's objects (a GEMV: reads the 181 MB once)
+            if backend == "nccl":
+                pending[slot] = dist.all_reduce(mixes[slot], async_op=True)
+            else:
+                m_host = mixes[slot].cpu()
+                dist.all_reduce(m_host)
+                mixes[slot].copy_(m_host)
+        elif do_gather:
             if backend == "nccl":
                 pending[slot] = dist.all_gather_into_tensor(gathered[slot], audios[slot], async_op=True)
             else:
@@ -381,7 +395,9 @@ def measure(args, ctx, global_ids, want_parity):
         elapsed = float(t.item())
     info1 = eng.info()
     assert all(torch.isfinite(a).all() for a in audios)
-    if do_gather and backend == "nccl":
+    if do_mix:
+        assert all(torch.isfinite(x).all() for x in mixes)
+    if do_gather and not do_mix and backend == "nccl":
         last = (n_calls[0] - 1) % n_buf
         assert torch.equal(gathered[last][rank * cmax:rank * cmax + n_obj], audios[last][:n_obj])
 
@@ -494,12 +510,15 @@ def main():
     head = order[0]
     m = legs[head]
     # what the collective costs: the head leg once more with the all-gather left out (reported beside it, never as `value`)
-    bare = None
+    bare = mixed = None
     if m["gather"] and not args.no_gather_cost:
         ctx["leg_without_gather"] = True
         ctx["counts"] = [args.objects] * world if head == "weak" else [hi - lo for lo, hi in spans]
         bare = measure(args, ctx, weak_ids if head == "weak" else strong_ids, want_parity=False)
         ctx["leg_without_gather"] = False
+        ctx["leg_mix"] = True
+        mixed = measure(args, ctx, weak_ids if head == "weak" else strong_ids, want_parity=False)
+        ctx["leg_mix"] = False
 
     if rank == 0:
         nb, M = args.buffers, args.modes
@@ -602,6 +621,12 @@ def main():
                         "step costs max(compute, gather); at these sizes the links, not the kernels, set the step time "
                         "whenever bytes_received_per_rank / xgmi_inbound_peak exceeds ms_per_step_without_gather",
             }
+        if mixed is not None:
+            out["mix"] = dict(leg_numbers(head, mixed), scaling=head, collective="all_reduce(sum) of one mixed row per rank",
+                              bytes_per_rank=nb * B * 4,
+                              note="the same leg when the consumer wants ONE mixed stream instead of every object's buffers (SURVEY 8(e)): "
+                                   "each rank sums its objects' audio and the ranks all-reduce nb * 513 floats; reported beside the "
+                                   "headline, never as `value`")
         for leg, r in legs.items():
             if leg != head:
                 out[leg] = dict(leg_numbers(leg, r), scaling=leg,

@@ -27,6 +27,8 @@ def test_two_ranks_on_one_gpu_print_one_line_with_gather_and_strong_leg():
     g = d["gather_cost"]
     assert g["bytes_sent_per_rank"] == 96 * 86 * 513 * 4 and g["bytes_received_per_rank"] == g["bytes_sent_per_rank"]
     assert g["ms_per_step_without_gather"] > 0 and g["value_without_gather"] > 0
+    mx = d["mix"]
+    assert mx["bytes_per_rank"] == 86 * 513 * 4 and mx["value"] > 0 and mx["objects_total"] == 192
     s = d["strong"]
     assert s["scaling"] == "strong" and s["objects_total"] == 96 and s["objects_rank0"] == 48 and s["gather"] is True
     # whole-job value: both ranks' objects over the slowest rank's time
