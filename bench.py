@@ -87,6 +87,9 @@ def parse(argv=None):
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the RCCL audio all-gather out of the timed region")
     ap.add_argument("--no-gather-cost", action="store_true", help="N > 1: skip the extra leg that times the same run without the all-gather")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the first timed step")
+    ap.add_argument("--no-f32-leg", action="store_true",
+                    help="--form block_bf16, one GPU: skip the second run of the same workload with the exact-f32 projection "
+                         "(--form block), reported beside the headline as exact_f32_projection")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-objects", type=int, default=0, help="objects in the CPU baseline sample (0 = auto)")
     return ap.parse_args(argv)
@@ -509,6 +512,14 @@ def main():
         legs[leg] = measure(args, ctx, ids, want_parity=(not args.no_parity and leg == order[0] and rank == 0))
     head = order[0]
     m = legs[head]
+    # one GPU, split-bf16 projection: the same workload once more with the exact-f32 projection, reported beside the headline
+    f32_leg = None
+    if world == 1 and args.form == "block_bf16" and not args.no_f32_leg and args.scenario == "impulses":
+        import copy
+        a32 = copy.copy(args)
+        a32.form = "block"
+        ctx["counts"] = [args.objects]
+        f32_leg = measure(a32, ctx, weak_ids, want_parity=(not args.no_parity and rank == 0))
     # what the collective costs: the head leg once more with the all-gather left out (reported beside it, never as `value`)
     bare = mixed = None
     if m["gather"] and not args.no_gather_cost:
@@ -621,6 +632,18 @@ def main():
                         "step costs max(compute, gather); at these sizes the links, not the kernels, set the step time "
                         "whenever bytes_received_per_rank / xgmi_inbound_peak exceeds ms_per_step_without_gather",
             }
+        if f32_leg is not None:
+            fn = leg_numbers(head, f32_leg)
+            out["exact_f32_projection"] = {
+                "value": fn["value"], "realtime_x": fn["realtime_x"], "ms_per_step": fn["ms_per_step"], "kernel_ms": f32_leg["kernel_ms"],
+                "max_err": f32_leg.get("parity", {}).get("max_err"), "parity_pass": f32_leg.get("parity", {}).get("pass"),
+                "note": "the same workload and engine with --form block: the output projection as an exact f32 MFMA product "
+                        "(v_mfma_f32_16x16x4_f32) instead of three bf16 x bf16 products with f32 accumulation; the state recurrence "
+                        "is f32 in both",
+            }
+            out["dtype_note"] = ("state recurrence f32; output projection of the headline as a split-bf16 product (two bf16 halves per operand, "
+                                 "16 significant bits, f32 accumulation) whose error against the fp64 oracle is max_err; "
+                                 "exact_f32_projection is the all-f32 figure")
         if mixed is not None:
             out["mix"] = dict(leg_numbers(head, mixed), scaling=head, collective="all_reduce(sum) of one mixed row per rank",
                               bytes_per_rank=nb * B * 4,
