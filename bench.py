@@ -642,8 +642,9 @@ def main():
                         "is f32 in both",
             }
             out["dtype_note"] = ("state recurrence f32; output projection of the headline as a split-bf16 product (two bf16 halves per operand, "
-                                 "16 significant bits, f32 accumulation) whose error against the fp64 oracle is max_err; "
-                                 "exact_f32_projection is the all-f32 figure")
+                                 "16 significant bits, f32 accumulation) whose error against the fp64 oracle is max_err (tolerance 5e-4 of peak; "
+                                 "the all-f32 PER-SAMPLE kernel, --form velocity, measures 5e-5 .. 1e-4 on the same workload); "
+                                 "exact_f32_projection is the all-f32 figure of the block form")
         if mixed is not None:
             out["mix"] = dict(leg_numbers(head, mixed), scaling=head, collective="all_reduce(sum) of one mixed row per rank",
                               bytes_per_rank=nb * B * 4,
