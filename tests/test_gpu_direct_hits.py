@@ -73,3 +73,24 @@ def test_messages_that_keep_the_general_path():
     assert np.array_equal(got["emitted"], want["emitted"])
     mx, l2 = rel_errors(got["audio"], want["audio"])
     assert (mx <= 5e-4).all() and (l2 <= 1e-3).all(), (mx, l2)
+
+
+@pytest.mark.parametrize("form,mpl", [(capi.FORM_BLOCK_BF16, 4), (capi.FORM_BLOCK_BF16, 1), (capi.FORM_BLOCK, 2), (capi.FORM_VELOCITY, 2)])
+def test_vertex_hits_on_large_teams(form, mpl, monkeypatch):
+    """4096-mode objects stepped by teams of 8 waves (16 in the per-sample kernel): the landing areas of the direct-hit
+    rows then sit beyond the first 64 KB of the workgroup's LDS, and an object is cut into several teams"""
+    monkeypatch.setenv("PBSO_TEAM_WAVES", "16")
+    n_modes, nb = 4096, 8
+    objs, evs = [], []
+    for i in range(2):
+        s = synth.seed_for(7, 60 + i)
+        objs.append(ObjSpec(synth.eigenvalues(n_modes, s), shapes=synth.mode_shapes(n_modes, s)))
+        vns = synth.unit_normals(nb, s)
+        for b in (0, 1, 3, 4, 6):
+            evs.append(force_ev(b, i, vid=17 * b + 3 * i, vn=vns[b]))
+        evs.append(dict(t=0, obj=i, kind="use_transfer", use=False))
+    want = run_oracle(objs, evs, nb)
+    got = run_engine(objs, evs, nb, form=form, modes_per_lane=mpl)
+    mx, l2 = rel_errors(got["audio"], want["audio"])
+    assert (mx <= 5e-4).all() and (l2 <= 1e-3).all(), (mx.max(), l2.max())
+    assert got["info"]["last_step_forced_rows"] == 0 and got["info"]["waves_per_object"] >= 8
