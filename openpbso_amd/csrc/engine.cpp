@@ -453,6 +453,38 @@ int Engine::set_ffat_maps(int obj, const pbso_ffat_map *maps, int n) {
     return PBSO_OK;
 }
 
+// Closed-form qnorm matrices (getQBufferNorm, modal_solver.h:270-273): G = sum_{k=0}^{B-1} (A^k)' e1 e1' A^k per mode,
+// in fp64, in the basis x = (q_k, q_k - q_{k-1}) (well conditioned at low frequency; the direct-form kernel forms the
+// difference itself): A = [[1-e, eps^2], [-e, eps^2]], e = 1 - c1 - c2, eps^2 = -c2.  Row r_k = e1' A^k: r_{k+1} = r_k A.
+// Built by finalize() for the engines that report qnorm rows in closed form, and by listeners_enable() for a block
+// engine created with PBSO_QNORM_OFF (the build of the bank that keeps block-start states always evaluates the rows).
+int Engine::build_gq() {
+    if (d_gq_.p) return PBSO_OK;
+    const int N = (int)objs_.size();
+    const size_t nm = (size_t)N * m_pad_;
+    std::vector<float> gq(3 * nm, 0.f);
+    for (int i = 0; i < N; ++i) {
+        const Object &o = objs_[i];
+        for (int m = 0; m < o.n_modes; ++m) {
+            const double eps2 = -o.c2[m], e = (1.0 - o.c1[m]) - o.c2[m];
+            const double a00 = 1.0 - e, a01 = eps2, a10 = -e, a11 = eps2;
+            double r0 = 1.0, r1 = 0.0, s11 = 0.0, s12 = 0.0, s22 = 0.0;
+            for (int k = 0; k < B_; ++k) {
+                s11 += r0 * r0; s12 += r0 * r1; s22 += r1 * r1;
+                const double n0 = r0 * a00 + r1 * a10, n1 = r0 * a01 + r1 * a11;
+                r0 = n0; r1 = n1;
+            }
+            const size_t k = (size_t)i * m_pad_ + m;
+            gq[k] = (float)s11;
+            gq[nm + k] = (float)(2.0 * s12);
+            gq[2 * nm + k] = (float)s22;
+        }
+    }
+    HIPTRY(d_gq_.ensure(3 * nm));
+    HIPTRY(hipMemcpy(d_gq_.p, gq.data(), 3 * nm * sizeof(float), hipMemcpyHostToDevice));
+    return PBSO_OK;
+}
+
 int Engine::finalize() {
     HIPTRY(hipSetDevice(desc_.device));      // the caller's thread may have another device current
     if (finalized_) return fail(PBSO_ERR_STATE, "finalize called twice");
@@ -598,29 +630,8 @@ int Engine::finalize() {
     HIPTRY(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(d_ss_.p), 0x3F800000, nm));      // scale 1.0f: state stored unscaled
     HIPTRY(hipMemcpy(d_c3_.p, c3.data(), nm * sizeof(double), hipMemcpyHostToDevice));
     if (desc_.qnorm_mode == PBSO_QNORM_CLOSED || (block && desc_.qnorm_mode != PBSO_QNORM_OFF)) {
-        // G = sum_{k=0}^{B-1} (A^k)' e1 e1' A^k per mode, in fp64, in the basis x = (q_k, q_k - q_{k-1})
-        // (well conditioned at low frequency; the direct-form kernel forms the difference itself):
-        // A = [[1-e, eps^2], [-e, eps^2]], e = 1 - c1 - c2, eps^2 = -c2.  Row r_k = e1' A^k: r_{k+1} = r_k A.
-        std::vector<float> gq(3 * nm, 0.f);
-        for (int i = 0; i < N; ++i) {
-            const Object &o = objs_[i];
-            for (int m = 0; m < o.n_modes; ++m) {
-                const double eps2 = -o.c2[m], e = (1.0 - o.c1[m]) - o.c2[m];
-                const double a00 = 1.0 - e, a01 = eps2, a10 = -e, a11 = eps2;
-                double r0 = 1.0, r1 = 0.0, s11 = 0.0, s12 = 0.0, s22 = 0.0;
-                for (int k = 0; k < B_; ++k) {
-                    s11 += r0 * r0; s12 += r0 * r1; s22 += r1 * r1;
-                    const double n0 = r0 * a00 + r1 * a10, n1 = r0 * a01 + r1 * a11;
-                    r0 = n0; r1 = n1;
-                }
-                const size_t k = (size_t)i * m_pad_ + m;
-                gq[k] = (float)s11;
-                gq[nm + k] = (float)(2.0 * s12);
-                gq[2 * nm + k] = (float)s22;
-            }
-        }
-        HIPTRY(d_gq_.ensure(3 * nm));
-        HIPTRY(hipMemcpy(d_gq_.p, gq.data(), 3 * nm * sizeof(float), hipMemcpyHostToDevice));
+        int rc = build_gq();
+        if (rc != PBSO_OK) return rc;
     }
 
     if (block) {
@@ -1799,6 +1810,10 @@ int Engine::listeners_enable(int obj) {
     HIPTRY(hipSetDevice(desc_.device));
     int rc = sync();
     if (rc) return rc;
+    // the build of the bank that keeps block-start states evaluates the closed-form qnorm rows whatever qnorm_mode says
+    // (a PBSO_QNORM_OFF engine has no G planes yet: the kernel would read through a null pointer)
+    rc = build_gq();
+    if (rc) return rc;
     HIPTRY(d_wtab32_.ensure((size_t)(n_dump_ + 1) * wt.size(), true, stream_));
     HIPTRY(hipMemcpyAsync(d_wtab32_.p + (size_t)n_dump_ * wt.size(), wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
     HIPTRY(hipStreamSynchronize(stream_));
@@ -1846,6 +1861,22 @@ int Engine::mix_listeners(int obj, const double *pos, int n_listeners, float *ou
         e = hipMemcpyAsync(rows.p, unit.data(), unit.size() * sizeof(double), hipMemcpyHostToDevice, stream_);
         if (e == hipSuccess) e = hipStreamSynchronize(stream_);
     }
+    if (e == hipSuccess) {
+        // a buffer whose waves left the scaled-state representation (a transfer weight outside [2^-20, 2^40]) was stepped
+        // per sample inside the block kernel and kept no block states: its scale row says 0.  The planner cannot know.
+        std::vector<float> sc((size_t)last_nb_ * m_pad_);
+        e = hipMemcpyAsync(sc.data(), d_xscale_.p + (size_t)dump_row_[obj] * last_nb_ * m_pad_, sc.size() * sizeof(float), hipMemcpyDeviceToHost, stream_);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+        if (e == hipSuccess)
+            for (int b = 0; b < last_nb_ && rc == PBSO_OK; ++b)
+                for (int m = 0; m < o.n_modes; ++m)
+                    if (sc[(size_t)b * m_pad_ + m] == 0.f) {
+                        rc = fail(PBSO_ERR_STATE, "the last step has a buffer of this object that was stepped per sample (a transfer weight outside "
+                                                  "the scaled-state range): no block states to mix");
+                        break;
+                    }
+    }
+    if (rc != PBSO_OK) { rows.release(); dout.release(); return rc; }
     if (e == hipSuccess) {
         const size_t row = (size_t)dump_row_[obj];
         int le = iir_block::launch_listener_mix(d_xdump_.p + row * last_nb_ * 32 * m_pad_ * 2, d_xscale_.p + row * last_nb_ * m_pad_,

@@ -174,6 +174,7 @@ public:
     int add_object(const pbso_object_desc &d, int *id);
     int set_ffat_maps(int obj, const pbso_ffat_map *maps, int n);
     int finalize();
+    int build_gq();                                      // closed-form qnorm matrices (once)
     int enqueue_force(int obj, const pbso_force_msg &m, int64_t not_before);
     int enqueue_force_batch(int n, const int *objs, const pbso_force_msg *msgs, const int64_t *stamps, unsigned char *accepted);
     int enqueue_arprm(int obj, const double a[2], double sigma, double mu, int64_t not_before);

@@ -259,12 +259,14 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
             dst[r * rowlen + lane_off()] = x2[r];
         }
     };
-    auto dump_scale = [&](bool block_buffer) {
+    // code: 1 = block buffer (the scale t), 0 = stepped per sample (no block states: the mix refuses the step),
+    // -1 = the reference's step() returned early (DESC_SKIP: no samples; the mix emits silence)
+    auto dump_scale = [&](int code) {
         if (DUMP && dump_row >= 0) {
             float *dst = p_xscale + ((size_t)dump_row * p.qn_nb + dump_b) * p.m_pad + team.col0;
             const unsigned utid = lane_off();
 #pragma unroll
-            for (int r = 0; r < R; ++r) dst[r * rowlen + utid] = block_buffer ? t[r] : 0.f;
+            for (int r = 0; r < R; ++r) dst[r * rowlen + utid] = code > 0 ? t[r] : (float)code;
         }
     };
     auto prefetch = [&](const BufDesc &nd) {
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
         dump_b = p.qn_b0 + b;
 
         if (flags & DESC_SKIP) {
-            dump_scale(false);
+            dump_scale(-1);
             // the reference's step() returned before stepping: no samples, state untouched
             for (int i = tid; i < B; i += blockDim.x) aout[(size_t)b * B + i] = 0.f;
             if (QN) {
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
         const bool impulse = (flags & DESC_IMPULSE) != 0;
         const bool dense = frow >= 0 && !impulse;
 
-        dump_scale(scaled && !dense);
+        dump_scale(scaled && !dense ? 1 : 0);
         if (scaled && !dense) {
             // ================= block path =================
             // sample 0, literal: d_0 = eps^2 d - e q + g T_0 ; q_0 = q + d_0   (nca = eps^2, ncb = -e)
@@ -768,13 +770,16 @@ __global__ __launch_bounds__(64) void listener_mix_kernel(
         for (int slab = 0; slab < m_pad / 64; ++slab) {
             const int m = slab * 64 + lane;
             __syncthreads();
-#pragma unroll
-            for (int n = 0; n < BN; ++n) *reinterpret_cast<f2 *>(st + n * ST_ROW + 2 * lane) = xs[(size_t)n * m_pad + m];
+            // scale < 0: the buffer was skipped (clearAllForces, modal_solver.h:186-189): silence, and the state rows were
+            // never written; scale 0 (a buffer stepped per sample) does not get here: Engine::mix_listeners refuses the step
             const float s = sc[m];
+            const bool live = s > 0.f;
+#pragma unroll
+            for (int n = 0; n < BN; ++n) *reinterpret_cast<f2 *>(st + n * ST_ROW + 2 * lane) = live ? xs[(size_t)n * m_pad + m] : f2{0.f, 0.f};
 #pragma unroll
             for (int l = 0; l < MIX_TILE; ++l) {
-                const bool on = l0 + l < n_listeners && m < n_modes;
-                tls[l][lane] = on ? (float)trows[(size_t)(l0 + l) * m_pad + m] / s : 0.f;     // scale 0 (per-sample buffer): NaN, on purpose
+                const bool on = live && l0 + l < n_listeners && m < n_modes;
+                tls[l][lane] = on ? (float)trows[(size_t)(l0 + l) * m_pad + m] / s : 0.f;
             }
             __syncthreads();
             if (grp == 0) {                            // sample 0 of the buffer = the Q component of block 0's start state

@@ -88,9 +88,10 @@ class Engine:
     def __init__(self, device=0, form=None, qnorm=capi.QNORM_ALL, modes_per_lane=0,
                  stream=None, frames_per_buffer=0):
         if form is None:
-            # PBSO_FORM=block|velocity|direct lets a whole test / bench run pick the oscillator-bank kernel
+            # the C ABI's default (a zeroed pbso_engine_desc): the block form with the exact f32 projection.
+            # PBSO_FORM=block|block_bf16|velocity|direct lets a whole test / bench run pick the oscillator-bank kernel
             form = {"block": capi.FORM_BLOCK, "velocity": capi.FORM_VELOCITY, "direct": capi.FORM_DIRECT,
-                    "block_bf16": capi.FORM_BLOCK_BF16}[os.environ.get("PBSO_FORM", "block_bf16")]
+                    "block_bf16": capi.FORM_BLOCK_BF16}[os.environ.get("PBSO_FORM", "block")]
         self.form = form
         self._l = capi.lib()
         d = capi.EngineDesc()

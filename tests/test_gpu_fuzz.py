@@ -119,8 +119,9 @@ def _run_seed(seed, size_choices, engine_kw, projected_hits=False):
 def test_random_scripts_match_oracle(seed, monkeypatch):
     if seed % 2:
         monkeypatch.setenv("PBSO_TEAM_WAVES", "16")     # whole objects as teams, as on a full chip
-    # every fourth seed on the block kernel with the f32 projection, the others on the default form (PBSO_FORM)
-    _run_seed(seed, [3, 40, 64, 100, 129, 300], dict(form=capi.FORM_BLOCK) if seed % 4 == 3 else {})
+    # seeds 2, 3 of every four on the block kernel with the split-bf16 projection, the others on the default form
+    # (PBSO_FORM; the block kernel with the f32 projection unless the run says otherwise)
+    _run_seed(seed, [3, 40, 64, 100, 129, 300], dict(form=capi.FORM_BLOCK_BF16) if seed % 4 >= 2 else {})
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PBSO_FUZZ_SHAPE_SEEDS", "60"))))

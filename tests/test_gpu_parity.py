@@ -760,7 +760,7 @@ def test_compute_transfer_batch_width_follows_the_map_count():
 
 
 @pytest.mark.parametrize("form", [capi.FORM_BLOCK, capi.FORM_BLOCK_BF16])
-def test_multi_listener_mix_matches_independent_solvers(form):
+def test_multi_listener_mix_matches_independent_solvers(form, monkeypatch):
     """SURVEY N4, multi-listener OUTPUT: pbso_mix_listeners returns one object's last step as heard at L positions --
     what L ModalSolvers fed the same force messages and computeTransfer(pos_l) (modal_solver.h:286-315) would emit.
     L = 11 (two accumulator tiles), 200 modes (padding columns), a second object beside it, launches cut at 3 buffers,
@@ -775,6 +775,7 @@ def test_multi_listener_mix_matches_independent_solvers(form):
     pos = rng.standard_normal((L, 3))
     pos = 0.3 * pos / np.linalg.norm(pos, axis=1, keepdims=True) * (1.0 + rng.random((L, 1)))     # outside the 0.03 half-size cube
     hits = {0: rng.standard_normal(n_modes) * 1e-3, 2: rng.standard_normal(n_modes) * 1e-3, 5: rng.standard_normal(n_modes) * 1e-3}
+    monkeypatch.setenv("PBSO_CHUNK_BUFFERS", "3")              # (read once, at engine creation)
     with Engine(form=form) as eng:
         oid = eng.add_object(lam, synth.RHO, synth.ALPHA, synth.BETA)
         eng.set_ffat_maps(oid, maps)
@@ -788,12 +789,8 @@ def test_multi_listener_mix_matches_independent_solvers(form):
         for b, dvec in hits.items():
             assert eng.enqueue_force(oid, ForceMessage(data=dvec), b)
         assert eng.enqueue_force(other, ForceMessage(data=np.ones(70) * 1e-3), 1)
-        import os
-        os.environ["PBSO_CHUNK_BUFFERS"] = "3"
-        try:
-            eng.step(nb)
-        finally:
-            os.environ.pop("PBSO_CHUNK_BUFFERS", None)
+        eng.step(nb)
+        assert eng.info()["total_block_launches"] == 3         # 7 buffers in launches of 3 + 3 + 1: states dumped across launch cuts
         single = eng.audio()[oid].astype(np.float64)
         mix = eng.mix_listeners(oid, pos).astype(np.float64)
         assert mix.shape == (L, nb * 513)
