@@ -312,6 +312,12 @@ int Engine::init() {
     form_ = desc_.recurrence_form;
     // the block form tiles a buffer as 1 + 2 * 16 * 16 samples (the reference's 513); other lengths step per sample
     if (is_block() && B_ != 1 + 2 * BLOCK_J * BLOCK_N) form_ = PBSO_FORM_VELOCITY;
+    // Launches that are mostly dense-profile buffers (sustained scraping): the f32 block kernel runs them in block form
+    // itself (forced block path); the split-bf16 build has no such path and hands them to the per-sample kernel K1.
+    // PBSO_DENSE_LAUNCHES=block|sample pins either; PBSO_FORCED_BLOCK=0 makes the block kernel step dense buffers per sample.
+    dense_to_k1_ = form_ == PBSO_FORM_BLOCK_BF16;
+    if (const char *v = std::getenv("PBSO_FORCED_BLOCK")) forced_block_ = std::atoi(v) != 0;
+    if (!forced_block_) dense_to_k1_ = true;
     if (const char *v = std::getenv("PBSO_DENSE_LAUNCHES")) dense_to_k1_ = std::string(v) != "block";
     if (const char *v = std::getenv("PBSO_BLOCK_TEAM_WAVES")) block_team_waves_ = std::min(MAX_WAVES_PER_BLOCK_TEAM, std::max(1, std::atoi(v)));
     if (desc_.qnorm_mode < PBSO_QNORM_OFF || desc_.qnorm_mode > PBSO_QNORM_CLOSED)
@@ -362,6 +368,7 @@ int Engine::init() {
     if (const char *v = std::getenv("PBSO_CENSUS")) census_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_ROTATE_PRIO")) rotate_prio_ = std::min(2, std::max(0, std::atoi(v)));
     if (const char *v = std::getenv("PBSO_DEVICE_PROFILES")) device_profiles_ = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PBSO_AR_SERIAL")) ar_serial_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_DIRECT_HITS")) direct_hits_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_TIMING_EVERY")) timing_every_ = std::max(0, std::atoi(v));
     if (const char *v = std::getenv("PBSO_CHUNK_BUFFERS")) chunk_buffers_ = std::max(1, std::atoi(v));
@@ -1601,7 +1608,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
 
     // K2 -> time-profile rows ; K3 / scatter -> data slots ; K4 -> transfer rows ; combine -> g rows
     if (device_profiles_)
-        LAUNCHTRY(launch_force_profiles(d_chain, n_chains, d_prow, d_pent, d_arstate_.p, ps.d_tprof.p, B_, b_pad_, sp));
+        LAUNCHTRY(launch_force_profiles(d_chain, n_chains, d_prow, d_pent, d_arstate_.p, ps.d_tprof.p, B_, b_pad_, ar_serial_ ? 1 : 0, sp));
     LAUNCHTRY(launch_scatter_rows(d_stage, d_stage_slot, (int)stage_slot_.size(), d_slots_.p, m_pad_, sp));
     LAUNCHTRY(launch_modal_project(d_proj, (int)proj_.size(), d_shapes_.p, d_shape_off_.p, d_n_modes_.p, d_slots_.p, m_pad_, sp));
     LAUNCHTRY(launch_ffat_lookup(d_ffat, (int)ffat_.size(), d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p, d_xfer_.p, m_pad_, sp));
@@ -1647,6 +1654,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.pc = d_pc_.p;
     kp.wtab = d_wtab_.p;
     kp.frames = B_;
+    kp.forced_block = (forced_block_ && n_prows_ > 0) ? 1 : 0;      // (the build with the forced block path only when a buffer needs it)
     if (timed) HIPTRY(hipEventRecord(evq.k0, sk));
     kp.audio_parts = n_part_rows_ ? d_audio_parts_.p + (size_t)b0 * B_ : nullptr;
     // Side by side only while everything is resident at once (largest teams first, on the engine's

@@ -259,7 +259,8 @@ private:
     DevBuf<float> d_pc_, d_wtab_;                        // block form: P = A^16 planes and the MFMA W table (kernels_block.hip)
     bool is_block() const { return form_ == PBSO_FORM_BLOCK || form_ == PBSO_FORM_BLOCK_BF16; }
     int form_ = PBSO_FORM_BLOCK;                         // the form that runs (block falls back to velocity for odd buffer lengths)
-    bool dense_to_k1_ = true;                            // PBSO_DENSE_LAUNCHES=block: dense-heavy launches stay on the block kernel
+    bool dense_to_k1_ = true;                            // dense-heavy launches run on the per-sample kernel K1 (split-bf16 form; PBSO_DENSE_LAUNCHES)
+    bool forced_block_ = true;                           // f32 block kernel: dense-profile buffers in block form (PBSO_FORCED_BLOCK=0: per sample)
     int block_team_waves_ = 0;                           // PBSO_BLOCK_TEAM_WAVES: waves per team of the block form (0 = policy)
     DevBuf<double> d_shapes_;
     DevBuf<long long> d_shape_off_;
@@ -301,6 +302,7 @@ private:
     int n_frows_ = 0, n_prows_ = 0;
     // K2: device-side time profiles
     bool device_profiles_ = true;                        // PBSO_DEVICE_PROFILES=0: host fp64 profiles, uploaded
+    bool ar_serial_ = false;                             // PBSO_AR_SERIAL=1: K2 runs the AR(2) recurrence as the reference's serial loop (16 us per row)
     std::vector<ProfEntry> prof_entries_;
     std::vector<ProfRow> prof_rows_;
     std::vector<int> chain_ptr_;

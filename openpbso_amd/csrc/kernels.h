@@ -81,6 +81,7 @@ struct IirParams {
     const float *pc;             // planes P11 - 1, P12, P21, P22 of P = A^16 in the (q, q - q_prev) basis, each [n_obj][m_pad] (stride gq_plane)
     const float *wtab;           // [n_obj * m_pad / 2][64]: MFMA A operand per pair of columns (a_j, b_j of both modes, j = 1..16)
     int frames;                  // samples per buffer
+    int forced_block;            // block form, f32 projection: dense-profile buffers run in block form too (kernels_block.hip)
     // multi-listener mix: objects with dump_row[obj] >= 0 keep their block-start states (nullptr: nobody does)
     float *xdump;                // [n_dump][qn_nb][32][m_pad] pairs (Q, D), scaled as the registers hold them
     float *xscale;               // [n_dump][qn_nb][m_pad] the scale (transfer weight) of that buffer; 0: stepped per sample
@@ -170,8 +171,9 @@ struct ProfRow {         // one dense profile row = one (object, buffer)
     int32_t entry_begin, entry_end;
 };
 // chains: rows of one object in buffer order are generated by ONE wave (the AR state is sequential)
+// ar_serial != 0: the AR(2) recurrence as the reference's serial loop (forces.h:107-117) instead of a parallel scan
 int launch_force_profiles(const int *chain_ptr, int n_chains, const ProfRow *rows, const ProfEntry *entries,
-                          ArState *states, float *tprof, int frames, int b_pad, hipStream_t stream);
+                          ArState *states, float *tprof, int frames, int b_pad, int ar_serial, hipStream_t stream);
 
 struct FfatGeom {        // FFAT_Map<double,3> runtime fields, one per (object, mode)
     double k;

@@ -64,6 +64,7 @@ struct BlkDims {
     long long plane;             // elements between the planes of p_gq / p_pc
     int qn_nb, qn_b0;
     int rotate;                  // != 0: the teams of a CU take turns at the highest wave priority, one buffer each
+    int forced_block;            // != 0 (f32 projection only): buffers with a dense force profile run in block form too
 };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -98,7 +99,9 @@ __device__ __forceinline__ void static_for(F &&f) {
 
 // DUMP: objects with a dump row (multi-listener mix, pbso_listeners_enable) also write every block-start state
 // (scaled, as the registers hold it) and the scale of the buffer to memory; other builds carry no trace of it.
-template <int R, int QNM, int PROJ, bool DUMP, int MAXT>
+// FORCED (f32 projection only): buffers with a dense force profile run in block form too ("forced block path" below); a
+// launch without such buffers uses the build without it (its registers are the kernel's peak at R = 4).
+template <int R, int QNM, int PROJ, bool DUMP, int MAXT, bool FORCED>
 __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     const float *__restrict__ p_ca, const float *__restrict__ p_cb, float *__restrict__ p_sq,
     float *__restrict__ p_sd, float *__restrict__ p_ss, const BufDesc *__restrict__ p_desc,
@@ -414,6 +417,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
         const bool dense = frow >= 0 && !impulse;
 
         dump_scale(scaled && !dense ? 1 : 0);
+        const bool forced_block = FORCED && PROJ == 0 && scaled && dense;
         if (scaled && !dense) {
             // ================= block path =================
             // sample 0, literal: d_0 = eps^2 d - e q + g T_0 ; q_0 = q + d_0   (nca = eps^2, ncb = -e)
@@ -588,6 +592,145 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                     }
                 });
             }
+        } else if (forced_block) {
+            if constexpr (PROJ == 0 && FORCED) {
+            // ================= forced block path: a dense force profile (Gaussian, AR: forces.h:92-128) in block form =================
+            // The lane that owns a mode still steps it through every sample (velocity form, exactly the literal path's
+            // arithmetic: the profile value T_k is wave-uniform and comes from scalar loads) -- but only to carry the state
+            // and the qnorm sum.  The per-sample sum over modes, which is what makes the literal path slow (a transpose
+            // tile and row sums per 16 samples), is not formed: with X_n the state at the start of block n and
+            // u = (1, 1)' the direction a force sample enters the state (d += f, q += d),
+            //     x_{16n+j} = A^j X_n + sum_{i=1..j} A^{j-i} u f_{16n+i},        f_k = g T_k,
+            // so the output of block n is the usual projection W . X_n (matrix pipe, as in the force-free path) plus a
+            // 16-tap FIR of the profile with taps h_d = sum_m g_m e1' A_m^d u -- h_0 = sum g, and h_1..h_16 are the
+            // projection of the virtual block-start state g u (one more column of the same W table: 32 MFMAs per
+            // slice and buffer).  The FIR itself is a [16 x 16 lower-triangular Toeplitz(h)] . [16 x 16 blocks of T]
+            // product: 4 MFMAs per group of 256 samples, accumulated into the projection's own accumulators.
+            const float *__restrict__ tprow = p_tprof + (size_t)(prow >= 0 ? prow : 0) * p.b_pad;
+            float *taps = stage + BN * ST_ROW;                   // [17] h_0 .. h_16 (behind the staging rows)
+            float qn[R];
+            lap(cy_head);
+            {
+                // sample 0 (literal) and h_0
+                const float tk0 = tprow[0];
+                float p0 = 0.f, gs = 0.f;
+#pragma unroll
+                for (int v = 0; v < R; ++v) {
+                    float a = nca[v] * x2[v].y;
+                    a = fmaf(ncb[v], x2[v].x, a);
+                    a = fmaf(g_[v], tk0, a);
+                    x2[v].y = a;
+                    x2[v].x = x2[v].x + a;
+                    p0 = (v == 0) ? x2[v].x : p0 + x2[v].x;
+                    gs = (v == 0) ? g_[v] : gs + g_[v];
+                    qn[v] = x2[v].x * x2[v].x;
+                }
+                p0 = wave_sum(p0);
+                gs = wave_sum(gs);
+                if (lane == 0) rg[GROUP * NG] = p0;
+                wave_sync();                                    // the previous buffer's staging reads are issued
+                if (lane == 0) taps[0] = gs;
+            }
+            float breg[32];
+            // ---- taps h_1 .. h_16: project the virtual state (g, g) of every slice (block row 0 of the staging area)
+            {
+                f4 ah0 = f4{0.f, 0.f, 0.f, 0.f}, ah1 = f4{0.f, 0.f, 0.f, 0.f};
+                static_for<0, R>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    if constexpr (r > 0) wave_sync();
+                    wdst[0] = f2{g_[r], g_[r]};
+                    wave_sync();
+#pragma unroll
+                    for (int s2 = 0; s2 < 32; ++s2) breg[s2] = bsrc[4 * s2];
+                    static_for<0, 32>([&](auto sc) {
+                        constexpr int s2 = decltype(sc)::value;
+                        if constexpr (s2 & 1) ah1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s2], breg[s2], ah1, 0, 0, 0);
+                        else ah0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s2], breg[s2], ah0, 0, 0, 0);
+                    });
+                });
+                const f4 ah = ah0 + ah1;                        // column 0 (lanes 0, 16, 32, 48): rows 4 (l >> 4) + v = tap index - 1
+                if ((lane & 15) == 0) {
+                    float *td = taps + 1 + 4 * (lane >> 4);
+                    td[0] = ah.x; td[1] = ah.y; td[2] = ah.z; td[3] = ah.w;
+                }
+                wave_sync();
+            }
+            // FIR operand A[j][i] = h_{j-i} (i <= j), k-step kk: lane holds row l & 15, column 4 kk + (l >> 4)
+            float fir_a[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int idx = (lane & 15) - 4 * kk - (lane >> 4);
+                fir_a[kk] = idx >= 0 ? taps[idx] : 0.f;
+            }
+            static_for<0, NG>([&](auto gc) {
+                constexpr int grp = decltype(gc)::value;
+                f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = f4{0.f, 0.f, 0.f, 0.f};
+                // the profile as the FIR's B operand: B[i][n] = T[1 + 256 grp + 16 n + i]
+                float fir_b[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) fir_b[kk] = tprow[1 + GROUP * grp + BJ * (lane & 15) + 4 * kk + (lane >> 4)];
+                static_for<0, R>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    wave_sync();                                // the staging area is free (operand reads of the previous slice issued)
+                    // The block's 16 profile values are wave-uniform: one s_load_dwordx16 per block, issued a block ahead.  Scalar
+                    // loads return out of order, so a use waits for EVERYTHING outstanding: the next block's load is issued
+                    // right after the first use of this block's values (the scheduling barriers pin that order).  Per sample
+                    // the dependent chain is two operations -- d' = (eps^2 d + g T) - e q, q' = q + d' -- not four.
+                    float ta[BJ], tb[BJ];
+                    auto load_t = [&](float (&dst)[BJ], int n) {
+                        const float *__restrict__ tk = tprow + 1 + GROUP * grp + BJ * n;
+#pragma unroll
+                        for (int k = 0; k < BJ; ++k) dst[k] = tk[k];
+                    };
+                    auto sample = [&](float tval) {
+                        const float gt = g_[r] * tval;
+                        const float in = fmaf(nca[r], x2[r].y, gt);
+                        x2[r].y = fmaf(ncb[r], x2[r].x, in);
+                        x2[r].x = x2[r].x + x2[r].y;
+                        if (QN) qn[r] = fmaf(x2[r].x, x2[r].x, qn[r]);
+                    };
+                    load_t(ta, 0);
+                    for (int n = 0; n < BN; n += 2) {
+                        wdst[n * (ST_ROW / 2)] = x2[r];
+                        sample(ta[0]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_t(tb, n + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k = 1; k < BJ; ++k) sample(ta[k]);
+                        wdst[(n + 1) * (ST_ROW / 2)] = x2[r];
+                        sample(tb[0]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_t(ta, n + 2 < BN ? n + 2 : n + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k = 1; k < BJ; ++k) sample(tb[k]);
+                    }
+                    wave_sync();
+#pragma unroll
+                    for (int s2 = 0; s2 < 32; ++s2) breg[s2] = bsrc[4 * s2];
+                    static_for<0, 32>([&](auto sc) {
+                        constexpr int s2 = decltype(sc)::value;
+                        if constexpr (s2 & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s2], breg[s2], acc1, 0, 0, 0);
+                        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s2], breg[s2], acc0, 0, 0, 0);
+                    });
+                });
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (kk & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fir_a[kk], fir_b[kk], acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fir_a[kk], fir_b[kk], acc0, 0, 0, 0);
+                }
+                const f4 acc = acc0 + acc1;
+                const unsigned l = lane_off() & 63u;
+                *reinterpret_cast<f4 *>(rg + GROUP * grp + 16 * (l & 15u) + 4 * (l >> 4)) = acc;
+            });
+            if (QN) {
+                const unsigned utid = lane_off();
+#pragma unroll
+                for (int r = 0; r < R; ++r) (b_qn + (size_t)b * p.m_pad)[r * rowlen + utid] = sqrtf(qn[r]) / t[r];
+            }
+            prefetch(next);
+            }
         } else {
             // ================= literal path: every sample stepped (velocity form), as K1 =================
             const float *__restrict__ tprow = p_tprof + (size_t)(prow >= 0 ? prow : 0) * p.b_pad;
@@ -697,20 +840,20 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     }
 }
 
-template <int R, int QNM, int PROJ, bool DUMP>
+template <int R, int QNM, int PROJ, bool DUMP, bool FORCED = false>
 static int launch_one(const IirParams &p, int n_teams, int W, hipStream_t stream) {
     const size_t lds = block_lds_bytes(W, R);
     // R = 8 is the one-wave-per-SIMD build (512 registers: the 256 W-table operands go to AGPRs): teams of <= 4 waves
     constexpr int MAXT = R == 8 ? 256 : 64 * MAX_WAVES_PER_BLOCK_TEAM;
     if (64 * W > MAXT) return (int)hipErrorInvalidValue;
-    auto kern = iir_block_kernel<R, QNM, PROJ, DUMP, MAXT>;
+    auto kern = iir_block_kernel<R, QNM, PROJ, DUMP, MAXT, FORCED>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     const int frames = p.frames;
-    const BlkDims dims = {p.nb, p.m_pad, p.b_pad, frames, (frames - 1) / GROUP, p.audio_stride, p.gq_plane, p.qn_nb, p.qn_b0, p.rotate_prio};
+    const BlkDims dims = {p.nb, p.m_pad, p.b_pad, frames, (frames - 1) / GROUP, p.audio_stride, p.gq_plane, p.qn_nb, p.qn_b0, p.rotate_prio, p.forced_block};
     hipLaunchKernelGGL(kern, dim3(n_teams), dim3(64 * W), lds, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows, p.g32, p.g32_off,
                        p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.census, p.xdump, p.xscale, p.dump_row, p.board, dims);
     return (int)hipGetLastError();
@@ -722,6 +865,7 @@ static int launch_r(const IirParams &p, int n_teams, int W, bool qn, int proj, h
         return proj ? launch_one<R, 2, 1, true>(p, n_teams, W, s) : launch_one<R, 2, 0, true>(p, n_teams, W, s);
     }
     if (proj) return qn ? launch_one<R, 2, 1, false>(p, n_teams, W, s) : launch_one<R, 0, 1, false>(p, n_teams, W, s);
+    if (p.forced_block) return qn ? launch_one<R, 2, 0, false, true>(p, n_teams, W, s) : launch_one<R, 0, 0, false, true>(p, n_teams, W, s);
     return qn ? launch_one<R, 2, 0, false>(p, n_teams, W, s) : launch_one<R, 0, 0, false>(p, n_teams, W, s);
 }
 

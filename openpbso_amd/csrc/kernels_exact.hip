@@ -150,7 +150,7 @@ constexpr int K2_THREADS = 256;           // candidate pairs evaluated per batch
 __global__ __launch_bounds__(K2_THREADS) void force_profile_kernel(
     const int *__restrict__ chain_ptr, int n_chains, const ProfRow *__restrict__ rows,
     const ProfEntry *__restrict__ entries, ArState *__restrict__ states, float *__restrict__ tprof,
-    int frames, int b_pad) {
+    int frames, int b_pad, int ar_serial) {
     extern __shared__ __attribute__((aligned(16))) double k2_lds[];
     double *nrm = k2_lds;
     double *acc = k2_lds + frames;
@@ -272,7 +272,72 @@ __global__ __launch_bounds__(K2_THREADS) void force_profile_kernel(
                 // critical path (LDS latency and the _buf index arithmetic are off it).
                 for (int ii = lane; ii < frames; ii += K2_THREADS) nrm[ii] = s.sigma * nrm[ii];
                 __syncthreads();
-                if (lane == 0) {
+                if (!ar_serial && wv == 0) {
+                    // ---- AR(2) as a parallel scan (the default).  x_k = a0 x_{k-1} + a1 x_{k-2} + c_k is linear with
+                    // constant coefficients within a row: lane l of wave 0 runs the recurrence over its L consecutive
+                    // samples from a zero state (lane 0: from the force's history), a Kogge-Stone scan over the lanes
+                    // composes the end states (every lane's map is the same matrix M = A^L, A = [[a0, a1], [1, 0]]), and the
+                    // state entering a lane is added back through row 0 of A^(j+1).  All in fp64; the SAME real-number
+                    // sequence as forces.h:107-117, rounded in another order -- it differs from the serial loop by a few
+                    // fp64 ulp (1e-16 relative), i.e. in none but ~1e-8 of the fp32 profile samples.  The serial loop
+                    // (PBSO_AR_SERIAL=1: three dependent fp64 operations per sample, ~75 shader cycles each step, 16 us per
+                    // 513-sample row) bounds a sustained-contact scene; this form takes ~1 us.
+                    const int l64 = lane;
+                    const int L = (frames + 63) / 64;
+                    const int k0 = l64 * L;
+                    const double a0 = s.a[0], a1 = s.a[1];
+                    const int bidx = s.buf_idx;
+                    const double h1 = bidx == 0 ? s.buf[2] : (bidx == 1 ? s.buf[0] : s.buf[1]);     // _buf[(idx + 3 - 1) % 3]
+                    const double h2 = bidx == 0 ? s.buf[1] : (bidx == 1 ? s.buf[2] : s.buf[0]);     // _buf[(idx + 3 - 2) % 3]
+                    double y1 = l64 == 0 ? h1 : 0.0, y2 = l64 == 0 ? h2 : 0.0;
+                    for (int j = 0; j < L; ++j) {
+                        const int k = k0 + j;
+                        double v = a0 * y1;
+                        v += a1 * y2;
+                        if (k < frames) { v += nrm[k]; nrm[k] = v; }
+                        y2 = y1;
+                        y1 = v;
+                    }
+                    // M = A^L
+                    double m00 = a0, m01 = a1, m10 = 1.0, m11 = 0.0;
+                    for (int i = 1; i < L; ++i) {
+                        const double n00 = m00 * a0 + m01, n01 = m00 * a1, n10 = m10 * a0 + m11, n11 = m10 * a1;
+                        m00 = n00; m01 = n01; m10 = n10; m11 = n11;
+                    }
+                    double b1 = y1, b2 = y2;                       // (x at the lane's last sample, the one before)
+#pragma unroll
+                    for (int d = 1; d < 64; d *= 2) {
+                        const double t1 = __shfl_up(b1, d, 64), t2 = __shfl_up(b2, d, 64);
+                        if (l64 >= d) {
+                            b1 += m00 * t1 + m01 * t2;
+                            b2 += m10 * t1 + m11 * t2;
+                        }
+                        const double n00 = m00 * m00 + m01 * m10, n01 = m00 * m01 + m01 * m11;
+                        const double n10 = m10 * m00 + m11 * m10, n11 = m10 * m01 + m11 * m11;
+                        m00 = n00; m01 = n01; m10 = n10; m11 = n11;
+                    }
+                    const double s1 = __shfl_up(b1, 1, 64), s2 = __shfl_up(b2, 1, 64);      // the state entering this lane
+                    if (l64 > 0) {
+                        double al = a0, be = a1;                   // row 0 of A^(j+1)
+                        for (int j = 0; j < L; ++j) {
+                            const int k = k0 + j;
+                            if (k < frames) nrm[k] += al * s1 + be * s2;
+                            const double na = al * a0 + be, nb = al * a1;
+                            al = na; be = nb;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (l64 == 0) {
+                        // value k of this row went to _buf[(idx + k) % 3]: the last three, back in place
+                        double b[3] = {s.buf[0], s.buf[1], s.buf[2]};
+                        for (int k = frames >= 3 ? frames - 3 : 0; k < frames; ++k) b[(bidx + k) % 3] = nrm[k];
+                        s.buf[0] = b[0]; s.buf[1] = b[1]; s.buf[2] = b[2];
+                        s.buf_idx = (bidx + frames) % 3;
+                    }
+                }
+                if (ar_serial && lane == 0) {
                     double b0 = s.buf[0], b1 = s.buf[1], b2 = s.buf[2];
                     int idx = s.buf_idx;
                     int ii = 0;
@@ -346,11 +411,11 @@ __global__ __launch_bounds__(K2_THREADS) void force_profile_kernel(
 }
 
 int launch_force_profiles(const int *chain_ptr, int n_chains, const ProfRow *rows, const ProfEntry *entries,
-                          ArState *states, float *tprof, int frames, int b_pad, hipStream_t stream) {
+                          ArState *states, float *tprof, int frames, int b_pad, int ar_serial, hipStream_t stream) {
     if (n_chains <= 0) return 0;
     const size_t lds = sizeof(double) * (2 * (size_t)frames + 2) + sizeof(uint32_t) * 2 * (K2_THREADS / 64);
     hipLaunchKernelGGL(force_profile_kernel, dim3(n_chains), dim3(K2_THREADS), lds, stream, chain_ptr, n_chains, rows,
-                       entries, states, tprof, frames, b_pad);
+                       entries, states, tprof, frames, b_pad, ar_serial);
     return (int)hipGetLastError();
 }
 

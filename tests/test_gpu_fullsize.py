@@ -117,16 +117,30 @@ def test_config5_8x4096_sustained_scraping_full_size():
             evs.append(force_ev(b, i, vids=rng.integers(0, synth.N_VERTS, 3), coords=bary / bary.sum(), vn=vns[b], force_type=2))
         evs.append(dict(t=30, obj=i, kind="arprm", a=[0.6, 0.2], sigma=0.002, mu=0.1))
         evs.append(force_ev(70, i, force_type=2, end=True))
-    # two launches: buffers 0..59 are all dense (sustained contact) -> the block form hands them to the per-sample
-    # kernel; buffers 60..85 hold ten dense ones -> block kernel, per-sample stepping inside it for those ten,
-    # starting from the state the other kernel left
-    got = run_engine(objs, evs, NB, qnorm=capi.QNORM_OFF, split=[60, 26])
-    assert got["info"]["recurrence_form"] in BLOCK_FORMS
-    assert got["info"]["total_sample_launches"] == 1 and got["info"]["total_block_launches"] == 1
     want = run_oracle(objs, evs, NB, threads=THREADS)
+    # (1) the f32 block kernel, dense-profile buffers in block form (forced block path), with and without qnorm rows;
+    #     tolerance 1e-4 of the peak (the general one is 5e-4)
+    for qn in (capi.QNORM_OFF, capi.QNORM_ALL):
+        got = run_engine(objs, evs, NB, qnorm=qn, form=capi.FORM_BLOCK)
+        assert got["info"]["recurrence_form"] == capi.FORM_BLOCK
+        assert got["info"]["total_sample_launches"] == 0 and got["info"]["total_block_launches"] == 1
+        assert np.array_equal(got["emitted"], want["emitted"])
+        mx, l2 = _assert_parity(got["audio"], want["audio"], "8x4096 scraping, forced block path")
+        assert mx <= 1e-4, mx
+        if qn != capi.QNORM_OFF:
+            for (i, b), w in want["qnorm"].items():
+                if b in (0, 1, 29, 30, 31, 69, 70, 85):          # around the start, the AR parameter update and the end of contact
+                    assert np.abs(got["qnorm"][(i, b)] - w).max() <= 5e-4 * np.abs(w).max(), (i, b)
+        print(f"C5 full size, forced block path, qnorm {'on' if qn else 'off'}: max/peak {mx:.2e} relL2 {l2:.2e}")
+    # (2) the hand-over between the two kernels (what the split-bf16 form does): buffers 0..59 are all dense (sustained
+    #     contact) -> the per-sample kernel; buffers 60..85 hold ten dense ones -> block kernel, per-sample stepping
+    #     inside it for those ten, starting from the state the other kernel left
+    got = run_engine(objs, evs, NB, qnorm=capi.QNORM_OFF, split=[60, 26], form=capi.FORM_BLOCK_BF16)
+    assert got["info"]["recurrence_form"] == capi.FORM_BLOCK_BF16
+    assert got["info"]["total_sample_launches"] == 1 and got["info"]["total_block_launches"] == 1
     assert np.array_equal(got["emitted"], want["emitted"])
     mx, l2 = _assert_parity(got["audio"], want["audio"], "8x4096 scraping")
-    one = run_engine(objs, evs, NB, qnorm=capi.QNORM_OFF)                  # one launch: per-sample kernel throughout
+    one = run_engine(objs, evs, NB, qnorm=capi.QNORM_OFF, form=capi.FORM_BLOCK_BF16)      # one launch: per-sample kernel throughout
     assert one["info"]["total_sample_launches"] == 1 and one["info"]["total_block_launches"] == 0
     _assert_parity(one["audio"], want["audio"], "8x4096 scraping, one launch")
     print(f"C5 full size: max/peak {mx:.2e} relL2 {l2:.2e}")

@@ -192,13 +192,20 @@ def test_device_and_host_profiles_agree_two_ar_objects(monkeypatch):
     evs.append(force_ev(8, 0, data=rng.standard_normal(n_modes) * 1e-3, force_type=2))   # plain (unsustained) AR force
     monkeypatch.setenv("PBSO_DEVICE_PROFILES", "1")
     dev = run_engine(objs, evs, nb, split=[4, 6])
+    monkeypatch.setenv("PBSO_AR_SERIAL", "1")            # K2's AR(2) as the reference's serial loop instead of the parallel scan
+    dev_serial = run_engine(objs, evs, nb, split=[4, 6])
+    monkeypatch.delenv("PBSO_AR_SERIAL")
     monkeypatch.setenv("PBSO_DEVICE_PROFILES", "0")
     host = run_engine(objs, evs, nb, split=[4, 6])
     want = run_oracle(objs, evs, nb)
     _check(dev, want)
+    _check(dev_serial, want)
     _check(host, want)
     peak = np.abs(host["audio"]).max(axis=1, keepdims=True)
     assert (np.abs(dev["audio"] - host["audio"]) <= 2e-6 * peak).all()
+    assert (np.abs(dev_serial["audio"] - host["audio"]) <= 2e-6 * peak).all()
+    # the scan rounds the same fp64 recurrence in another order: the fp32 profile rows differ in (almost) no sample
+    assert (np.abs(dev["audio"] - dev_serial["audio"]) <= 2e-7 * peak).all()
 
 
 def test_one_message_per_buffer_queueing():
@@ -608,8 +615,8 @@ def test_long_steps_cut_into_launches(monkeypatch):
         evs += [force_ev(0, i, data=rng.standard_normal(m) * 1e-3), force_ev(3, i, data=rng.standard_normal(m) * 1e-3, force_type=2),
                 force_ev(6, i, clear=True), force_ev(8, i, data=rng.standard_normal(m) * 1e-3, force_type=1, width=900.0),
                 dict(t=0, obj=i, kind="use_transfer", use=False)]
-    # (the block form hands launches that are mostly dense-profile buffers to the per-sample kernel, whose sums
-    #  run in another order: bit-identity across cuts is a property of ONE kernel, so pin it here; the automatic
+    # (the split-bf16 block form hands launches that are mostly dense-profile buffers to the per-sample kernel, whose
+    #  sums run in another order: bit-identity across cuts is a property of ONE kernel, so pin it here; the automatic
     #  choice is checked against the oracle at the end)
     monkeypatch.setenv("PBSO_DENSE_LAUNCHES", "block")
     monkeypatch.setenv("PBSO_CHUNK_BUFFERS", "1000")
@@ -629,8 +636,19 @@ def test_long_steps_cut_into_launches(monkeypatch):
     monkeypatch.setenv("PBSO_CHUNK_BUFFERS", "1")          # buffers 3..5 (AR force alive) become launches of their own
     auto = run_engine(objs, evs, nb, modes_per_lane=1)
     if auto["info"]["recurrence_form"] == capi.FORM_BLOCK:
-        assert auto["info"]["total_sample_launches"] >= 3 and auto["info"]["total_block_launches"] >= 6
+        # the f32 block kernel runs dense-profile buffers in block form itself (forced block path): no hand-over
+        assert auto["info"]["total_sample_launches"] == 0 and auto["info"]["total_block_launches"] >= 9
     _check(auto, want)
+    # the hand-over between the two kernels at launch boundaries (what the split-bf16 form does by itself)
+    monkeypatch.setenv("PBSO_DENSE_LAUNCHES", "sample")
+    hand = run_engine(objs, evs, nb, modes_per_lane=1)
+    if hand["info"]["recurrence_form"] in (capi.FORM_BLOCK, capi.FORM_BLOCK_BF16):
+        assert hand["info"]["total_sample_launches"] >= 3 and hand["info"]["total_block_launches"] >= 6
+    _check(hand, want)
+    # ... and the f32 block kernel stepping dense buffers per sample (the path it had before the forced block path)
+    monkeypatch.setenv("PBSO_DENSE_LAUNCHES", "block")
+    monkeypatch.setenv("PBSO_FORCED_BLOCK", "0")
+    _check(run_engine(objs, evs, nb, modes_per_lane=1), want)
 
 
 def test_live_assert_of_the_reference_is_a_status_and_poisons_the_engine():
