@@ -159,6 +159,8 @@ __global__ __launch_bounds__(K2_THREADS) void force_profile_kernel(
     uint32_t *sh_cnt = sh_u + 2;                               // [2][waves] accepted pairs per wave, by batch parity
     const int c = blockIdx.x;
     if (c >= n_chains) return;
+    // (raising the wave priority here -- s_setprio 3 -- takes the chains from 0.71 to 0.57 ms for 86 rows beside the oscillator
+    //  bank of the 8 x 4096 scraping scene, and the bank's slowest team from 0.74 to 0.83 ms: nothing gained)
     const int lane = threadIdx.x;                              // 0 .. K2_THREADS-1: one candidate pair per batch
     const int wv = threadIdx.x >> 6;
     constexpr int NWV = K2_THREADS / 64;
@@ -166,10 +168,14 @@ __global__ __launch_bounds__(K2_THREADS) void force_profile_kernel(
     uint32_t a4 = 16807u;
     a4 = mulmod31(a4, a4);
     a4 = mulmod31(a4, a4);                                     // a^4
-    uint32_t pj = 1u, q64 = 1u;
-    for (int i = 0; i < K2_THREADS; ++i) {
-        if (i < lane) pj = mulmod31(pj, a4);
-        q64 = mulmod31(q64, a4);
+    uint32_t pj = 1u, q64 = 1u;                               // a4^lane and a4^K2_THREADS by square-and-multiply
+    {
+        uint32_t b = a4;
+        for (unsigned e = (unsigned)lane, f = (unsigned)K2_THREADS; e | f; e >>= 1, f >>= 1) {
+            if (e & 1u) pj = mulmod31(pj, b);
+            if (f & 1u) q64 = mulmod31(q64, b);
+            b = mulmod31(b, b);
+        }
     }
     const double R = 2147483646.0;                             // max - min + 1
     const double R2 = 4611686009837453316.0;                   // (double)((long double)R * R), as libstdc++ forms it
@@ -180,13 +186,24 @@ __global__ __launch_bounds__(K2_THREADS) void force_profile_kernel(
     // is needed and at the end of the chain.
     int cached = -1;
     ArState s;
-    for (int ri = chain_ptr[c]; ri < chain_ptr[c + 1]; ++ri) {
-        const ProfRow row = rows[ri];
+    // (a row's descriptor and its first entry are fetched a row ahead: two dependent misses -- the plan has just
+    //  arrived from the host -- cost more than the row's arithmetic)
+    const int ri_end = chain_ptr[c + 1];
+    if (chain_ptr[c] >= ri_end) return;
+    ProfRow row_next = rows[chain_ptr[c]];
+    ProfEntry e_next = entries[row_next.entry_begin < row_next.entry_end ? row_next.entry_begin : 0];
+    for (int ri = chain_ptr[c]; ri < ri_end; ++ri) {
+        const ProfRow row = row_next;
+        const ProfEntry e_first = e_next;
+        if (ri + 1 < ri_end) {
+            row_next = rows[ri + 1];
+            e_next = entries[row_next.entry_begin < row_next.entry_end ? row_next.entry_begin : 0];
+        }
         float *out = tprof + (size_t)row.prow * b_pad;
         for (int i = lane; i < frames; i += K2_THREADS) acc[i] = 0.0;                  // setZero, modal_solver.h:206
         __syncthreads();
         for (int ei = row.entry_begin; ei < row.entry_end; ++ei) {
-            const ProfEntry e = entries[ei];
+            const ProfEntry e = ei == row.entry_begin ? e_first : entries[ei];
             if (e.kind == 0) {                                                 // PointForce, forces.h:81-90
                 if (lane == 0) acc[0] += 1.;
             } else if (e.kind == 1) {                                          // GaussianForce, forces.h:92-105
