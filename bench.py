@@ -40,18 +40,22 @@ B = 513
 SAMPLE_RATE = 44100
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_PEAK_TFLOPS = 157.3        # fp32 vector peak = dense fp32 MFMA peak (same guide; 64 FLOP/clk/SIMD either way)
+BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (same guide)
 FLOP_REF = 10                  # reference arithmetic per mode-sample incl. qnorm
-# what the block form executes per mode-sample: 2 MFMA products (a_j Q + b_j D = 4 flop) + the coarse
-# recurrence (4 FMA per mode per 16 samples = 0.5 flop); the per-sample form executes what the counters say
-FLOP_BLOCK = 4.5
-# split-bf16 projection: the same contraction as three bf16 products (12 bf16 flop per mode-sample on the matrix pipe)
-# + the coarse recurrence and the hi/lo split on the vector ALU: 11 VALU instructions per mode and block of 16 samples
-# (profiles/r02_pmc_summary_bf16.txt: 1431 wave-instructions per wave-buffer of 256 modes x 513 samples at R = 4, incl. the buffer head)
-FLOP_BF16_MFMA = 12.0
-VALU_OPS_BF16 = 1510 * 64 / (256 * 513.0)      # = 0.74 lane-operations per mode-sample (SQ_INSTS_VALU - SQ_INSTS_MFMA per wave and buffer)
-BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+# Minimum work of the block formulation per mode-sample: the output projection a_j Q + b_j D of every
+# sample = 2 products = 4 flop on the f32 matrix pipe (or 3 bf16 x bf16 products = 12 bf16 flop in the split form), and
+# the coarse recurrence x <- P x = 4 FMA per mode per 16 samples = 0.5 flop on the vector ALU.
+FLOP_PROJ_F32, FLOP_PROJ_BF16, FLOP_COARSE = 4.0, 12.0, 0.5
+# forced block path (dense force profiles): the state is stepped per sample (2 FMA + 1 add = 5 flop, + 2 with qnorm rows)
+# and projected on the matrix pipe (4 flop)
+FLOP_FORCED_STATE, FLOP_QNORM = 5.0, 2.0
 XGMI_LINK_GBPS = 153.0         # one xGMI link (point to point; 7 per GPU): the figure the task statement and the guide quote
 TOL_MAX, TOL_L2 = 5e-4, 1e-3   # stated fp32 tolerance vs the fp64 oracle
+DTYPE_OF_FORM = {
+    "block": "f32",
+    "block_bf16": "f32 state, bf16x3 projection (operands split into two bf16 halves = 16 significant bits, three products, f32 accumulation)",
+    "velocity": "f32", "direct": "f32",
+}
 
 
 def parse(argv=None):
@@ -65,9 +69,10 @@ def parse(argv=None):
     ap.add_argument("--objects", type=int, default=1024, help="objects per GPU (weak scaling); the total for the strong leg")
     ap.add_argument("--modes", type=int, default=512)
     ap.add_argument("--buffers", type=int, default=86, help="audio buffers per step")
-    ap.add_argument("--form", choices=["block_bf16", "block", "velocity", "direct"], default="block_bf16",
-                    help="block_bf16: block state-space form, output projection as a split-bf16 MFMA product (default); block: the same "
-                         "with an exact f32 MFMA projection; velocity / direct: per-sample kernel (K1)")
+    ap.add_argument("--form", choices=["block", "block_bf16", "velocity", "direct"], default="block",
+                    help="block: block state-space form with the exact f32 MFMA projection (default: every product of the line is f32); "
+                         "block_bf16: the same with the output projection as a split-bf16 MFMA product (mixed precision, reported as "
+                         "such); velocity / direct: per-sample kernel (K1)")
     ap.add_argument("--plan-threads", type=int, default=2,
                     help="host planner threads (PBSO_PLAN_THREADS; the helper is pinned into the caller's core complex).  With the "
                          "split-bf16 kernel one host thread (0.42 ms planning + 0.17 ms feeding + 0.15 ms launches per step) is as "
@@ -87,9 +92,9 @@ def parse(argv=None):
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the RCCL audio all-gather out of the timed region")
     ap.add_argument("--no-gather-cost", action="store_true", help="N > 1: skip the extra leg that times the same run without the all-gather")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the first timed step")
-    ap.add_argument("--no-f32-leg", action="store_true",
-                    help="--form block_bf16, one GPU: skip the second run of the same workload with the exact-f32 projection "
-                         "(--form block), reported beside the headline as exact_f32_projection")
+    ap.add_argument("--no-second-form", "--no-f32-leg", dest="no_second_form", action="store_true",
+                    help="one GPU, impulses: skip the second run of the same workload in the OTHER block form (headline f32 -> "
+                         "mixed_precision_projection; headline block_bf16 -> exact_f32_projection), reported beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-objects", type=int, default=0, help="objects in the CPU baseline sample (0 = auto)")
     return ap.parse_args(argv)
@@ -120,7 +125,8 @@ def spawn_ranks(n, argv):
 
 # ----------------------------------------------------------------------------------------------------
 def build_inputs(args, global_ids, total_buffers):
-    """Deterministic inputs per GLOBAL object id: eigenvalues, mode shapes, hit script."""
+    """Deterministic inputs per GLOBAL object id: eigenvalues, mode shapes and the scenario's script (hit vertices and
+    normals; scraping: one face hit per buffer; listener: FFAT maps and a listener position per buffer)."""
     from openpbso_amd import synth
     M = args.modes
     lam = np.empty((len(global_ids), M))
@@ -129,19 +135,44 @@ def build_inputs(args, global_ids, total_buffers):
         seed = synth.seed_for(4, gid)
         lam[i] = synth.eigenvalues(M, seed)
         shapes.append(synth.mode_shapes(M, seed))
-        scripts.append((synth.poisson_hits(total_buffers, seed), synth.unit_normals(total_buffers, seed)))
+        sc = {"hits": synth.poisson_hits(total_buffers, seed), "vns": synth.unit_normals(total_buffers, seed)}
+        if args.scenario == "scraping":
+            rng = np.random.default_rng(synth.seed_for(5, gid))
+            bary = rng.random((total_buffers, 3))
+            sc["bary"] = bary / bary.sum(axis=1, keepdims=True)
+            sc["fids"] = rng.integers(0, synth.N_VERTS, (total_buffers, 3))
+        elif args.scenario == "listener":
+            sc["maps"] = synth.ffat_maps(lam[i], synth.seed_for(3, gid))
+            sc["path"] = synth.listener_path(total_buffers) * (1.0 + 0.001 * i)
+        scripts.append(sc)
     return lam, shapes, scripts
 
 
-def measured_traffic(args, objects):
+def pmc_counts(form, objects, args):
+    """instruction counts per wave and buffer of the block kernel from the PMC passes kept under profiles/ (same configuration only)"""
+    for name in ("r03_pmc_counts.json", "r02_pmc_counts.json"):
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name)))
+            e = t["forms"][form]
+            c = e["config"]
+            qn = "off" if args.no_qnorm else args.qnorm
+            if (c["objects_per_gpu"], c["modes"], c["buffers_per_step"], c["qnorm"], c["scenario"]) == (
+                    objects, args.modes, args.buffers, qn, args.scenario):
+                return dict(e, file="profiles/" + name)
+        except Exception:
+            pass
+    return None
+
+
+def measured_traffic(args, form, objects):
     """HBM bytes per launch from the PMC passes kept under profiles/ (same configuration only)."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic_%s.json" % form, "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
             c = t["config"]
             qn = "off" if args.no_qnorm else args.qnorm
             if (c["objects_per_gpu"], c["modes"], c["buffers_per_step"], c["qnorm"], c["form"]) == (
-                    objects, args.modes, args.buffers, qn, args.form):
+                    objects, args.modes, args.buffers, qn, form) and c.get("scenario", "impulses") == args.scenario:
                 return t["traffic_bytes_per_launch"], name
         except Exception:
             pass
@@ -178,7 +209,7 @@ def cpu_baseline(args, lam, shapes, scripts):
     hit_data = np.zeros((n_obj, M))
     mask = np.zeros((n_obj, nb), dtype=np.uint8)
     for i in range(n_obj):
-        hits, vns = scripts[i]
+        hits, vns = scripts[i]["hits"], scripts[i]["vns"]
         mask[i] = (hits[:nb] >= 0).astype(np.uint8)
         first = int(np.argmax(hits[:nb] >= 0)) if mask[i].any() else 0
         # one spatial vector per object (the CPU leg times stepping, not projection)
@@ -213,7 +244,8 @@ def cpu_baseline(args, lam, shapes, scripts):
 
 
 def oracle_rows(args, lam, shapes, scripts, rows, n_steps):
-    """fp64 oracle audio of step n_steps - 1 (0-based) for the local objects `rows`, stepped from the start."""
+    """fp64 oracle audio of step n_steps - 1 (0-based) for the local objects `rows`, stepped from the start with the
+    scenario's own script (what measure() feeds the engine)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle_py as orc
     from openpbso_amd import synth
@@ -221,14 +253,29 @@ def oracle_rows(args, lam, shapes, scripts, rows, n_steps):
 
     def one(i):
         s = orc.Solver(lam[i], synth.RHO, synth.ALPHA, synth.BETA)
-        s.set_use_transfer(False)
-        hits, vns = scripts[i]
+        sc = scripts[i]
+        hits, vns = sc["hits"], sc["vns"]
+        if args.scenario == "listener":
+            maps = sc["maps"]
+            s.read_ffat_maps([orc.uniform_cube(m["mode_id"], m["k"], m["center"], m["cell_size"], int(m["n_elements"][0][0]), m["psi"])
+                              for m in maps])
+        else:
+            s.set_use_transfer(False)
+        if args.scenario == "scraping":
+            # tools/...:754-776: the dummy start message (data = 0) carries the one AutoregressiveForce of the contact
+            assert s.enqueue_force(np.zeros(lam.shape[1]), orc.make_force(orc.AR), sustained_start=True)
         out = None
         for k in range(n_steps):
             bufs = []
             for b in range(k * nb, (k + 1) * nb):
-                if hits[b] >= 0:
-                    s.enqueue_force(orc.modal_force_vertex(shapes[i], int(hits[b]), vns[b]))
+                if args.scenario == "scraping":
+                    if b >= 1:
+                        s.enqueue_force(orc.modal_force_face(shapes[i], sc["fids"][b], sc["bary"][b], vns[b]), orc.make_force(orc.AR))
+                else:
+                    if args.scenario == "listener":
+                        s.compute_transfer(sc["path"][b])
+                    if hits[b] >= 0:
+                        s.enqueue_force(orc.modal_force_vertex(shapes[i], int(hits[b]), vns[b]))
                 snd = s.step()[0]
                 if k == n_steps - 1:
                     bufs.append(snd.copy())
@@ -262,28 +309,26 @@ def measure(args, ctx, global_ids, want_parity):
     for i, gid in enumerate(global_ids):
         eng.add_object(lam[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
         if args.scenario == "listener":
-            eng.set_ffat_maps(i, synth.ffat_maps(lam[i], synth.seed_for(3, gid)))
+            eng.set_ffat_maps(i, scripts[i]["maps"])
     eng.finalize()
     n_hits = 0
     feed_obj, feed_vid, feed_vn, feed_t, feed_bary = [], [], [], [], []
     for i, gid in enumerate(global_ids):
-        hits, vns = scripts[i]
+        sc = scripts[i]
+        hits, vns = sc["hits"], sc["vns"]
         if args.scenario == "scraping":
             # tools/...:754-776 + :1127-1160: dummy start message, then one GetModalForceFace per frame
             eng.set_use_transfer(i, False)
-            rng = np.random.default_rng(synth.seed_for(5, gid))
             assert eng.enqueue_force(i, ForceMessage(forceType=capi.AUTOREGRESSIVE_FORCE, sustainedForceStart=True), 0)
-            bary = rng.random((total_buffers, 3))
-            fids = rng.integers(0, synth.N_VERTS, (total_buffers, 3))
             feed_obj.append(np.full(total_buffers - 1, i, dtype=np.int32))
-            feed_vid.append(fids[1:].astype(np.int32))
-            feed_bary.append((bary / bary.sum(axis=1, keepdims=True))[1:])
+            feed_vid.append(sc["fids"][1:].astype(np.int32))
+            feed_bary.append(sc["bary"][1:])
             feed_vn.append(vns[1:total_buffers])
             feed_t.append(np.arange(1, total_buffers, dtype=np.int64))
             n_hits += total_buffers - 1
             continue
         if args.scenario == "listener":
-            path = synth.listener_path(total_buffers) * (1.0 + 0.001 * i)
+            path = sc["path"]
             for b in range(total_buffers):
                 eng.compute_transfer(i, path[b], int(b))
         else:
@@ -325,10 +370,12 @@ def measure(args, ctx, global_ids, want_parity):
     # leg "mix": the consumer wants ONE mixed stream: every rank sums its objects' buffers and the ranks
     # all-reduce that row (nb * 513 floats) instead of gathering every object's audio
     do_mix = bool(do_gather and ctx.get("leg_mix"))
+    # leg "root": only rank 0 consumes the buffers: a gather to the root (send / receive) instead of the all-gather
+    do_root = bool(do_gather and ctx.get("leg_root"))
     n_buf = 2 if do_gather else 1
     audios = [torch.zeros((cmax, nb * B), dtype=torch.float32, device=dev) for _ in range(n_buf)]
     gathered = ([torch.empty((world * cmax, nb * B), dtype=torch.float32, device=dev) for _ in range(n_buf)]
-                if do_gather and not do_mix else None)
+                if do_gather and not do_mix and (not do_root or rank == 0) else None)
     mixes = [torch.zeros(nb * B, dtype=torch.float32, device=dev) for _ in range(n_buf)] if do_mix else None
     ones_obj = torch.ones(n_obj, dtype=torch.float32, device=dev) if do_mix else None
     pending = [None] * n_buf
@@ -362,6 +409,15 @@ def measure(args, ctx, global_ids, want_parity):
                 m_host = mixes[slot].cpu()
                 dist.all_reduce(m_host)
                 mixes[slot].copy_(m_host)
+        elif do_root:
+            if backend == "nccl":
+                pending[slot] = dist.gather(audios[slot], list(gathered[slot].chunk(world)) if rank == 0 else None, dst=0, async_op=True)
+            else:
+                host = audios[slot].cpu()
+                parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, parts, dst=0)
+                if rank == 0:
+                    gathered[slot].copy_(torch.cat(parts, dim=0))
         elif do_gather:
             if backend == "nccl":
                 pending[slot] = dist.all_gather_into_tensor(gathered[slot], audios[slot], async_op=True)
@@ -400,7 +456,7 @@ def measure(args, ctx, global_ids, want_parity):
     assert all(torch.isfinite(a).all() for a in audios)
     if do_mix:
         assert all(torch.isfinite(x).all() for x in mixes)
-    if do_gather and not do_mix and backend == "nccl":
+    if do_gather and not do_mix and backend == "nccl" and gathered is not None:
         last = (n_calls[0] - 1) % n_buf
         assert torch.equal(gathered[last][rank * cmax:rank * cmax + n_obj], audios[last][:n_obj])
 
@@ -413,7 +469,20 @@ def measure(args, ctx, global_ids, want_parity):
         "plan_ms": (info1["total_host_plan_ms"] - info0["total_host_plan_ms"]) / args.steps,
         "enqueue_ms": enqueue_s[0] / args.steps * 1e3, "info": info1, "form_run": info1.get("recurrence_form"),
     }
-    if want_parity and args.scenario == "impulses":
+    if ctx.get("measure_d2h"):
+        # what a HOST-side consumer of every object's buffers (the reference's PortAudio callback takes them from a host
+        # queue, modal_solver.h:79-82, 359-363) would add: the step's audio, device to pinned host memory
+        pinned = torch.empty((n_obj, nb * B), dtype=torch.float32, pin_memory=True)
+        torch.cuda.synchronize()
+        reps = []
+        for _ in range(3):
+            td = time.perf_counter()
+            pinned.copy_(audios[0][:n_obj], non_blocking=True)
+            torch.cuda.synchronize()
+            reps.append(time.perf_counter() - td)
+        res["d2h_ms"] = float(np.median(reps)) * 1e3
+        res["d2h_bytes"] = n_obj * nb * B * 4
+    if want_parity:
         tp = time.perf_counter()
         got = captured[0].cpu().numpy().astype(np.float64)
         want = oracle_rows(args, lam, shapes, scripts, rows, args.settle + args.warmup + 1)
@@ -442,8 +511,10 @@ def main():
 
     # host planner threads (per-thread planning contexts merged in object order; the helpers are pinned into the
     # caller's core complex: unpinned they wander over the two sockets of these hosts and lose).  With N ranks on
-    # one node every rank gets its share of the cores.
-    os.environ.setdefault("PBSO_PLAN_THREADS", str(args.plan_threads))
+    # one node every rank gets its share of the cores: max(1, cores // ranks - 1) helpers at most.
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    plan_threads = max(1, min(args.plan_threads, host_cores() // max(1, world_env) - 1))
+    os.environ.setdefault("PBSO_PLAN_THREADS", str(plan_threads))
     os.environ.setdefault("PBSO_PLAN_PIN", "1" if int(os.environ["PBSO_PLAN_THREADS"]) > 1 else "0")
     # kernel durations for the roofline: HIP events around every 4th launch (around every launch they cost the stream
     # ~15 us per step; rocprofv3's average over ALL launches of the same command is in profiles/)
@@ -509,28 +580,37 @@ def main():
     for leg in order:
         ids = weak_ids if leg == "weak" else strong_ids
         ctx["counts"] = [args.objects] * world if leg == "weak" else [hi - lo for lo, hi in spans]
+        ctx["measure_d2h"] = leg == order[0] and rank == 0
         legs[leg] = measure(args, ctx, ids, want_parity=(not args.no_parity and leg == order[0] and rank == 0))
+        ctx["measure_d2h"] = False
     head = order[0]
     m = legs[head]
-    # one GPU, split-bf16 projection: the same workload once more with the exact-f32 projection, reported beside the headline
-    f32_leg = None
-    if world == 1 and args.form == "block_bf16" and not args.no_f32_leg and args.scenario == "impulses":
+    # one GPU: the same workload once more in the OTHER block form, reported beside the headline
+    second = second_form = None
+    if world == 1 and args.form in ("block", "block_bf16") and not args.no_second_form and args.scenario == "impulses":
         import copy
-        a32 = copy.copy(args)
-        a32.form = "block"
+        a2 = copy.copy(args)
+        a2.form = second_form = "block_bf16" if args.form == "block" else "block"
         ctx["counts"] = [args.objects]
-        f32_leg = measure(a32, ctx, weak_ids, want_parity=(not args.no_parity and rank == 0))
-    # what the collective costs: the head leg once more with the all-gather left out (reported beside it, never as `value`)
-    bare = mixed = None
+        second = measure(a2, ctx, weak_ids, want_parity=(not args.no_parity and rank == 0))
+    # what the collective costs: the head leg once more with the all-gather left out, with a gather to rank 0 only
+    # (send / receive) and with the reduce a consumer of ONE mixed stream needs (reported beside it, never as `value`)
+    bare = mixed = rooted = None
     if m["gather"] and not args.no_gather_cost:
+        cnt = [args.objects] * world if head == "weak" else [hi - lo for lo, hi in spans]
+        ids = weak_ids if head == "weak" else strong_ids
+        ctx["counts"] = cnt
         ctx["leg_without_gather"] = True
-        ctx["counts"] = [args.objects] * world if head == "weak" else [hi - lo for lo, hi in spans]
-        bare = measure(args, ctx, weak_ids if head == "weak" else strong_ids, want_parity=False)
+        bare = measure(args, ctx, ids, want_parity=False)
         ctx["leg_without_gather"] = False
         ctx["leg_mix"] = True
-        mixed = measure(args, ctx, weak_ids if head == "weak" else strong_ids, want_parity=False)
+        mixed = measure(args, ctx, ids, want_parity=False)
         ctx["leg_mix"] = False
+        ctx["leg_root"] = True
+        rooted = measure(args, ctx, ids, want_parity=False)
+        ctx["leg_root"] = False
 
+    rc = 0
     if rank == 0:
         nb, M = args.buffers, args.modes
 
@@ -541,30 +621,97 @@ def main():
                     "ms_per_step": r["elapsed"] / args.steps * 1e3, "objects_total": total_obj,
                     "objects_rank0": r["n_local"], "kernel_ms_rank0": r["kernel_ms"], "gather": r["gather"]}
 
+        def roofline_of(form, r):
+            """roofline of the dominant kernel of one measured leg: HIP events on the launch stream, this rank.
+            frac = (minimum work of the formulation that ran) / (kernel time): every term can be recomputed from this dict."""
+            k_ms = r["kernel_ms"]
+            ms = r["n_local"] * M * nb * B                       # mode-samples per launch
+            info = r["info"]
+            qn_on = not (args.no_qnorm or args.qnorm == "off")
+            # (a block-form engine may run launches that are mostly dense-profile buffers on the per-sample kernel)
+            block = r["form_run"] in (0, 3) and info["total_block_launches"] >= info["total_sample_launches"]
+            bf16 = block and r["form_run"] == 3
+            dense = args.scenario == "scraping"
+            per_s = 1.0 / (k_ms * 1e-3)
+            if block and not bf16 and not dense:
+                work = {"f32_matrix_pipe": FLOP_PROJ_F32, "f32_vector_alu": FLOP_COARSE}
+                flop, peak, bound = FLOP_PROJ_F32 + FLOP_COARSE, F32_PEAK_TFLOPS, "mfma"
+                note = ("block state-space form, f32 projection: per mode-sample 4 flop on v_mfma_f32_16x16x4_f32 (a_j Q + b_j D) + 0.5 flop of "
+                        "coarse recurrence on the vector ALU.  On gfx950 the f32-input MFMA and the f32 VALU share one 157.3 TFLOP/s "
+                        "datapath: their cycles ADD (profiles/r03_mfma_valu_mix.txt: one MFMA + K v_fma_f32 takes 36 + 2.25 K cycles per "
+                        "SIMD at two waves per SIMD, 32 alone; SQ_VALU_MFMA_COEXEC_CYCLES = 0), so min time = (4 + 0.5) x mode-samples / peak")
+            elif block and bf16 and not dense:
+                work = {"bf16_matrix_pipe": FLOP_PROJ_BF16, "f32_vector_alu": FLOP_COARSE}
+                flop, peak, bound = FLOP_PROJ_BF16, BF16_PEAK_TFLOPS, "mfma"
+                note = ("block state-space form, split-bf16 projection: per mode-sample 12 bf16 flop on v_mfma_f32_16x16x32_bf16 (three products of "
+                        "bf16 halves) + 0.5 f32 flop of coarse recurrence on the vector ALU; the bf16 MFMA co-executes with the VALU, so min "
+                        "time = max(12 x mode-samples / 2500 TFLOP/s, 0.5 x mode-samples / 157.3 TFLOP/s) = the matrix term; what the kernel "
+                        "actually spends its time on is vector-ALU ISSUE (hi / lo split and packing of every block-start state: issue_utilisation)")
+            elif block and dense:
+                flop = FLOP_FORCED_STATE + FLOP_PROJ_F32 + (FLOP_QNORM if qn_on else 0.0)
+                work = {"f32_matrix_pipe": FLOP_PROJ_F32, "f32_vector_alu": flop - FLOP_PROJ_F32}
+                peak, bound = F32_PEAK_TFLOPS, "valu"
+                note = ("forced block path (dense force profile every buffer): per mode-sample the state is stepped literally on the vector ALU "
+                        "(2 FMA + 1 add, + 1 FMA with qnorm rows) and projected on the f32 matrix pipe (4 flop); 512 waves on 1024 SIMDs: the "
+                        "launch is bound by ONE wave's issue rate (one VALU instruction per 4 cycles), not by the chip's peak")
+            else:
+                flop, peak, bound = float(FLOP_REF), F32_PEAK_TFLOPS, "valu"
+                work = {"f32_vector_alu": flop}
+                note = "per-sample kernel K1: the reference's 10 flop per mode-sample on the fp32 vector ALU (157.3 TFLOP/s, also the dense fp32 MFMA peak)"
+            tf = flop * ms * per_s * 1e-12
+            min_ms = max((FLOP_PROJ_BF16 * ms / (BF16_PEAK_TFLOPS * 1e12), FLOP_COARSE * ms / (F32_PEAK_TFLOPS * 1e12))) * 1e3 if (block and bf16 and not dense) \
+                else flop * ms / (peak * 1e12) * 1e3
+            # algorithmic bytes of one launch (SURVEY 8(d) formula with NB_l = nb; M = modes per object); the block
+            # form also reads its operand table once per launch (128 B per mode) and the coarse-step matrix (16 B)
+            bytes_alg = r["n_local"] * (M * (12 + 8 + 8 + (4 + 4 + 4) * nb + (144 if block else 0)) + nb * B * (4 + 4))
+            gbs = bytes_alg * per_s * 1e-9
+            traffic, traffic_src = measured_traffic(args, form, r["n_local"])
+            out = {
+                "bound": bound, "kernel": "iir_block_kernel" if block else "iir_bank_kernel",
+                "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                "min_work": {"flop_per_mode_sample_by_pipe": work, "mode_samples_per_launch": ms, "min_kernel_ms": min_ms,
+                             "kernel_ms": k_ms, "note": note},
+                "kernel_ms": k_ms,
+                "kernel_ms_source": "HIP events on the launch stream around every %s-th launch of the timed region: %d launches" % (
+                    os.environ["PBSO_TIMING_EVERY"], r["kernel_samples"]),
+                "reference_equivalent": {"flop_per_mode_sample": FLOP_REF, "achieved": FLOP_REF * ms * per_s * 1e-12,
+                                         "frac_of_f32_peak": FLOP_REF * ms * per_s * 1e-12 / F32_PEAK_TFLOPS,
+                                         "note": "the reference's 10 flop per mode-sample at this kernel time: above 1 means the kernel does "
+                                                 "not execute the reference's arithmetic (block reformulation), not that a roof was broken"},
+                "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": bytes_alg},
+                "traffic": traffic,
+                "traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/{traffic_src})" if traffic else None,
+            }
+            pc = pmc_counts(form, r["n_local"], args) if block else None
+            if pc:
+                # instruction-issue view, only for the configuration the PMC passes were taken on
+                wb = r["n_local"] * M / (64.0 * info["modes_per_lane"]) * nb       # wave-buffers per launch
+                out["issue_utilisation"] = {
+                    "valu_per_wave_buffer": pc["valu_per_wave_buffer"], "mfma_per_wave_buffer": pc["mfma_per_wave_buffer"],
+                    "valu_issue_slots_frac": pc["valu_per_wave_buffer"] * wb * 64 * 2 * per_s * 1e-12 / F32_PEAK_TFLOPS,
+                    "source": pc["file"] + ": " + pc.get("source", ""),
+                    "note": "every VALU instruction counted as 64 lanes x 2 flop against the 157.3 TFLOP/s f32 vector peak: issue-slot "
+                            "utilisation, not a flop roofline (split / pack / head instructions count as much as FMAs)"}
+            return out
+
         hn = leg_numbers(head, m)
-        # roofline of the dominant kernel: HIP events on the launch stream, this rank
-        k_ms = m["kernel_ms"]
-        mode_samples = m["n_local"] * M * nb * B
-        # (a block-form engine runs launches that are mostly dense-profile buffers on the per-sample kernel)
-        block = m["form_run"] in (0, 3) and m["info"]["total_block_launches"] >= m["info"]["total_sample_launches"]
-        bf16 = block and m["form_run"] == 3
-        # bf16 form: the vector ALU binds (instruction issue); one VALU instruction = 64 lanes x 2 flop-equivalents
-        flop_exec = 2 * VALU_OPS_BF16 if bf16 else (FLOP_BLOCK if block else FLOP_REF)
-        tf_exec = flop_exec * mode_samples / (k_ms * 1e-3) * 1e-12
-        tf_ref = FLOP_REF * mode_samples / (k_ms * 1e-3) * 1e-12
-        # algorithmic bytes of one launch (SURVEY 8(d) formula with NB_l = nb; M = modes per object); the block
-        # form also reads its operand table once per launch (128 B per mode) and the coarse-step matrix (16 B)
-        bytes_alg = m["n_local"] * (M * (12 + 8 + 8 + (4 + 4 + 4) * nb + (144 if block else 0)) + nb * B * (4 + 4))
-        gbs = bytes_alg / (k_ms * 1e-3) * 1e-9
-        traffic, traffic_src = measured_traffic(args, m["n_local"])
         info = m["info"]
+        roof = roofline_of(args.form, m)
+        block_run = m["form_run"] in (0, 3) and info["total_block_launches"] >= info["total_sample_launches"]
+        qn_txt = "off" if (args.no_qnorm or args.qnorm == "off") else (
+            "rows on (closed form x0' G x0 in force-free block buffers, per-sample sums in dense-profile buffers)" if block_run else
+            ("rows on (closed form)" if args.qnorm == "closed" else "rows on (per-sample sums)"))
+        coll_txt = ("RCCL" if backend == "nccl" else backend + " (host transport standing in for RCCL)")
+        host_ms = m["plan_ms"] + m["enqueue_ms"]
         out = {
             "metric": "audio samples/s & real-time x at N_obj x N_modes",
             "value": hn["value"], "unit": "audio samples/s", "realtime_x": hn["realtime_x"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle,
             "ms_per_step": hn["ms_per_step"],
             "higher_is_better": True, "scaling": head, "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": DTYPE_OF_FORM[args.form], "data": "synthetic",
+            "hbm_frac": roof["hbm"]["frac"],
             "config": {
                 "workload": f"{m['n_local']} objects x {M} modes on rank 0 ({hn['objects_total']} in the job), " + {
                                 "impulses": "Poisson impulse stream (~20 PointForce hits/s/object, on-device vertex projection), unit transfer, ",
@@ -572,50 +719,36 @@ def main():
                                             "profiles generated on the device), unit transfer, ",
                                 "listener": "Poisson impulse stream + FFAT maps (16x16 cube faces) with a new listener position every buffer, ",
                             }[args.scenario] + f"{nb} buffers x 513 samples per step, "
-                            f"qnorm {'off' if args.no_qnorm else args.qnorm}, {args.form} recurrence form"
-                            + (", RCCL all-gather of the audio buffers inside the timed region" if m["gather"] else ""),
+                            f"qnorm {qn_txt}, {args.form} recurrence form"
+                            + (f", {coll_txt} all-gather of the audio buffers inside the timed region" if m["gather"] else ""),
                 "scenario": args.scenario, "objects_per_gpu": m["n_local"], "modes": M, "buffers_per_step": nb, "frames_per_buffer": B,
                 "hits": m["n_hits"], "modes_per_lane": info["modes_per_lane"], "waves_per_object": info["waves_per_object"],
-                "recurrence_form": args.form, "gather": m["gather"], "rccl_ranks": rccl_ranks, "backend": backend if use_dist else None,
-                "host_planner_threads": int(os.environ["PBSO_PLAN_THREADS"]), "parallelism": f"object-sharded x{world}", "launched_by": "bench.py" if os.environ.get("PBSO_BENCH_SPAWNED") else
-                               ("torch.distributed.run" if use_dist else "single process"),
+                "recurrence_form": args.form, "gather": m["gather"], "group_ranks": rccl_ranks, "rccl_ranks": rccl_ranks if backend == "nccl" else None,
+                "backend": backend if use_dist else None,
+                "host_planner_threads": int(os.environ["PBSO_PLAN_THREADS"]), "host_cores": host_cores(), "parallelism": f"object-sharded x{world}",
+                "launched_by": "bench.py" if os.environ.get("PBSO_BENCH_SPAWNED") else ("torch.distributed.run" if use_dist else "single process"),
             },
-            "roofline": {
-                "bound": "valu" if bf16 or not block else "mfma",
-                "kernel": "iir_block_kernel" if block else "iir_bank_kernel",
-                "bound_note": ("vector-ALU instruction issue: the output projection runs as a split-bf16 product on "
-                               "v_mfma_f32_16x16x32_bf16 (12 bf16 flop per mode-sample = " + ("%.0f" % (FLOP_BF16_MFMA * mode_samples / (k_ms * 1e-3) * 1e-12)) +
-                               " TFLOP/s, " + ("%.2f" % (FLOP_BF16_MFMA * mode_samples / (k_ms * 1e-3) * 1e-12 / BF16_PEAK_TFLOPS)) + " of the dense bf16 peak: not the "
-                               "limiter) and co-executes with the vector ALU, which carries the f32 coarse recurrence and the hi / lo "
-                               "split of every block-start state: 1510 VALU instructions per wave and buffer (PMC, profiles/r02_pmc_summary_bf16.txt); "
-                               "achieved / frac count every VALU instruction as 64 lanes x 2 flop against the 157.3 TFLOP/s f32 vector "
-                               "peak (32 lanes per cycle and SIMD), i.e. issue-slot utilisation; the kernel is bound by what ONE wave can issue -- at most "
-                               "one instruction of any kind per 4 cycles (profiles/r02_valu_issue.txt), and the register file holds two waves per SIMD: "
-                               "~3000 instructions per wave and buffer (vector, LDS, scalar, MFMA) in 15.7 K cycles (profiles/r02_census_1024x512.txt); "
-                               "reference_equivalent credits the reference's 10 flop per mode-sample") if bf16 else
-                              ("f32 matrix pipe: the per-sample sum over modes is a [16 x 2M].[2M x 16 blocks] product on "
-                               "v_mfma_f32_16x16x4_f32 (4 flop per mode-sample) + the coarse recurrence on the vector ALU "
-                               "(0.5 flop); on gfx950 the f32 MFMA and the f32 VALU do not co-execute "
-                               "(SQ_VALU_MFMA_COEXEC_CYCLES = 0, profiles/r02_pmc_summary.txt), so their cycles add against ONE "
-                               "157.3 TFLOP/s peak; frac counts the flops the kernel executes; reference_equivalent credits the "
-                               "reference's 10 flop per mode-sample") if block else
-                              ("fp32 vector-ALU issue; the peak used, 157.3 TFLOP/s, is also the dense fp32 MFMA peak"),
-                "achieved": tf_exec, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_exec / F32_PEAK_TFLOPS,
-                "flop_per_mode_sample": flop_exec, "kernel_ms": k_ms,
-                "kernel_ms_source": "HIP events on the launch stream around every %s-th launch of the timed region: %d launches" % (
-                    os.environ["PBSO_TIMING_EVERY"], m["kernel_samples"]),
-                "reference_equivalent": {"flop_per_mode_sample": FLOP_REF, "achieved": tf_ref, "frac": tf_ref / F32_PEAK_TFLOPS},
-                "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                        "algorithmic_bytes_per_launch": bytes_alg},
-                "traffic": traffic,
-                "traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/{traffic_src})",
-            },
-            "timing": {"device_pipeline_ms": m["device_ms"], "host_plan_ms": m["plan_ms"], "host_enqueue_ms": m["enqueue_ms"]},
+            "roofline": roof,
+            "timing": {"device_pipeline_ms": m["device_ms"], "host_plan_ms": m["plan_ms"], "host_enqueue_ms": m["enqueue_ms"],
+                       "host_ms": host_ms, "host_bound": bool(host_ms > 0.8 * m["kernel_ms"]),
+                       "note": "host_ms = planning + feeding per step (overlapped with the device); host_bound: host_ms > 0.8 x kernel_ms"},
         }
+        if "d2h_ms" in m:
+            step_s = nb * B / SAMPLE_RATE
+            out["host_delivered"] = {
+                "d2h_ms_per_step": m["d2h_ms"], "bytes_per_step": m["d2h_bytes"],
+                "realtime_x_if_copied_after_each_step": step_s / ((hn["ms_per_step"] + m["d2h_ms"]) * 1e-3),
+                "realtime_x_if_copy_overlaps_compute": step_s / (max(hn["ms_per_step"], m["d2h_ms"]) * 1e-3),
+                "note": "`value` leaves every object's audio in HBM (SURVEY 8(b)/(e): the consumer is the gather / mix).  The reference's consumer is "
+                        "host-side (a queue of SoundMessages, modal_solver.h:79-82, 359-363): delivering all objects' buffers to pinned host "
+                        "memory (pbso_read_audio) costs d2h_ms_per_step on top -- measured here after the timed region, never part of `value`",
+            }
         if "parity" in m:
             out["parity"] = m["parity"]
             out["parity_checked_objects"] = m["parity"]["parity_checked_objects"]
             out["max_err"] = m["parity"]["max_err"]
+            if not m["parity"]["pass"]:
+                rc = 3
         if bare is not None:
             bn = leg_numbers(head, bare)
             per_rank = max(ctx["counts"]) * nb * B * 4
@@ -632,25 +765,35 @@ def main():
                         "step costs max(compute, gather); at these sizes the links, not the kernels, set the step time "
                         "whenever bytes_received_per_rank / xgmi_inbound_peak exceeds ms_per_step_without_gather",
             }
-        if f32_leg is not None:
-            fn = leg_numbers(head, f32_leg)
-            out["exact_f32_projection"] = {
-                "value": fn["value"], "realtime_x": fn["realtime_x"], "ms_per_step": fn["ms_per_step"], "kernel_ms": f32_leg["kernel_ms"],
-                "max_err": f32_leg.get("parity", {}).get("max_err"), "parity_pass": f32_leg.get("parity", {}).get("pass"),
-                "note": "the same workload and engine with --form block: the output projection as an exact f32 MFMA product "
-                        "(v_mfma_f32_16x16x4_f32) instead of three bf16 x bf16 products with f32 accumulation; the state recurrence "
-                        "is f32 in both",
+        if second is not None:
+            sn = leg_numbers(head, second)
+            key = "mixed_precision_projection" if second_form == "block_bf16" else "exact_f32_projection"
+            out[key] = {
+                "value": sn["value"], "realtime_x": sn["realtime_x"], "ms_per_step": sn["ms_per_step"], "kernel_ms": second["kernel_ms"],
+                "dtype": DTYPE_OF_FORM[second_form], "recurrence_form": second_form,
+                "max_err": second.get("parity", {}).get("max_err"), "parity_pass": second.get("parity", {}).get("pass"),
+                "roofline": roofline_of(second_form, second),
+                "timing": {"host_plan_ms": second["plan_ms"], "host_enqueue_ms": second["enqueue_ms"]},
+                "note": ("the same workload and engine with --form block_bf16: the output projection as three bf16 x bf16 products of split "
+                         "operands (16 significant bits each, f32 accumulation) on v_mfma_f32_16x16x32_bf16 instead of the exact f32 MFMA "
+                         "product; the state recurrence is f32 in both.  A mixed-precision variant: never the line's `value`, never `dtype` f32")
+                        if second_form == "block_bf16" else
+                        ("the same workload and engine with --form block: the output projection as an exact f32 MFMA product "
+                         "(v_mfma_f32_16x16x4_f32); the state recurrence is f32 in both"),
             }
-            out["dtype_note"] = ("state recurrence f32; output projection of the headline as a split-bf16 product (two bf16 halves per operand, "
-                                 "16 significant bits, f32 accumulation) whose error against the fp64 oracle is max_err (tolerance 5e-4 of peak; "
-                                 "the all-f32 PER-SAMPLE kernel, --form velocity, measures 5e-5 .. 1e-4 on the same workload); "
-                                 "exact_f32_projection is the all-f32 figure of the block form")
+            if "parity" in second and not second["parity"]["pass"]:
+                rc = 3
         if mixed is not None:
             out["mix"] = dict(leg_numbers(head, mixed), scaling=head, collective="all_reduce(sum) of one mixed row per rank",
                               bytes_per_rank=nb * B * 4,
                               note="the same leg when the consumer wants ONE mixed stream instead of every object's buffers (SURVEY 8(e)): "
                                    "each rank sums its objects' audio and the ranks all-reduce nb * 513 floats; reported beside the "
                                    "headline, never as `value`")
+        if rooted is not None:
+            out["gather_to_root"] = dict(leg_numbers(head, rooted), scaling=head, collective="gather to rank 0 (send / receive)",
+                                         bytes_received_by_root=max(ctx["counts"]) * nb * B * 4 * (world - 1),
+                                         note="the same leg when only rank 0 consumes the buffers (SURVEY 8(e): ncclSend / ncclRecv to a root): "
+                                              "the root's inbound links carry what every rank's carry in the all-gather; the other ranks only send")
         for leg, r in legs.items():
             if leg != head:
                 out[leg] = dict(leg_numbers(leg, r), scaling=leg,
@@ -662,13 +805,13 @@ def main():
             except Exception as ex:   # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(out), flush=True)
-        if "parity" in m and not m["parity"]["pass"]:
-            print("PARITY FAILED: " + json.dumps(m["parity"]), file=sys.stderr)
-            if use_dist:
-                dist.destroy_process_group()
-            sys.exit(3)
+        if rc:
+            bad = [x["parity"] for x in (m, second or {}) if "parity" in x and not x["parity"]["pass"]]
+            print("PARITY FAILED: " + json.dumps(bad), file=sys.stderr)
     if use_dist:
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

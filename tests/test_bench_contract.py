@@ -80,4 +80,4 @@ def test_bench_defaults_are_the_single_gpu_headline(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
     assert (a.gpus, a.objects, a.modes, a.buffers) == (1, 1024, 512, 86)
-    assert a.steps > 0 and a.warmup >= 0 and a.qnorm == "sample" and a.form == "block_bf16"
+    assert a.steps > 0 and a.warmup >= 0 and a.qnorm == "sample" and a.form == "block"

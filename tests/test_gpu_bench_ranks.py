@@ -21,7 +21,10 @@ def test_two_ranks_on_one_gpu_print_one_line_with_gather_and_strong_leg():
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout                     # ONE JSON line, from rank 0
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["gather"] is True and d["config"]["rccl_ranks"] == 2
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["gather"] is True and d["config"]["group_ranks"] == 2
+    # the transport is named for what it is: gloo here, never "RCCL"
+    assert d["config"]["rccl_ranks"] is None and d["config"]["backend"] == "gloo" and "gloo" in d["config"]["workload"] and "RCCL all-gather" not in d["config"]["workload"]
+    assert d["dtype"] == "f32" and d["config"]["recurrence_form"] == "block"
     assert d["config"]["launched_by"] == "bench.py" and d["config"]["objects_per_gpu"] == 96
     assert d["parity"]["pass"] and d["parity_checked_objects"] == 8
     g = d["gather_cost"]
@@ -29,6 +32,11 @@ def test_two_ranks_on_one_gpu_print_one_line_with_gather_and_strong_leg():
     assert g["ms_per_step_without_gather"] > 0 and g["value_without_gather"] > 0
     mx = d["mix"]
     assert mx["bytes_per_rank"] == 86 * 513 * 4 and mx["value"] > 0 and mx["objects_total"] == 192
+    gr = d["gather_to_root"]
+    assert gr["bytes_received_by_root"] == 96 * 86 * 513 * 4 and gr["value"] > 0 and gr["objects_total"] == 192
+    # every rank got its share of the host's cores for planning, and says whether the host was the bottleneck
+    assert 1 <= d["config"]["host_planner_threads"] <= max(1, d["config"]["host_cores"] // 2 - 1)
+    assert isinstance(d["timing"]["host_bound"], bool)
     s = d["strong"]
     assert s["scaling"] == "strong" and s["objects_total"] == 96 and s["objects_rank0"] == 48 and s["gather"] is True
     # whole-job value: both ranks' objects over the slowest rank's time
@@ -53,3 +61,4 @@ def test_one_rank_under_torchrun_runs_the_rccl_gather_path():
     assert d["n_gpus"] == 1 and d["config"]["gather"] is True and d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 1
     assert d["config"]["launched_by"] == "torch.distributed.run" and d["parity"]["pass"]
     assert d["gather_cost"]["bytes_sent_per_rank"] == 256 * 86 * 513 * 4 and d["gather_cost"]["bytes_received_per_rank"] == 0
+    assert "RCCL all-gather" in d["config"]["workload"] and d["gather_to_root"]["value"] > 0 and d["mix"]["value"] > 0
