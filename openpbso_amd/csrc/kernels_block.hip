@@ -353,6 +353,8 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
         __syncthreads();
         prio_rank = (int)(__builtin_bit_cast(unsigned, lds[ST_FLOATS]) & 3u);       // wave 0's ring[0]
         __syncthreads();
+        // (starting the teams of a CU half a slice period apart -- one wave's vector burst under its SIMD partner's matrix
+        //  burst -- changed nothing: 0.948 ms with any stagger of 1, 2 or 4 K cycles on either rank bit, 0.948 without)
     }
     for (int b = 0; b < p.nb; ++b) {
         const BufDesc cur = next;
@@ -449,9 +451,16 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
             if (lane == 0) rg[GROUP * NG] = p0;
 
             if constexpr (PROJ == 0) {
-            // ---- software pipeline over the U = NG * R slices of the buffer.  Slice u's 32 MFMAs take their
-            // B operands from registers (breg); between them run the coarse steps of slice u + 1 (which overwrite
-            // the staging area: its reads for slice u were issued before) and then the operand reads of slice u + 1.
+            // ---- software pipeline over the U = NG * R slices of the buffer, in BURSTS.  Slice u's 32 MFMAs take their B
+            // operands from registers (breg).  A wave alternates a vector burst -- the 16 coarse steps of slice u + 1, which
+            // overwrite the staging area (its reads for slice u were issued during the previous matrix burst) -- and a
+            // matrix burst: the 32 MFMAs of slice u back to back, each followed by the LDS read that refills the operand
+            // register it has just consumed with slice u + 1's.  Why bursts: on gfx950 an instruction issued behind an
+            // f32-input MFMA of the SAME wave waits 12 .. 16 cycles for it (MFMA + 1 v_fma_f32: 48 cycles, not 36), while
+            // another wave's vector instructions issue beside it (profiles/r03_mfma_valu_mix.txt, "roles": one wave MFMAs
+            // only at 38 cycles each while its SIMD partner issues a v_fma_f32 every 4).  With one step (4 VALU + 1 LDS)
+            // between every two MFMAs each of the two waves of a SIMD paid that wait 16 times per slice; in bursts the
+            // partner's vector burst runs under this wave's matrix burst.
             float breg[32];
             lap(cy_head);
             wave_sync();                               // the previous buffer's staging reads are issued
@@ -459,7 +468,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
             for (int n = 0; n < BN; ++n) coarse(0, n, n);
             wave_sync();
 #pragma unroll
-            for (int s = 0; s < 16; ++s) breg[s] = bsrc[4 * s];
+            for (int s = 0; s < 32; ++s) breg[s] = bsrc[4 * s];
             f4 acc0, acc1;
             static_for<0, U>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
@@ -470,30 +479,29 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                     acc0 = f4{0.f, 0.f, 0.f, 0.f};
                     acc1 = f4{0.f, 0.f, 0.f, 0.f};
                 }
-#pragma unroll
-                for (int s = 16; s < 32; ++s) breg[s] = bsrc[4 * s];
-                wave_sync();
+                wave_sync();                           // this slice's operand reads are issued: the staging area is free
                 __builtin_amdgcn_sched_barrier(0);
-                static_for<0, 16>([&](auto sc) {
+                if constexpr (more) {
+#pragma unroll
+                    for (int n = 0; n < BN; ++n) coarse(rn, n, BN * ((u + 1) / R) + n);
+                    wave_sync();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, 32>([&](auto sc) {
                     constexpr int s = decltype(sc)::value;
                     if constexpr (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s], breg[s], acc1, 0, 0, 0);
                     else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s], breg[s], acc0, 0, 0, 0);
-                    if constexpr (more) coarse(rn, s, BN * ((u + 1) / R) + s);
+                    // refill, two MFMAs behind (the MFMA reads its operands in its first pass)
+                    if constexpr (more && s >= 2) breg[s - 2] = bsrc[4 * (s - 2)];
+                    // last slice: nothing to refill -- half way through the burst the first operand registers are free and the
+                    // next buffer's inputs land in them
+                    if constexpr (!more && s == 15) prefetch(next);
                     __builtin_amdgcn_sched_barrier(0);
                 });
-                if constexpr (more) wave_sync();
-                // last slice: the first-half operand registers are free -- the next buffer's inputs land in them
-                if constexpr (!more) prefetch(next);
-                static_for<16, 16>([&](auto sc) {
-                    constexpr int s = decltype(sc)::value;
-                    if constexpr (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s], breg[s], acc1, 0, 0, 0);
-                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s], breg[s], acc0, 0, 0, 0);
-                    if constexpr (more && s < 24) {
-                        breg[2 * (s - 16)] = bsrc[8 * (s - 16)];
-                        breg[2 * (s - 16) + 1] = bsrc[8 * (s - 16) + 4];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                });
+                if constexpr (more) {
+                    breg[30] = bsrc[4 * 30];
+                    breg[31] = bsrc[4 * 31];
+                }
                 if constexpr (r == R - 1) {
                     const f4 acc = acc0 + acc1;
                     const unsigned l = lane_off() & 63u;       // (recomputed: not worth two registers across the pipeline)

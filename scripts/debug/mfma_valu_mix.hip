@@ -35,6 +35,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     asm volatile("v_mfma_f32_16x16x32_bf16 %[c0], %[ah], %[bh], %[c0]\n" FILL              \
                  "v_mfma_f32_16x16x32_bf16 %[c1], %[ah], %[bh], %[c1]\n" FILL OPERANDS);
 #define BODY_NONE(FILL) asm volatile(FILL FILL OPERANDS);
+// K ds_read_b32 fillers per MFMA (the block kernel's operand reads): does the LDS pipe disturb back-to-back MFMA issue?
+#define L1(i) "ds_read_b32 %[x" #i "], %[la] offset:" #i "*256\n"
+#define LFILL1 L1(0)
+#define LFILL2 L1(0) L1(1)
+#define LFILL4 L1(0) L1(1) L1(2) L1(3)
+#define BODY_LDS(FILL)                                                                      \
+    asm volatile("v_mfma_f32_16x16x4_f32 %[c0], %[a], %[b], %[c0]\n" FILL                  \
+                 "v_mfma_f32_16x16x4_f32 %[c1], %[a], %[b], %[c1]\n" FILL "s_waitcnt lgkmcnt(0)\n"                                    \
+                 : [c0] "+v"(c0), [c1] "+v"(c1), [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3)        \
+                 : [a] "v"(a), [b] "v"(b), [la] "v"(la));
 
 template <int KIND, int K>
 __global__ __launch_bounds__(512) void kern(float *out, unsigned long long *cyc, int iters) {
@@ -45,6 +55,8 @@ __global__ __launch_bounds__(512) void kern(float *out, unsigned long long *cyc,
     bf16x8 ah, bh;
     for (int i = 0; i < 8; ++i) { ah[i] = (__bf16)(a + i); bh[i] = (__bf16)(b - i); }
     f4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+    const unsigned la = (unsigned)(size_t)lds + 4 * tid;
+    lds[tid] = 1.f; lds[tid + 512] = 2.f; lds[tid + 1024] = 3.f; lds[tid + 1536] = 4.f;
     if (iters < 0) lds[tid] = 1;
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -60,6 +72,13 @@ __global__ __launch_bounds__(512) void kern(float *out, unsigned long long *cyc,
             else if constexpr (K == 2) { REP4(BODY_BF16(FILL2)) } else if constexpr (K == 4) { REP4(BODY_BF16(FILL4)) }
             else if constexpr (K == 6) { REP4(BODY_BF16(FILL6)) } else if constexpr (K == 8) { REP4(BODY_BF16(FILL8)) }
             else if constexpr (K == 12) { REP4(BODY_BF16(FILL12)) } else { REP4(BODY_BF16(FILL16)) }
+        } else if constexpr (KIND == 3) {
+            if constexpr (K == 1) { REP4(BODY_LDS(LFILL1)) } else if constexpr (K == 2) { REP4(BODY_LDS(LFILL2)) } else { REP4(BODY_LDS(LFILL4)) }
+        } else if constexpr (KIND == 4) {
+            // roles: waves 0..3 of the workgroup issue MFMAs only, waves 4..7 the K fillers per group only (two waves per SIMD)
+            if (tid < 256) { REP4(BODY_F32(FILL0)) }
+            else if constexpr (K == 2) { REP4(BODY_NONE(FILL2)) } else if constexpr (K == 4) { REP4(BODY_NONE(FILL4)) }
+            else if constexpr (K == 8) { REP4(BODY_NONE(FILL8)) } else { REP4(BODY_NONE(FILL16)) }
         } else {
             if constexpr (K == 1) { REP4(BODY_NONE(FILL1)) } else if constexpr (K == 2) { REP4(BODY_NONE(FILL2)) }
             else if constexpr (K == 4) { REP4(BODY_NONE(FILL4)) } else if constexpr (K == 6) { REP4(BODY_NONE(FILL6)) }
@@ -126,6 +145,15 @@ int main() {
         run<1, 4>("v_mfma_f32_16x16x32_bf16", w, d_out, d_cyc, n_cu);
         run<1, 6>("v_mfma_f32_16x16x32_bf16", w, d_out, d_cyc, n_cu);
         run<1, 8>("v_mfma_f32_16x16x32_bf16", w, d_out, d_cyc, n_cu);
+        run<3, 1>("f32 MFMA + K ds_read_b32", w, d_out, d_cyc, n_cu);
+        run<3, 2>("f32 MFMA + K ds_read_b32", w, d_out, d_cyc, n_cu);
+        run<3, 4>("f32 MFMA + K ds_read_b32", w, d_out, d_cyc, n_cu);
+        if (w == 2) {
+            run<4, 2>("roles: MFMA wave | VALU wave", w, d_out, d_cyc, n_cu);
+            run<4, 4>("roles: MFMA wave | VALU wave", w, d_out, d_cyc, n_cu);
+            run<4, 8>("roles: MFMA wave | VALU wave", w, d_out, d_cyc, n_cu);
+            run<4, 16>("roles: MFMA wave | VALU wave", w, d_out, d_cyc, n_cu);
+        }
         run<2, 4>("(no MFMA)", w, d_out, d_cyc, n_cu);
         run<2, 8>("(no MFMA)", w, d_out, d_cyc, n_cu);
         run<2, 16>("(no MFMA)", w, d_out, d_cyc, n_cu);
