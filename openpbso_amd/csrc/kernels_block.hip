@@ -908,10 +908,12 @@ int launch_iir_block(const IirParams &p, int n_teams, int R, int W, int qnm, int
     if (p.frames != 1 + 2 * GROUP) return (int)hipErrorInvalidValue;      // the ring holds two groups (513 samples)
     const bool qn = qnm != 0;
     switch (R) {
+#ifndef PBSO_ONLY_R4          // (tests/test_kernel_asm_guards.py compiles the R = 4 builds alone: the headline shape's)
     case 1: return launch_r<1>(p, n_teams, W, qn, proj, s);
     case 2: return launch_r<2>(p, n_teams, W, qn, proj, s);
-    case 4: return launch_r<4>(p, n_teams, W, qn, proj, s);
     case 8: return launch_r<8>(p, n_teams, W, qn, proj, s);
+#endif
+    case 4: return launch_r<4>(p, n_teams, W, qn, proj, s);
     }
     return (int)hipErrorInvalidValue;
 }

@@ -38,3 +38,63 @@ def test_iir_kernel_generated_code(tmp_path):
     m = re.search(r"\.name:\s+_ZN4pbso10iir_scalar15iir_bank_kernelILi2ELi0ELi1ELi256E.*?\.vgpr_count:\s+(\d+)", meta, re.S)
     if m:
         assert int(m.group(1)) <= 128                            # 4 waves per SIMD need <= 128 VGPRs
+
+
+@pytest.fixture(scope="module")
+def block_asm(tmp_path_factory):
+    """kernels_block.hip -> gfx950 assembly, the R = 4 builds only (-DPBSO_ONLY_R4: the headline shape's; ~30 s)"""
+    out = tmp_path_factory.mktemp("kb") / "kb.s"
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-DPBSO_ONLY_R4",
+                    "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+                    os.path.join(CSRC, "kernels_block.hip"), "-o", str(out)], check=True, capture_output=True)
+    asm = open(out).read()
+    kernels = {}
+    for k in re.split(r"\n(?=_ZN4pbso9iir_block16iir_block_kernel\S*:)", asm)[1:]:
+        t = re.search(r"ILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)ELb(\d)E", k.split(":")[0])
+        # key: (R, QNM, PROJ, DUMP, FORCED)
+        kernels[tuple(int(t.group(i)) for i in (1, 2, 3, 4, 6))] = k.split("s_endpgm")[0]
+    return asm, kernels
+
+
+def _meta(asm, mangled_part):
+    meta = asm[asm.find(".amdgpu_metadata"):]
+    m = re.search(r"\.name:\s+_ZN4pbso9iir_block16iir_block_kernel" + mangled_part + r".*?\.private_segment_fixed_size:\s+(\d+).*?"
+                  r"\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", meta, re.S)
+    return tuple(int(x) for x in m.groups())
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
+def test_block_kernel_generated_code(block_asm):
+    """K1b, the kernel behind the headline: the f32 build <R=4, qnorm, f32 projection> and the split-bf16 build keep
+    0 bytes of scratch and <= 256 VGPRs (two waves per SIMD), the matrix work per buffer is the count the roofline prices
+    (8 slices x 32 = 256 v_mfma_f32_16x16x4_f32; 8 x 12 = 96 v_mfma_f32_16x16x32_bf16), the LDS-DMA of a direct hit sets M0 right
+    before every global_load_lds_dword and nothing else touches M0, and the coarse step stays on full-rate instructions."""
+    asm, kernels = block_asm
+    assert len(kernels) == 8
+    f32 = kernels[(4, 2, 0, 0, 0)]
+    f32_noqn = kernels[(4, 0, 0, 0, 0)]
+    bf16 = kernels[(4, 2, 1, 0, 0)]
+    for part in ("ILi4ELi2ELi0ELb0ELi512ELb0E", "ILi4ELi0ELi0ELb0ELi512ELb0E", "ILi4ELi2ELi1ELb0ELi512ELb0E", "ILi4ELi0ELi1ELb0ELi512ELb0E"):
+        scratch, vgprs, spilled = _meta(asm, part)
+        assert scratch == 0 and spilled == 0 and vgprs <= 256, (part, scratch, vgprs, spilled)
+    for body in (f32, f32_noqn, bf16):
+        assert "scratch_" not in body
+    # matrix instructions of ONE buffer body (the slice pipeline is fully unrolled; the per-sample path has none)
+    assert len(re.findall(r"\bv_mfma_f32_16x16x4_f32\b", f32)) == 256 and "v_mfma_f32_16x16x32_bf16" not in f32
+    assert len(re.findall(r"\bv_mfma_f32_16x16x32_bf16\b", bf16)) == 96 and "v_mfma_f32_16x16x4_f32" not in bf16
+    # the forced block path (dense force profiles) adds its own: per group R x 32 + 4 (FIR), + R x 32 for the taps
+    forced = kernels[(4, 2, 0, 0, 1)]
+    assert len(re.findall(r"\bv_mfma_f32_16x16x4_f32\b", forced)) == 256 + 2 * (4 * 32 + 4) + 4 * 32
+    for body in kernels.values():
+        lines = body.splitlines()
+        m0 = [i for i, l in enumerate(lines) if re.search(r"\bm0\b", l) and not l.strip().startswith(";")]
+        dma = [i for i, l in enumerate(lines) if "global_load_lds_dword" in l]
+        assert dma and len(m0) == len(dma)
+        assert all("s_mov_b32 m0" in lines[i] for i in m0)
+        assert all(i - 1 in m0 for i in dma)                       # M0 (the LDS address) is written right before its load
+        # no half-rate packed arithmetic or bf16 conversion anywhere near the recurrence (profiles/r02_valu_issue.txt): the only packed
+        # ops are the few v_pk_add_f32 that add accumulator pairs
+        assert not re.search(r"\bv_pk_(fma|mul)_f32\b", body) and "v_cvt_pk_bf16" not in body
+        assert len(re.findall(r"\bv_pk_add_f32\b", body)) <= 16
+    # descriptors come through scalar loads (one s_load_dwordx8 per BufDesc)
+    assert "s_load_dwordx8" in f32 and "s_load_dwordx8" in bf16
