@@ -48,13 +48,15 @@ def test_config3_64x256_moving_listener_full_size():
     print(f"C3 full size: max/peak {mx:.2e} relL2 {l2:.2e}")
 
 
-def test_config4_1024x512_impulse_stream_full_size():
+@pytest.mark.parametrize("form", [capi.FORM_BLOCK, capi.FORM_BLOCK_BF16])
+def test_config4_1024x512_impulse_stream_full_size(form):
     """configs[3] on one GPU: 1024 objects x 512 modes x 86 buffers, Poisson PointForce stream with on-device
-    vertex projection -- the shape bench.py times (R = 4, two-wave teams, four teams per CU).  24 objects spread
+    vertex projection -- the shape bench.py times (R = 4, two-wave teams, four teams per CU), in BOTH block forms (the f32
+    projection bench.py reports as `value`, and the split-bf16 projection of its mixed-precision leg).  24 objects spread
     over the id range go through the oracle; `emitted` is checked for all 1024."""
     n_obj, M = 1024, 512
     lams, shapes, scripts = [], [], []
-    with Engine(qnorm=capi.QNORM_ALL) as eng:
+    with Engine(qnorm=capi.QNORM_ALL, form=form) as eng:
         for i in range(n_obj):
             seed = synth.seed_for(4, i)
             lams.append(synth.eigenvalues(M, seed))
@@ -79,7 +81,7 @@ def test_config4_1024x512_impulse_stream_full_size():
         rng = np.random.default_rng(4)
         sample = sorted(set([0, 1, 511, 512, 1022, 1023] + rng.integers(0, n_obj, 18).tolist()))
         qn_got = {(k, b): eng.qnorm(i, b).copy() for k, i in enumerate(sample) for b in (0, 40, 85)}
-    assert info["recurrence_form"] in BLOCK_FORMS and info["modes_per_lane"] == 4 and info["n_teams"] == 1024
+    assert info["recurrence_form"] == form and info["modes_per_lane"] == 4 and info["n_teams"] == 1024
     assert emitted.all() and emitted.shape == (n_obj, NB)
     objs = [ObjSpec(lams[i], shapes=shapes[i]) for i in sample]
     evs = []
@@ -91,8 +93,10 @@ def test_config4_1024x512_impulse_stream_full_size():
     mx, l2 = _assert_parity(audio[sample], want["audio"], "1024x512 impulses")
     for key, g in qn_got.items():
         w = want["qnorm"][key]
-        assert np.abs(g[:M] - w).max() <= 2e-3 * np.abs(w).max(), key
-    print(f"C4 full size: {len(sample)} objects, max/peak {mx:.2e} relL2 {l2:.2e}")
+        assert np.abs(g[:M] - w).max() <= 5e-4 * np.abs(w).max(), key
+    # measured: 9e-6 (f32 projection), 2e-5 (split bf16); the stated tolerance is 5e-4
+    assert mx <= (2e-5 if form == capi.FORM_BLOCK else 5e-5), mx
+    print(f"C4 full size, form {form}: {len(sample)} objects, max/peak {mx:.2e} relL2 {l2:.2e}")
 
 
 def test_config5_8x4096_sustained_scraping_full_size():

@@ -104,14 +104,14 @@ def _run_seed(seed, size_choices, engine_kw, projected_hits=False):
     assert (mx <= 5e-4).all() and (l2 <= 1e-3).all(), (mx, l2)
     for a, w in zip(got["latest"], want["latest"]):
         assert np.array_equal(a, w)
-    # qnorm: 2e-3 of the buffer's largest entry, plus 2e-6 of the object's peak over the run -- the ringing
+    # qnorm: 5e-4 of the buffer's largest entry, plus 2e-6 of the object's peak over the run -- the ringing
     # left behind by a smooth (Gaussian) pulse is a 1e-4 residue of the response during the pulse, and
     # fp32 resolves it only relative to that response (seed 519)
     peak = {}
     for (oi, _), w in want["qnorm"].items():
         peak[oi] = max(peak.get(oi, 0.0), float(np.abs(w).max()))
     for key, w in want["qnorm"].items():
-        tol = 2e-3 * max(np.abs(w).max(), 1e-30) + 2e-6 * peak[key[0]]
+        tol = 5e-4 * max(np.abs(w).max(), 1e-30) + 2e-6 * peak[key[0]]
         assert np.abs(got["qnorm"][key] - w).max() <= tol, key
 
 

@@ -48,9 +48,9 @@ def test_config1_wine_glass_one_impulse():
     # qnorm (getQBufferNorm) and integrator state too
     for b in (0, 1, NB - 1):
         q_got, q_want = got["qnorm"][(0, b)], want["qnorm"][(0, b)]
-        assert np.abs(q_got - q_want).max() <= 2e-3 * np.abs(q_want).max()
+        assert np.abs(q_got - q_want).max() <= 5e-4 * np.abs(q_want).max()
     for a, w in zip(got["state"][0], want["state"][0]):
-        assert np.abs(a - w).max() <= 2e-3 * max(np.abs(want["state"][0][0]).max(), 1e-300)
+        assert np.abs(a - w).max() <= 5e-4 * max(np.abs(want["state"][0][0]).max(), 1e-300)
 
 
 @pytest.mark.parametrize("mpl", [1, 2, 3, 4])
@@ -149,7 +149,7 @@ def test_size_classes_mixed_team_shapes():
         for b in (0, 5, 8):
             for i in range(len(sizes)):
                 w = want["qnorm"][(i, b)]
-                assert np.abs(got["qnorm"][(i, b)] - w).max() <= 2e-3 * max(np.abs(w).max(), 1e-30)
+                assert np.abs(got["qnorm"][(i, b)] - w).max() <= 5e-4 * max(np.abs(w).max(), 1e-30)
 
 
 @pytest.mark.parametrize("device_profiles", ["1", "0"])
@@ -323,9 +323,9 @@ def test_transfer_weights_outside_the_scaled_state_range():
         assert np.array_equal(got["latest"][0], want["latest"][0])
         for b in range(nb):
             w = want["qnorm"][(0, b)]
-            assert np.abs(got["qnorm"][(0, b)] - w).max() <= 2e-3 * max(np.abs(w).max(), 1e-30)
+            assert np.abs(got["qnorm"][(0, b)] - w).max() <= 5e-4 * max(np.abs(w).max(), 1e-30)
         q1, q2 = got["state"][0]
-        np.testing.assert_allclose(q1, want["state"][0][0], rtol=0, atol=2e-3 * np.abs(want["state"][0][0]).max())
+        np.testing.assert_allclose(q1, want["state"][0][0], rtol=0, atol=5e-4 * np.abs(want["state"][0][0]).max())
 
 
 def test_force_script_batch_enqueue_matches_single_calls():
@@ -410,9 +410,9 @@ def test_objects_split_over_several_teams():
         for i in range(3):
             for b in (0, 3, 6):
                 w = want["qnorm"][(i, b)]
-                assert np.abs(got["qnorm"][(i, b)] - w).max() <= 2e-3 * max(np.abs(w).max(), 1e-30)
+                assert np.abs(got["qnorm"][(i, b)] - w).max() <= 5e-4 * max(np.abs(w).max(), 1e-30)
             np.testing.assert_allclose(got["state"][i][0], want["state"][i][0], rtol=0,
-                                       atol=2e-3 * np.abs(want["state"][i][0]).max())
+                                       atol=5e-4 * np.abs(want["state"][i][0]).max())
         assert np.array_equal(got["latest"][1], want["latest"][1])
         if mpl == 0:
             ref = got["audio"]
@@ -532,7 +532,7 @@ def test_qnorm_closed_form_matches_per_sample_and_oracle(form):
     c = run_engine(objs, evs, nb, qnorm=capi.QNORM_CLOSED, form=form)
     want = run_oracle(objs, evs, nb)
     assert np.array_equal(a["audio"], c["audio"])
-    tol = 2e-3 if form == capi.FORM_VELOCITY else 3e-2
+    tol = 5e-4 if form == capi.FORM_VELOCITY else 3e-2
     for b in range(nb):
         w = want["qnorm"][(0, b)]
         scale = np.abs(w).max()
@@ -859,3 +859,31 @@ def test_compute_transfer_batch_chunks_large_maps_and_reused_output():
                 eng.compute_transfer(oid, pos[i], 0)
                 eng.step(1)
                 assert np.array_equal(eng.latest_transfer(oid), keep[i])
+
+
+def test_split_bf16_projection_carries_no_bias_against_the_f32_projection():
+    """The split-bf16 projection TRUNCATES both bf16 parts of every block-start state, which loses (7.2 +- 6.4)e-6 of a value on
+    average; the mean is folded into the operand table by the host (kernels.h TRUNC_SPLIT_GAIN).  Both block forms run the SAME
+    f32 recurrence, so the difference of their outputs isolates the projection: the signed mean of (bf16 - f32) / |f32| over the
+    loud samples must vanish.  Without the constant it is -7e-6; states with mantissas near 1.0 lose 7.6e-6 on average and
+    states near 2.0 half of that, so the residue of any ONE distribution stays within +-4e-6.  Three kinds of spectra: one
+    dominant mode (a single mantissa sweeping as the mode decays), a few modes, and the headline's dense random spectrum."""
+    nb = 6
+    rng = np.random.default_rng(1234)
+    cases = []
+    for n_modes, n_hot in ((128, 1), (128, 5), (512, 512)):
+        lam = synth.eigenvalues(n_modes, 4000 + n_hot)
+        d = np.zeros(n_modes)
+        hot = rng.choice(n_modes // 2, n_hot, replace=False) if n_hot < n_modes else np.arange(n_modes)
+        d[hot] = rng.standard_normal(hot.size) * 1e-3
+        cases.append((lam, d))
+    for lam, d in cases:
+        objs = [ObjSpec(lam)]
+        evs = [force_ev(0, 0, data=d), dict(t=0, obj=0, kind="use_transfer", use=False)]
+        f32 = run_engine(objs, evs, nb, form=capi.FORM_BLOCK)["audio"][0].astype(np.float64)
+        b16 = run_engine(objs, evs, nb, form=capi.FORM_BLOCK_BF16)["audio"][0].astype(np.float64)
+        loud = np.abs(f32) > 0.05 * np.abs(f32).max()
+        rel = (b16[loud] - f32[loud]) / np.abs(f32[loud]) * np.sign(f32[loud])
+        assert loud.sum() > 200
+        assert abs(rel.mean()) <= 4e-6, rel.mean()                 # (-7.2e-6 without the gain)
+        assert np.abs(b16 - f32).max() <= 5e-5 * np.abs(f32).max()
