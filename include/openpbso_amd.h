@@ -254,6 +254,11 @@ int pbso_read_emitted(pbso_engine *e, unsigned char *host_out, size_t n);
 int pbso_read_qnorm(pbso_engine *e, int object_id, int buffer, float *host_out, int n);
 /* integrator state after the last step: q_{k-1}, q_{k-2} (modal_integrator.h:24) */
 int pbso_read_state(pbso_engine *e, int object_id, double *q1, double *q2, int n);
+/* the counterpart (checkpoint / resume: the reference has none; its integrator state is the ring
+ * _q[3] of modal_integrator.h:24,29): sets q_{k-1}, q_{k-2} of the first n modes of an object (rounded once to
+ * fp32; modes beyond n keep their state).  Force lists, queues and the transfer in effect are not part of it:
+ * a resumed run re-sends its pending messages.  Waits for the launches in flight.                              */
+int pbso_write_state(pbso_engine *e, int object_id, const double *q1, const double *q2, int n);
 void *pbso_audio_device_ptr(pbso_engine *e);
 
 /* PaModalCallback body (tools/real_time_modal_sound.cpp:207-210): mono sound

@@ -23,7 +23,7 @@ EXPORTS = [
     "pbso_object_read_ffat_maps", "pbso_fatcube_parse", "pbso_ffat_map_free", "pbso_finalize",
     "pbso_enqueue_force", "pbso_enqueue_force_batch", "pbso_enqueue_arprm", "pbso_compute_transfer", "pbso_compute_transfer_batch", "pbso_object_n_maps", "pbso_listeners_enable", "pbso_mix_listeners",
     "pbso_set_use_transfer", "pbso_get_latest_transfer", "pbso_step", "pbso_step_into", "pbso_sync",
-    "pbso_read_audio", "pbso_read_emitted", "pbso_read_qnorm", "pbso_read_state",
+    "pbso_read_audio", "pbso_read_emitted", "pbso_read_qnorm", "pbso_read_state", "pbso_write_state",
     "pbso_audio_device_ptr", "pbso_pa_convert", "pbso_get_info",
     "pbso_modes_read", "pbso_num_modes_audible", "pbso_material_read", "pbso_free", "pbso_read_census", "pbso_obj_read",
 ]
@@ -118,6 +118,7 @@ def lib():
     l.pbso_read_emitted.argtypes = [vp, C.POINTER(C.c_ubyte), C.c_size_t]
     l.pbso_read_qnorm.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]
     l.pbso_read_state.argtypes = [vp, C.c_int, dp, dp, C.c_int]
+    l.pbso_write_state.argtypes = [vp, C.c_int, dp, dp, C.c_int]
     l.pbso_audio_device_ptr.restype = vp
     l.pbso_audio_device_ptr.argtypes = [vp]
     l.pbso_pa_convert.argtypes = [C.POINTER(C.c_float), C.c_ulong, C.POINTER(C.c_float)]

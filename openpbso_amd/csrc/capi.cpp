@@ -394,6 +394,14 @@ int pbso_read_state(pbso_engine *e, int obj, double *q1, double *q2, int n) {
     GUARD_END(e)
 }
 
+int pbso_write_state(pbso_engine *e, int obj, const double *q1, const double *q2, int n) {
+    NEED(e);
+    if (!q1 || !q2) return PBSO_ERR_INVALID;
+    GUARD_BEGIN
+    return e->impl->write_state(obj, q1, q2, n);
+    GUARD_END(e)
+}
+
 void *pbso_audio_device_ptr(pbso_engine *e) {
     if (!e || !e->impl) return nullptr;
     return e->impl->audio_ptr();

@@ -258,7 +258,7 @@ Engine::~Engine() {
     d_ca_.release(); d_cb_.release(); d_sq_.release(); d_sd_.release(); d_ss_.release(); d_c3_.release(); d_gq_.release();
     d_shapes_.release(); d_shape_off_.release(); d_g32_.release(); d_g32_off_.release(); d_n_modes_.release(); d_geom_.release();
     d_geom_off_.release(); d_psi_.release(); d_slots_.release(); d_xfer_.release();
-    d_pc_.release(); d_wtab_.release(); d_dump_row_.release(); d_xdump_.release(); d_xscale_.release(); d_wtab32_.release();
+    d_pc_.release(); d_wtab_.release(); d_ftab_.release(); d_dump_row_.release(); d_xdump_.release(); d_xscale_.release(); d_wtab32_.release();
     d_arstate_.release(); d_board_.release(); d_teams_.release(); d_split_.release(); d_audio_parts_.release();
     d_audio_.release(); d_qnorm_.release(); d_grows_[0].release(); d_grows_[1].release(); d_census_.release();
     for (hipEvent_t ev : {ev_prep_done_[0], ev_prep_done_[1], ev_k1_done_[0], ev_k1_done_[1]})
@@ -708,6 +708,30 @@ int Engine::finalize() {
         }
         HIPTRY(d_pc_.ensure(4 * nm));
         HIPTRY(hipMemcpy(d_pc_.p, pc.data(), 4 * nm * sizeof(float), hipMemcpyHostToDevice));
+        if (form_ == PBSO_FORM_BLOCK && R_ <= 2 && forced_block_) {
+            // Forced block path without qnorm rows (kernels_block.hip, FT): a force sample f enters the state as f u, u = (1, 1)'
+            // (d += f, q += d), so the samples 16 n + i, i = 1..16, of a dense profile move the next block-start state by
+            // sum_i A^(16 - i) u f_i.  Plane 2 i' + c holds component c of A^(15 - i') u, i' = 0..15, per mode (fp64, rounded once).
+            // Engines with more than two modes per lane keep the per-sample path (no registers left for 32 constants per mode).
+            std::vector<float> ft((size_t)32 * nm, 0.f);
+            for (int i = 0; i < N; ++i) {
+                const Object &o = objs_[i];
+                for (int m = 0; m < o.n_modes; ++m) {
+                    const double eps2 = -o.c2[m], e = (1.0 - o.c1[m]) - o.c2[m];
+                    double v0 = 1.0, v1 = 1.0;                              // A^delta u, delta = 0, 1, ...
+                    const size_t k = (size_t)i * m_pad_ + m;
+                    for (int delta = 0; delta < BLOCK_J; ++delta) {
+                        const int ip = BLOCK_J - 1 - delta;                // in-block sample index (0-based) this power belongs to
+                        ft[(size_t)(2 * ip) * nm + k] = (float)v0;
+                        ft[(size_t)(2 * ip + 1) * nm + k] = (float)v1;
+                        const double n0 = (1.0 - e) * v0 + eps2 * v1, n1 = -e * v0 + eps2 * v1;
+                        v0 = n0; v1 = n1;
+                    }
+                }
+            }
+            HIPTRY(d_ftab_.ensure(ft.size()));
+            HIPTRY(hipMemcpy(d_ftab_.p, ft.data(), ft.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         HIPTRY(d_wtab_.ensure(wt.size()));
         HIPTRY(hipMemcpy(d_wtab_.p, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
     }
@@ -1654,6 +1678,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.pc = d_pc_.p;
     kp.wtab = d_wtab_.p;
     kp.frames = B_;
+    kp.ftab = d_ftab_.p;
     kp.forced_block = (forced_block_ && n_prows_ > 0) ? 1 : 0;      // (the build with the forced block path only when a buffer needs it)
     if (timed) HIPTRY(hipEventRecord(evq.k0, sk));
     kp.audio_parts = n_part_rows_ ? d_audio_parts_.p + (size_t)b0 * B_ : nullptr;
@@ -1773,6 +1798,27 @@ int Engine::read_state(int obj, double *q1, double *q2, int n) {
         q2[i] = form_ != PBSO_FORM_DIRECT ? qa - qb : qb;
     }
     return PBSO_OK;
+}
+
+// Restore of the integrator state (the pair pbso_read_state returns): stored unscaled (scale 1), in the form's
+// own variables -- (q_{k-1}, q_{k-1} - q_{k-2}) for the velocity and block forms, (q_{k-1}, q_{k-2}) for the direct form.
+int Engine::write_state(int obj, const double *q1, const double *q2, int n) {
+    if (!finalized_) return fail(PBSO_ERR_STATE, "write_state before finalize");
+    if (!valid_obj(obj) || n < 0 || n > objs_[obj].n_modes) return fail(PBSO_ERR_INVALID, "write_state arguments");
+    if (failed_) return fail(PBSO_ERR_STATE, "an earlier step failed half-way: create a new engine");
+    HIPTRY(hipSetDevice(desc_.device));
+    int rc = sync();
+    if (rc) return rc;
+    std::vector<float> a(n), b(n), sc(n, 1.f);
+    for (int i = 0; i < n; ++i) {
+        a[i] = (float)q1[i];
+        b[i] = form_ != PBSO_FORM_DIRECT ? (float)(q1[i] - q2[i]) : (float)q2[i];
+    }
+    const size_t off = (size_t)obj * m_pad_;
+    HIPTRY(hipMemcpyAsync(d_sq_.p + off, a.data(), n * sizeof(float), hipMemcpyHostToDevice, stream_));
+    HIPTRY(hipMemcpyAsync(d_sd_.p + off, b.data(), n * sizeof(float), hipMemcpyHostToDevice, stream_));
+    HIPTRY(hipMemcpyAsync(d_ss_.p + off, sc.data(), n * sizeof(float), hipMemcpyHostToDevice, stream_));
+    return sync();
 }
 
 // ModalSolver::getLatestTransfer, modal_solver.h:145-147

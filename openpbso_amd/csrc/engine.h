@@ -192,6 +192,7 @@ public:
     int read_emitted(unsigned char *out, size_t n);
     int read_qnorm(int obj, int buffer, float *out, int n);
     int read_state(int obj, double *q1, double *q2, int n);
+    int write_state(int obj, const double *q1, const double *q2, int n);
     void *audio_ptr() { return last_audio_; }
     int read_census(unsigned long long *out, size_t n);
     int info(pbso_engine_info *out);
@@ -256,6 +257,7 @@ private:
     bool dump_rows_dirty_ = false;
     DevBuf<int> d_dump_row_;
     DevBuf<float> d_xdump_, d_xscale_, d_wtab32_;
+    DevBuf<float> d_ftab_;                               // forced block path: A^(15-i) u per mode (engines with <= 2 modes per lane)
     DevBuf<float> d_pc_, d_wtab_;                        // block form: P = A^16 planes and the MFMA W table (kernels_block.hip)
     bool is_block() const { return form_ == PBSO_FORM_BLOCK || form_ == PBSO_FORM_BLOCK_BF16; }
     int form_ = PBSO_FORM_BLOCK;                         // the form that runs (block falls back to velocity for odd buffer lengths)

@@ -81,6 +81,7 @@ struct IirParams {
     const float *pc;             // planes P11 - 1, P12, P21, P22 of P = A^16 in the (q, q - q_prev) basis, each [n_obj][m_pad] (stride gq_plane)
     const float *wtab;           // [n_obj * m_pad / 2][64]: MFMA A operand per pair of columns (a_j, b_j of both modes, j = 1..16)
     int frames;                  // samples per buffer
+    const float *ftab;           // forced block path: 32 planes [n_obj][m_pad] (stride gq_plane): A^(15-i) u, i = 0..15, components (q, d)
     int forced_block;            // block form, f32 projection: dense-profile buffers run in block form too (kernels_block.hip)
     // multi-listener mix: objects with dump_row[obj] >= 0 keep their block-start states (nullptr: nobody does)
     float *xdump;                // [n_dump][qn_nb][32][m_pad] pairs (Q, D), scaled as the registers hold them

@@ -186,6 +186,8 @@ __global__ __launch_bounds__(K2_THREADS) void force_profile_kernel(
     // is needed and at the end of the chain.
     int cached = -1;
     ArState s;
+    double mpow[6][4];                                         // AR(2) scan: powers of the L-sample matrix (valid while a0, a1 stand)
+    bool pow_valid = false;
     // (a row's descriptor and its first entry are fetched a row ahead: two dependent misses -- the plan has just
     //  arrived from the host -- cost more than the row's arithmetic)
     const int ri_end = chain_ptr[c + 1];
@@ -217,7 +219,9 @@ __global__ __launch_bounds__(K2_THREADS) void force_profile_kernel(
                     __syncthreads();
                     s = states[e.state];
                     cached = e.state;
+                    pow_valid = false;
                 }
+                if (e.flags & 3) pow_valid = false;
                 if (e.flags & 1) {                                             // default-constructed, forces.h:73-76
                     s.x = 1u; s.saved_available = 0; s.saved = 0.0;
                     s.buf[0] = s.buf[1] = s.buf[2] = 0.0; s.buf_idx = 0;
@@ -236,6 +240,9 @@ __global__ __launch_bounds__(K2_THREADS) void force_profile_kernel(
                 __syncthreads();
                 uint32_t xb = s.x;                                              // state before candidate K2_THREADS k
                 int acc_pairs = 0;
+#ifdef PBSO_K2_ABLATE_RNG
+                acc_pairs = pairs_needed;
+#endif
                 for (int batch = 0; acc_pairs < pairs_needed; ++batch) {
                     uint32_t st = mulmod31(xb, pj);                             // state before candidate K2_THREADS k + lane
                     const uint32_t d1 = (st = mulmod31(st, 16807u));
@@ -289,7 +296,11 @@ __global__ __launch_bounds__(K2_THREADS) void force_profile_kernel(
                 // critical path (LDS latency and the _buf index arithmetic are off it).
                 for (int ii = lane; ii < frames; ii += K2_THREADS) nrm[ii] = s.sigma * nrm[ii];
                 __syncthreads();
+#ifdef PBSO_K2_ABLATE_SCAN
+                if (false) {
+#else
                 if (!ar_serial && wv == 0) {
+#endif
                     // ---- AR(2) as a parallel scan (the default).  x_k = a0 x_{k-1} + a1 x_{k-2} + c_k is linear with
                     // constant coefficients within a row: lane l of wave 0 runs the recurrence over its L consecutive
                     // samples from a zero state (lane 0: from the force's history), a Kogge-Stone scan over the lanes
@@ -306,40 +317,49 @@ __global__ __launch_bounds__(K2_THREADS) void force_profile_kernel(
                     const int bidx = s.buf_idx;
                     const double h1 = bidx == 0 ? s.buf[2] : (bidx == 1 ? s.buf[0] : s.buf[1]);     // _buf[(idx + 3 - 1) % 3]
                     const double h2 = bidx == 0 ? s.buf[1] : (bidx == 1 ? s.buf[2] : s.buf[0]);     // _buf[(idx + 3 - 2) % 3]
+                    // (explicit fma: this file is built without contraction for the kernels that match the oracle bit for bit)
                     double y1 = l64 == 0 ? h1 : 0.0, y2 = l64 == 0 ? h2 : 0.0;
                     for (int j = 0; j < L; ++j) {
                         const int k = k0 + j;
-                        double v = a0 * y1;
-                        v += a1 * y2;
-                        if (k < frames) { v += nrm[k]; nrm[k] = v; }
+                        const double c = k < frames ? nrm[k] : 0.0;
+                        const double v = fma(a0, y1, fma(a1, y2, c));
+                        if (k < frames) nrm[k] = v;
                         y2 = y1;
                         y1 = v;
                     }
-                    // M = A^L
-                    double m00 = a0, m01 = a1, m10 = 1.0, m11 = 0.0;
-                    for (int i = 1; i < L; ++i) {
-                        const double n00 = m00 * a0 + m01, n01 = m00 * a1, n10 = m10 * a0 + m11, n11 = m10 * a1;
-                        m00 = n00; m01 = n01; m10 = n10; m11 = n11;
+                    // M^(2^i), M = A^L: the same for every lane and for every row until the parameters change
+                    if (!pow_valid) {
+                        double m00 = a0, m01 = a1, m10 = 1.0, m11 = 0.0;
+                        for (int i = 1; i < L; ++i) {
+                            const double n00 = fma(m00, a0, m01), n01 = m00 * a1, n10 = fma(m10, a0, m11), n11 = m10 * a1;
+                            m00 = n00; m01 = n01; m10 = n10; m11 = n11;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) {
+                            mpow[i][0] = m00; mpow[i][1] = m01; mpow[i][2] = m10; mpow[i][3] = m11;
+                            const double n00 = fma(m00, m00, m01 * m10), n01 = fma(m00, m01, m01 * m11);
+                            const double n10 = fma(m10, m00, m11 * m10), n11 = fma(m10, m01, m11 * m11);
+                            m00 = n00; m01 = n01; m10 = n10; m11 = n11;
+                        }
+                        pow_valid = true;
                     }
                     double b1 = y1, b2 = y2;                       // (x at the lane's last sample, the one before)
 #pragma unroll
-                    for (int d = 1; d < 64; d *= 2) {
+                    for (int i = 0; i < 6; ++i) {
+                        const int d = 1 << i;
                         const double t1 = __shfl_up(b1, d, 64), t2 = __shfl_up(b2, d, 64);
                         if (l64 >= d) {
-                            b1 += m00 * t1 + m01 * t2;
-                            b2 += m10 * t1 + m11 * t2;
+                            b1 = fma(mpow[i][0], t1, fma(mpow[i][1], t2, b1));
+                            b2 = fma(mpow[i][2], t1, fma(mpow[i][3], t2, b2));
                         }
-                        const double n00 = m00 * m00 + m01 * m10, n01 = m00 * m01 + m01 * m11;
-                        const double n10 = m10 * m00 + m11 * m10, n11 = m10 * m01 + m11 * m11;
-                        m00 = n00; m01 = n01; m10 = n10; m11 = n11;
                     }
                     const double s1 = __shfl_up(b1, 1, 64), s2 = __shfl_up(b2, 1, 64);      // the state entering this lane
                     if (l64 > 0) {
                         double al = a0, be = a1;                   // row 0 of A^(j+1)
                         for (int j = 0; j < L; ++j) {
                             const int k = k0 + j;
-                            if (k < frames) nrm[k] += al * s1 + be * s2;
-                            const double na = al * a0 + be, nb = al * a1;
+                            if (k < frames) nrm[k] = fma(al, s1, fma(be, s2, nrm[k]));
+                            const double na = fma(al, a0, be), nb = al * a1;
                             al = na; be = nb;
                         }
                     }

@@ -308,6 +308,13 @@ class Engine:
         self._chk(self._l.pbso_read_state(self._h, obj, _dp(q1), _dp(q2), n))
         return q1[:n], q2[:n]
 
+    def set_state(self, obj, q1, q2):
+        """pbso_write_state: restore (q_{k-1}, q_{k-2}) as state() returned them"""
+        a = np.ascontiguousarray(q1, dtype=np.float64)
+        b = np.ascontiguousarray(q2, dtype=np.float64)
+        assert a.size == b.size
+        self._chk(self._l.pbso_write_state(self._h, obj, _dp(a), _dp(b), a.size))
+
     def census(self):
         """per-workgroup (start, end [100 MHz ticks], HW_ID, XCC_ID, clock start/end, block form: cycles in head / pipeline / barrier / combine) of the last launch (PBSO_CENSUS=1)."""
         n = self.info()["n_teams"] * 12

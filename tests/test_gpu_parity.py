@@ -887,3 +887,51 @@ def test_split_bf16_projection_carries_no_bias_against_the_f32_projection():
         assert loud.sum() > 200
         assert abs(rel.mean()) <= 4e-6, rel.mean()                 # (-7.2e-6 without the gain)
         assert np.abs(b16 - f32).max() <= 5e-5 * np.abs(f32).max()
+
+
+@pytest.mark.parametrize("form", [capi.FORM_BLOCK, capi.FORM_BLOCK_BF16, capi.FORM_VELOCITY, capi.FORM_DIRECT])
+def test_state_restore_resumes_a_run(form):
+    """pbso_write_state (checkpoint / resume): a fresh engine given the state pbso_read_state returned after 5 buffers
+    continues like the engine that kept running (the state makes one extra fp64 -> fp32 round trip: not bit for bit), and like
+    the oracle; restoring part of the modes leaves the others untouched."""
+    from openpbso_amd import Engine
+    n_modes, nb1, nb2 = 200, 5, 6
+    lam = synth.eigenvalues(n_modes, 606)
+    rng = np.random.default_rng(606)
+    d0, d1 = rng.standard_normal(n_modes) * 1e-3, rng.standard_normal(n_modes) * 1e-3
+
+    def make():
+        eng = Engine(form=form)
+        eng.add_object(lam, synth.RHO, synth.ALPHA, synth.BETA)
+        eng.finalize()
+        eng.set_use_transfer(0, False)
+        return eng
+
+    with make() as a, make() as b:
+        assert a.enqueue_force(0, ForceMessage(data=d0), 0)
+        a.step(nb1)
+        q1, q2 = a.state(0)
+        assert np.abs(q1).max() > 0
+        assert a.enqueue_force(0, ForceMessage(data=d1), nb1 + 2)
+        a.step(nb2)
+        cont = a.audio()[0].astype(np.float64)
+        b.set_state(0, q1, q2)
+        r1, r2 = b.state(0)
+        np.testing.assert_allclose(r1, q1, rtol=2e-7, atol=0)
+        assert b.enqueue_force(0, ForceMessage(data=d1), 2)           # (a fresh engine counts its buffers from 0)
+        b.step(nb2)
+        resumed = b.audio()[0].astype(np.float64)
+        # (block / velocity forms: (q, q - q_prev) goes through fp64 and back: the difference is re-rounded once; the literal
+        #  direct form stores (q1, q2) themselves, but amplifies every rounding difference of the two runs' arithmetic: SURVEY B-4)
+        assert np.abs(resumed - cont).max() <= (2e-6 if form != capi.FORM_DIRECT else 2e-4) * np.abs(cont).max()
+        # a partial restore: the first 50 modes only
+        b.set_state(0, np.zeros(50), np.zeros(50))
+        p1, _ = b.state(0)
+        assert not p1[:50].any() and p1[50:].any()
+        with pytest.raises(Exception):
+            b.set_state(0, np.zeros(n_modes + 1), np.zeros(n_modes + 1))
+    want = run_oracle([ObjSpec(lam)], [force_ev(0, 0, data=d0), force_ev(nb1 + 2, 0, data=d1),
+                                       dict(t=0, obj=0, kind="use_transfer", use=False)], nb1 + nb2)
+    w = want["audio"][0][nb1 * B:]
+    tol = 5e-4 if form != capi.FORM_DIRECT else 2e-2      # (the literal direct form in fp32: SURVEY B-4)
+    assert np.abs(resumed - w).max() <= tol * np.abs(want["audio"][0]).max()
