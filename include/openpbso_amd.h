@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PBSO_ABI_VERSION 2
+#define PBSO_ABI_VERSION 3
 #define PBSO_SAMPLE_RATE 44100          /* config.h:13 */
 #define PBSO_FRAMES_PER_BUFFER 513      /* config.h:14 */
 
@@ -296,6 +296,8 @@ typedef struct pbso_engine_info {
     int64_t total_timed_launches;     /* launches whose HIP-event times are in total_kernel_ms / total_device_ms: all of
                                        * them, or every n-th with env PBSO_TIMING_EVERY=n (an event pair costs the
                                        * stream ~8 us per launch; 0 = none)                                           */
+    int64_t total_split_launches;     /* of the block launches, those on the time-split kernel K1s (kernels_split.hip): engines
+                                       * with less than one wave of oscillators per SIMD, two waves per 64 modes            */
 } pbso_engine_info;
 int pbso_get_info(pbso_engine *e, pbso_engine_info *out);
 /* diagnostics (engine created with env PBSO_CENSUS=1): for every object's

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBSO_LIB") or os.path.join(_HERE, "libopenpbso_amd.so")      # PBSO_LIB: A/B runs of two builds in one process tree
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_STATE, ERR_IO, ERR_MISSING_MAP, ERR_ASSERT, ERR_NOMEM = -1, -2, -3, -4, -5, -6, -7
 POINT_FORCE, GAUSSIAN_FORCE, AUTOREGRESSIVE_FORCE = 0, 1, 2
@@ -67,7 +67,7 @@ class EngineInfo(C.Structure):
                 ("total_kernel_ms", C.c_double), ("total_device_ms", C.c_double),
                 ("total_host_plan_ms", C.c_double), ("total_steps", C.c_int64), ("n_teams", C.c_int),
                 ("recurrence_form", C.c_int), ("total_block_launches", C.c_int64), ("total_sample_launches", C.c_int64),
-                ("total_timed_launches", C.c_int64)]
+                ("total_timed_launches", C.c_int64), ("total_split_launches", C.c_int64)]
 
 
 _lib = None

@@ -259,7 +259,7 @@ Engine::~Engine() {
     d_shapes_.release(); d_shape_off_.release(); d_g32_.release(); d_g32_off_.release(); d_n_modes_.release(); d_geom_.release();
     d_geom_off_.release(); d_psi_.release(); d_slots_.release(); d_xfer_.release();
     d_pc_.release(); d_wtab_.release(); d_ftab_.release(); d_dump_row_.release(); d_xdump_.release(); d_xscale_.release(); d_wtab32_.release();
-    d_arstate_.release(); d_board_.release(); d_teams_.release(); d_split_.release(); d_audio_parts_.release();
+    d_arstate_.release(); d_board_.release(); d_teams_.release(); d_split_.release(); d_ts_teams_.release(); d_ts_split_.release(); d_audio_parts_.release();
     d_audio_.release(); d_qnorm_.release(); d_grows_[0].release(); d_grows_[1].release(); d_census_.release();
     for (hipEvent_t ev : {ev_prep_done_[0], ev_prep_done_[1], ev_k1_done_[0], ev_k1_done_[1]})
         if (ev) (void)hipEventDestroy(ev);
@@ -600,6 +600,41 @@ int Engine::finalize() {
         if (n_split_) {
             HIPTRY(d_split_.ensure(split.size()));
             HIPTRY(hipMemcpy(d_split_.p, split.data(), split.size() * sizeof(SplitObj), hipMemcpyHostToDevice));
+        }
+    }
+
+    // K1s: fewer than one wave of oscillators per SIMD even with one mode per lane -- two waves per 64 modes share the
+    // time axis instead (kernels_split.hip).  f32 block form only; PBSO_SPLIT=0 keeps the one-wave-per-64-modes kernel.
+    {
+        split_ok_ = false;
+        const char *env = std::getenv("PBSO_SPLIT");
+        long long chunks = 0;
+        for (const Object &o : objs_) chunks += std::max(1, (o.n_modes + 63) / 64);
+        if (block && form_ == PBSO_FORM_BLOCK && R_ == 1 && 2 * chunks <= 4LL * n_cus_ && !(env && std::atoi(env) == 0)) {
+            std::vector<TeamDesc> ts;
+            std::vector<SplitObj> tsplit;
+            n_ts_part_rows_ = 0;
+            for (int i = 0; i < N; ++i) {
+                const int parts = std::max(1, (objs_[i].n_modes + 63) / 64);
+                if (parts > 1) {
+                    SplitObj so = {i, n_ts_part_rows_, parts, 0};
+                    tsplit.push_back(so);
+                }
+                for (int c = 0; c < parts; ++c) {
+                    TeamDesc td = {i, 64 * c, parts > 1 ? n_ts_part_rows_++ : -1, (int)ts.size()};
+                    ts.push_back(td);
+                }
+            }
+            n_ts_teams_ = (int)ts.size();
+            n_ts_split_ = (int)tsplit.size();
+            HIPTRY(d_ts_teams_.ensure(ts.size()));
+            HIPTRY(hipMemcpy(d_ts_teams_.p, ts.data(), ts.size() * sizeof(TeamDesc), hipMemcpyHostToDevice));
+            if (n_ts_split_) {
+                HIPTRY(d_ts_split_.ensure(tsplit.size()));
+                HIPTRY(hipMemcpy(d_ts_split_.p, tsplit.data(), tsplit.size() * sizeof(SplitObj), hipMemcpyHostToDevice));
+            }
+            split_ok_ = true;
+            split_always_ = env && std::atoi(env) == 2;
         }
     }
 
@@ -1025,7 +1060,7 @@ int Engine::plan_object(PlanCtx &c, int oi, int b, int nb, int64_t t) {
         plain_hit = m0.force_type == PBSO_POINT_FORCE && !m0.clear_all && !m0.sustained_start && !m0.sustained_end &&
                     (m0.data_kind == PBSO_DATA_VERTEX || m0.data_kind == PBSO_DATA_FACE);
     }
-    if (plain_hit && direct_hits_ && o.force_q.front().data_kind == PBSO_DATA_VERTEX && 3 * o.force_q.front().vids[0] + 2 < o.n_dof) {
+    if (plain_hit && direct_hits_ && !use_split() && o.force_q.front().data_kind == PBSO_DATA_VERTEX && 3 * o.force_q.front().vids[0] + 2 < o.n_dof) {
         // ... and when the hit is at a vertex, not even a row: the oscillator bank dots the hit's normal with three rows
         // of the object's (float)(c3 * shape) table itself (DESC_DIRECT).  No work for any preparation kernel.
         const HostForceMsg &m0 = o.force_q.front();
@@ -1484,7 +1519,11 @@ int Engine::step(int nb, void *d_audio_user) {
         dump_nb_ = nb;
         std::fill(dump_valid_.begin(), dump_valid_.end(), 1);
     }
-    if (n_part_rows_) HIPTRY(d_audio_parts_.ensure((size_t)n_part_rows_ * nb * B_, false, stream_));
+    {
+        // (a step's launches may run on different kernels: room for either kind's partial rows)
+        const int rows = std::max(use_split() ? n_ts_part_rows_ : 0, n_part_rows_);
+        if (rows) HIPTRY(d_audio_parts_.ensure((size_t)rows * nb * B_, false, stream_));
+    }
     emitted_.assign((size_t)N * nb, 1);
     const int64_t step_id = tot_steps_;
     double plan_ms = 0;
@@ -1498,7 +1537,6 @@ int Engine::step(int nb, void *d_audio_user) {
         }
         plan_ms += last_plan_ms_;
     }
-    LAUNCHTRY(launch_sum_parts(d_split_.p, n_split_, d_audio_parts_.p, audio, (long long)nb * B_, stream_));
     last_plan_ms_ = plan_ms;
     tot_plan_ms_ += plan_ms;
     tot_steps_ += 1;
@@ -1681,7 +1719,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.ftab = d_ftab_.p;
     kp.forced_block = (forced_block_ && n_prows_ > 0) ? 1 : 0;      // (the build with the forced block path only when a buffer needs it)
     if (timed) HIPTRY(hipEventRecord(evq.k0, sk));
-    kp.audio_parts = n_part_rows_ ? d_audio_parts_.p + (size_t)b0 * B_ : nullptr;
+    kp.audio_parts = d_audio_parts_.p ? d_audio_parts_.p + (size_t)b0 * B_ : nullptr;
     // Side by side only while everything is resident at once (largest teams first, on the engine's
     // stream); an engine that needs several rounds of workgroups runs its classes one after the other
     // (512 x 512 + 4096 x 64: 3.1 ms in sequence, 3.7 ms side by side -- teams of different size fragment
@@ -1692,7 +1730,13 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     // rules are shared, so the two kernels hand over at any launch boundary.  (Audio then is bit-identical
     // across different cuts of a step only while both cuts pick the same kernel; always within tolerance.)
     // PBSO_DENSE_LAUNCHES=block keeps every launch on the block kernel (bit-identical audio for any cut of a step).
-    (dense_heavy || !is_block() ? tot_sample_launches_ : tot_block_launches_) += 1;
+    // K1s takes the launch unless most of its (object, buffer) pairs carry a dense force profile (sustained scraping): there the
+    // profile kernel K2 is the step's critical chain, and K1s -- one wave on EVERY SIMD -- slows it 2.7 x (1.28 ms against
+    // 0.48 for 8 chains of 86 rows beside K1b's 512 waves); K1b's forced block path takes those launches (state and teams
+    // hand over at any launch boundary)
+    const bool split_launch = use_split() && (split_always_ || !((long long)n_prows_ * 2 > (long long)N * nb));      // (PBSO_SPLIT=2: always)
+    (split_launch || !(dense_heavy || !is_block()) ? tot_block_launches_ : tot_sample_launches_) += 1;
+    if (split_launch) tot_split_launches_ += 1;
     if (n_dump_ > 0) {
         // the mix needs block states: a launch on the per-sample kernel leaves none, a dense-profile buffer neither
         for (int i = 0; i < N; ++i) {
@@ -1703,9 +1747,13 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         }
     }
     bool used[N_CLASS_STREAMS] = {false, false, false};
-    const bool fork = classes_.size() > 1 && ev_fork_ && total_team_waves_ <= 16LL * n_cus_;
+    if (split_launch) {
+        kp.teams = d_ts_teams_.p;
+        LAUNCHTRY(iir_split::launch_iir_split(kp, n_ts_teams_, desc_.qnorm_mode, sk));
+    }
+    const bool fork = !split_launch && classes_.size() > 1 && ev_fork_ && total_team_waves_ <= 16LL * n_cus_;
     if (fork) HIPTRY(hipEventRecord(ev_fork_, sk));
-    for (size_t ci = 0; ci < classes_.size(); ++ci) {
+    for (size_t ci = 0; ci < (split_launch ? 0 : classes_.size()); ++ci) {
         const SizeClass &c = classes_[ci];
         hipStream_t s = sk;
         if (fork && ci > 0) {
@@ -1727,6 +1775,11 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         HIPTRY(hipEventRecord(ev_join_[j], class_stream_[j]));
         HIPTRY(hipStreamWaitEvent(sk, ev_join_[j], 0));
     }
+    // objects stepped by several teams: the teams' partial sums of this launch's buffers, added in team order
+    if (split_launch)
+        LAUNCHTRY(launch_sum_parts(d_ts_split_.p, n_ts_split_, kp.audio_parts, audio + (size_t)b0 * B_, (long long)nb_total * B_, (long long)nb * B_, sk));
+    else
+        LAUNCHTRY(launch_sum_parts(d_split_.p, n_split_, kp.audio_parts, audio + (size_t)b0 * B_, (long long)nb_total * B_, (long long)nb * B_, sk));
     if (timed) HIPTRY(hipEventRecord(evq.k1, sk));
     // _latest_transfer = trans (modal_solver.h:251), then re-park a still-queued transfer
     LAUNCHTRY(launch_copy_rows(d_copy, d_copy + (n_cl + n_cq), n_cl, d_xfer_.p, m_pad_, sk));
@@ -2014,6 +2067,7 @@ int Engine::info(pbso_engine_info *out) {
     out->recurrence_form = form_;
     out->total_block_launches = tot_block_launches_;
     out->total_sample_launches = tot_sample_launches_;
+    out->total_split_launches = tot_split_launches_;
     out->buffers_done = buffers_done_;
     out->last_step_host_plan_ms = last_plan_ms_;
     out->last_step_forced_rows = last_frows_;

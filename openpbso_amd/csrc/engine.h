@@ -246,6 +246,14 @@ private:
     DevBuf<SplitObj> d_split_;                           // objects stepped by more than one team
     DevBuf<float> d_audio_parts_;                        // [n_part_rows_][nb * B] their partial sample sums
     int n_teams_ = 0, n_split_ = 0, n_part_rows_ = 0;
+    // K1s (kernels_split.hip): the team table of the time-split kernel -- one team of two waves per 64 columns -- for
+    // engines with less than a wave of oscillators per SIMD (f32 block form, one mode per lane; PBSO_SPLIT=0: never)
+    bool split_ok_ = false, split_always_ = false;      // PBSO_SPLIT=2: also the launches that are mostly dense-profile buffers
+    DevBuf<TeamDesc> d_ts_teams_;
+    DevBuf<SplitObj> d_ts_split_;
+    int n_ts_teams_ = 0, n_ts_split_ = 0, n_ts_part_rows_ = 0;
+    int64_t tot_split_launches_ = 0;
+    bool use_split() const { return split_ok_ && n_dump_ == 0; }
     int n_cus_ = 256;                                     // hipDeviceProp_t::multiProcessorCount of the engine's device
     long long total_team_waves_ = 0;
     DevBuf<float> d_gq_;                                 // closed-form qnorm: G11, 2 G12, G22 planes

@@ -130,6 +130,12 @@ int launch_listener_mix(const float *xdump, const float *xscale, const float *wt
                         int nb, int m_pad, int n_modes, int n_listeners, long long out_stride, hipStream_t stream);
 }
 
+// ---- K1s: the block form for an under-filled chip (kernels_split.hip): teams of TWO waves that own the same 64 modes
+// (one mode per lane, f32 projection), wave g projecting group g of every buffer; p.teams lists one team per 64 columns
+namespace iir_split {
+int launch_iir_split(const IirParams &p, int n_teams, int qnorm_mode, hipStream_t stream);
+}
+
 // ---- exact fp64 helper kernels (kernels_exact.hip, built with -ffp-contract=off)
 struct ProjectEvent {
     int obj;
@@ -202,9 +208,9 @@ int launch_ffat_lookup(const FfatEvent *events, int n_events, const FfatGeom *ge
 // writes rows[p][0 .. n_maps)
 int launch_ffat_batch(const double *pos, int n_pos, const FfatGeom *geom_of_object, int n_maps, const double *psi,
                       double *rows, int m_pad, hipStream_t stream);
-// audio[obj][i] = sum over the object's teams, in team order (deterministic)
+// audio[obj][i] = sum over the object's teams, in team order (deterministic), i < n; rows are `stride` apart
 struct SplitObj { int obj, first_row, n_rows, pad; };
-int launch_sum_parts(const SplitObj *split, int n_split, const float *parts, float *audio, long long stride,
+int launch_sum_parts(const SplitObj *split, int n_split, const float *parts, float *audio, long long stride, long long n,
                      hipStream_t stream);
 int launch_copy_rows(const int *src_row, const int *dst_row, int n, double *rows, int m_pad,
                      hipStream_t stream);

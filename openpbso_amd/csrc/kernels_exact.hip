@@ -587,20 +587,20 @@ int launch_ffat_batch(const double *pos, int n_pos, const FfatGeom *geom_of_obje
 // Objects stepped by several teams: add the teams' partial sample sums, team 0 first.
 __global__ __launch_bounds__(256) void sum_parts_kernel(const SplitObj *__restrict__ split,
                                                         const float *__restrict__ parts,
-                                                        float *__restrict__ audio, long long stride) {
+                                                        float *__restrict__ audio, long long stride, long long n) {
     const SplitObj so = split[blockIdx.y];
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= stride) return;
+    if (i >= n) return;
     float acc = parts[(size_t)so.first_row * stride + i];
     for (int r = 1; r < so.n_rows; ++r) acc += parts[(size_t)(so.first_row + r) * stride + i];
     audio[(size_t)so.obj * stride + i] = acc;
 }
 
-int launch_sum_parts(const SplitObj *split, int n_split, const float *parts, float *audio, long long stride,
+int launch_sum_parts(const SplitObj *split, int n_split, const float *parts, float *audio, long long stride, long long n,
                      hipStream_t stream) {
-    if (n_split <= 0) return 0;
-    dim3 grid((unsigned)((stride + 255) / 256), n_split);
-    hipLaunchKernelGGL(sum_parts_kernel, grid, dim3(256), 0, stream, split, parts, audio, stride);
+    if (n_split <= 0 || n <= 0) return 0;
+    dim3 grid((unsigned)((n + 255) / 256), n_split);
+    hipLaunchKernelGGL(sum_parts_kernel, grid, dim3(256), 0, stream, split, parts, audio, stride, n);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,355 @@
+// K1s: the block state-space oscillator bank for an UNDER-FILLED chip (gfx950, wave64, f32 MFMA).
+//
+// Replaces the same reference code as K1 / K1b: the hot loop of ModalSolver::step (modal_solver.h:262-272) around
+// ModalIntegrator::Step (modal_integrator.h:103-113).  Same formulation as kernels_block.hip (read that first): a buffer
+// is sample 0 + 2 groups of 16 blocks of 16 samples; block-start states are parked in LDS and projected on the f32
+// matrix pipe with the per-mode table W = (a_j, b_j).
+//
+// When a scene has fewer than one wave of oscillators per SIMD (BASELINE configs[1], [2], [4]: 8 .. 512 waves for 1024
+// SIMDs), a launch is bound by the LATENCY of one buffer in one wave -- a lone wave issues one vector instruction per
+// four cycles whatever the chip could do -- and most SIMDs idle.  K1s spends the idle SIMDs on time: a team is TWO waves
+// that own the SAME 64 modes (one mode per lane), and wave g projects group g of every buffer.
+//   * force-free buffers: wave 0 steps sample 0 and the 32 coarse steps, parking t x; both waves project their 256
+//     samples side by side (32 MFMAs each instead of 64 in one wave);
+//   * buffers with a dense force profile (Gaussian, AR: forces.h:92-128), no qnorm rows: the response is linear, so wave
+//     1 steps group 1 FROM ZERO under the profile's second half while wave 0 steps group 0 from the real state; when
+//     wave 0 hands over the state at the group boundary, wave 1 adds its free response (16 coarse steps) to its parked
+//     block states (superposition) and returns the end state.  256 dependent samples per buffer instead of 512;
+//   * dense buffers with qnorm rows (getQBufferNorm needs the true state of every sample): wave 0 steps all 512 samples,
+//     the projection is still shared.
+// The registers hold the state UNSCALED (the parked values carry the transfer weight: two products per block, nothing
+// in a latency-bound launch), so there is no literal fallback for unusable weights and no rescaling when the listener
+// moves.  Two workgroup barriers per buffer; every output sample is produced by exactly one wave and stored straight
+// from the MFMA's result registers.
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace pbso {
+namespace iir_split {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int BJ = BLOCK_J, BN = BLOCK_N, GROUP = BJ * BN;
+constexpr int ST_ROW = 130;                          // as K1b: [16 blocks][64 lanes][Q, D], row stride 130 floats
+constexpr int ST_AREA = BN * ST_ROW + 32 + 132;      // + the wave's FIR taps h_0 .. h_16 + one row for the taps' virtual state
+
+struct SplitDims {
+    int nb, m_pad, b_pad, frames;
+    long long audio_stride, plane;
+    int qn_nb, qn_b0;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});
+    v += dpp(v, std::integral_constant<int, 0x4E>{});
+    v += dpp(v, std::integral_constant<int, 0x141>{});
+    v += dpp(v, std::integral_constant<int, 0x140>{});
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+template <int K0, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (N > 0) {
+        f(std::integral_constant<int, K0>{});
+        static_for<K0 + 1, N - 1>(f);
+    }
+}
+
+template <int QNM>
+__global__ __launch_bounds__(128) void iir_split_kernel(
+    const float *__restrict__ p_ca, const float *__restrict__ p_cb, float *__restrict__ p_sq, float *__restrict__ p_sd,
+    float *__restrict__ p_ss, const BufDesc *__restrict__ p_desc, const float *__restrict__ p_grows,
+    const float *__restrict__ p_tprof, const double *__restrict__ p_xfer_rows, const int *__restrict__ p_xfer_init,
+    float *__restrict__ p_audio, float *__restrict__ p_qnorm, const float *__restrict__ p_gq, const float *__restrict__ p_pc,
+    const float *__restrict__ p_wtab, const TeamDesc *__restrict__ p_teams, float *__restrict__ p_audio_parts, const SplitDims p) {
+    constexpr bool QN = QNM != 0;
+    __shared__ __attribute__((aligned(16))) float lds_stage[2][2][ST_AREA];       // [buffer parity][group]
+    __shared__ f2 hand16[64], hand32[64];            // the state at the group boundary (wave 0 -> 1) and at the buffer's end (1 -> 0)
+    const TeamDesc team = p_teams[blockIdx.x];
+    const int obj = team.obj;
+    const int lane = threadIdx.x & 63;
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);             // this wave projects group grp
+    const size_t ubase = (size_t)obj * p.m_pad + team.col0;
+    const unsigned ul = (unsigned)lane;
+
+    // per-mode constants (one mode per lane)
+    const float nca = (p_ca + ubase)[ul], ncb = (p_cb + ubase)[ul];                // eps^2, -e  (velocity form, as K1)
+    const float p11 = (p_pc + ubase)[ul], p12 = (p_pc + p.plane + ubase)[ul];     // P = A^16: P11 - 1, P12, P21, P22
+    const float p21 = (p_pc + 2 * p.plane + ubase)[ul], p22 = (p_pc + 3 * p.plane + ubase)[ul];
+    const bool dead = nca == 0.f && ncb == 0.f;                                   // a padding column
+    float g11 = 0.f, g12 = 0.f, g22 = 0.f;
+    if (QN) {
+        g11 = (p_gq + ubase)[ul];
+        g12 = (p_gq + p.plane + ubase)[ul];
+        g22 = (p_gq + 2 * p.plane + ubase)[ul];
+    }
+    float wreg[32];                                  // the MFMA A operand of the 32 pairs of columns (as K1b)
+    {
+        const float *__restrict__ wsrc = p_wtab + (ubase / 2) * 64;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) wreg[s] = wsrc[s * 64 + lane];
+    }
+    // state, unscaled (the arrays hold scale x state, kernels_iir.hip "scaled state")
+    f2 x;
+    {
+        const float s0 = (p_ss + ubase)[ul];
+        x.x = (p_sq + ubase)[ul] / s0;
+        x.y = (p_sd + ubase)[ul] / s0;
+    }
+    float t;
+    {
+        const int row0 = p_xfer_init[obj];
+        const float tr = row0 >= 0 ? (float)(p_xfer_rows + (size_t)row0 * p.m_pad + team.col0)[ul] : 1e7f;
+        t = dead ? 1.f : tr;
+    }
+    const BufDesc *__restrict__ dsc = p_desc + (size_t)obj * p.nb;
+    float *__restrict__ aout = team.part_row >= 0 ? p_audio_parts + (size_t)team.part_row * p.audio_stride
+                                                  : p_audio + (size_t)obj * p.audio_stride;
+    float *__restrict__ b_qn = p_qnorm + ((size_t)obj * p.qn_nb + p.qn_b0) * p.m_pad + team.col0;
+    const int B = p.frames;
+
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto coarse = [&](f2 v) {                        // v <- P v
+        const float qa = fmaf(p11, v.x, v.x);
+        const float da = p21 * v.x;
+        return f2{fmaf(p12, v.y, qa), fmaf(p22, v.y, da)};
+    };
+
+    int par = 0;                                     // staging parity: flips with every buffer that is stepped (skipped ones pass no barrier)
+    for (int b = 0; b < p.nb; ++b) {
+        const BufDesc cur = dsc[b];
+        float *__restrict__ ao = aout + (size_t)b * B;
+        if (cur.flags & DESC_SKIP) {
+            // the reference's step() returned before stepping: no samples, state untouched (no barrier in this buffer: both waves skip)
+            for (int i = threadIdx.x; i < B; i += 128) ao[i] = 0.f;
+            if (QN && grp == 0) (b_qn + (size_t)b * p.m_pad)[ul] = 0.f;
+            continue;
+        }
+        if (cur.trow != XFER_KEEP) {
+            const float tr = cur.trow >= 0 ? (float)(p_xfer_rows + (size_t)cur.trow * p.m_pad + team.col0)[ul] : 1e7f;
+            t = dead ? 1.f : tr;
+        }
+        const int frow = cur.frow;
+        const float g = frow >= 0 ? (p_grows + (size_t)frow * p.m_pad + team.col0)[ul] : 0.f;
+        const bool impulse = (cur.flags & DESC_IMPULSE) != 0;
+        const bool dense = frow >= 0 && !impulse;
+        par ^= 1;
+        float *stage0 = lds_stage[par][0], *stage1 = lds_stage[par][1];
+        float *stage = grp == 0 ? stage0 : stage1;
+        float *taps = stage + BN * ST_ROW;
+        const float *__restrict__ tprow = p_tprof + (size_t)(cur.prow >= 0 && dense ? cur.prow : 0) * p.b_pad;
+        auto park = [&](float *st, int n, f2 v) { *reinterpret_cast<f2 *>(st + n * ST_ROW + 2 * lane) = f2{t * v.x, t * v.y}; };
+        const float *bsrc = stage + (lane & 15) * ST_ROW + 2 * (lane >> 5) + ((lane >> 4) & 1);
+        float breg[32];
+
+        // per-sample stepping of 16 blocks under the dense profile, parking every block-start state; T values: one
+        // s_load_dwordx16 per block issued a block ahead (scalar loads return out of order: first use, then the next load)
+        auto step_group = [&](float *st, int first_sample, f2 &v, float &qacc) {
+            float ta[BJ], tb[BJ];
+            auto load_t = [&](float (&dst)[BJ], int n) {
+                const float *__restrict__ tk = tprow + first_sample + BJ * n;
+#pragma unroll
+                for (int k = 0; k < BJ; ++k) dst[k] = tk[k];
+            };
+            auto samples = [&](const float (&tv)[BJ]) {
+#pragma unroll
+                for (int k = 0; k < BJ; ++k) {
+                    const float in = fmaf(nca, v.y, g * tv[k]);
+                    v.y = fmaf(ncb, v.x, in);
+                    v.x = v.x + v.y;
+                    if (QN) qacc = fmaf(v.x, v.x, qacc);
+                }
+            };
+            load_t(ta, 0);
+            for (int n = 0; n < BN; n += 2) {
+                park(st, n, v);
+                const float probe = ta[0];
+                asm volatile("" :: "s"(probe));
+                __builtin_amdgcn_sched_barrier(0);
+                load_t(tb, n + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                samples(ta);
+                park(st, n + 1, v);
+                const float probe2 = tb[0];
+                asm volatile("" :: "s"(probe2));
+                __builtin_amdgcn_sched_barrier(0);
+                load_t(ta, n + 2 < BN ? n + 2 : n + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                samples(tb);
+            }
+        };
+
+        float fir_a[4] = {0.f, 0.f, 0.f, 0.f};
+        bool late_b = false;                         // wave 0, dense buffer without qnorm rows: barrier B comes after its projection
+        if (!dense) {
+            // ================= force-free buffer (or an impulse at sample 0) =================
+            if (grp == 0) {
+                const bool hit0 = frow >= 0 && (cur.tile_mask & 1u);
+                float a = nca * x.y;
+                a = fmaf(ncb, x.x, a);
+                if (hit0) a = fmaf(g, cur.amp, a);
+                x.y = a;
+                x.x = x.x + a;
+                if (QN) {
+                    // sum_{k=0}^{B-1} q_k^2 = x0' G x0, x0 = state after sample 0 (the rest of the buffer is force-free)
+                    float e = g22 * x.y * x.y;
+                    e = fmaf(g12 * x.x, x.y, e);
+                    e = fmaf(g11 * x.x, x.x, e);
+                    (b_qn + (size_t)b * p.m_pad)[ul] = __builtin_amdgcn_sqrtf(fmaxf(e, 0.f));
+                }
+                const float p0 = wave_sum(t * x.x);
+                if (lane == 0) ao[0] = p0;
+#pragma unroll
+                for (int n = 0; n < BN; ++n) {
+                    park(stage0, n, x);
+                    x = coarse(x);
+                }
+#pragma unroll
+                for (int n = 0; n < BN; ++n) {
+                    park(stage1, n, x);
+                    x = coarse(x);
+                }
+            }
+            __syncthreads();                         // A: both groups' block-start states are parked
+            __syncthreads();                         // B (every buffer passes both barriers)
+        } else {
+            // ================= dense force profile =================
+            // FIR taps of this wave (both waves need them: the forced response inside a block, see kernels_block.hip):
+            // h_0 = sum t g, h_1 .. h_16 = projection of the virtual block-start state t g u, u = (1, 1)'
+            {
+                // (a row of its own: in a qnorm build wave 0 parks into BOTH groups' staging areas while wave 1 is here; only
+                //  column 0 of the result is read, so every lane may read the one row)
+                float *trow = taps + 32;
+                const float *tsrc = trow + 2 * (lane >> 5) + ((lane >> 4) & 1);
+                const float tg = t * g;
+                const float gs = wave_sum(tg);
+                *reinterpret_cast<f2 *>(trow + 2 * lane) = f2{tg, tg};
+                if (lane == 0) taps[0] = gs;
+                wave_sync();
+#pragma unroll
+                for (int s = 0; s < 32; ++s) breg[s] = tsrc[4 * s];
+                f4 ah0 = f4{0.f, 0.f, 0.f, 0.f}, ah1 = f4{0.f, 0.f, 0.f, 0.f};
+                static_for<0, 32>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    if constexpr (s & 1) ah1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], breg[s], ah1, 0, 0, 0);
+                    else ah0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], breg[s], ah0, 0, 0, 0);
+                });
+                const f4 ah = ah0 + ah1;
+                if ((lane & 15) == 0) {
+                    float *td = taps + 1 + 4 * (lane >> 4);
+                    td[0] = ah.x; td[1] = ah.y; td[2] = ah.z; td[3] = ah.w;
+                }
+                wave_sync();
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int idx = (lane & 15) - 4 * kk - (lane >> 4);
+                    fir_a[kk] = idx >= 0 ? taps[idx] : 0.f;
+                }
+            }
+            float qacc = 0.f;
+            if (grp == 0) {
+                // sample 0
+                float a = nca * x.y;
+                a = fmaf(ncb, x.x, a);
+                a = fmaf(g, tprow[0], a);
+                x.y = a;
+                x.x = x.x + a;
+                if (QN) qacc = x.x * x.x;
+                const float p0 = wave_sum(t * x.x);
+                if (lane == 0) ao[0] = p0;
+                step_group(stage0, 1, x, qacc);
+                if (QN) {
+                    // qnorm rows: the true state of every sample is needed -- this wave steps the second group as well
+                    step_group(stage1, 1 + GROUP, x, qacc);
+                    (b_qn + (size_t)b * p.m_pad)[ul] = sqrtf(qacc);
+                } else {
+                    hand16[lane] = x;
+                    late_b = true;
+                }
+            } else if (!QN) {
+                // group 1 from a zero state under the second half of the profile (its response to the force alone)
+                f2 z = f2{0.f, 0.f};
+                step_group(stage1, 1 + GROUP, z, qacc);
+                __syncthreads();                     // A: wave 0 has reached the group boundary
+                // + the free response of the state wave 0 handed over: 16 coarse steps, added to the parked states
+                f2 xf = hand16[lane];
+#pragma unroll
+                for (int n = 0; n < BN; ++n) {
+                    f2 *slot = reinterpret_cast<f2 *>(stage1 + n * ST_ROW + 2 * lane);
+                    const f2 cur_v = *slot;
+                    *slot = f2{fmaf(t, xf.x, cur_v.x), fmaf(t, xf.y, cur_v.y)};
+                    xf = coarse(xf);
+                }
+                hand32[lane] = f2{z.x + xf.x, z.y + xf.y};
+                __syncthreads();                     // B: the buffer's end state is handed back
+            }
+            if (grp == 0 || QN) {
+                __syncthreads();                     // A
+                if (!late_b) __syncthreads();        // B
+            }
+        }
+
+        // ---- projection of this wave's group: 32 MFMAs over the 32 pairs of columns (+ the profile's FIR)
+        wave_sync();
+#pragma unroll
+        for (int s = 0; s < 32; ++s) breg[s] = bsrc[4 * s];
+        f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = f4{0.f, 0.f, 0.f, 0.f};
+        static_for<0, 32>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if constexpr (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], breg[s], acc1, 0, 0, 0);
+            else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], breg[s], acc0, 0, 0, 0);
+        });
+        if (dense) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float fb = tprow[1 + GROUP * grp + BJ * (lane & 15) + 4 * kk + (lane >> 4)];
+                if (kk & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fir_a[kk], fb, acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fir_a[kk], fb, acc0, 0, 0, 0);
+            }
+        }
+        {
+            const f4 acc = acc0 + acc1;              // D[i = 4 (l >> 4) + v][n = l & 15] = sample 16 n + i of the group
+            float *o = ao + 1 + GROUP * grp + 16 * (lane & 15) + 4 * (lane >> 4);
+            o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
+        }
+        if (late_b) {
+            __syncthreads();                         // B: wave 1 has added the free response and hands the end state back
+            x = hand32[lane];
+        }
+    }
+
+    if (grp == 0) {
+        (p_sq + ubase)[ul] = x.x;
+        (p_sd + ubase)[ul] = x.y;
+        (p_ss + ubase)[ul] = 1.f;
+    }
+}
+
+int launch_iir_split(const IirParams &p, int n_teams, int qnorm_mode, hipStream_t stream) {
+    if (n_teams <= 0) return 0;
+    if (p.frames != 1 + 2 * GROUP) return (int)hipErrorInvalidValue;
+    const SplitDims dims = {p.nb, p.m_pad, p.b_pad, p.frames, p.audio_stride, p.gq_plane, p.qn_nb, p.qn_b0};
+    if (qnorm_mode != 0)
+        hipLaunchKernelGGL(iir_split_kernel<2>, dim3(n_teams), dim3(128), 0, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows, p.tprof,
+                           p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, dims);
+    else
+        hipLaunchKernelGGL(iir_split_kernel<0>, dim3(n_teams), dim3(128), 0, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows, p.tprof,
+                           p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, dims);
+    return (int)hipGetLastError();
+}
+
+}  // namespace iir_split
+}  // namespace pbso

@@ -12,6 +12,13 @@ pytestmark = pytest.mark.gpu
 NB = 24
 
 
+@pytest.fixture(autouse=True)
+def _one_wave_per_64_modes(monkeypatch):
+    """these scenes are small: the f32 block form would run them on the time-split kernel K1s (kernels_split.hip), which takes
+    every hit's gain from the combine kernel's row; DESC_DIRECT is a feature of K1 / K1b"""
+    monkeypatch.setenv("PBSO_SPLIT", "0")
+
+
 def _scene(n_obj=6, n_modes=300, seed=5):
     objs, evs = [], []
     rng = np.random.default_rng(seed)

@@ -475,6 +475,8 @@ def test_projection_bit_exact_through_state(monkeypatch, direct_hits):
     bank's own (float)(c3 * shape) table -- three f32 products instead of the rounded fp64 dot: equal to
     f32 rounding (the face hit, and any hit on an object with live forces, still is the fp64 path)."""
     monkeypatch.setenv("PBSO_DIRECT_HITS", direct_hits)
+    if direct_hits == "1":
+        monkeypatch.setenv("PBSO_SPLIT", "0")        # (the table path is K1 / K1b's; the time-split kernel of small engines has none)
     from oracle import oracle_py as orc
     n_modes = 200
     seed = 44
@@ -619,27 +621,37 @@ def test_long_steps_cut_into_launches(monkeypatch):
     #  sums run in another order: bit-identity across cuts is a property of ONE kernel, so pin it here; the automatic
     #  choice is checked against the oracle at the end)
     monkeypatch.setenv("PBSO_DENSE_LAUNCHES", "block")
-    monkeypatch.setenv("PBSO_CHUNK_BUFFERS", "1000")
-    one = run_engine(objs, evs, nb, modes_per_lane=1)
-    for chunk in ("1", "4"):
-        monkeypatch.setenv("PBSO_CHUNK_BUFFERS", chunk)
-        cut = run_engine(objs, evs, nb, modes_per_lane=1)
-        assert np.array_equal(one["audio"], cut["audio"]) and np.array_equal(one["emitted"], cut["emitted"])
-        assert not one["emitted"][:, 6].any()
-        for key in one["qnorm"]:
-            assert np.array_equal(one["qnorm"][key], cut["qnorm"][key]), key
-        for a, b in zip(one["state"], cut["state"]):
-            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     want = run_oracle(objs, evs, nb)
-    _check(one, want)
+    # ... and so does the choice between K1b and the time-split kernel K1s (small f32 engines; it takes a launch unless most of
+    # its buffers carry a dense profile): "0" = K1b for every launch, "2" = K1s for every launch
+    for split in ("0", "2"):
+        monkeypatch.setenv("PBSO_SPLIT", split)
+        monkeypatch.setenv("PBSO_CHUNK_BUFFERS", "1000")
+        one = run_engine(objs, evs, nb, modes_per_lane=1)
+        assert one["info"]["total_split_launches"] == (0 if split == "0" or one["info"]["recurrence_form"] != capi.FORM_BLOCK else 1)
+        for chunk in ("1", "4"):
+            monkeypatch.setenv("PBSO_CHUNK_BUFFERS", chunk)
+            cut = run_engine(objs, evs, nb, modes_per_lane=1)
+            assert np.array_equal(one["audio"], cut["audio"]) and np.array_equal(one["emitted"], cut["emitted"])
+            assert not one["emitted"][:, 6].any()
+            for key in one["qnorm"]:
+                assert np.array_equal(one["qnorm"][key], cut["qnorm"][key]), key
+            for a, b in zip(one["state"], cut["state"]):
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        _check(one, want)
+    monkeypatch.delenv("PBSO_SPLIT")
     monkeypatch.delenv("PBSO_DENSE_LAUNCHES")
     monkeypatch.setenv("PBSO_CHUNK_BUFFERS", "1")          # buffers 3..5 (AR force alive) become launches of their own
     auto = run_engine(objs, evs, nb, modes_per_lane=1)
     if auto["info"]["recurrence_form"] == capi.FORM_BLOCK:
-        # the f32 block kernel runs dense-profile buffers in block form itself (forced block path): no hand-over
+        # the f32 block kernels run dense-profile buffers in block form themselves (forced block path): no hand-over to the
+        # per-sample kernel; the launches that are all dense (buffers 3..5) go to K1b, the others to the time-split kernel
         assert auto["info"]["total_sample_launches"] == 0 and auto["info"]["total_block_launches"] >= 9
+        assert 6 <= auto["info"]["total_split_launches"] <= auto["info"]["total_block_launches"] - 3
     _check(auto, want)
-    # the hand-over between the two kernels at launch boundaries (what the split-bf16 form does by itself)
+    # the hand-over between the two kernels at launch boundaries (what the split-bf16 form does by itself; small f32 engines
+    # run on the time-split kernel K1s, which never hands over: switched off here)
+    monkeypatch.setenv("PBSO_SPLIT", "0")
     monkeypatch.setenv("PBSO_DENSE_LAUNCHES", "sample")
     hand = run_engine(objs, evs, nb, modes_per_lane=1)
     if hand["info"]["recurrence_form"] in (capi.FORM_BLOCK, capi.FORM_BLOCK_BF16):
