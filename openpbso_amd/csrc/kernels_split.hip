@@ -32,6 +32,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 constexpr int BJ = BLOCK_J, BN = BLOCK_N, GROUP = BJ * BN;
+
 constexpr int ST_ROW = 130;                          // as K1b: [16 blocks][64 lanes][Q, D], row stride 130 floats
 constexpr int ST_AREA = BN * ST_ROW + 32 + 132;      // + the wave's FIR taps h_0 .. h_16 + one row for the taps' virtual state
 
@@ -128,22 +129,35 @@ __global__ __launch_bounds__(128) void iir_split_kernel(
         return f2{fmaf(p12, v.y, qa), fmaf(p22, v.y, da)};
     };
 
+    // A buffer's inputs from memory -- its descriptor, the force gain row, a new transfer row -- are fetched while the
+    // previous buffer runs: three dependent round trips to L2 / HBM (~1 us) would otherwise be half of a buffer's time.
+    float g_next = 0.f, t_next = 0.f;
+    auto fetch_rows = [&](const BufDesc &nd) {
+        if (nd.frow >= 0) g_next = (p_grows + (size_t)nd.frow * p.m_pad + team.col0)[ul];
+        if (nd.trow >= 0) t_next = (float)(p_xfer_rows + (size_t)nd.trow * p.m_pad + team.col0)[ul];
+    };
+    auto prefetch = [&](const BufDesc &nd) { fetch_rows(nd); };
+    BufDesc next = dsc[0];
+    prefetch(next);
     int par = 0;                                     // staging parity: flips with every buffer that is stepped (skipped ones pass no barrier)
     for (int b = 0; b < p.nb; ++b) {
-        const BufDesc cur = dsc[b];
+        const BufDesc cur = next;
+        next = dsc[b + 1 < p.nb ? b + 1 : b];
+        const float g_cur = g_next, t_cur = t_next;
         float *__restrict__ ao = aout + (size_t)b * B;
         if (cur.flags & DESC_SKIP) {
             // the reference's step() returned before stepping: no samples, state untouched (no barrier in this buffer: both waves skip)
             for (int i = threadIdx.x; i < B; i += 128) ao[i] = 0.f;
             if (QN && grp == 0) (b_qn + (size_t)b * p.m_pad)[ul] = 0.f;
+            prefetch(next);
             continue;
         }
         if (cur.trow != XFER_KEEP) {
-            const float tr = cur.trow >= 0 ? (float)(p_xfer_rows + (size_t)cur.trow * p.m_pad + team.col0)[ul] : 1e7f;
+            const float tr = cur.trow >= 0 ? t_cur : 1e7f;
             t = dead ? 1.f : tr;
         }
         const int frow = cur.frow;
-        const float g = frow >= 0 ? (p_grows + (size_t)frow * p.m_pad + team.col0)[ul] : 0.f;
+        const float g = frow >= 0 ? g_cur : 0.f;
         const bool impulse = (cur.flags & DESC_IMPULSE) != 0;
         const bool dense = frow >= 0 && !impulse;
         par ^= 1;
@@ -223,6 +237,9 @@ __global__ __launch_bounds__(128) void iir_split_kernel(
                     x = coarse(x);
                 }
             }
+            // (handing the state over after sample 0 and letting wave 1 jump over group 0 with P^16 -- 17 coarse steps on the
+            //  critical path instead of 32 -- ran 17 % SLOWER: 0.173 against 0.148 ms for 86 buffers of 1 x 512 modes; a hand-over
+            //  through LDS and a workgroup barrier costs more than sixteen coarse steps)
             __syncthreads();                         // A: both groups' block-start states are parked
             __syncthreads();                         // B (every buffer passes both barriers)
         } else {
@@ -303,6 +320,7 @@ __global__ __launch_bounds__(128) void iir_split_kernel(
         }
 
         // ---- projection of this wave's group: 32 MFMAs over the 32 pairs of columns (+ the profile's FIR)
+        prefetch(next);                              // (the next descriptor has long arrived: its rows are fetched under the MFMAs)
         wave_sync();
 #pragma unroll
         for (int s = 0; s < 32; ++s) breg[s] = bsrc[4 * s];
