@@ -337,10 +337,15 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     auto coarse = [&](int r, int n, int blk) {
         dump_state(r, blk);
         wdst[n * (ST_ROW / 2)] = f2{x2[r].x, x2[r].y};
-        const float qa = fmaf(c1[r].x, x2[r].x, x2[r].x);
-        const float da = c1[r].y * x2[r].x;
-        x2[r].x = fmaf(c2[r].x, x2[r].y, qa);
-        x2[r].y = fmaf(c2[r].y, x2[r].y, da);
+        // four instructions: the three-operand v_fma_f32 (through the builtin the compiler emits v_mov + v_fmac for
+        // q + (P11 - 1) q, a fifth vector instruction per step: 128 of the kernel's 855 per wave and buffer)
+        float qa, da, qn, dn;
+        asm("v_fma_f32 %0, %1, %2, %2" : "=v"(qa) : "v"(c1[r].x), "v"(x2[r].x));
+        asm("v_mul_f32 %0, %1, %2" : "=v"(da) : "v"(c1[r].y), "v"(x2[r].x));
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(qn) : "v"(c2[r].x), "v"(x2[r].y), "v"(qa));
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(dn) : "v"(c2[r].y), "v"(x2[r].y), "v"(da));
+        x2[r].x = qn;
+        x2[r].y = dn;
     };
 
     // diagnostics (PBSO_CENSUS=1): where wave 0's shader cycles go
@@ -551,7 +556,8 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                     hdst[n * H_ROW] = hp;
                     hdst[H_PLANE + n * H_ROW] = lp;
                     // t = ((P11 - 1) q + P12 d, P21 q + P22 d);  q' = q + t.x (the small term last), d' = t.y
-                    // (plain f32 ops: v_pk_fma_f32 / v_pk_mul_f32 issue at half rate, a packed step is no shorter)
+                    // (plain f32 ops: v_pk_fma_f32 / v_pk_mul_f32 issue at half rate, a packed step is no shorter; spelling the
+                    //  three-operand v_fma_f32 out in asm as the f32 projection's step does made THIS kernel 4 % slower)
                     const float qa = fmaf(c1[r].x, x.x, x.x);
                     const float da = c1[r].y * x.x;
                     x2[r].x = fmaf(c2[r].x, x.y, qa);

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out/r03k2; export TMPDIR=/tmp; R=$PWD
-for v in base RNG SCAN; do
+for v in base RNG SCAN BOTH; do
   if [ $v = base ]; then unset PBSO_LIB; else export PBSO_LIB=$R/openpbso_amd/libpbso_abl_$v.so; fi
   # tiny oscillator bank (64 modes): K2 runs practically alone
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03k2/$v -- python3 $R/bench.py --no-cpu-baseline --no-parity --form block --objects 8 --modes 64 --scenario scraping --steps 30 --warmup 2 > $R/gpurun_out/r03k2/$v.log 2>&1)
