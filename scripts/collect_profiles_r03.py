@@ -17,9 +17,11 @@ for f in sorted(glob.glob(src + "/*")):
     shutil.copy(f, os.path.join(dst, f"{rnd}_{n}"))
 
 
-def counter(text, kernel_re, name):
-    m = re.search(r"\S+\s+\S*%s\S*\s+%s\s+(\S+)" % (kernel_re, name), text)
-    return float(m.group(1)) if m else None
+def counter(text, kernel, name):
+    for line in text.splitlines():
+        if kernel in line and re.search(r"\s%s\s" % name, line):
+            return float(line.split(name)[1].split()[0])
+    return None
 
 
 counts = {"note": "per wave and buffer of iir_block_kernel at the headline shape (1024 objects x 512 modes, R = 4: 2048 waves x 86 buffers per launch): "
