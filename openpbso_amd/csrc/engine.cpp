@@ -260,19 +260,18 @@ Engine::~Engine() {
     d_geom_off_.release(); d_psi_.release(); d_slots_.release(); d_xfer_.release();
     d_pc_.release(); d_wtab_.release(); d_ftab_.release(); d_dump_row_.release(); d_xdump_.release(); d_xscale_.release(); d_wtab32_.release();
     d_arstate_.release(); d_board_.release(); d_teams_.release(); d_split_.release(); d_ts_teams_.release(); d_ts_split_.release(); d_audio_parts_.release();
-    d_audio_.release(); d_qnorm_.release(); d_grows_[0].release(); d_grows_[1].release(); d_census_.release();
-    for (hipEvent_t ev : {ev_prep_done_[0], ev_prep_done_[1], ev_k1_done_[0], ev_k1_done_[1]})
-        if (ev) (void)hipEventDestroy(ev);
+    d_audio_.release(); d_qnorm_.release(); d_census_.release();
+    for (DevBuf<float> &g : d_grows_) g.release();
+    for (int i = 0; i < N_SETS; ++i)
+        for (hipEvent_t ev : {ev_prep_done_[i], ev_k1_done_[i], ev_set_[i]})
+            if (ev) (void)hipEventDestroy(ev);
     if (prep_stream_) (void)hipStreamDestroy(prep_stream_);
     for (hipStream_t cs : class_stream_)
         if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     for (hipEvent_t ev : ev_join_)
         if (ev) (void)hipEventDestroy(ev);
-    set_[0].release();
-    set_[1].release();
-    for (hipEvent_t ev : {ev_set_[0], ev_set_[1]})
-        if (ev) (void)hipEventDestroy(ev);
+    for (PlanSet &ps : set_) ps.release();
     for (auto *v : {&ev_free_, &ev_pending_})
         for (EvQuad &q : *v)
             for (hipEvent_t ev : {q.k0, q.k1, q.p0, q.p1}) (void)hipEventDestroy(ev);
@@ -343,8 +342,7 @@ int Engine::init() {
         HIPTRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
         own_stream_ = true;
     }
-    HIPTRY(hipEventCreateWithFlags(&ev_set_[0], hipEventDisableTiming));
-    HIPTRY(hipEventCreateWithFlags(&ev_set_[1], hipEventDisableTiming));
+    for (int i = 0; i < N_SETS; ++i) HIPTRY(hipEventCreateWithFlags(&ev_set_[i], hipEventDisableTiming));
     // preparation of step k+1 (plan upload, projection, FFAT lookup, force combination)
     // runs on its own stream beside the oscillator bank of step k
     // High priority: its kernels are small, the oscillator bank waits for them, and the runtime maps
@@ -356,7 +354,7 @@ int Engine::init() {
         HIPTRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPTRY(hipStreamCreateWithPriority(&prep_stream_, hipStreamNonBlocking, greatest));
     }
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < N_SETS; ++i) {
         HIPTRY(hipEventCreateWithFlags(&ev_prep_done_[i], hipEventDisableTiming));
         HIPTRY(hipEventCreateWithFlags(&ev_k1_done_[i], hipEventDisableTiming));
     }
@@ -1403,7 +1401,7 @@ int Engine::plan(int nb) {
     if ((int)need_all > xfer_cap_) {
         const int ncap = std::max<int>((int)need_all, 2 * xfer_cap_ + 16);
         // rows [2N + s*cap, ...) change meaning with cap: nothing may be in flight (ensure() drains)
-        HIPTRY(d_xfer_.ensure((size_t)(2 * N + 2 * ncap) * m_pad_, true, stream_));
+        HIPTRY(d_xfer_.ensure((size_t)(2 * N + N_SETS * ncap) * m_pad_, true, stream_));
         HIPTRY(hipDeviceSynchronize());
         xfer_cap_ = ncap;
     }
@@ -1789,7 +1787,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     if (timed) ev_pending_.push_back(evq);
     else ev_free_.push_back(evq);
     buffers_done_ += nb;
-    cur_set_ ^= 1;
+    cur_set_ = (cur_set_ + 1) % N_SETS;
     hprof_[4] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - last_plan_ms_;
     hprof_[5] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
     return PBSO_OK;

@@ -218,14 +218,21 @@ private:
     bool finalized_ = false, own_stream_ = false;
     hipStream_t stream_ = nullptr;                       // oscillator bank (caller's stream if given)
     hipStream_t prep_stream_ = nullptr;                  // plan upload + projection + FFAT + combine
-    hipEvent_t ev_prep_done_[2] = {nullptr, nullptr}, ev_k1_done_[2] = {nullptr, nullptr};
+    // Plan sets: the host plans and uploads step k while the device still runs step k - N_SETS + 1.  Two sets are enough for
+    // a host that never stalls; with four, a hiccup of the host thread (the boxes of this pool stall it for a millisecond now
+    // and then) is absorbed by the steps already queued instead of idling the device.
+#ifndef PBSO_N_SETS
+#define PBSO_N_SETS 4
+#endif
+    static constexpr int N_SETS = PBSO_N_SETS;
+    hipEvent_t ev_prep_done_[N_SETS] = {}, ev_k1_done_[N_SETS] = {};
     // engines with several team sizes: the size classes are launched side by side on these streams
     // (one class alone rarely fills the chip), forked from and joined into stream_ with events
     static constexpr int N_CLASS_STREAMS = 3;
     hipStream_t class_stream_[N_CLASS_STREAMS] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork_ = nullptr, ev_join_[N_CLASS_STREAMS] = {nullptr, nullptr, nullptr};
     int xfer_cap_ = 0;                                   // scratch transfer rows per plan set
-    hipEvent_t ev_set_[2] = {nullptr, nullptr};
+    hipEvent_t ev_set_[N_SETS] = {};
     struct EvQuad { hipEvent_t k0, k1, p0, p1; int64_t step_id; };
     std::vector<EvQuad> ev_free_, ev_pending_;           // one quad per step, harvested in info()
     int harvest_timing();
@@ -304,8 +311,8 @@ private:
         DevBuf<float> d_tprof;                           // device-generated force profile rows (K2)
         size_t off_xfer_init = 0, front_bytes = 0, last_bytes = 0;
         void release();
-    } set_[2];
-    DevBuf<float> d_grows_[2];                           // g rows, one arena per plan set
+    } set_[N_SETS];
+    DevBuf<float> d_grows_[N_SETS];                      // g rows, one arena per plan set
     // plan scratch (host)
     std::vector<int> row_ptr_, slot_idx_, row_obj_, stage_slot_, busy_;
     std::vector<float> tprof_;
