@@ -947,3 +947,51 @@ def test_state_restore_resumes_a_run(form):
     w = want["audio"][0][nb1 * B:]
     tol = 5e-4 if form != capi.FORM_DIRECT else 2e-2      # (the literal direct form in fp32: SURVEY B-4)
     assert np.abs(resumed - w).max() <= tol * np.abs(want["audio"][0]).max()
+
+
+@pytest.mark.parametrize("qnorm", [capi.QNORM_ALL, capi.QNORM_OFF])
+def test_time_split_kernel_every_buffer_kind(qnorm, monkeypatch):
+    """K1s (kernels_split.hip), pinned for every launch (PBSO_SPLIT=2): two waves per 64 modes, wave g projects group g.
+    Force-free and impulse buffers, a Gaussian over several buffers, sustained AR scraping with a parameter update (dense
+    profiles: without qnorm rows wave 1 steps its half from a zero state and adds the free response of the state wave 0
+    hands over; with qnorm rows wave 0 steps all 512 samples), a clearAllForces hole, a listener moving through FFAT maps
+    with a zero weight on one mode (the registers hold the state unscaled: no fallback path), objects of 1, 64, 65 and 300
+    modes (padding lanes, several teams per object)."""
+    monkeypatch.setenv("PBSO_SPLIT", "2")
+    nb = 16
+    rng = np.random.default_rng(2024)
+    sizes = [1, 64, 65, 300]
+    objs, evs = [], []
+    for i, m in enumerate(sizes):
+        lam = synth.eigenvalues(m, 900 + i)
+        maps = synth.ffat_maps(lam, 900 + i, dim=4, cell_size=0.01) if i == 3 else None
+        if maps is not None:
+            for mm in maps:
+                mm["psi"] = np.array(mm["psi"], dtype=np.float64)
+            maps[7]["psi"][:] = 0.0
+        objs.append(ObjSpec(lam, maps=maps))
+        evs += [force_ev(0, i, data=rng.standard_normal(m) * 1e-3),
+                force_ev(2, i, data=rng.standard_normal(m) * 1e-3, force_type=1, width=1500.0),
+                force_ev(5, i, clear=True),
+                force_ev(6, i, data=rng.standard_normal(m) * 1e-3, force_type=2, start=True),
+                force_ev(8, i, data=rng.standard_normal(m) * 1e-3, force_type=2),
+                dict(t=9, obj=i, kind="arprm", a=[0.5, 0.3], sigma=0.004, mu=0.2),
+                force_ev(12, i, force_type=2, end=True),
+                force_ev(14, i, data=rng.standard_normal(m) * 1e-3)]
+        if maps is None:
+            evs.append(dict(t=0, obj=i, kind="use_transfer", use=False))
+        else:
+            dirs = np.array([[1, .2, .3], [.2, 1, .3], [.2, .3, 1], [-1, .2, .3]], dtype=float)
+            evs += [dict(t=b, obj=i, kind="listener", pos=0.5 * dirs[b % 4] / np.linalg.norm(dirs[b % 4])) for b in range(0, nb, 3)]
+    want = run_oracle(objs, evs, nb)
+    for split in (None, [1, 4, 11]):
+        got = run_engine(objs, evs, nb, split=split, form=capi.FORM_BLOCK, qnorm=qnorm)
+        info = got["info"]
+        assert info["total_split_launches"] == info["total_block_launches"] == (1 if split is None else 3) and info["total_sample_launches"] == 0
+        _check(got, want)
+        assert np.array_equal(got["emitted"], want["emitted"]) and not got["emitted"][:, 5].any()
+        if qnorm != capi.QNORM_OFF:
+            for key, w in want["qnorm"].items():
+                assert np.abs(got["qnorm"][key] - w).max() <= 5e-4 * max(np.abs(w).max(), 1e-30) + 2e-6 * np.abs(want["audio"][key[0]]).max(), key
+        for i in range(len(sizes)):
+            np.testing.assert_allclose(got["state"][i][0], want["state"][i][0], rtol=0, atol=5e-4 * max(np.abs(want["state"][i][0]).max(), 1e-30))
