@@ -73,10 +73,10 @@ def parse(argv=None):
                     help="block: block state-space form with the exact f32 MFMA projection (default: every product of the line is f32); "
                          "block_bf16: the same with the output projection as a split-bf16 MFMA product (mixed precision, reported as "
                          "such); velocity / direct: per-sample kernel (K1)")
-    ap.add_argument("--plan-threads", type=int, default=2,
-                    help="host planner threads (PBSO_PLAN_THREADS; the helper is pinned into the caller's core complex).  With the "
-                         "split-bf16 kernel one host thread (0.42 ms planning + 0.17 ms feeding + 0.15 ms launches per step) is as "
-                         "long as the device's step; a second planner thread (0.26 ms) gives the margin that keeps the run device-bound")
+    ap.add_argument("--plan-threads", type=int, default=1,
+                    help="host planner threads (PBSO_PLAN_THREADS; helpers are pinned into the caller's core complex).  One -- the engine's "
+                         "own default -- since round 3: a step's vertex hits go to the engine as one borrowed script "
+                         "(pbso_enqueue_vertex_hits: 0.02 ms) and are planned in 0.07 ms; a second thread's hand-shake costs more than it saves")
     ap.add_argument("--qnorm", choices=["sample", "closed", "off"], default="sample",
                     help="getQBufferNorm rows: on (the block form evaluates them in closed form), closed form, or off")
     ap.add_argument("--no-qnorm", action="store_true", help="same as --qnorm off")
@@ -351,14 +351,21 @@ def measure(args, ctx, global_ids, want_parity):
         fo, fv, fn, ft = (np.concatenate(x) for x in (feed_obj, feed_vid, feed_vn, feed_t))
         fb = np.concatenate(feed_bary) if feed_bary else None
         step_of = ft // args.buffers
-        order = np.lexsort((fo, ft))                 # time-major: per object the stamps stay ascending
+        # per step object by object, each object's stamps ascending: pbso_enqueue_force_batch then cuts the batch at its
+        # threads' object ranges instead of walking it in every thread
+        order = np.lexsort((ft, fo, step_of))
         fo, fv, fn, ft, step_of = fo[order], fv[order], fn[order], ft[order], step_of[order]
         fb = fb[order] if fb is not None else None
         bounds = np.searchsorted(step_of, np.arange(n_steps_all + 1))
         for k in range(n_steps_all):
             a, b = bounds[k], bounds[k + 1]
-            feeds[k] = eng.hit_messages(fo[a:b], fv[a:b], fn[a:b], ft[a:b], coords=None if fb is None else fb[a:b],
-                                        force_type=capi.AUTOREGRESSIVE_FORCE if args.scenario == "scraping" else capi.POINT_FORCE)
+            if fb is None:
+                # plain vertex hits: parallel arrays handed over as they are (pbso_enqueue_vertex_hits borrows them until the step)
+                feeds[k] = ("hits", np.ascontiguousarray(fo[a:b], dtype=np.int32), np.ascontiguousarray(fv[a:b], dtype=np.int32),
+                            np.ascontiguousarray(fn[a:b], dtype=np.float64), np.ascontiguousarray(ft[a:b], dtype=np.int64))
+            else:
+                feeds[k] = ("msgs",) + eng.hit_messages(fo[a:b], fv[a:b], fn[a:b], ft[a:b], coords=fb[a:b],
+                                                        force_type=capi.AUTOREGRESSIVE_FORCE if args.scenario == "scraping" else capi.POINT_FORCE)
 
     nb = args.buffers
     # Gather: the finished buffers of all ranks are all-gathered over RCCL.  Audio and gather
@@ -393,9 +400,9 @@ def measure(args, ctx, global_ids, want_parity):
     def feed(k):
         if feeds[k] is not None:
             te = time.perf_counter()
-            taken = eng.enqueue_force_batch(*feeds[k])
+            taken = (eng.enqueue_vertex_hits if feeds[k][0] == "hits" else eng.enqueue_force_batch)(*feeds[k][1:])
             enqueue_s[0] += time.perf_counter() - te
-            assert taken == feeds[k][0].size, "force queue overflow"
+            assert taken == feeds[k][1].size, "force queue overflow"
 
     feed(0)
 

@@ -208,6 +208,18 @@ int pbso_enqueue_force(pbso_engine *e, int object_id, const pbso_force_msg *m, i
  * result; returns the number enqueued, or a negative pbso_status on the first hard error.     */
 int pbso_enqueue_force_batch(pbso_engine *e, int n, const int *object_ids, const pbso_force_msg *msgs,
                              const int64_t *not_before, unsigned char *accepted);
+/* A step's worth of PLAIN VERTEX HITS -- what the tool does on a mouse click: GetModalForceVertex with a fresh
+ * PointForce, then enqueueForceMessage (tools/real_time_modal_sound.cpp:268-295, 594-622) -- as parallel arrays,
+ * object by object (object_ids ascending, not_before ascending within an object): hit i strikes vertex vids[i] of
+ * object object_ids[i] along vn[3 i .. 3 i + 2] at buffer stamp not_before[i].  Semantically n calls of
+ * pbso_enqueue_force in that order, except that nothing is copied: the arrays are BORROWED until the next pbso_step
+ * returns.  That step consumes them -- the hits of an idle object with an empty queue go straight into the step's
+ * descriptors (no queue round trip), the others, and the hits stamped beyond the step, enter the object's queue as if
+ * enqueued one by one (a queue that cannot take them, 1023 slots, fails that step: PBSO_ERR_STATE).  One script may be
+ * pending at a time; any other enqueue call for the engine first moves a pending script into the queues (order is kept).
+ * Returns n, or PBSO_ERR_INVALID (ids / vertex ids out of range, object order) / PBSO_ERR_STATE (a script is pending). */
+int pbso_enqueue_vertex_hits(pbso_engine *e, int n, const int *object_ids, const int *vids, const double *vn,
+                             const int64_t *not_before);
 /* ModalSolver::enqueueArprmMessageNoFail (modal_solver.h:382-393); 1-slot queue */
 int pbso_enqueue_arprm(pbso_engine *e, int object_id, const double a[2], double sigma,
                        double mu, int64_t not_before);

@@ -21,7 +21,7 @@ EXPORTS = [
     "pbso_abi_version", "pbso_status_string", "pbso_engine_create", "pbso_engine_destroy",
     "pbso_last_error", "pbso_add_object", "pbso_add_object_from_files", "pbso_object_set_ffat_maps",
     "pbso_object_read_ffat_maps", "pbso_fatcube_parse", "pbso_ffat_map_free", "pbso_finalize",
-    "pbso_enqueue_force", "pbso_enqueue_force_batch", "pbso_enqueue_arprm", "pbso_compute_transfer", "pbso_compute_transfer_batch", "pbso_object_n_maps", "pbso_listeners_enable", "pbso_mix_listeners",
+    "pbso_enqueue_force", "pbso_enqueue_force_batch", "pbso_enqueue_vertex_hits", "pbso_enqueue_arprm", "pbso_compute_transfer", "pbso_compute_transfer_batch", "pbso_object_n_maps", "pbso_listeners_enable", "pbso_mix_listeners",
     "pbso_set_use_transfer", "pbso_get_latest_transfer", "pbso_step", "pbso_step_into", "pbso_sync",
     "pbso_read_audio", "pbso_read_emitted", "pbso_read_qnorm", "pbso_read_state", "pbso_write_state",
     "pbso_audio_device_ptr", "pbso_pa_convert", "pbso_get_info",
@@ -101,6 +101,7 @@ def lib():
     l.pbso_ffat_map_free.restype = None
     l.pbso_finalize.argtypes = [vp]
     l.pbso_enqueue_force.argtypes = [vp, C.c_int, C.POINTER(ForceMsg), C.c_int64]
+    l.pbso_enqueue_vertex_hits.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     l.pbso_enqueue_force_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(ForceMsg), C.POINTER(C.c_int64),
                                            C.POINTER(C.c_ubyte)]
     l.pbso_enqueue_arprm.argtypes = [vp, C.c_int, dp, C.c_double, C.c_double, C.c_int64]

@@ -281,6 +281,14 @@ int pbso_enqueue_force_batch(pbso_engine *e, int n, const int *objs, const pbso_
     GUARD_END(e)
 }
 
+int pbso_enqueue_vertex_hits(pbso_engine *e, int n, const int *objs, const int *vids, const double *vn, const int64_t *nb) {
+    NEED(e);
+    if (n < 0 || (n && (!objs || !vids || !vn || !nb))) return PBSO_ERR_INVALID;
+    GUARD_BEGIN
+    return e->impl->enqueue_vertex_hits(n, objs, vids, vn, nb);
+    GUARD_END(e)
+}
+
 int pbso_enqueue_arprm(pbso_engine *e, int obj, const double a[2], double sigma, double mu, int64_t nb) {
     NEED(e);
     if (!a) return PBSO_ERR_INVALID;

@@ -912,7 +912,96 @@ int Engine::enqueue_force_impl(int obj, const pbso_force_msg &m, int64_t not_bef
     return 1;
 }
 
+// pbso_enqueue_vertex_hits: a step's plain vertex hits as borrowed parallel arrays, object by object.
+int Engine::enqueue_vertex_hits(int n, const int *objs, const int *vids, const double *vn, const int64_t *stamps) {
+    if (!finalized_) return fail(PBSO_ERR_STATE, "enqueue_vertex_hits before finalize");
+    if (script_.n > 0) return fail(PBSO_ERR_STATE, "a hit script is already pending (one per step)");
+    if (n == 0) return 0;
+    const int N = (int)objs_.size();
+    hit_off_.assign((size_t)N + 1, 0);
+    int prev = 0;
+    for (int i = 0; i < n; ++i) {
+        const int o = objs[i];
+        if (o < prev || o >= N) return fail(PBSO_ERR_INVALID, "enqueue_vertex_hits: object ids must be valid and ascending");
+        const int n_dof = objs_[o].n_dof;
+        if (vids[i] < 0 || 3 * vids[i] + 2 >= n_dof)
+            return fail(PBSO_ERR_INVALID, n_dof ? "vertex id out of range" : "object has no mode shapes for on-device projection");
+        prev = o;
+        hit_off_[(size_t)o + 1] = i + 1;
+    }
+    for (int o = 0; o < N; ++o)                       // objects without hits: an empty range at the running offset
+        if (hit_off_[(size_t)o + 1] < hit_off_[o]) hit_off_[(size_t)o + 1] = hit_off_[o];
+    script_.n = n; script_.objs = objs; script_.vids = vids; script_.vn = vn; script_.stamps = stamps;
+    return n;
+}
+
+// hits h0 .. h1 - 1 of the script (all of object oi) enter the object's queue exactly as pbso_enqueue_force would put them
+int Engine::script_to_queue(int oi, int h0, int h1, const char **why) {
+    Object &o = objs_[oi];
+    for (int h = h0; h < h1; ++h) {
+        if (o.force_q.size() >= 1023) { *why = "force queue overflow while taking a hit script (1023 slots, modal_solver.h:105)"; return PBSO_ERR_STATE; }
+        HostForceMsg m;
+        m.force_type = PBSO_POINT_FORCE;
+        m.data_kind = PBSO_DATA_VERTEX;
+        m.not_before = script_.stamps[h];
+        m.vids[0] = script_.vids[h];
+        for (int j = 0; j < 3; ++j) m.vn[j] = script_.vn[3 * (size_t)h + j];
+        if (!o.force_q.empty()) m.not_before = std::max(m.not_before, o.force_q.back().not_before);
+        o.force_q.push_back(std::move(m));
+    }
+    return PBSO_OK;
+}
+
+int Engine::flush_script() {
+    if (script_.n <= 0) return PBSO_OK;
+    const int N = (int)objs_.size();
+    const char *why = "";
+    for (int o = 0; o < N; ++o) {
+        int rc = script_to_queue(o, hit_off_[o], hit_off_[(size_t)o + 1], &why);
+        if (rc != PBSO_OK) { script_.n = 0; return fail(rc, why); }
+    }
+    script_.n = 0;
+    return PBSO_OK;
+}
+
+// Planner, before an object's buffers are planned: its share of the pending hit script.  An object that is idle -- no live
+// force, nothing queued, no pending listener / parameter call -- takes its hits straight into the descriptors of this launch:
+// hit after hit at buffer max(stamp, previous hit's buffer + 1), which is where ModalSolver::step would have dequeued it
+// (at most one message per buffer, modal_solver.h:184), each a DESC_DIRECT impulse.  Everything else goes through the queue.
+int Engine::consume_script(PlanCtx &c, int oi, int nb) {
+    if (script_.n <= 0) return PBSO_OK;
+    const int h0 = hit_off_[oi], h1 = hit_off_[(size_t)oi + 1];
+    if (h0 >= h1) return PBSO_OK;
+    Object &o = objs_[oi];
+    const bool idle = o.force_q.empty() && o.active.empty() && !o.sustained && o.pending.empty() && !o.trans_full &&
+                      !(!o.use_transfer && o.latest_row != XFER_UNIT) && !o.arprm_full;
+    int h = h0;
+    if (idle && device_profiles_ && direct_hits_ && !use_split()) {
+        int next_b = 0;
+        for (; h < h1; ++h) {
+            const int64_t rel = script_.stamps[h] - buffers_done_;
+            const int b = (int)std::max<int64_t>(rel, next_b);
+            if (b >= nb) break;
+            BufDesc &d = plan_desc_[(size_t)oi * nb + b];
+            const double *vnd = script_.vn + 3 * (size_t)h;
+            const float vn[3] = {(float)vnd[0], (float)vnd[1], (float)vnd[2]};
+            d.frow = 3 * script_.vids[h];
+            std::memcpy(&d.prow, &vn[0], 4);
+            std::memcpy(&d.tile_mask, &vn[1], 4);
+            std::memcpy(&d.pad[0], &vn[2], 4);
+            d.flags |= DESC_IMPULSE | DESC_DIRECT;
+            d.amp = 1.f;
+            next_b = b + 1;
+        }
+    }
+    const char *why = "";
+    int rc = script_to_queue(oi, h, h1, &why);       // what is left: beyond this launch, or the object is busy
+    if (rc != PBSO_OK) return cfail(c, rc, why);
+    return PBSO_OK;
+}
+
 int Engine::enqueue_force(int obj, const pbso_force_msg &m, int64_t not_before) {
+    if (script_.n > 0) { int frc = flush_script(); if (frc != PBSO_OK) return frc; }
     const char *why = "";
     const int rc = enqueue_force_impl(obj, m, not_before, &why);
     return rc < 0 ? fail(rc, why) : rc;
@@ -922,15 +1011,26 @@ int Engine::enqueue_force(int obj, const pbso_force_msg &m, int64_t not_before) 
 // (PBSO_PLAN_THREADS > 1) every thread enqueues the messages of its own range of objects.
 int Engine::enqueue_force_batch(int n, const int *objs, const pbso_force_msg *msgs, const int64_t *stamps,
                                 unsigned char *accepted) {
+    if (script_.n > 0) { int frc = flush_script(); if (frc != PBSO_OK) return frc; }
     const int N = (int)objs_.size();
     const int T = (plan_threads_ > 1 && n >= 4096 && N >= 64) ? plan_threads_ : 1;
     std::vector<int> taken(T, 0), rcs(T, 0);
     std::vector<const char *> whys(T, "");
+    // A script given object by object (ids ascending; each object's messages in their own order) is cut at the threads'
+    // object ranges by binary search: no thread walks messages that are not its own, and an object's queue takes its
+    // messages back to back (one ring's tail stays in the core's cache).  Any other order: every thread walks the batch.
+    bool by_object = n > 0 && objs[0] >= 0 && objs[n - 1] < N;
+    for (int i = 1; i < n && by_object; ++i) by_object = objs[i - 1] <= objs[i];
     auto job = [&](int t) {
         const int lo = (int)((long long)N * t / T), hi = (int)((long long)N * (t + 1) / T);
-        for (int i = 0; i < n; ++i) {
+        int i0 = 0, i1 = n;
+        if (by_object) {
+            i0 = (int)(std::lower_bound(objs, objs + n, lo) - objs);
+            i1 = (int)(std::lower_bound(objs, objs + n, hi) - objs);
+        }
+        for (int i = i0; i < i1; ++i) {
             const int o = objs[i];
-            const bool mine = (o >= lo && o < hi) || (t == 0 && (o < 0 || o >= N));   // bad ids: reported by thread 0
+            const bool mine = by_object || (o >= lo && o < hi) || (t == 0 && (o < 0 || o >= N));   // bad ids: reported by thread 0
             if (!mine) continue;
             const int rc = enqueue_force_impl(o, msgs[i], stamps[i], &whys[t]);
             if (rc < 0) { rcs[t] = rc; return; }
@@ -1340,6 +1440,10 @@ int Engine::plan_object(PlanCtx &c, int oi, int b, int nb, int64_t t) {
 // messages an idle object needs no bookkeeping at all: jump to the next stamp.
 int Engine::plan_object_span(PlanCtx &c, int oi, int nb) {
     Object &o = objs_[oi];
+    {
+        int rc = consume_script(c, oi, nb);
+        if (rc != PBSO_OK) return rc;
+    }
     int b = 0;
     while (b < nb) {
         const int64_t t = buffers_done_ + b;
@@ -1379,7 +1483,8 @@ int Engine::plan(int nb) {
         const Object &o = objs_[i];
         h_xfer_init[i] = o.latest_row;
         if (!o.force_q.empty() || !o.active.empty() || !o.pending.empty() || o.trans_full ||
-            o.sustained || (!o.use_transfer && o.latest_row != XFER_UNIT))
+            o.sustained || (!o.use_transfer && o.latest_row != XFER_UNIT) ||
+            (script_.n > 0 && hit_off_[(size_t)i + 1] > hit_off_[i]))
             busy_.push_back(i);
     }
     // contiguous shares of the busy objects, one planning context (host thread) each
@@ -1431,6 +1536,7 @@ int Engine::plan(int nb) {
         job(0);
     }
     const auto tp2 = std::chrono::steady_clock::now();
+    script_.n = 0;                                   // (every object with hits was busy: all of the script is consumed)
     for (int t = 0; t < T; ++t)
         if (ctx_[t].rc != PBSO_OK) return fail(ctx_[t].rc, ctx_[t].err);
 

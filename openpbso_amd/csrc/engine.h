@@ -177,6 +177,7 @@ public:
     int build_gq();                                      // closed-form qnorm matrices (once)
     int enqueue_force(int obj, const pbso_force_msg &m, int64_t not_before);
     int enqueue_force_batch(int n, const int *objs, const pbso_force_msg *msgs, const int64_t *stamps, unsigned char *accepted);
+    int enqueue_vertex_hits(int n, const int *objs, const int *vids, const double *vn, const int64_t *stamps);
     int enqueue_arprm(int obj, const double a[2], double sigma, double mu, int64_t not_before);
     int compute_transfer(int obj, const double pos[3], int64_t not_before);
     int compute_transfer_batch(int obj, const double *pos, int n_pos, double *out, int out_cols);
@@ -210,6 +211,13 @@ private:
     int plan(int nb);                                    // host bookkeeping for one batch
     int plan_object(PlanCtx &c, int o, int b, int nb, int64_t t);
     int plan_object_span(PlanCtx &c, int o, int nb);
+    // the borrowed script of plain vertex hits (pbso_enqueue_vertex_hits): arrays of the caller, valid until the next step
+    // has planned; hit_off_[o] .. hit_off_[o + 1] are object o's hits
+    struct HitScript { int n = 0; const int *objs = nullptr, *vids = nullptr; const double *vn = nullptr; const int64_t *stamps = nullptr; } script_;
+    std::vector<int> hit_off_;
+    int script_to_queue(int oi, int h0, int h1, const char **why);     // hits h0 .. h1 - 1 of object oi enter its queue, in order
+    int flush_script();                                                 // all of it (another enqueue call came before the step)
+    int consume_script(PlanCtx &c, int oi, int nb);                     // planner: the object's hits of this launch
     static int cfail(PlanCtx &c, int code, const char *msg) { c.err = msg; return code; }
 
     pbso_engine_desc desc_;

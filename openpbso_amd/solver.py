@@ -115,6 +115,7 @@ class Engine:
         self.B = frames_per_buffer or 513
         self.qnorm_mode = qnorm
         self._last_nb = 0
+        self._borrowed = None
 
     # -- plumbing -----------------------------------------------------------
     def _chk(self, rc):
@@ -229,6 +230,20 @@ class Engine:
             self._h, objs.size, objs.ctypes.data_as(C.POINTER(C.c_int)), msgs.ctypes.data_as(C.POINTER(capi.ForceMsg)),
             not_before.ctypes.data_as(C.POINTER(C.c_int64)), None))
 
+    def enqueue_vertex_hits(self, objs, vids, vns, not_before):
+        """pbso_enqueue_vertex_hits: a step's plain PointForce vertex hits as parallel arrays, object by object (ids ascending,
+        stamps ascending within an object).  The arrays are borrowed by the engine until the next step() returns: they are kept
+        alive here; do not modify them in between.  Arrays of the right dtype and layout are passed through without a copy."""
+        o = np.ascontiguousarray(objs, dtype=np.int32)
+        v = np.ascontiguousarray(vids, dtype=np.int32)
+        n = np.ascontiguousarray(vns, dtype=np.float64).reshape(-1, 3)
+        t = np.ascontiguousarray(not_before, dtype=np.int64)
+        assert o.size == v.size == t.size == n.shape[0]
+        self._borrowed = (o, v, n, t)
+        return self._chk(self._l.pbso_enqueue_vertex_hits(
+            self._h, o.size, o.ctypes.data_as(C.POINTER(C.c_int)), v.ctypes.data_as(C.POINTER(C.c_int)), _dp(n),
+            t.ctypes.data_as(C.POINTER(C.c_int64))))
+
     def enqueue_arprm(self, obj, a, sigma, mu, not_before=0):
         a = np.ascontiguousarray(a, dtype=np.float64)
         return bool(self._chk(self._l.pbso_enqueue_arprm(self._h, obj, _dp(a), sigma, mu, not_before)))
@@ -280,6 +295,7 @@ class Engine:
         else:
             self._chk(self._l.pbso_step_into(self._h, n_buffers, C.c_void_p(into)))
         self._last_nb = n_buffers
+        self._borrowed = None                           # (a hit script is consumed by the step that follows it)
 
     def sync(self):
         self._chk(self._l.pbso_sync(self._h))

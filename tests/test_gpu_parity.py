@@ -995,3 +995,82 @@ def test_time_split_kernel_every_buffer_kind(qnorm, monkeypatch):
                 assert np.abs(got["qnorm"][key] - w).max() <= 5e-4 * max(np.abs(w).max(), 1e-30) + 2e-6 * np.abs(want["audio"][key[0]]).max(), key
         for i in range(len(sizes)):
             np.testing.assert_allclose(got["state"][i][0], want["state"][i][0], rtol=0, atol=5e-4 * max(np.abs(want["state"][i][0]).max(), 1e-30))
+
+
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_vertex_hit_script_equals_message_by_message_enqueue(split, monkeypatch):
+    """pbso_enqueue_vertex_hits (a step's plain vertex hits as borrowed parallel arrays, object by object) == the same hits
+    through pbso_enqueue_force one by one, bit for bit: idle objects (hits written straight into the step's descriptors),
+    two hits stamped for the same buffer (one message per buffer: the second moves on), hits stamped beyond the step
+    (they wait in the queue), an object kept busy by a Gaussian force (its hits take the queue), launches cut at 3 buffers,
+    a regular enqueue call between the script and the step (the script is moved into the queues first: order kept), and the
+    argument errors."""
+    from openpbso_amd import Engine
+    from openpbso_amd.solver import PbsoError
+    monkeypatch.setenv("PBSO_SPLIT", split)
+    monkeypatch.setenv("PBSO_CHUNK_BUFFERS", "3")
+    n_obj, n_modes, nb = 4, 130, 8
+    rng = np.random.default_rng(77)
+    lams = [synth.eigenvalues(n_modes, 500 + i) for i in range(n_obj)]
+    shapes = [synth.mode_shapes(n_modes, 500 + i) for i in range(n_obj)]
+    n_verts = shapes[0].shape[1] // 3
+    # (object, vertex, stamp): object 0 plain, object 1 with a double stamp and a hit beyond the second step, object 2 busy, object 3 none
+    hits = [(0, 3, 0), (0, 9, 2), (0, 4, 5), (1, 1, 1), (1, 2, 1), (1, 7, 6), (1, 8, 40), (2, 5, 0), (2, 6, 3)]
+    vns = synth.unit_normals(len(hits), 9)
+    gauss = rng.standard_normal(n_modes) * 1e-3
+
+    def run(script):
+        with Engine(form=capi.FORM_BLOCK) as eng:
+            for i in range(n_obj):
+                eng.add_object(lams[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
+            eng.finalize()
+            for i in range(n_obj):
+                eng.set_use_transfer(i, False)
+            assert eng.enqueue_force(2, ForceMessage(data=gauss, forceType=capi.GAUSSIAN_FORCE, gaussianWidth=1500.0), 0)
+            o = np.array([h[0] for h in hits], dtype=np.int32)
+            v = np.array([h[1] for h in hits], dtype=np.int32)
+            t = np.array([h[2] for h in hits], dtype=np.int64)
+            if script:
+                assert eng.enqueue_vertex_hits(o, v, vns, t) == len(hits)
+                with pytest.raises(PbsoError):
+                    eng.enqueue_vertex_hits(o, v, vns, t)                  # one script per step
+            else:
+                for k, (oi, vid, st) in enumerate(hits):
+                    assert eng.enqueue_force(oi, ForceMessage(vid=vid, vn=vns[k]), st)
+            out = []
+            eng.step(nb)
+            out.append(eng.audio().copy())
+            eng.step(nb)
+            out.append(eng.audio().copy())
+            # second script, with a regular message for object 0 enqueued AFTER it: the script's hit comes first
+            o2, v2, t2 = np.array([0, 3], dtype=np.int32), np.array([11, 12], dtype=np.int32), np.array([2 * nb, 2 * nb], dtype=np.int64)
+            if script:
+                assert eng.enqueue_vertex_hits(o2, v2, vns[:2], t2) == 2
+            else:
+                for k in range(2):
+                    assert eng.enqueue_force(int(o2[k]), ForceMessage(vid=int(v2[k]), vn=vns[k]), int(t2[k]))
+            assert eng.enqueue_force(0, ForceMessage(vid=13, vn=vns[2]), 2 * nb)
+            eng.step(nb)
+            out.append(eng.audio().copy())
+            info = eng.info()
+            if script:
+                with pytest.raises(PbsoError):
+                    eng.enqueue_vertex_hits(np.array([1, 0], dtype=np.int32), v2, vns[:2], t2)          # objects not ascending
+                with pytest.raises(PbsoError):
+                    eng.enqueue_vertex_hits(o2, np.array([0, n_verts], dtype=np.int32), vns[:2], t2)     # vertex id out of range
+        return np.concatenate(out, axis=1), info
+
+    a, info = run(True)
+    b, _ = run(False)
+    assert np.array_equal(a, b)
+    assert np.abs(a[0]).max() > 0 and np.abs(a[1]).max() > 0 and np.abs(a[2]).max() > 0 and np.abs(a[3, 2 * nb * B:]).max() > 0
+    assert info["total_block_launches"] == 9
+    # against the oracle
+    objs = [ObjSpec(lams[i], shapes=shapes[i]) for i in range(n_obj)]
+    evs = [dict(t=0, obj=i, kind="use_transfer", use=False) for i in range(n_obj)]
+    evs.append(force_ev(0, 2, data=gauss, force_type=1, width=1500.0))
+    evs += [force_ev(st, oi, vid=vid, vn=vns[k]) for k, (oi, vid, st) in enumerate(hits)]
+    evs += [force_ev(2 * nb, 0, vid=11, vn=vns[0]), force_ev(2 * nb, 3, vid=12, vn=vns[1]), force_ev(2 * nb, 0, vid=13, vn=vns[2])]
+    want = run_oracle(objs, evs, 3 * nb)
+    mx, l2 = rel_errors(a, want["audio"])
+    assert (mx <= 5e-4).all() and (l2 <= 1e-3).all(), (mx, l2)
