@@ -274,7 +274,7 @@ Engine::~Engine() {
     for (PlanSet &ps : set_) ps.release();
     for (auto *v : {&ev_free_, &ev_pending_})
         for (EvQuad &q : *v)
-            for (hipEvent_t ev : {q.k0, q.k1, q.p0, q.p1}) (void)hipEventDestroy(ev);
+            for (hipEvent_t ev : {q.k0, q.k1, q.p0, q.p1, q.f0, q.f1}) (void)hipEventDestroy(ev);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -367,6 +367,7 @@ int Engine::init() {
     if (const char *v = std::getenv("PBSO_ROTATE_PRIO")) rotate_prio_ = std::min(2, std::max(0, std::atoi(v)));
     if (const char *v = std::getenv("PBSO_DEVICE_PROFILES")) device_profiles_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_AR_SERIAL")) ar_serial_ = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PBSO_K2_PRIO")) { k2_prio_ = std::min(3, std::max(0, std::atoi(v))); k2_prio_auto_ = false; }
     if (const char *v = std::getenv("PBSO_DIRECT_HITS")) direct_hits_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_TIMING_EVERY")) timing_every_ = std::max(0, std::atoi(v));
     if (const char *v = std::getenv("PBSO_CHUNK_BUFFERS")) chunk_buffers_ = std::max(1, std::atoi(v));
@@ -1690,8 +1691,8 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     HIPTRY(grows.ensure(std::max<size_t>(1, (size_t)n_frows) * m_pad_, false, sp));
     const bool qn = desc_.qnorm_mode != PBSO_QNORM_OFF;
 
-    if (ev_pending_.size() >= 256) {          // bound the number of live events
-        int hrc = harvest_timing();
+    {
+        int hrc = harvest_timing(ev_pending_.size() >= 256);      // (what has finished; everything when too many events are live)
         if (hrc != PBSO_OK) return hrc;
     }
     EvQuad evq;
@@ -1703,8 +1704,11 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         HIPTRY(hipEventCreate(&evq.k1));
         HIPTRY(hipEventCreate(&evq.p0));
         HIPTRY(hipEventCreate(&evq.p1));
+        HIPTRY(hipEventCreate(&evq.f0));
+        HIPTRY(hipEventCreate(&evq.f1));
     }
     evq.step_id = step_id;
+    evq.has_k2 = false;
     // (two timing events before and three after the bank cost the stream ~15 us per launch -- 2 % of a 0.7 ms step)
     const bool timed = timing_every_ > 0 && (launch_seq_ % (unsigned)timing_every_) == 0;
     // ---- preparation stream: this set's device buffers are free once the oscillator
@@ -1773,8 +1777,10 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     const FfatEvent *d_ffat = reinterpret_cast<const FfatEvent *>(da + o_ffat);
 
     // K2 -> time-profile rows ; K3 / scatter -> data slots ; K4 -> transfer rows ; combine -> g rows
+    if (device_profiles_ && timed && n_chains > 0) { HIPTRY(hipEventRecord(evq.f0, sp)); evq.has_k2 = true; }
     if (device_profiles_)
-        LAUNCHTRY(launch_force_profiles(d_chain, n_chains, d_prow, d_pent, d_arstate_.p, ps.d_tprof.p, B_, b_pad_, ar_serial_ ? 1 : 0, sp));
+        LAUNCHTRY(launch_force_profiles(d_chain, n_chains, d_prow, d_pent, d_arstate_.p, ps.d_tprof.p, B_, b_pad_, ar_serial_ ? 1 : 0, k2_prio_, sp));
+    if (evq.has_k2) HIPTRY(hipEventRecord(evq.f1, sp));
     LAUNCHTRY(launch_scatter_rows(d_stage, d_stage_slot, (int)stage_slot_.size(), d_slots_.p, m_pad_, sp));
     LAUNCHTRY(launch_modal_project(d_proj, (int)proj_.size(), d_shapes_.p, d_shape_off_.p, d_n_modes_.p, d_slots_.p, m_pad_, sp));
     LAUNCHTRY(launch_ffat_lookup(d_ffat, (int)ffat_.size(), d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p, d_xfer_.p, m_pad_, sp));
@@ -2176,7 +2182,7 @@ int Engine::info(pbso_engine_info *out) {
     out->last_step_host_plan_ms = last_plan_ms_;
     out->last_step_forced_rows = last_frows_;
     out->last_step_transfer_rows = last_trows_;
-    int rc = harvest_timing();
+    int rc = harvest_timing(true);
     if (rc) return rc;
     out->last_step_kernel_ms = last_kernel_ms_;
     out->last_step_device_ms = last_device_ms_;
@@ -2188,11 +2194,19 @@ int Engine::info(pbso_engine_info *out) {
     return PBSO_OK;
 }
 
-int Engine::harvest_timing() {
+// Reads the HIP-event pairs of finished launches into the totals.  blocking: waits for everything in flight (pbso_get_info);
+// otherwise only the launches whose last event has already completed are read (called once per launch: keeps the number of live
+// events small and lets the K2 priority follow the workload without ever stalling the host).
+int Engine::harvest_timing(bool blocking) {
     if (ev_pending_.empty()) return PBSO_OK;
-    int rc = sync();
-    if (rc) return rc;
-    for (EvQuad &q : ev_pending_) {
+    if (blocking) {
+        int rc = sync();
+        if (rc) return rc;
+    }
+    size_t done = 0;
+    for (; done < ev_pending_.size(); ++done) {
+        EvQuad &q = ev_pending_[done];
+        if (!blocking && hipEventQuery(q.p1) != hipSuccess) break;
         float ms = 0, ms2 = 0;
         HIPTRY(hipEventElapsedTime(&ms, q.k0, q.k1));
         HIPTRY(hipEventElapsedTime(&ms2, q.p0, q.p1));
@@ -2201,6 +2215,14 @@ int Engine::harvest_timing() {
             last_kernel_ms_ = 0;
             last_device_ms_ = 0;
         }
+        if (q.has_k2) {
+            float msf = 0;
+            HIPTRY(hipEventElapsedTime(&msf, q.f0, q.f1));
+            // exponential averages over the last few timed launches
+            k2_ms_avg_ = k2_ms_n_ ? 0.75 * k2_ms_avg_ + 0.25 * msf : msf;
+            k2_bank_ms_avg_ = k2_ms_n_ ? 0.75 * k2_bank_ms_avg_ + 0.25 * ms : ms;
+            k2_ms_n_ += 1;
+        }
         last_kernel_ms_ += ms;
         tot_kernel_ms_ += ms;
         tot_timed_launches_ += 1;
@@ -2208,7 +2230,15 @@ int Engine::harvest_timing() {
         tot_device_ms_ += ms2;
         ev_free_.push_back(q);
     }
-    ev_pending_.clear();
+    ev_pending_.erase(ev_pending_.begin(), ev_pending_.begin() + (long)done);
+    if (k2_prio_auto_ && k2_ms_n_ >= 2) {
+        // the longer of the two kernels that run side by side gets the SIMDs they share (with hysteresis)
+        const int want = k2_ms_avg_ > (k2_prio_ ? 0.85 : 0.95) * k2_bank_ms_avg_ ? 3 : 0;
+        if (want != k2_prio_ && std::getenv("PBSO_HOST_PROFILE"))
+            std::fprintf(stderr, "pbso: force-profile kernel %.3f ms, oscillator bank %.3f ms per timed launch: K2 wave priority %d -> %d\n",
+                         k2_ms_avg_, k2_bank_ms_avg_, k2_prio_, want);
+        k2_prio_ = want;
+    }
     return PBSO_OK;
 }
 

@@ -241,9 +241,9 @@ private:
     hipEvent_t ev_fork_ = nullptr, ev_join_[N_CLASS_STREAMS] = {nullptr, nullptr, nullptr};
     int xfer_cap_ = 0;                                   // scratch transfer rows per plan set
     hipEvent_t ev_set_[N_SETS] = {};
-    struct EvQuad { hipEvent_t k0, k1, p0, p1; int64_t step_id; };
+    struct EvQuad { hipEvent_t k0, k1, p0, p1, f0, f1; int64_t step_id; bool has_k2; };      // bank, pipeline, force-profile kernel
     std::vector<EvQuad> ev_free_, ev_pending_;           // one quad per step, harvested in info()
-    int harvest_timing();
+    int harvest_timing(bool blocking);
     double tot_kernel_ms_ = 0, tot_device_ms_ = 0, tot_plan_ms_ = 0, last_kernel_ms_ = 0, last_device_ms_ = 0;
     int64_t tot_steps_ = 0, tot_block_launches_ = 0, tot_sample_launches_ = 0, tot_timed_launches_ = 0;
     int timing_every_ = 1;                               // PBSO_TIMING_EVERY=n: HIP-event pairs around every n-th launch only (0: none)
@@ -327,6 +327,14 @@ private:
     int n_frows_ = 0, n_prows_ = 0;
     // K2: device-side time profiles
     bool device_profiles_ = true;                        // PBSO_DEVICE_PROFILES=0: host fp64 profiles, uploaded
+    // Wave priority of the force-profile kernel K2 (s_setprio 0..3).  K2 is a handful of latency-bound workgroups that run beside
+    // the oscillator bank of the previous step; whichever of the two is longer bounds the step, and they share SIMDs.  Auto
+    // (PBSO_K2_PRIO unset): 3 while the timed launches say K2 is the longer one, 0 otherwise -- a scheduling hint only, results
+    // do not depend on it (8 x 4096 scraping without qnorm rows: 1400 -> 1460 x; with them the bank is longer and 0 is right).
+    int k2_prio_ = 0;
+    bool k2_prio_auto_ = true;
+    double k2_ms_avg_ = 0, k2_bank_ms_avg_ = 0;
+    int k2_ms_n_ = 0;
     bool ar_serial_ = false;                             // PBSO_AR_SERIAL=1: K2 runs the AR(2) recurrence as the reference's serial loop (16 us per row)
     std::vector<ProfEntry> prof_entries_;
     std::vector<ProfRow> prof_rows_;

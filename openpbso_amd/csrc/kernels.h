@@ -180,7 +180,7 @@ struct ProfRow {         // one dense profile row = one (object, buffer)
 // chains: rows of one object in buffer order are generated by ONE wave (the AR state is sequential)
 // ar_serial != 0: the AR(2) recurrence as the reference's serial loop (forces.h:107-117) instead of a parallel scan
 int launch_force_profiles(const int *chain_ptr, int n_chains, const ProfRow *rows, const ProfEntry *entries,
-                          ArState *states, float *tprof, int frames, int b_pad, int ar_serial, hipStream_t stream);
+                          ArState *states, float *tprof, int frames, int b_pad, int ar_serial, int high_prio, hipStream_t stream);
 
 struct FfatGeom {        // FFAT_Map<double,3> runtime fields, one per (object, mode)
     double k;

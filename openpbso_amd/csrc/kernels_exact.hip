@@ -150,8 +150,14 @@ constexpr int K2_THREADS = 256;           // candidate pairs evaluated per batch
 __global__ __launch_bounds__(K2_THREADS) void force_profile_kernel(
     const int *__restrict__ chain_ptr, int n_chains, const ProfRow *__restrict__ rows,
     const ProfEntry *__restrict__ entries, ArState *__restrict__ states, float *__restrict__ tprof,
-    int frames, int b_pad, int ar_serial) {
+    int frames, int b_pad, int ar_serial, int high_prio) {
     extern __shared__ __attribute__((aligned(16))) double k2_lds[];
+    switch (high_prio) {
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    case 3: __builtin_amdgcn_s_setprio(3); break;
+    default: break;
+    }
     double *nrm = k2_lds;
     double *acc = k2_lds + frames;
     double *sh_saved = k2_lds + 2 * frames;                    // [0] saved variate
@@ -448,11 +454,11 @@ __global__ __launch_bounds__(K2_THREADS) void force_profile_kernel(
 }
 
 int launch_force_profiles(const int *chain_ptr, int n_chains, const ProfRow *rows, const ProfEntry *entries,
-                          ArState *states, float *tprof, int frames, int b_pad, int ar_serial, hipStream_t stream) {
+                          ArState *states, float *tprof, int frames, int b_pad, int ar_serial, int high_prio, hipStream_t stream) {
     if (n_chains <= 0) return 0;
     const size_t lds = sizeof(double) * (2 * (size_t)frames + 2) + sizeof(uint32_t) * 2 * (K2_THREADS / 64);
     hipLaunchKernelGGL(force_profile_kernel, dim3(n_chains), dim3(K2_THREADS), lds, stream, chain_ptr, n_chains, rows,
-                       entries, states, tprof, frames, b_pad, ar_serial);
+                       entries, states, tprof, frames, b_pad, ar_serial, high_prio);
     return (int)hipGetLastError();
 }
 
