@@ -259,6 +259,8 @@ Engine::~Engine() {
     d_shapes_.release(); d_shape_off_.release(); d_g32_.release(); d_g32_off_.release(); d_n_modes_.release(); d_geom_.release();
     d_geom_off_.release(); d_psi_.release(); d_slots_.release(); d_xfer_.release();
     d_pc_.release(); d_wtab_.release(); d_ftab_.release(); d_dump_row_.release(); d_xdump_.release(); d_xscale_.release(); d_wtab32_.release();
+    d_ar_snaps_.release(); d_ar_vnorm_.release(); d_ar_cbuf_.release(); d_ar_vstate_.release(); d_ar_segcount_.release();
+    d_ar_recs_.release(); d_ar_fins_.release();
     d_arstate_.release(); d_board_.release(); d_teams_.release(); d_split_.release(); d_ts_teams_.release(); d_ts_split_.release(); d_audio_parts_.release();
     d_audio_.release(); d_qnorm_.release(); d_census_.release();
     for (DevBuf<float> &g : d_grows_) g.release();
@@ -367,6 +369,8 @@ int Engine::init() {
     if (const char *v = std::getenv("PBSO_ROTATE_PRIO")) rotate_prio_ = std::min(2, std::max(0, std::atoi(v)));
     if (const char *v = std::getenv("PBSO_DEVICE_PROFILES")) device_profiles_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_AR_SERIAL")) ar_serial_ = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PBSO_K2_ROWS")) k2_rows_ = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PBSO_K2_MARGIN_PCT")) k2_margin_pct_ = std::min(400, std::max(1, std::atoi(v)));
     if (const char *v = std::getenv("PBSO_K2_PRIO")) { k2_prio_ = std::min(3, std::max(0, std::atoi(v))); k2_prio_auto_ = false; }
     if (const char *v = std::getenv("PBSO_DIRECT_HITS")) direct_hits_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_TIMING_EVERY")) timing_every_ = std::max(0, std::atoi(v));
@@ -1582,6 +1586,7 @@ int Engine::plan(int nb) {
         c.free_slots.insert(c.free_slots.end(), c.freed_this_plan.begin(), c.freed_this_plan.end());
         c.free_ar.insert(c.free_ar.end(), c.freed_ar.begin(), c.freed_ar.end());
     }
+    build_ar_tables();
     const auto tp3 = std::chrono::steady_clock::now();
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
@@ -1590,6 +1595,68 @@ int Engine::plan(int nb) {
     hprof_[2] += ms(tp1, tp2);
     hprof_[3] += ms(tp2, tp3);
     return PBSO_OK;
+}
+
+// ---------------------------------------------------------------------------
+// The row-parallel form of K2 (kernels_exact.hip): which AR forces add samples in this launch, in which rows, and how many
+// candidate pairs of each force's engine to evaluate.  A force needs ceil(n_uses * frames / 2) accepted pairs (one more when a
+// cached variate is not there to start with: counted); a candidate is accepted with probability pi / 4, so
+// pairs / 0.7854 + 8 sigma of the binomial + one batch is asked for -- ar_zero_state_kernel continues the sequence by itself
+// should that ever fall short.
+void Engine::build_ar_tables() {
+    ar_streams_.clear(); ar_uses_.clear(); seg_stream_.clear();
+    ar_max_segs_ = 0;
+    k2_rows_launch_ = device_profiles_ && k2_rows_ && !ar_serial_ && B_ >= 3 && !prof_rows_.empty();
+    if (!k2_rows_launch_) return;
+    const size_t n_states = n_ar_states_.load();
+    if (ar_stream_of_state_.size() < n_states) ar_stream_of_state_.resize(n_states, -1);
+    ar_last_use_.clear(); ar_epoch_.clear(); ar_param_.clear();
+    for (size_t ei = 0; ei < prof_entries_.size(); ++ei) {
+        ProfEntry &e = prof_entries_[ei];
+        if (e.kind != PBSO_AUTOREGRESSIVE_FORCE) continue;
+        int &si = ar_stream_of_state_[(size_t)e.state];
+        if (si < 0) {
+            si = (int)ar_streams_.size();
+            ArStream S;
+            std::memset(&S, 0, sizeof(S));
+            S.state = e.state;
+            S.reset = (e.flags & 1) ? 1 : 0;
+            ar_streams_.push_back(S);
+            ar_last_use_.push_back(-1); ar_epoch_.push_back(-1); ar_param_.push_back(-1);
+        } else if (e.flags & 1) {
+            k2_rows_launch_ = false;                 // a slot constructed twice within one launch: the planner never does this
+            break;
+        }
+        ArUse U;
+        std::memset(&U, 0, sizeof(U));
+        U.entry = (int)ei;
+        U.stream = si;
+        U.u = ar_streams_[(size_t)si].n_uses++;
+        if (e.flags & 3) { ar_epoch_[(size_t)si] = U.u; ar_param_[(size_t)si] = (int)ei; }
+        U.epoch_u = ar_epoch_[(size_t)si];
+        U.param_entry = ar_param_[(size_t)si];
+        e.count = (int)ar_uses_.size();
+        ar_last_use_[(size_t)si] = (int)ar_uses_.size();
+        ar_uses_.push_back(U);
+    }
+    int use0 = 0, seg0 = 0;
+    for (size_t si = 0; si < ar_streams_.size(); ++si) {
+        ArStream &S = ar_streams_[si];
+        ar_stream_of_state_[(size_t)S.state] = -1;
+        if (!k2_rows_launch_) continue;
+        ar_uses_[(size_t)ar_last_use_[si]].last = 1;
+        S.use0 = use0;
+        use0 += S.n_uses;
+        const double pairs = 0.5 * ((double)S.n_uses * B_ + 1.0);
+        const double want = (pairs / 0.78539 + 8.0 * std::sqrt(pairs) + 256.0) * (k2_margin_pct_ / 100.0);
+        S.n_seg = std::max(1, (int)std::ceil(want / K2_SEG));
+        S.seg_base = seg0;
+        seg0 += S.n_seg;
+        ar_max_segs_ = std::max(ar_max_segs_, S.n_seg);
+        seg_stream_.insert(seg_stream_.end(), (size_t)S.n_seg, (int)si);
+    }
+    if (ar_max_segs_ > 8192) k2_rows_launch_ = false;     // (the prefix table of a stream's segments lives in LDS: > 8 M candidates per force and launch)
+    if (!k2_rows_launch_) { ar_streams_.clear(); ar_uses_.clear(); seg_stream_.clear(); }
 }
 
 // ---------------------------------------------------------------------------
@@ -1733,6 +1800,8 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     const size_t o_pent = place(device_profiles_ ? prof_entries_.size() * sizeof(ProfEntry) : 0);
     const size_t o_prow = place(device_profiles_ ? prof_rows_.size() * sizeof(ProfRow) : 0);
     const size_t o_chain = place(device_profiles_ ? chain_ptr_.size() * sizeof(int) : 0);
+    const size_t o_aruse = place(ar_uses_.size() * sizeof(ArUse)), o_arstream = place(ar_streams_.size() * sizeof(ArStream));
+    const size_t o_arseg = place(seg_stream_.size() * sizeof(int));
     const size_t o_tprof = place(device_profiles_ ? 0 : tprof_.size() * sizeof(float));
     const size_t o_stage = place(stage_.size() * sizeof(double)), o_stage_slot = place(stage_slot_.size() * sizeof(int));
     const size_t o_proj = place(proj_.size() * sizeof(ProjectEvent)), o_projd = place(proj_direct_.size() * sizeof(ProjectEvent));
@@ -1749,6 +1818,20 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         put(o_pent, prof_entries_.data(), prof_entries_.size() * sizeof(ProfEntry));
         put(o_prow, prof_rows_.data(), prof_rows_.size() * sizeof(ProfRow));
         put(o_chain, chain_ptr_.data(), chain_ptr_.size() * sizeof(int));
+        put(o_aruse, ar_uses_.data(), ar_uses_.size() * sizeof(ArUse));
+        put(o_arstream, ar_streams_.data(), ar_streams_.size() * sizeof(ArStream));
+        put(o_arseg, seg_stream_.data(), seg_stream_.size() * sizeof(int));
+        if (k2_rows_launch_) {
+            const size_t ns = std::max<size_t>(1, ar_streams_.size()), nu = std::max<size_t>(1, ar_uses_.size());
+            const size_t ng = std::max<size_t>(1, seg_stream_.size());
+            HIPTRY(d_ar_snaps_.ensure(ns, false, sp));
+            HIPTRY(d_ar_fins_.ensure(ns, false, sp));
+            HIPTRY(d_ar_recs_.ensure(nu, false, sp));
+            HIPTRY(d_ar_cbuf_.ensure(nu * (size_t)b_pad_, false, sp));
+            HIPTRY(d_ar_vnorm_.ensure(ng * 2 * K2_SEG, false, sp));
+            HIPTRY(d_ar_vstate_.ensure(ng * K2_SEG, false, sp));
+            HIPTRY(d_ar_segcount_.ensure(ng, false, sp));
+        }
         HIPTRY(ps.d_tprof.ensure(std::max<size_t>(1, (size_t)n_prows_) * b_pad_, false, sp));
         HIPTRY(d_arstate_.ensure(std::max<size_t>(1, n_ar_states_.load()), true, sp));
     } else {
@@ -1778,7 +1861,12 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
 
     // K2 -> time-profile rows ; K3 / scatter -> data slots ; K4 -> transfer rows ; combine -> g rows
     if (device_profiles_ && timed && n_chains > 0) { HIPTRY(hipEventRecord(evq.f0, sp)); evq.has_k2 = true; }
-    if (device_profiles_)
+    if (device_profiles_ && k2_rows_launch_)
+        LAUNCHTRY(launch_force_rows(d_prow, (int)prof_rows_.size(), d_pent, reinterpret_cast<const ArUse *>(da + o_aruse), (int)ar_uses_.size(),
+                                    reinterpret_cast<const ArStream *>(da + o_arstream), reinterpret_cast<const int *>(da + o_arseg),
+                                    (int)seg_stream_.size(), ar_max_segs_, d_arstate_.p, d_ar_snaps_.p, d_ar_vnorm_.p, d_ar_vstate_.p,
+                                    d_ar_segcount_.p, d_ar_cbuf_.p, d_ar_recs_.p, d_ar_fins_.p, ps.d_tprof.p, B_, b_pad_, b_pad_, sp));
+    else if (device_profiles_)
         LAUNCHTRY(launch_force_profiles(d_chain, n_chains, d_prow, d_pent, d_arstate_.p, ps.d_tprof.p, B_, b_pad_, ar_serial_ ? 1 : 0, k2_prio_, sp));
     if (evq.has_k2) HIPTRY(hipEventRecord(evq.f1, sp));
     LAUNCHTRY(launch_scatter_rows(d_stage, d_stage_slot, (int)stage_slot_.size(), d_slots_.p, m_pad_, sp));

@@ -341,6 +341,22 @@ private:
     std::vector<int> chain_ptr_;
     std::atomic<size_t> n_ar_states_{0};
     DevBuf<ArState> d_arstate_;
+    // K2, row-parallel form (the default; PBSO_K2_ROWS=0 or PBSO_AR_SERIAL=1: one workgroup walks an object's rows in order).
+    // build_ar_tables() lists the launch's AR forces (streams), their uses and the candidate segments of their engines.
+    bool k2_rows_ = true;
+    int k2_margin_pct_ = 100;                            // PBSO_K2_MARGIN_PCT: scales the candidate range (tests: < 100 forces the shortfall path)
+    bool k2_rows_launch_ = false;                        // this launch takes the row-parallel form
+    std::vector<ArStream> ar_streams_;
+    std::vector<ArUse> ar_uses_;
+    std::vector<int> seg_stream_, ar_stream_of_state_, ar_last_use_, ar_epoch_, ar_param_;
+    int ar_max_segs_ = 0;
+    DevBuf<ArState> d_ar_snaps_;
+    DevBuf<double> d_ar_vnorm_, d_ar_cbuf_;
+    DevBuf<uint32_t> d_ar_vstate_;
+    DevBuf<int> d_ar_segcount_;
+    DevBuf<ArRec> d_ar_recs_;
+    DevBuf<ArFin> d_ar_fins_;
+    void build_ar_tables();
     std::vector<double> stage_;
     std::vector<ProjectEvent> proj_, proj_direct_;         // projections into pool rows / evaluated on the fly by the combine kernel
     BufDesc *plan_desc_ = nullptr;                       // the descriptor table being planned (front of the set's arena)

@@ -182,6 +182,32 @@ struct ProfRow {         // one dense profile row = one (object, buffer)
 int launch_force_profiles(const int *chain_ptr, int n_chains, const ProfRow *rows, const ProfEntry *entries,
                           ArState *states, float *tprof, int frames, int b_pad, int ar_serial, int high_prio, hipStream_t stream);
 
+// ---- K2, row-parallel form: every row of a launch at once (kernels_exact.hip)
+constexpr int K2_SEG = 1024;     // candidate pairs of a force's engine evaluated by one workgroup of ar_variates_kernel
+struct ArStream {        // one AR force that adds samples in this launch
+    int32_t state;       // ArState slot
+    int32_t reset;       // its first use constructs it (engine at the default seed)
+    int32_t n_uses;      // rows it contributes to
+    int32_t use0;        // its uses' records: recs / cbuf rows use0 .. use0 + n_uses - 1
+    int32_t seg_base, n_seg;     // its candidate segments
+    int32_t pad[2];
+};
+struct ArUse {           // one AR entry of the launch (ProfEntry::count of an AR entry = its index here)
+    int32_t entry;       // index in the launch's entries
+    int32_t stream;
+    int32_t u;           // use number within the stream: variates u * frames ... of the launch
+    int32_t epoch_u;     // the use at which construction / SetParam last cleared the history; -1: the force's own history
+    int32_t param_entry; // the entry that last set the parameters (flags != 0); -1: the force's own
+    int32_t last;        // the stream's last use in this launch: writes the ArState back
+    int32_t pad[2];
+};
+struct ArRec { double z1, z2, m00, m01, m10, m11; };     // per use: the state reached from rest, M = A^frames
+struct ArFin { uint32_t x; int32_t saved_available; double saved; };      // per stream: the engine after the launch
+int launch_force_rows(const ProfRow *rows, int n_rows, const ProfEntry *entries, const ArUse *uses, int n_uses,
+                      const ArStream *streams, const int *seg_stream, int n_segs, int max_segs_per_stream, ArState *states,
+                      ArState *snaps, double *vnorm, uint32_t *vstate, int *seg_count, double *cbuf, ArRec *recs, ArFin *fins,
+                      float *tprof, int frames, int b_pad, int c_pitch, hipStream_t stream);
+
 struct FfatGeom {        // FFAT_Map<double,3> runtime fields, one per (object, mode)
     double k;
     double center3[3];

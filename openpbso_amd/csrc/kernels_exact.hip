@@ -248,6 +248,7 @@ __global__ __launch_bounds__(K2_THREADS) void force_profile_kernel(
                 int acc_pairs = 0;
 #ifdef PBSO_K2_ABLATE_RNG
                 acc_pairs = pairs_needed;
+                for (int i = lane; i < frames; i += K2_THREADS) nrm[i] = 0.25;
 #endif
                 for (int batch = 0; acc_pairs < pairs_needed; ++batch) {
                     uint32_t st = mulmod31(xb, pj);                             // state before candidate K2_THREADS k + lane
@@ -459,6 +460,402 @@ int launch_force_profiles(const int *chain_ptr, int n_chains, const ProfRow *row
     const size_t lds = sizeof(double) * (2 * (size_t)frames + 2) + sizeof(uint32_t) * 2 * (K2_THREADS / 64);
     hipLaunchKernelGGL(force_profile_kernel, dim3(n_chains), dim3(K2_THREADS), lds, stream, chain_ptr, n_chains, rows,
                        entries, states, tprof, frames, b_pad, ar_serial, high_prio);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// K2, row-parallel form (the default).  The chain kernel above walks an object's rows one after another because three
+// things are carried from row to row: the engine state (how many candidate pairs the rejection loop consumed), the cached
+// second variate and the AR(2) history.  None of them needs the walk:
+//  * candidate pair j of a force's engine is draws 4j+1..4j+4 of an LCG that jumps ahead in closed form, so whether it is
+//    accepted -- and the two variates it yields -- depends on j alone: `ar_variates_kernel` evaluates a launch's candidates
+//    K2_SEG per workgroup, all streams and segments side by side, and compacts the accepted ones per segment in order;
+//    variate n of the stream is then component (n - saved) & 1 of accepted pair (n - saved) >> 1, found through the prefix
+//    sums of the segments' counts;
+//  * the AR(2) recurrence is linear: the state entering use u is M^(u - e) s_e + sum_v M^(u-1-v) z_v (M = A^frames, z_v = the
+//    state use v reaches from rest, e = the use at which SetParam / construction last cleared the history):
+//    `ar_zero_state_kernel` (one workgroup per AR use) gathers the use's variates and produces z_v and M,
+//    `force_rows_kernel` (one workgroup per profile row) folds them (Horner, <= uses-1 steps of four fma) and then runs the
+//    SAME wave-level scan as the chain kernel with that history -- the real-number sequence of forces.h:107-117 once more.
+// The host sizes a stream's candidate range with a margin of many standard deviations over pairs / (pi/4); should the
+// accepted pairs still fall short, the workgroup that needs more continues the candidate sequence past the last segment by
+// itself (the chain kernel's batch loop) -- exercised by PBSO_K2_MARGIN_PCT < 100 in the tests, never met otherwise.
+struct Candidate {
+    bool ok;
+    double n0, n1;       // distribution(generator) returns n0 first, caches n1
+    uint32_t st;         // engine state after the candidate's four draws
+};
+// x = engine state before the candidate (generate_canonical<double,53> twice, Marsaglia polar: GCC 11 bits/random.tcc)
+__device__ __forceinline__ Candidate eval_candidate(uint32_t st) {
+    const double R = 2147483646.0;                             // max - min + 1
+    const double R2 = 4611686009837453316.0;                   // (double)((long double)R * R), as libstdc++ forms it
+    const uint32_t d1 = (st = mulmod31(st, 16807u));
+    const uint32_t d2 = (st = mulmod31(st, 16807u));
+    const uint32_t d3 = (st = mulmod31(st, 16807u));
+    const uint32_t d4 = (st = mulmod31(st, 16807u));
+    double s1 = (double)(d1 - 1u) * 1.0;
+    s1 += (double)(d2 - 1u) * R;
+    double c1 = s1 / R2;
+    if (c1 >= 1.0) c1 = 0.99999999999999988898;
+    double s2 = (double)(d3 - 1u) * 1.0;
+    s2 += (double)(d4 - 1u) * R;
+    double c2 = s2 / R2;
+    if (c2 >= 1.0) c2 = 0.99999999999999988898;
+    const double x = 2.0 * c1 - 1.0;
+    const double y = 2.0 * c2 - 1.0;
+    const double r2 = x * x + y * y;
+    Candidate c;
+    c.ok = !(r2 > 1.0 || r2 == 0.0);
+    c.st = st;
+    c.n0 = 0.0; c.n1 = 0.0;
+    if (c.ok) {
+        const double mult = sqrt(-2 * log(r2) / r2);
+        c.n0 = y * mult;
+        c.n1 = x * mult;
+    }
+    return c;
+}
+__device__ __forceinline__ uint32_t powmod31(uint32_t b, unsigned e) {
+    uint32_t r = 1u;
+    for (; e; e >>= 1) {
+        if (e & 1u) r = mulmod31(r, b);
+        b = mulmod31(b, b);
+    }
+    return r;
+}
+__device__ __forceinline__ uint32_t lcg_a4() {
+    uint32_t a4 = mulmod31(16807u, 16807u);
+    return mulmod31(a4, a4);
+}
+// order of the accepted candidates of one batch of K2_THREADS: (index of this thread's among them, their number)
+__device__ __forceinline__ void batch_rank(bool ok, uint32_t *cnt /*[NWV] of this batch's parity*/, int lane, int &rank, int &total) {
+    constexpr int NWV = K2_THREADS / 64;
+    const unsigned long long m = __ballot(ok);
+    const int wv = lane >> 6;
+    if ((lane & 63) == 0) cnt[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    int before = 0;
+    total = 0;
+    for (int w = 0; w < NWV; ++w) {
+        const int cw = (int)cnt[w];
+        if (w < wv) before += cw;
+        total += cw;
+    }
+    rank = before + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+__device__ __forceinline__ void ar_defaults(ArState &s) {          // forces.h:73-76
+    s.x = 1u; s.saved_available = 0; s.saved = 0.0;
+    s.buf[0] = s.buf[1] = s.buf[2] = 0.0; s.buf_idx = 0;
+    s.a[0] = 0.783; s.a[1] = 0.116; s.sigma = 0.00148; s.mu = 0.142;
+}
+
+__global__ __launch_bounds__(K2_THREADS) void ar_variates_kernel(
+    const int *__restrict__ seg_stream, const ArStream *__restrict__ streams, const ArState *__restrict__ states,
+    ArState *__restrict__ snaps, double *__restrict__ vnorm, uint32_t *__restrict__ vstate, int *__restrict__ seg_count) {
+    __shared__ uint32_t cnt[2][K2_THREADS / 64];
+    const int seg = blockIdx.x, lane = threadIdx.x;
+    const int si = seg_stream[seg];
+    const ArStream S = streams[si];
+    const int k = seg - S.seg_base;
+    if (k == 0 && lane == 0) {                     // the force as this launch finds it (read by the two kernels that follow)
+        ArState s = states[S.state];
+        if (S.reset) ar_defaults(s);
+        snaps[si] = s;
+    }
+    const uint32_t a4 = lcg_a4();
+    const uint32_t pj = powmod31(a4, (unsigned)lane), q = powmod31(a4, (unsigned)K2_THREADS);
+    uint32_t xb = mulmod31(S.reset ? 1u : states[S.state].x, powmod31(a4, (unsigned)k * (unsigned)K2_SEG));
+    double *vn = vnorm + (size_t)seg * 2 * K2_SEG;
+    uint32_t *vs = vstate + (size_t)seg * K2_SEG;
+    int acc = 0;
+    for (int batch = 0; batch < K2_SEG / K2_THREADS; ++batch) {
+        const Candidate c = eval_candidate(mulmod31(xb, pj));
+        int rank, total;
+        batch_rank(c.ok, cnt[batch & 1], lane, rank, total);
+        if (c.ok) {
+            vn[2 * (acc + rank)] = c.n0;
+            vn[2 * (acc + rank) + 1] = c.n1;
+            vs[acc + rank] = c.st;
+        }
+        acc += total;
+        xb = mulmod31(xb, q);
+    }
+    if (lane == 0) seg_count[seg] = acc;
+}
+
+// x_k = a0 x_{k-1} + a1 x_{k-2} + c_k over nrm[0 .. frames) in place, history (h1, h2) = (x_{-1}, x_{-2}): ONE wave, the scan
+// of the chain kernel (lane l owns L consecutive samples; Kogge-Stone over the lanes' end states; the entering state
+// added back through row 0 of A^(j+1))
+__device__ __forceinline__ void ar_scan_wave(double *nrm, int frames, int l64, double a0, double a1, double h1, double h2) {
+    const int L = (frames + 63) / 64;
+    const int k0 = l64 * L;
+    double y1 = l64 == 0 ? h1 : 0.0, y2 = l64 == 0 ? h2 : 0.0;
+    for (int j = 0; j < L; ++j) {
+        const int k = k0 + j;
+        const double c = k < frames ? nrm[k] : 0.0;
+        const double v = fma(a0, y1, fma(a1, y2, c));
+        if (k < frames) nrm[k] = v;
+        y2 = y1;
+        y1 = v;
+    }
+    double m00 = a0, m01 = a1, m10 = 1.0, m11 = 0.0;           // A^L
+    for (int i = 1; i < L; ++i) {
+        const double n00 = fma(m00, a0, m01), n01 = m00 * a1, n10 = fma(m10, a0, m11), n11 = m10 * a1;
+        m00 = n00; m01 = n01; m10 = n10; m11 = n11;
+    }
+    double b1 = y1, b2 = y2;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int d = 1 << i;
+        const double t1 = __shfl_up(b1, d, 64), t2 = __shfl_up(b2, d, 64);
+        if (l64 >= d) {
+            b1 = fma(m00, t1, fma(m01, t2, b1));
+            b2 = fma(m10, t1, fma(m11, t2, b2));
+        }
+        const double n00 = fma(m00, m00, m01 * m10), n01 = fma(m00, m01, m01 * m11);
+        const double n10 = fma(m10, m00, m11 * m10), n11 = fma(m10, m01, m11 * m11);
+        m00 = n00; m01 = n01; m10 = n10; m11 = n11;
+    }
+    const double s1 = __shfl_up(b1, 1, 64), s2 = __shfl_up(b2, 1, 64);      // the state entering this lane
+    if (l64 > 0) {
+        double al = a0, be = a1;                   // row 0 of A^(j+1)
+        for (int j = 0; j < L; ++j) {
+            const int k = k0 + j;
+            if (k < frames) nrm[k] = fma(al, s1, fma(be, s2, nrm[k]));
+            const double na = fma(al, a0, be), nb = al * a1;
+            al = na; be = nb;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// the parameters in force at a use: the launch's entry that last set them, or the force as the launch found it
+__device__ __forceinline__ void ar_params(const ArUse &U, const ProfEntry *__restrict__ entries, const ArState &snap,
+                                          double &a0, double &a1, double &sigma, double &mu) {
+    a0 = snap.a[0]; a1 = snap.a[1]; sigma = snap.sigma; mu = snap.mu;          // (a constructed force: the defaults, see ar_variates_kernel)
+    if (U.param_entry >= 0) {
+        const ProfEntry pe = entries[U.param_entry];
+        if (pe.flags & 2) { a0 = pe.a0; a1 = pe.a1; sigma = pe.sigma; mu = pe.mu; }
+        else { a0 = 0.783; a1 = 0.116; sigma = 0.00148; mu = 0.142; }
+    }
+}
+
+// one workgroup per AR use: c_k = sigma n_k into cbuf, the state the use reaches from rest and M = A^frames into recs;
+// the last use of a stream also says where the engine stands after the launch (fins)
+__global__ __launch_bounds__(K2_THREADS) void ar_zero_state_kernel(
+    const ArUse *__restrict__ uses, const ArStream *__restrict__ streams, const ProfEntry *__restrict__ entries,
+    const ArState *__restrict__ snaps, const double *__restrict__ vnorm, const uint32_t *__restrict__ vstate,
+    const int *__restrict__ seg_count, double *__restrict__ cbuf, ArRec *__restrict__ recs, ArFin *__restrict__ fins,
+    int frames, int c_pitch) {
+    extern __shared__ __attribute__((aligned(16))) double k2_lds[];
+    __shared__ uint32_t cnt[2][K2_THREADS / 64];
+    __shared__ int carry;
+    double *nrm = k2_lds;
+    int *pre = reinterpret_cast<int *>(k2_lds + frames);        // [n_seg + 1] accepted pairs before segment i
+    const int lane = threadIdx.x, wv = lane >> 6, l64 = lane & 63;
+    const ArUse U = uses[blockIdx.x];
+    const ArStream S = streams[U.stream];
+    const ArState snap = snaps[U.stream];
+    double a0, a1, sigma, mu;
+    ar_params(U, entries, snap, a0, a1, sigma, mu);
+    if (wv == 0) {                                              // exclusive prefix sums of the stream's segment counts
+        int run = 0;
+        for (int base = 0; base < S.n_seg; base += 64) {
+            const int i = base + l64;
+            int v = i < S.n_seg ? seg_count[S.seg_base + i] : 0;
+            const int own = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(v, d, 64);
+                if (l64 >= d) v += t;
+            }
+            if (i < S.n_seg) pre[i] = run + v - own;
+            run += __shfl(v, 63, 64);
+        }
+        if (l64 == 0) { pre[S.n_seg] = run; carry = run; }
+    }
+    __syncthreads();
+    const int total = carry;
+    const int sa0 = snap.saved_available ? 1 : 0;
+    const long long n_lo = (long long)U.u * frames;            // the use's variates: n_lo .. n_lo + frames - 1 of the stream
+    const long long last_n = n_lo + frames - 1 - sa0;          // (past the cached one)
+    const int p_hi = last_n >= 0 ? (int)(last_n >> 1) : -1;     // last accepted pair this use touches
+    const double *vn = vnorm + (size_t)S.seg_base * 2 * K2_SEG;
+    auto seg_of = [&](int pair) {                               // segment holding accepted pair `pair` (< total)
+        int lo = 0, hi = S.n_seg - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (pre[mid] <= pair) lo = mid; else hi = mid - 1;
+        }
+        return lo;
+    };
+    for (int k = lane; k < frames; k += K2_THREADS) {
+        const long long n = n_lo + k - sa0;
+        double v = 0.0;
+        if (n < 0) v = snap.saved;
+        else if ((int)(n >> 1) < total) {
+            const int pair = (int)(n >> 1), sg = seg_of(pair);
+            v = vn[(size_t)sg * 2 * K2_SEG + 2 * (pair - pre[sg]) + (int)(n & 1)];
+        }
+        nrm[k] = sigma * v;
+    }
+    uint32_t fin_x = snap.x;
+    double fin_saved = 0.0;
+    bool fin_here = false;                                      // this thread evaluated the last pair itself
+    if (p_hi >= total) {                                        // (uniform) short of accepted pairs: continue the candidate sequence
+        const uint32_t a4 = lcg_a4();
+        const uint32_t pj = powmod31(a4, (unsigned)lane), q = powmod31(a4, (unsigned)K2_THREADS);
+        uint32_t xb = mulmod31(snap.x, powmod31(a4, (unsigned)S.n_seg * (unsigned)K2_SEG));
+        int accp = total;
+        for (int batch = 0; accp <= p_hi; ++batch) {
+            const Candidate c = eval_candidate(mulmod31(xb, pj));
+            int rank, tb;
+            batch_rank(c.ok, cnt[batch & 1], lane, rank, tb);
+            const int idx = accp + rank;
+            if (c.ok && idx <= p_hi) {
+                const long long k0 = 2ll * idx + sa0 - n_lo;
+                if (k0 >= 0 && k0 < frames) nrm[k0] = sigma * c.n0;
+                if (k0 + 1 >= 0 && k0 + 1 < frames) nrm[k0 + 1] = sigma * c.n1;
+                if (idx == p_hi) { fin_x = c.st; fin_saved = c.n1; fin_here = true; }
+            }
+            accp += tb;
+            xb = mulmod31(xb, q);
+        }
+    }
+    __syncthreads();
+    double *crow = cbuf + (size_t)(S.use0 + U.u) * c_pitch;
+    for (int k = lane; k < frames; k += K2_THREADS) crow[k] = nrm[k];
+    if (U.last) {                                               // the engine after the launch: after the last pair used
+        if (p_hi >= 0 && p_hi < total && lane == 0) {
+            const int sg = seg_of(p_hi);
+            fin_x = vstate[(size_t)(S.seg_base + sg) * K2_SEG + (p_hi - pre[sg])];
+            fin_saved = vn[(size_t)sg * 2 * K2_SEG + 2 * (p_hi - pre[sg]) + 1];
+            fin_here = true;
+        }
+        if (p_hi < 0 && lane == 0) fin_here = true;            // only the cached variate was used: the engine stands
+        if (fin_here) {
+            ArFin f;
+            f.x = fin_x;
+            f.saved_available = (p_hi >= 0 && ((last_n & 1) == 0)) ? 1 : 0;       // the pair's second variate is still cached
+            f.saved = f.saved_available ? fin_saved : 0.0;
+            fins[U.stream] = f;
+        }
+    }
+    __syncthreads();
+    if (wv == 0) {
+        ar_scan_wave(nrm, frames, l64, a0, a1, 0.0, 0.0);
+        if (l64 == 0) {
+            ArRec r;
+            r.z1 = nrm[frames - 1];
+            r.z2 = frames >= 2 ? nrm[frames - 2] : 0.0;
+            recs[S.use0 + U.u].z1 = r.z1;
+            recs[S.use0 + U.u].z2 = r.z2;
+        }
+    } else if (lane == 64) {                                    // M = A^frames by square and multiply
+        double r00 = 1.0, r01 = 0.0, r10 = 0.0, r11 = 1.0, b00 = a0, b01 = a1, b10 = 1.0, b11 = 0.0;
+        for (unsigned e = (unsigned)frames; e; e >>= 1) {
+            if (e & 1u) {
+                const double n00 = fma(r00, b00, r01 * b10), n01 = fma(r00, b01, r01 * b11);
+                const double n10 = fma(r10, b00, r11 * b10), n11 = fma(r10, b01, r11 * b11);
+                r00 = n00; r01 = n01; r10 = n10; r11 = n11;
+            }
+            const double n00 = fma(b00, b00, b01 * b10), n01 = fma(b00, b01, b01 * b11);
+            const double n10 = fma(b10, b00, b11 * b10), n11 = fma(b10, b01, b11 * b11);
+            b00 = n00; b01 = n01; b10 = n10; b11 = n11;
+        }
+        ArRec *r = recs + S.use0 + U.u;
+        r->m00 = r00; r->m01 = r01; r->m10 = r10; r->m11 = r11;
+    }
+}
+
+// one workgroup per profile row: Force::Add of every live force of the (object, buffer) in list order (forces.h:81-128)
+__global__ __launch_bounds__(K2_THREADS) void force_rows_kernel(
+    const ProfRow *__restrict__ rows, const ProfEntry *__restrict__ entries, const ArUse *__restrict__ uses,
+    const ArStream *__restrict__ streams, const ArState *__restrict__ snaps, const ArRec *__restrict__ recs,
+    const ArFin *__restrict__ fins, const double *__restrict__ cbuf, ArState *__restrict__ states, float *__restrict__ tprof,
+    int frames, int b_pad, int c_pitch) {
+    extern __shared__ __attribute__((aligned(16))) double k2_lds[];
+    double *nrm = k2_lds;
+    double *acc = k2_lds + frames;
+    const int lane = threadIdx.x, wv = lane >> 6, l64 = lane & 63;
+    const ProfRow row = rows[blockIdx.x];
+    float *out = tprof + (size_t)row.prow * b_pad;
+    for (int i = lane; i < frames; i += K2_THREADS) acc[i] = 0.0;                  // setZero, modal_solver.h:206
+    __syncthreads();
+    for (int ei = row.entry_begin; ei < row.entry_end; ++ei) {
+        const ProfEntry e = entries[ei];
+        if (e.kind == 0) {                                                 // PointForce, forces.h:81-90
+            if (lane == 0) acc[0] += 1.;
+        } else if (e.kind == 1) {                                          // GaussianForce, forces.h:92-105
+            for (int ii = lane; ii < frames; ii += K2_THREADS) {
+                const double z = (double)(e.count + ii - e.center) / (double)e.width_samples;
+                acc[ii] += exp(-0.5 * (z * z));
+            }
+        } else {                                                           // AutoregressiveForce, :107-128
+            const ArUse U = uses[e.count];
+            const ArStream S = streams[U.stream];
+            const ArState snap = snaps[U.stream];
+            double a0, a1, sigma, mu;
+            ar_params(U, entries, snap, a0, a1, sigma, mu);
+            const double *crow = cbuf + (size_t)(S.use0 + U.u) * c_pitch;
+            for (int k = lane; k < frames; k += K2_THREADS) nrm[k] = crow[k];
+            // the history entering this use
+            const int bidx0 = snap.buf_idx;                                // _bufIdx when the launch began (0 for a constructed force)
+            double h1 = 0.0, h2 = 0.0;
+            int v = U.epoch_u;
+            if (v < 0) {                                                   // the force's own history carries on
+                h1 = bidx0 == 0 ? snap.buf[2] : (bidx0 == 1 ? snap.buf[0] : snap.buf[1]);     // _buf[(idx + 3 - 1) % 3]
+                h2 = bidx0 == 0 ? snap.buf[1] : (bidx0 == 1 ? snap.buf[2] : snap.buf[0]);     // _buf[(idx + 3 - 2) % 3]
+                v = 0;
+            }
+            for (; v < U.u; ++v) {
+                const ArRec r = recs[S.use0 + v];
+                const double n1 = fma(r.m00, h1, fma(r.m01, h2, r.z1));
+                const double n2 = fma(r.m10, h1, fma(r.m11, h2, r.z2));
+                h1 = n1; h2 = n2;
+            }
+            __syncthreads();
+            if (wv == 0) {
+                ar_scan_wave(nrm, frames, l64, a0, a1, h1, h2);
+                if (U.last && l64 == 0) {                                  // the force after this launch
+                    ArState s = snap;
+                    const ArFin f = fins[U.stream];
+                    s.x = f.x; s.saved_available = f.saved_available; s.saved = f.saved;
+                    s.a[0] = a0; s.a[1] = a1; s.sigma = sigma; s.mu = mu;
+                    // value k of this use went to _buf[(idx + k) % 3]: the last three, back in place
+                    const int bidx = (int)(((long long)bidx0 + (long long)U.u * frames) % 3);
+                    double b[3] = {0.0, 0.0, 0.0};
+                    for (int k = frames - 3; k < frames; ++k) b[(bidx + k) % 3] = nrm[k];
+                    s.buf[0] = b[0]; s.buf[1] = b[1]; s.buf[2] = b[2];
+                    s.buf_idx = (bidx + frames) % 3;
+                    states[S.state] = s;
+                }
+            }
+            __syncthreads();
+            for (int ii = lane; ii < frames; ii += K2_THREADS) acc[ii] += mu + nrm[ii];   // forceSpread(ii) += mu_e
+        }
+        __syncthreads();
+    }
+    for (int i = lane; i < b_pad; i += K2_THREADS) out[i] = i < frames ? (float)acc[i] : 0.f;
+}
+
+int launch_force_rows(const ProfRow *rows, int n_rows, const ProfEntry *entries, const ArUse *uses, int n_uses,
+                      const ArStream *streams, const int *seg_stream, int n_segs, int max_segs_per_stream, ArState *states,
+                      ArState *snaps, double *vnorm, uint32_t *vstate, int *seg_count, double *cbuf, ArRec *recs, ArFin *fins,
+                      float *tprof, int frames, int b_pad, int c_pitch, hipStream_t stream) {
+    if (n_rows <= 0) return 0;
+    if (n_segs > 0)
+        hipLaunchKernelGGL(ar_variates_kernel, dim3(n_segs), dim3(K2_THREADS), 0, stream, seg_stream, streams, states, snaps, vnorm,
+                           vstate, seg_count);
+    if (n_uses > 0) {
+        const size_t lds = sizeof(double) * (size_t)frames + sizeof(int) * ((size_t)max_segs_per_stream + 2);
+        hipLaunchKernelGGL(ar_zero_state_kernel, dim3(n_uses), dim3(K2_THREADS), lds, stream, uses, streams, entries, snaps, vnorm,
+                           vstate, seg_count, cbuf, recs, fins, frames, c_pitch);
+    }
+    hipLaunchKernelGGL(force_rows_kernel, dim3(n_rows), dim3(K2_THREADS), sizeof(double) * 2 * (size_t)frames, stream, rows, entries,
+                       uses, streams, snaps, recs, fins, cbuf, states, tprof, frames, b_pad, c_pitch);
     return (int)hipGetLastError();
 }
 

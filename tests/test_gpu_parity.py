@@ -1074,3 +1074,43 @@ def test_vertex_hit_script_equals_message_by_message_enqueue(split, monkeypatch)
     want = run_oracle(objs, evs, 3 * nb)
     mx, l2 = rel_errors(a, want["audio"])
     assert (mx <= 5e-4).all() and (l2 <= 1e-3).all(), (mx, l2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("margin", ["100", "45"])
+def test_row_parallel_profiles_equal_the_chain_kernel(margin, monkeypatch):
+    """K2 row-parallel (every profile row of a launch at once: candidate segments, zero-state uses, Horner over the
+    uses) against the chain kernel (one workgroup walks an object's rows in order) and the oracle: three objects scraping
+    from default-seeded engines, parameters changed twice (once in the first buffer of a launch), a second plain AR
+    force and a Gaussian overlapping, an odd number of 513-sample rows so the cached variate crosses launches, launches
+    of 1 .. 11 buffers.  margin 45: the candidate range is cut below what is needed -- every use past the first few
+    continues the candidate sequence itself."""
+    n_modes, nb = 96, 27
+    objs = [ObjSpec(synth.eigenvalues(n_modes, 700 + i)) for i in range(3)]
+    rng = np.random.default_rng(700)
+    evs = []
+    for i in range(3):
+        evs.append(force_ev(i, i, data=rng.standard_normal(n_modes) * 1e-3, force_type=2, start=True))
+        for b in range(i + 1, nb - 3, 2):
+            evs.append(force_ev(b, i, data=rng.standard_normal(n_modes) * 1e-3, force_type=2))
+        evs.append(dict(t=0, obj=i, kind="use_transfer", use=False))
+    evs.append(dict(t=5, obj=0, kind="arprm", a=[0.5, 0.3], sigma=0.004, mu=0.2))
+    evs.append(dict(t=9, obj=0, kind="arprm", a=[0.9, -0.2], sigma=0.001, mu=0.1))
+    evs.append(dict(t=4, obj=1, kind="arprm", a=[0.2, 0.1], sigma=0.01, mu=0.0))
+    evs.append(force_ev(20, 2, force_type=2, end=True))
+    evs.append(force_ev(21, 2, data=rng.standard_normal(n_modes) * 1e-3, force_type=1, width=1500.0))
+    evs.append(force_ev(21, 2, data=rng.standard_normal(n_modes) * 1e-3, force_type=2))       # plain AR force: a new engine
+    evs.append(force_ev(22, 2, data=rng.standard_normal(n_modes) * 1e-3))
+    split = [4, 1, 11, 2, 9]
+    monkeypatch.setenv("PBSO_K2_ROWS", "0")
+    chain = run_engine(objs, evs, nb, split=split)
+    monkeypatch.setenv("PBSO_K2_ROWS", "1")
+    monkeypatch.setenv("PBSO_K2_MARGIN_PCT", margin)
+    rows = run_engine(objs, evs, nb, split=split)
+    whole = run_engine(objs, evs, nb)
+    want = run_oracle(objs, evs, nb)
+    _check(rows, want)
+    _check(chain, want)
+    peak = np.abs(chain["audio"]).max(axis=1, keepdims=True)
+    assert (np.abs(rows["audio"] - chain["audio"]) <= 2e-7 * peak).all()
+    assert (np.abs(whole["audio"] - chain["audio"]) <= 2e-7 * peak).all()
