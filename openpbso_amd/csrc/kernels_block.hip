@@ -54,6 +54,7 @@ constexpr int RING = BLOCK_RING_FLOATS;            // per wave and parity: sampl
 // split-bf16 projection (PROJ == 1): staging planes "hi" and "lo", [16 blocks][64 lanes] dwords = (Q, D) as two
 // bf16; the row stride of 72 dwords makes the ds_read_b128 of (4 modes of block n) conflict-free in all four
 // 16-lane groups
+constexpr int FTM_U_ROW = 36;                      // FTM: [64 modes][16 Q increments | 16 D increments] + 4 floats of padding
 constexpr int H_ROW = 72;
 constexpr int H_PLANE = BN * H_ROW;
 static_assert(BN * ST_ROW <= ST_FLOATS && BJ * LIT_ROW <= ST_FLOATS && 2 * H_PLANE <= ST_FLOATS, "staging area");
@@ -179,8 +180,24 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     // Forced block path without qnorm rows (FT): the state increment of a block under a dense force profile is
     // F . T_n with F = [A^15 u .. A u, u] (2 x 16 per mode, u = (1, 1)'): 32 constants per mode, resident for the launch
     constexpr bool FT = FORCED && PROJ == 0 && !QN && R <= 2;
-    float fq[FT ? R : 1][BJ], fd[FT ? R : 1][BJ];
-    if constexpr (FT) {
+    // FTM (one mode per lane): the 16 increments of a group's blocks are a [16 blocks x 16 taps] . [16 taps x 16 modes] product
+    // per tile of 16 modes and state component -- 32 MFMAs per group whose A operand is the profile exactly as the FIR's B
+    // operand holds it; the tiles come back to "lane = mode" through an LDS area of [64 modes][U_ROW] floats behind the landing
+    // areas (per block the vector ALU is left with the coarse step and two FMAs: 8.5 K -> 4 K cycles per buffer).
+    constexpr bool FTM = FT && R == 1;
+    constexpr int U_ROW = FTM_U_ROW;
+    float fB[FTM ? 4 : 1][2][4];
+    if constexpr (FTM) {
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    fB[tl][c][ks] = (p_ftab + (size_t)(2 * (4 * ks + (lane >> 4)) + c) * p.plane + ubase)[64 * wave + 16 * tl + (lane & 15)];
+    }
+    float fq[FT && !FTM ? R : 1][BJ], fd[FT && !FTM ? R : 1][BJ];
+    if constexpr (FT && !FTM) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
 #pragma unroll
@@ -767,7 +784,39 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                     // d' = (eps^2 d + T) - e q, q' = q + d'.
                     lap(cy_pipe);
                     const float gr = g_[r];
-                    if constexpr (FT) {
+                    if constexpr (FTM) {
+                        float *ua = lds + (blockDim.x >> 6) * (WAVE_FLOATS + 3 * R * 64) + wave * (64 * U_ROW);
+                        static_for<0, 4>([&](auto tc) {
+                            constexpr int tl = decltype(tc)::value;
+                            f4 dq = f4{0.f, 0.f, 0.f, 0.f}, dd = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int ks = 0; ks < 4; ++ks) {
+                                dq = __builtin_amdgcn_mfma_f32_16x16x4f32(fir_b[ks], fB[tl][0][ks], dq, 0, 0, 0);
+                                dd = __builtin_amdgcn_mfma_f32_16x16x4f32(fir_b[ks], fB[tl][1][ks], dd, 0, 0, 0);
+                            }
+                            // D[block 4 (l >> 4) + v][mode 16 tl + (l & 15)]
+                            float *dst = ua + (16 * tl + (lane & 15)) * U_ROW + 4 * (lane >> 4);
+                            *reinterpret_cast<f4 *>(dst) = dq;
+                            *reinterpret_cast<f4 *>(dst + BN) = dd;
+                        });
+                        wave_sync();
+                        f4 uq[4], ud[4];
+                        {
+                            const f4 *src = reinterpret_cast<const f4 *>(ua + lane * U_ROW);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { uq[i] = src[i]; ud[i] = src[4 + i]; }
+                        }
+                        static_for<0, BN>([&](auto nc) {
+                            constexpr int n = decltype(nc)::value;
+                            wdst[n * (ST_ROW / 2)] = x2[r];
+                            const float qa = fmaf(c1[r].x, x2[r].x, x2[r].x);
+                            const float da = c1[r].y * x2[r].x;
+                            const float qn_ = fmaf(c2[r].x, x2[r].y, qa);
+                            const float dn_ = fmaf(c2[r].y, x2[r].y, da);
+                            x2[r].x = fmaf(gr, uq[n / 4][n % 4], qn_);
+                            x2[r].y = fmaf(gr, ud[n / 4][n % 4], dn_);
+                        });
+                    } else if constexpr (FT) {
                         // No qnorm rows asked for: nothing needs the state of every sample.  One block at a time,
                         //     x_{n+1} = P x_n + g (F . T_n)        (32 independent FMAs with the profile values as operands + the
                         // coarse step) -- 36 vector instructions per 16 samples instead of 48 in a dependent chain.
@@ -959,7 +1008,8 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
 
 template <int R, int QNM, int PROJ, bool DUMP, bool FORCED = false>
 static int launch_one(const IirParams &p, int n_teams, int W, hipStream_t stream) {
-    const size_t lds = block_lds_bytes(W, R);
+    // (the forced block path of a one-mode-per-lane engine without qnorm rows transposes its increments through LDS: FTM)
+    const size_t lds = block_lds_bytes(W, R) + (FORCED && PROJ == 0 && QNM == 0 && R == 1 ? sizeof(float) * (size_t)W * 64 * FTM_U_ROW : 0);
     // R = 8 is the one-wave-per-SIMD build (512 registers: the 256 W-table operands go to AGPRs): teams of <= 4 waves
     constexpr int MAXT = R == 8 ? 256 : 64 * MAX_WAVES_PER_BLOCK_TEAM;
     if (64 * W > MAXT) return (int)hipErrorInvalidValue;
