@@ -1114,3 +1114,53 @@ def test_row_parallel_profiles_equal_the_chain_kernel(margin, monkeypatch):
     peak = np.abs(chain["audio"]).max(axis=1, keepdims=True)
     assert (np.abs(rows["audio"] - chain["audio"]) <= 2e-7 * peak).all()
     assert (np.abs(whole["audio"] - chain["audio"]) <= 2e-7 * peak).all()
+
+
+@pytest.mark.parametrize("mpl", [1, 2, 4])
+@pytest.mark.parametrize("qnorm", [capi.QNORM_ALL, capi.QNORM_OFF])
+def test_block_kernel_forced_path_every_buffer_kind(qnorm, mpl, monkeypatch):
+    """K1b pinned for every launch (PBSO_SPLIT=0), f32 block form: dense-profile buffers take the forced block path -- with
+    one mode per lane and no qnorm rows the blocks' state increments F . T come from the matrix pipe (FTM), with two from
+    32 vector FMAs per block, otherwise (qnorm rows, four modes per lane) the lane steps every sample -- between force-free,
+    impulse and skipped buffers, with a Gaussian alive over several buffers, sustained AR scraping with a parameter update,
+    a listener moving through FFAT maps with a zero weight on one mode (that wave leaves the scaled-state form: literal
+    path), objects of 1, 64, 65 and 300 modes."""
+    monkeypatch.setenv("PBSO_SPLIT", "0")
+    nb = 16
+    rng = np.random.default_rng(2025)
+    sizes = [1, 64, 65, 300]
+    objs, evs = [], []
+    for i, m in enumerate(sizes):
+        lam = synth.eigenvalues(m, 940 + i)
+        maps = synth.ffat_maps(lam, 940 + i, dim=4, cell_size=0.01) if i == 3 else None
+        if maps is not None:
+            for mm in maps:
+                mm["psi"] = np.array(mm["psi"], dtype=np.float64)
+            maps[7]["psi"][:] = 0.0
+        objs.append(ObjSpec(lam, maps=maps))
+        evs += [force_ev(0, i, data=rng.standard_normal(m) * 1e-3),
+                force_ev(2, i, data=rng.standard_normal(m) * 1e-3, force_type=1, width=1500.0),
+                force_ev(5, i, clear=True),
+                force_ev(6, i, data=rng.standard_normal(m) * 1e-3, force_type=2, start=True),
+                force_ev(8, i, data=rng.standard_normal(m) * 1e-3, force_type=2),
+                dict(t=9, obj=i, kind="arprm", a=[0.5, 0.3], sigma=0.004, mu=0.2),
+                force_ev(12, i, force_type=2, end=True),
+                force_ev(14, i, data=rng.standard_normal(m) * 1e-3)]
+        if maps is None:
+            evs.append(dict(t=0, obj=i, kind="use_transfer", use=False))
+        else:
+            dirs = np.array([[1, .2, .3], [.2, 1, .3], [.2, .3, 1], [-1, .2, .3]], dtype=float)
+            evs += [dict(t=b, obj=i, kind="listener", pos=0.5 * dirs[b % 4] / np.linalg.norm(dirs[b % 4])) for b in range(0, nb, 3)]
+    want = run_oracle(objs, evs, nb)
+    for split in (None, [1, 4, 11]):
+        got = run_engine(objs, evs, nb, split=split, form=capi.FORM_BLOCK, qnorm=qnorm, modes_per_lane=mpl)
+        info = got["info"]
+        assert info["total_split_launches"] == 0 and info["total_sample_launches"] == 0
+        assert info["total_block_launches"] == (1 if split is None else 3)
+        _check(got, want)
+        assert np.array_equal(got["emitted"], want["emitted"]) and not got["emitted"][:, 5].any()
+        if qnorm != capi.QNORM_OFF:
+            for key, w in want["qnorm"].items():
+                assert np.abs(got["qnorm"][key] - w).max() <= 5e-4 * max(np.abs(w).max(), 1e-30) + 2e-6 * np.abs(want["audio"][key[0]]).max(), key
+        for i in range(len(sizes)):
+            np.testing.assert_allclose(got["state"][i][0], want["state"][i][0], rtol=0, atol=5e-4 * max(np.abs(want["state"][i][0]).max(), 1e-30))
