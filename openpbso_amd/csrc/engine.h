@@ -227,10 +227,12 @@ private:
     hipStream_t stream_ = nullptr;                       // oscillator bank (caller's stream if given)
     hipStream_t prep_stream_ = nullptr;                  // plan upload + projection + FFAT + combine
     // Plan sets: the host plans and uploads step k while the device still runs step k - N_SETS + 1.  Two sets are enough for
-    // a host that never stalls; with four, a hiccup of the host thread (the boxes of this pool stall it for a millisecond now
-    // and then) is absorbed by the steps already queued instead of idling the device.
+    // a host that never stalls; with three, a hiccup of the host thread (the boxes of this pool stall it for a millisecond now
+    // and then) is absorbed by the steps already queued instead of idling the device.  Not four: with three steps of preparation
+    // kernels queued ahead, the 64 x 256 scene with a listener move per buffer loses the overlap between its steps (0.24 -> 0.36 ms
+    // per step, scripts/debug/r03_sets.sh; the headline and the scraping scene do not care).
 #ifndef PBSO_N_SETS
-#define PBSO_N_SETS 4
+#define PBSO_N_SETS 3
 #endif
     static constexpr int N_SETS = PBSO_N_SETS;
     hipEvent_t ev_prep_done_[N_SETS] = {}, ev_k1_done_[N_SETS] = {};
