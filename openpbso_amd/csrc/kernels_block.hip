@@ -37,6 +37,7 @@
 #include <type_traits>
 
 #include "kernels.h"
+#include "wave_ops.h"
 
 namespace pbso {
 namespace iir_block {
@@ -205,6 +206,24 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 fq[r][i] = (p_ftab + (size_t)(2 * i) * p.plane + ubase)[r * rowlen + utid];
                 fd[r][i] = (p_ftab + (size_t)(2 * i + 1) * p.plane + ubase)[r * rowlen + utid];
             }
+        }
+    }
+
+    // Forced block path, one mode per lane: the FIR taps h_d = sum over modes of g phi_d, phi_d = e1' A^d u, as sixteen wave sums
+    // in one butterfly (wave_ops.h) instead of projecting the virtual state g u on the matrix pipe (32 operand reads + 32 MFMAs
+    // for one useful column: 2 K cycles per buffer against 0.5 K).  phi: sixteen constants per mode, stepped here once per
+    // launch in fp64 from the per-sample coefficients.
+    constexpr bool TAPS_VALU = FORCED && PROJ == 0 && R == 1;
+    float phi[TAPS_VALU ? 16 : 1];
+    if constexpr (TAPS_VALU) {
+        const double ea = (double)b_ca[utid], eb = (double)b_cb[utid];
+        double vq = 1.0, vd = 1.0;
+        phi[0] = 1.f;
+#pragma unroll
+        for (int d = 1; d < 16; ++d) {
+            vd = ea * vd + eb * vq;
+            vq = vq + vd;
+            phi[d] = dead[0] ? 0.f : (float)vq;
         }
     }
 
@@ -656,6 +675,17 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
             float *taps = stage + BN * ST_ROW;                   // [17] h_0 .. h_16 (behind the staging rows)
             float qn[R];
             lap(cy_head);
+            // the profile as the FIR's B operand, B[i][n] = T[1 + 256 grp + 16 n + i], both groups: fetched here, under the
+            // taps' 2 K cycles (at the head of its group the first MFMA waited out an L2 round trip)
+            // (engines of one or two modes per lane: the builds of four and eight have no registers to spare)
+            constexpr bool FIR_EARLY = R <= 2;
+            float fir_ball[FIR_EARLY ? NG : 1][4];
+            if constexpr (FIR_EARLY) {
+#pragma unroll
+                for (int grp = 0; grp < NG; ++grp)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) fir_ball[grp][kk] = tprow[1 + GROUP * grp + BJ * (lane & 15) + 4 * kk + (lane >> 4)];
+            }
             {
                 // sample 0 (literal) and h_0
                 const float tk0 = tprow[0];
@@ -672,14 +702,21 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                     qn[v] = x2[v].x * x2[v].x;
                 }
                 p0 = wave_sum(p0);
-                gs = wave_sum(gs);
+                if (!TAPS_VALU) gs = wave_sum(gs);
                 if (lane == 0) rg[GROUP * NG] = p0;
                 wave_sync();                                    // the previous buffer's staging reads are issued
-                if (lane == 0) taps[0] = gs;
+                if (!TAPS_VALU && lane == 0) taps[0] = gs;
             }
             float breg[32];
+            if constexpr (TAPS_VALU) {
+                float pv[16];
+#pragma unroll
+                for (int d = 0; d < 16; ++d) pv[d] = g_[0] * phi[d];
+                const float hd = wave_sum16(pv, lane, stage + ST_ROW, wave_sync);        // (scratch: staging row 1, free until the first park)
+                if (lane < 16) taps[taps_index(lane)] = hd;
+                wave_sync();
+            } else {
             // ---- taps h_1 .. h_16: project the virtual state (g, g) of every slice (block row 0 of the staging area)
-            {
                 f4 ah0 = f4{0.f, 0.f, 0.f, 0.f}, ah1 = f4{0.f, 0.f, 0.f, 0.f};
                 static_for<0, R>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
@@ -712,10 +749,10 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
             static_for<0, NG>([&](auto gc) {
                 constexpr int grp = decltype(gc)::value;
                 f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = f4{0.f, 0.f, 0.f, 0.f};
-                // the profile as the FIR's B operand: B[i][n] = T[1 + 256 grp + 16 n + i]
                 float fir_b[4];
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) fir_b[kk] = tprow[1 + GROUP * grp + BJ * (lane & 15) + 4 * kk + (lane >> 4)];
+                for (int kk = 0; kk < 4; ++kk)
+                    fir_b[kk] = FIR_EARLY ? fir_ball[FIR_EARLY ? grp : 0][kk] : tprow[1 + GROUP * grp + BJ * (lane & 15) + 4 * kk + (lane >> 4)];
                 static_for<0, R>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
                     wave_sync();                                // the staging area is free (operand reads of the previous slice issued)

@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "kernels.h"
+#include "wave_ops.h"
 
 namespace pbso {
 namespace iir_split {
@@ -35,6 +36,7 @@ constexpr int BJ = BLOCK_J, BN = BLOCK_N, GROUP = BJ * BN;
 
 constexpr int ST_ROW = 130;                          // as K1b: [16 blocks][64 lanes][Q, D], row stride 130 floats
 constexpr int ST_AREA = BN * ST_ROW + 32 + 132;      // + the wave's FIR taps h_0 .. h_16 + one row for the taps' virtual state
+constexpr int U_ROW = 36;                            // increments: [64 modes][16 Q | 16 D] + 4 floats of padding (as K1b's FTM)
 
 struct SplitDims {
     int nb, m_pad, b_pad, frames;
@@ -71,9 +73,11 @@ __global__ __launch_bounds__(128) void iir_split_kernel(
     float *__restrict__ p_ss, const BufDesc *__restrict__ p_desc, const float *__restrict__ p_grows,
     const float *__restrict__ p_tprof, const double *__restrict__ p_xfer_rows, const int *__restrict__ p_xfer_init,
     float *__restrict__ p_audio, float *__restrict__ p_qnorm, const float *__restrict__ p_gq, const float *__restrict__ p_pc,
-    const float *__restrict__ p_wtab, const TeamDesc *__restrict__ p_teams, float *__restrict__ p_audio_parts, const SplitDims p) {
+    const float *__restrict__ p_wtab, const TeamDesc *__restrict__ p_teams, float *__restrict__ p_audio_parts,
+    const float *__restrict__ p_ftab, const SplitDims p) {
     constexpr bool QN = QNM != 0;
     __shared__ __attribute__((aligned(16))) float lds_stage[2][2][ST_AREA];       // [buffer parity][group]
+    __shared__ __attribute__((aligned(16))) float lds_incr[QN ? 1 : 2][QN ? 4 : 64 * U_ROW];     // [group]: the blocks' state increments on their way back to lane = mode
     __shared__ f2 hand16[64], hand32[64];            // the state at the group boundary (wave 0 -> 1) and at the buffer's end (1 -> 0)
     const TeamDesc team = p_teams[blockIdx.x];
     const int obj = team.obj;
@@ -98,6 +102,37 @@ __global__ __launch_bounds__(128) void iir_split_kernel(
         const float *__restrict__ wsrc = p_wtab + (ubase / 2) * 64;
 #pragma unroll
         for (int s = 0; s < 32; ++s) wreg[s] = wsrc[s * 64 + lane];
+    }
+    // Dense profiles without qnorm rows: a block's state increment is F . T_n, F = [A^15 u .. A u, u] (the table of K1b's forced
+    // block path; absent -- PBSO_FORCED_BLOCK=0 -- the group is stepped sample by sample).  The increments of a group's 16
+    // blocks are a [16 blocks x 16 taps] . [16 taps x 16 modes] product per tile of 16 modes and state component: 32 MFMAs
+    // whose A operand is the profile as the FIR's B operand holds it and whose B operand is F, resident here.
+    const bool ft = !QN && p_ftab != nullptr;
+    float fB[QN ? 1 : 4][2][4];
+    if (!QN && ft) {
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    fB[QN ? 0 : tl][c][ks] = (p_ftab + (size_t)(2 * (4 * ks + (lane >> 4)) + c) * p.plane + ubase)[16 * tl + (lane & 15)];
+    }
+    // FIR taps of a dense profile (kernels_block.hip, "forced block path"): h_d = sum over modes of t g phi_d, phi_d = e1' A^d u the
+    // mode's response d samples after a unit force sample (u = (1, 1)': d += f, q += d).  phi is sixteen constants per mode,
+    // stepped here once per launch (fp64 from the f32 coefficients the per-sample kernels use); the sixteen sums over the wave
+    // are one butterfly (wave_ops.h) -- the projection of a virtual block-start state on the matrix pipe that this replaces
+    // (32 operand reads + 32 MFMAs for one useful column) was 2 K of a dense buffer's 6 K cycles on the critical path.
+    float phi[16];
+    {
+        double vq = 1.0, vd = 1.0;
+        phi[0] = 1.f;
+#pragma unroll
+        for (int d = 1; d < 16; ++d) {
+            vd = (double)nca * vd + (double)ncb * vq;
+            vq = vq + vd;
+            phi[d] = dead ? 0.f : (float)vq;
+        }
     }
     // state, unscaled (the arrays hold scale x state, kernels_iir.hip "scaled state")
     f2 x;
@@ -207,6 +242,43 @@ __global__ __launch_bounds__(128) void iir_split_kernel(
         };
 
         float fir_a[4] = {0.f, 0.f, 0.f, 0.f};
+        // the profile of this wave's group as the FIR's B operand, B[i][n] = T[1 + 256 grp + 16 n + i] (fetched under the taps)
+        float fir_b[4] = {0.f, 0.f, 0.f, 0.f};
+        if (dense) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) fir_b[kk] = tprow[1 + GROUP * grp + BJ * (lane & 15) + 4 * kk + (lane >> 4)];
+        }
+        // 16 blocks of this wave's group a block at a time: v_{n+1} = P v_n + g (F . T_n), parking every block-start state
+        auto step_group_ft = [&](float *st, f2 &v) {
+            if constexpr (!QN) {
+                float *ua = lds_incr[grp];
+                static_for<0, 4>([&](auto tc) {
+                    constexpr int tl = decltype(tc)::value;
+                    f4 dq = f4{0.f, 0.f, 0.f, 0.f}, dd = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        dq = __builtin_amdgcn_mfma_f32_16x16x4f32(fir_b[ks], fB[tl][0][ks], dq, 0, 0, 0);
+                        dd = __builtin_amdgcn_mfma_f32_16x16x4f32(fir_b[ks], fB[tl][1][ks], dd, 0, 0, 0);
+                    }
+                    float *dst = ua + (16 * tl + (lane & 15)) * U_ROW + 4 * (lane >> 4);       // D[block 4 (l >> 4) + v][mode 16 tl + (l & 15)]
+                    *reinterpret_cast<f4 *>(dst) = dq;
+                    *reinterpret_cast<f4 *>(dst + BN) = dd;
+                });
+                wave_sync();
+                f4 uq[4], ud[4];
+                {
+                    const f4 *src = reinterpret_cast<const f4 *>(ua + lane * U_ROW);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { uq[i] = src[i]; ud[i] = src[4 + i]; }
+                }
+                static_for<0, BN>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    park(st, n, v);
+                    const f2 w = coarse(v);
+                    v = f2{fmaf(g, uq[n / 4][n % 4], w.x), fmaf(g, ud[n / 4][n % 4], w.y)};
+                });
+            }
+        };
         bool late_b = false;                         // wave 0, dense buffer without qnorm rows: barrier B comes after its projection
         if (!dense) {
             // ================= force-free buffer (or an impulse at sample 0) =================
@@ -247,28 +319,15 @@ __global__ __launch_bounds__(128) void iir_split_kernel(
             // FIR taps of this wave (both waves need them: the forced response inside a block, see kernels_block.hip):
             // h_0 = sum t g, h_1 .. h_16 = projection of the virtual block-start state t g u, u = (1, 1)'
             {
-                // (a row of its own: in a qnorm build wave 0 parks into BOTH groups' staging areas while wave 1 is here; only
-                //  column 0 of the result is read, so every lane may read the one row)
-                float *trow = taps + 32;
-                const float *tsrc = trow + 2 * (lane >> 5) + ((lane >> 4) & 1);
+                // (scratch and taps behind this wave's staging rows: in a qnorm build wave 0 parks into BOTH groups' staging areas
+                //  while wave 1 is here)
                 const float tg = t * g;
-                const float gs = wave_sum(tg);
-                *reinterpret_cast<f2 *>(trow + 2 * lane) = f2{tg, tg};
-                if (lane == 0) taps[0] = gs;
-                wave_sync();
+                float pv[16];
 #pragma unroll
-                for (int s = 0; s < 32; ++s) breg[s] = tsrc[4 * s];
-                f4 ah0 = f4{0.f, 0.f, 0.f, 0.f}, ah1 = f4{0.f, 0.f, 0.f, 0.f};
-                static_for<0, 32>([&](auto sc) {
-                    constexpr int s = decltype(sc)::value;
-                    if constexpr (s & 1) ah1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], breg[s], ah1, 0, 0, 0);
-                    else ah0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], breg[s], ah0, 0, 0, 0);
-                });
-                const f4 ah = ah0 + ah1;
-                if ((lane & 15) == 0) {
-                    float *td = taps + 1 + 4 * (lane >> 4);
-                    td[0] = ah.x; td[1] = ah.y; td[2] = ah.z; td[3] = ah.w;
-                }
+                for (int d = 0; d < 16; ++d) pv[d] = tg * phi[d];
+                const float hd = wave_sum16(pv, lane, taps + 32, wave_sync);
+                wave_sync();                             // (the scratch reads are done before anything parks there again)
+                if (lane < 16) taps[taps_index(lane)] = hd;
                 wave_sync();
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
@@ -287,7 +346,8 @@ __global__ __launch_bounds__(128) void iir_split_kernel(
                 if (QN) qacc = x.x * x.x;
                 const float p0 = wave_sum(t * x.x);
                 if (lane == 0) ao[0] = p0;
-                step_group(stage0, 1, x, qacc);
+                if (ft) step_group_ft(stage0, x);
+                else step_group(stage0, 1, x, qacc);
                 if (QN) {
                     // qnorm rows: the true state of every sample is needed -- this wave steps the second group as well
                     step_group(stage1, 1 + GROUP, x, qacc);
@@ -299,7 +359,8 @@ __global__ __launch_bounds__(128) void iir_split_kernel(
             } else if (!QN) {
                 // group 1 from a zero state under the second half of the profile (its response to the force alone)
                 f2 z = f2{0.f, 0.f};
-                step_group(stage1, 1 + GROUP, z, qacc);
+                if (ft) step_group_ft(stage1, z);
+                else step_group(stage1, 1 + GROUP, z, qacc);
                 __syncthreads();                     // A: wave 0 has reached the group boundary
                 // + the free response of the state wave 0 handed over: 16 coarse steps, added to the parked states
                 f2 xf = hand16[lane];
@@ -333,9 +394,8 @@ __global__ __launch_bounds__(128) void iir_split_kernel(
         if (dense) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const float fb = tprow[1 + GROUP * grp + BJ * (lane & 15) + 4 * kk + (lane >> 4)];
-                if (kk & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fir_a[kk], fb, acc1, 0, 0, 0);
-                else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fir_a[kk], fb, acc0, 0, 0, 0);
+                if (kk & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fir_a[kk], fir_b[kk], acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fir_a[kk], fir_b[kk], acc0, 0, 0, 0);
             }
         }
         {
@@ -362,10 +422,10 @@ int launch_iir_split(const IirParams &p, int n_teams, int qnorm_mode, hipStream_
     const SplitDims dims = {p.nb, p.m_pad, p.b_pad, p.frames, p.audio_stride, p.gq_plane, p.qn_nb, p.qn_b0};
     if (qnorm_mode != 0)
         hipLaunchKernelGGL(iir_split_kernel<2>, dim3(n_teams), dim3(128), 0, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows, p.tprof,
-                           p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, dims);
+                           p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.ftab, dims);
     else
         hipLaunchKernelGGL(iir_split_kernel<0>, dim3(n_teams), dim3(128), 0, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows, p.tprof,
-                           p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, dims);
+                           p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.ftab, dims);
     return (int)hipGetLastError();
 }
 
