@@ -1902,7 +1902,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.gq_plane = (long long)N * m_pad_;
     kp.census = nullptr;
     if (census_) {
-        HIPTRY(d_census_.ensure((size_t)n_teams_ * CENSUS_WORDS, false, sk));
+        HIPTRY(d_census_.ensure((size_t)std::max(n_teams_, use_split() ? n_ts_teams_ : 0) * CENSUS_WORDS, false, sk));
         kp.census = d_census_.p;
     }
     kp.nb = nb; kp.n_tiles = n_tiles_; kp.m_pad = m_pad_; kp.b_pad = b_pad_;

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(128) void iir_split_kernel(
     const float *__restrict__ p_tprof, const double *__restrict__ p_xfer_rows, const int *__restrict__ p_xfer_init,
     float *__restrict__ p_audio, float *__restrict__ p_qnorm, const float *__restrict__ p_gq, const float *__restrict__ p_pc,
     const float *__restrict__ p_wtab, const TeamDesc *__restrict__ p_teams, float *__restrict__ p_audio_parts,
-    const float *__restrict__ p_ftab, const SplitDims p) {
+    const float *__restrict__ p_ftab, unsigned long long *__restrict__ p_census, const SplitDims p) {
     constexpr bool QN = QNM != 0;
     __shared__ __attribute__((aligned(16))) float lds_stage[2][2][ST_AREA];       // [buffer parity][group]
     __shared__ __attribute__((aligned(16))) float lds_incr[QN ? 1 : 2][QN ? 4 : 64 * U_ROW];     // [group]: the blocks' state increments on their way back to lane = mode
@@ -174,6 +174,17 @@ __global__ __launch_bounds__(128) void iir_split_kernel(
     auto prefetch = [&](const BufDesc &nd) { fetch_rows(nd); };
     BufDesc next = dsc[0];
     prefetch(next);
+    // diagnostics (PBSO_CENSUS=1): where the two waves' shader cycles go -- words 0..5 wave 0, 6..11 wave 1:
+    // head + taps | first stepping phase | wait at A | second phase (stepping / free response / projection of group 0) | wait at B | projection
+    unsigned long long cy[6] = {0, 0, 0, 0, 0, 0}, cy_mark = 0;
+    auto lap = [&](int k) {
+        if (p_census) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            cy[k] += now - cy_mark;
+            cy_mark = now;
+        }
+    };
+    if (p_census) cy_mark = __builtin_amdgcn_s_memtime();
     int par = 0;                                     // staging parity: flips with every buffer that is stepped (skipped ones pass no barrier)
     for (int b = 0; b < p.nb; ++b) {
         const BufDesc cur = next;
@@ -213,32 +224,50 @@ __global__ __launch_bounds__(128) void iir_split_kernel(
 #pragma unroll
                 for (int k = 0; k < BJ; ++k) dst[k] = tk[k];
             };
-            auto samples = [&](const float (&tv)[BJ]) {
+            // Unit-force form (as K1b): with z = v / g the forcing term is the profile value itself -- an operand of the FMA, no
+            // product g T per sample: four vector instructions per sample with the qnorm sum, two of them a dependent chain.
+            // Floating point is scale-invariant but for its range: the wave takes this form when every lane's z stays well
+            // inside it (a zero / tiny gain on some mode -- the dummy start message of a sustained contact -- takes the general form).
+            const float gi = __builtin_amdgcn_rcpf(g);
+            f2 w = f2{v.x * gi, v.y * gi};
+            const bool z_ok = g != 0.f && fabsf(gi) < 0x1p100f && fabsf(w.x) < 0x1p50f && fabsf(w.y) < 0x1p50f;      // (NaN / inf fail)
+            auto run = [&](auto unit_c) {
+                constexpr bool unit = decltype(unit_c)::value;
+                if (!unit) w = v;
+                const float tsc = unit ? t * g : t;
+                float qz = 0.f;
+                auto samples = [&](const float (&tv)[BJ]) {
 #pragma unroll
-                for (int k = 0; k < BJ; ++k) {
-                    const float in = fmaf(nca, v.y, g * tv[k]);
-                    v.y = fmaf(ncb, v.x, in);
-                    v.x = v.x + v.y;
-                    if (QN) qacc = fmaf(v.x, v.x, qacc);
+                    for (int k = 0; k < BJ; ++k) {
+                        const float in = unit ? fmaf(nca, w.y, tv[k]) : fmaf(nca, w.y, g * tv[k]);
+                        w.y = fmaf(ncb, w.x, in);
+                        w.x = w.x + w.y;
+                        if (QN) qz = fmaf(w.x, w.x, qz);
+                    }
+                };
+                auto park_w = [&](int n) { *reinterpret_cast<f2 *>(st + n * ST_ROW + 2 * lane) = f2{tsc * w.x, tsc * w.y}; };
+                load_t(ta, 0);
+                for (int n = 0; n < BN; n += 2) {
+                    park_w(n);
+                    const float probe = ta[0];
+                    asm volatile("" :: "s"(probe));
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_t(tb, n + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    samples(ta);
+                    park_w(n + 1);
+                    const float probe2 = tb[0];
+                    asm volatile("" :: "s"(probe2));
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_t(ta, n + 2 < BN ? n + 2 : n + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    samples(tb);
                 }
+                v = unit ? f2{g * w.x, g * w.y} : w;
+                if (QN) qacc = unit ? fmaf(g * g, qz, qacc) : qacc + qz;
             };
-            load_t(ta, 0);
-            for (int n = 0; n < BN; n += 2) {
-                park(st, n, v);
-                const float probe = ta[0];
-                asm volatile("" :: "s"(probe));
-                __builtin_amdgcn_sched_barrier(0);
-                load_t(tb, n + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                samples(ta);
-                park(st, n + 1, v);
-                const float probe2 = tb[0];
-                asm volatile("" :: "s"(probe2));
-                __builtin_amdgcn_sched_barrier(0);
-                load_t(ta, n + 2 < BN ? n + 2 : n + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                samples(tb);
-            }
+            if (__all(z_ok)) run(std::true_type{});
+            else run(std::false_type{});
         };
 
         float fir_a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -279,9 +308,35 @@ __global__ __launch_bounds__(128) void iir_split_kernel(
                 });
             }
         };
+        // projection of group gi from its parked block-start states (+ the profile's FIR, operand fb): 256 samples, stored straight
+        // from the MFMA's result registers
+        auto project = [&](int gi, const float (&fb)[4]) {
+            const float *bs = (gi == 0 ? stage0 : stage1) + (lane & 15) * ST_ROW + 2 * (lane >> 5) + ((lane >> 4) & 1);
+            wave_sync();
+#pragma unroll
+            for (int s = 0; s < 32; ++s) breg[s] = bs[4 * s];
+            f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = f4{0.f, 0.f, 0.f, 0.f};
+            static_for<0, 32>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                if constexpr (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], breg[s], acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], breg[s], acc0, 0, 0, 0);
+            });
+            if (dense) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (kk & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fir_a[kk], fb[kk], acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fir_a[kk], fb[kk], acc0, 0, 0, 0);
+                }
+            }
+            const f4 acc = acc0 + acc1;              // D[i = 4 (l >> 4) + v][n = l & 15] = sample 16 n + i of the group
+            float *o = ao + 1 + GROUP * gi + 16 * (lane & 15) + 4 * (lane >> 4);
+            o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
+        };
+        bool fetched = false;
         bool late_b = false;                         // wave 0, dense buffer without qnorm rows: barrier B comes after its projection
         if (!dense) {
             // ================= force-free buffer (or an impulse at sample 0) =================
+            lap(0);
             if (grp == 0) {
                 const bool hit0 = frow >= 0 && (cur.tile_mask & 1u);
                 float a = nca * x.y;
@@ -312,15 +367,18 @@ __global__ __launch_bounds__(128) void iir_split_kernel(
             // (handing the state over after sample 0 and letting wave 1 jump over group 0 with P^16 -- 17 coarse steps on the
             //  critical path instead of 32 -- ran 17 % SLOWER: 0.173 against 0.148 ms for 86 buffers of 1 x 512 modes; a hand-over
             //  through LDS and a workgroup barrier costs more than sixteen coarse steps)
+            lap(1);
             __syncthreads();                         // A: both groups' block-start states are parked
+            lap(2);
             __syncthreads();                         // B (every buffer passes both barriers)
+            lap(4);
         } else {
             // ================= dense force profile =================
             // FIR taps of this wave (both waves need them: the forced response inside a block, see kernels_block.hip):
             // h_0 = sum t g, h_1 .. h_16 = projection of the virtual block-start state t g u, u = (1, 1)'
-            {
+            if (!QN || grp == 1) {
                 // (scratch and taps behind this wave's staging rows: in a qnorm build wave 0 parks into BOTH groups' staging areas
-                //  while wave 1 is here)
+                //  while wave 1 -- the only one that projects dense buffers there -- is here)
                 const float tg = t * g;
                 float pv[16];
 #pragma unroll
@@ -335,6 +393,7 @@ __global__ __launch_bounds__(128) void iir_split_kernel(
                     fir_a[kk] = idx >= 0 ? taps[idx] : 0.f;
                 }
             }
+            lap(0);
             float qacc = 0.f;
             if (grp == 0) {
                 // sample 0
@@ -349,9 +408,19 @@ __global__ __launch_bounds__(128) void iir_split_kernel(
                 if (ft) step_group_ft(stage0, x);
                 else step_group(stage0, 1, x, qacc);
                 if (QN) {
-                    // qnorm rows: the true state of every sample is needed -- this wave steps the second group as well
+                    // qnorm rows: the true state of every sample is needed -- this wave steps the second group as well, and wave 1
+                    // projects BOTH groups: group 0 while this wave steps group 1, group 1 while this wave is already in the next
+                    // buffer (the staging areas alternate with the buffer parity).  The buffer costs the stepping alone.
+                    lap(1);
+                    __syncthreads();                 // A: group 0's block-start states are parked
+                    lap(2);
+                    prefetch(next);                  // (this wave has no projection to fetch the next buffer's rows under)
+                    fetched = true;
                     step_group(stage1, 1 + GROUP, x, qacc);
                     (b_qn + (size_t)b * p.m_pad)[ul] = sqrtf(qacc);
+                    lap(3);
+                    __syncthreads();                 // B: group 1's
+                    lap(4);
                 } else {
                     hand16[lane] = x;
                     late_b = true;
@@ -361,7 +430,9 @@ __global__ __launch_bounds__(128) void iir_split_kernel(
                 f2 z = f2{0.f, 0.f};
                 if (ft) step_group_ft(stage1, z);
                 else step_group(stage1, 1 + GROUP, z, qacc);
+                lap(1);
                 __syncthreads();                     // A: wave 0 has reached the group boundary
+                lap(2);
                 // + the free response of the state wave 0 handed over: 16 coarse steps, added to the parked states
                 f2 xf = hand16[lane];
 #pragma unroll
@@ -372,43 +443,41 @@ __global__ __launch_bounds__(128) void iir_split_kernel(
                     xf = coarse(xf);
                 }
                 hand32[lane] = f2{z.x + xf.x, z.y + xf.y};
+                lap(3);
                 __syncthreads();                     // B: the buffer's end state is handed back
+                lap(4);
             }
-            if (grp == 0 || QN) {
+            if (QN && grp == 1) {
+                float fir_b0[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) fir_b0[kk] = tprow[1 + BJ * (lane & 15) + 4 * kk + (lane >> 4)];
+                lap(1);
                 __syncthreads();                     // A
-                if (!late_b) __syncthreads();        // B
+                lap(2);
+                project(0, fir_b0);
+                lap(3);
+                __syncthreads();                     // B
+                lap(4);
             }
+            if (!QN && grp == 0) { lap(1); __syncthreads(); lap(2); }    // A (B comes after this wave's projection: late_b)
         }
 
         // ---- projection of this wave's group: 32 MFMAs over the 32 pairs of columns (+ the profile's FIR)
-        prefetch(next);                              // (the next descriptor has long arrived: its rows are fetched under the MFMAs)
-        wave_sync();
-#pragma unroll
-        for (int s = 0; s < 32; ++s) breg[s] = bsrc[4 * s];
-        f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = f4{0.f, 0.f, 0.f, 0.f};
-        static_for<0, 32>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            if constexpr (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], breg[s], acc1, 0, 0, 0);
-            else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], breg[s], acc0, 0, 0, 0);
-        });
-        if (dense) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                if (kk & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fir_a[kk], fir_b[kk], acc1, 0, 0, 0);
-                else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fir_a[kk], fir_b[kk], acc0, 0, 0, 0);
-            }
-        }
-        {
-            const f4 acc = acc0 + acc1;              // D[i = 4 (l >> 4) + v][n = l & 15] = sample 16 n + i of the group
-            float *o = ao + 1 + GROUP * grp + 16 * (lane & 15) + 4 * (lane >> 4);
-            o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
-        }
+        if (!fetched) prefetch(next);                // (the next descriptor has long arrived: its rows are fetched under the MFMAs)
+        if (!(QN && dense && grp == 0)) project(grp, fir_b);
         if (late_b) {
+            lap(5);
             __syncthreads();                         // B: wave 1 has added the free response and hands the end state back
+            lap(4);
             x = hand32[lane];
         }
+        if (!late_b) lap(5);
     }
 
+    if (p_census && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p_census[(size_t)blockIdx.x * CENSUS_WORDS + 6 * grp + k] = cy[k];
+    }
     if (grp == 0) {
         (p_sq + ubase)[ul] = x.x;
         (p_sd + ubase)[ul] = x.y;
@@ -422,10 +491,10 @@ int launch_iir_split(const IirParams &p, int n_teams, int qnorm_mode, hipStream_
     const SplitDims dims = {p.nb, p.m_pad, p.b_pad, p.frames, p.audio_stride, p.gq_plane, p.qn_nb, p.qn_b0};
     if (qnorm_mode != 0)
         hipLaunchKernelGGL(iir_split_kernel<2>, dim3(n_teams), dim3(128), 0, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows, p.tprof,
-                           p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.ftab, dims);
+                           p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.ftab, p.census, dims);
     else
         hipLaunchKernelGGL(iir_split_kernel<0>, dim3(n_teams), dim3(128), 0, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows, p.tprof,
-                           p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.ftab, dims);
+                           p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.ftab, p.census, dims);
     return (int)hipGetLastError();
 }
 

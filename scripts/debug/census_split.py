@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""PBSO_CENSUS=1 with the time-split kernel K1s pinned (PBSO_SPLIT=2) on the 8 x 4096 sustained-scraping scene: where the two
+waves of a team spend their shader cycles (words 0..5 wave 0, 6..11 wave 1 of every team's census row)."""
+import os
+import sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ["PBSO_CENSUS"] = "1"
+os.environ["PBSO_SPLIT"] = "2"
+from openpbso_amd import Engine, ForceMessage, synth, capi   # noqa: E402
+n_obj, M, nb = 8, 4096, 86
+qn = capi.QNORM_OFF if len(sys.argv) > 1 and sys.argv[1] == "off" else capi.QNORM_ALL
+eng = Engine(qnorm=qn, form=capi.FORM_BLOCK)
+rng = np.random.default_rng(0)
+for i in range(n_obj):
+    eng.add_object(synth.eigenvalues(M, 100 + i), synth.RHO, synth.ALPHA, synth.BETA)
+eng.finalize()
+for i in range(n_obj):
+    eng.set_use_transfer(i, False)
+    eng.enqueue_force(i, ForceMessage(forceType=capi.AUTOREGRESSIVE_FORCE, sustainedForceStart=True), 0)
+    for b in range(1, 3 * nb):
+        eng.enqueue_force(i, ForceMessage(data=rng.standard_normal(M) * 1e-3, forceType=capi.AUTOREGRESSIVE_FORCE), b)
+for _ in range(3):
+    eng.step(nb)
+eng.sync()
+info = eng.info()
+c = eng.census().astype(np.float64)
+print(f"qnorm {'off' if qn == capi.QNORM_OFF else 'on'}: kernel_ms={info['last_step_kernel_ms']:.3f} split launches {info['total_split_launches']}; cycles per buffer (median over {c.shape[0]} teams)")
+names = ["head + taps", "first stepping phase", "wait at A", "second phase", "wait at B", "projection"]
+for w in (0, 1):
+    row = c[:, 6 * w:6 * w + 6]
+    print(f"  wave {w}: " + "; ".join(f"{n} {np.median(row[:, k]) / nb:.0f}" for k, n in enumerate(names)) + f"; total {np.median(row.sum(axis=1)) / nb:.0f}")
