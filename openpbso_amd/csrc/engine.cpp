@@ -1932,11 +1932,12 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     // profile kernel K2 is the step's critical chain, and K1s -- one wave on EVERY SIMD -- slows it 2.7 x (1.28 ms against
     // 0.48 for 8 chains of 86 rows beside K1b's 512 waves); K1b's forced block path takes those launches (state and teams
     // hand over at any launch boundary)
-    // -- that was the chain form of K2; with the row-parallel form (a few tens of microseconds) K1s keeps those launches too when
-    // no qnorm rows are asked for (its waves step a block at a time, increments on the matrix pipe: 0.36 ms against K1b's 0.47
-    // for 8 x 4096 x 86); with qnorm rows wave 0 steps every sample of both groups and K1b's forced path is the faster one.
+    // -- that was the chain form of K2; with the row-parallel form (a few tens of microseconds) K1s keeps those launches too:
+    // without qnorm rows its waves step a block at a time, increments on the matrix pipe (0.31 ms against K1b's 0.43 for
+    // 8 x 4096 x 86; needs the F table of the forced block path); with qnorm rows wave 0 steps every sample and wave 1 projects
+    // both groups behind it (0.66 ms against 0.74).
     const bool dense_majority = (long long)n_prows_ * 2 > (long long)N * nb;
-    const bool split_dense_ok = desc_.qnorm_mode == PBSO_QNORM_OFF && d_ftab_.p != nullptr && k2_rows_launch_;
+    const bool split_dense_ok = k2_rows_launch_ && (desc_.qnorm_mode != PBSO_QNORM_OFF || d_ftab_.p != nullptr);
     const bool split_launch = use_split() && (split_always_ || !dense_majority || split_dense_ok);      // (PBSO_SPLIT=2: always)
     (split_launch || !(dense_heavy || !is_block()) ? tot_block_launches_ : tot_sample_launches_) += 1;
     if (split_launch) tot_split_launches_ += 1;

@@ -191,6 +191,9 @@ def test_device_and_host_profiles_agree_two_ar_objects(monkeypatch):
     evs.append(force_ev(8, 0, data=rng.standard_normal(n_modes) * 1e-3))
     evs.append(force_ev(8, 0, data=rng.standard_normal(n_modes) * 1e-3, force_type=2))   # plain (unsustained) AR force
     monkeypatch.setenv("PBSO_DEVICE_PROFILES", "1")
+    # (one oscillator-bank kernel for the three runs: which one takes a dense launch of a small engine depends on the profile
+    #  kernel's form, and the comparisons below are about the profiles)
+    monkeypatch.setenv("PBSO_SPLIT", "0")
     dev = run_engine(objs, evs, nb, split=[4, 6])
     monkeypatch.setenv("PBSO_AR_SERIAL", "1")            # K2's AR(2) as the reference's serial loop instead of the parallel scan
     dev_serial = run_engine(objs, evs, nb, split=[4, 6])
@@ -644,10 +647,10 @@ def test_long_steps_cut_into_launches(monkeypatch):
     monkeypatch.setenv("PBSO_CHUNK_BUFFERS", "1")          # buffers 3..5 (AR force alive) become launches of their own
     auto = run_engine(objs, evs, nb, modes_per_lane=1)
     if auto["info"]["recurrence_form"] == capi.FORM_BLOCK:
-        # the f32 block kernels run dense-profile buffers in block form themselves (forced block path): no hand-over to the
-        # per-sample kernel; the launches that are all dense (buffers 3..5) go to K1b, the others to the time-split kernel
+        # the f32 block kernels run dense-profile buffers in block form themselves: no hand-over to the per-sample kernel; a
+        # small engine like this one runs every launch -- the all-dense ones (buffers 3..5) too -- on the time-split kernel
         assert auto["info"]["total_sample_launches"] == 0 and auto["info"]["total_block_launches"] >= 9
-        assert 6 <= auto["info"]["total_split_launches"] <= auto["info"]["total_block_launches"] - 3
+        assert auto["info"]["total_split_launches"] == auto["info"]["total_block_launches"]
     _check(auto, want)
     # the hand-over between the two kernels at launch boundaries (what the split-bf16 form does by itself; small f32 engines
     # run on the time-split kernel K1s, which never hands over: switched off here)
@@ -1102,6 +1105,7 @@ def test_row_parallel_profiles_equal_the_chain_kernel(margin, monkeypatch):
     evs.append(force_ev(21, 2, data=rng.standard_normal(n_modes) * 1e-3, force_type=2))       # plain AR force: a new engine
     evs.append(force_ev(22, 2, data=rng.standard_normal(n_modes) * 1e-3))
     split = [4, 1, 11, 2, 9]
+    monkeypatch.setenv("PBSO_SPLIT", "0")       # (one oscillator-bank kernel for all runs: the comparison is about the profiles)
     monkeypatch.setenv("PBSO_K2_ROWS", "0")
     chain = run_engine(objs, evs, nb, split=split)
     monkeypatch.setenv("PBSO_K2_ROWS", "1")
