@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""PBSO_CENSUS=1 on the 8 x 4096 sustained-scraping scene (BASELINE configs[4]): where wave 0 of every team spends its cycles"""
+"""PBSO_CENSUS=1 on the 8 x 4096 sustained-scraping scene (BASELINE configs[4]) with K1b pinned (PBSO_SPLIT=0: one wave per 64 modes,
+the forced block path): where wave 0 of every team spends its cycles.  (The engine's own choice for this scene is the time-split
+kernel: scripts/debug/census_split.py.)"""
 import os
 import sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["PBSO_CENSUS"] = "1"
+os.environ["PBSO_SPLIT"] = "0"
 from openpbso_amd import Engine, ForceMessage, synth, capi   # noqa: E402
 n_obj, M, nb = 8, 4096, 86
 qn = capi.QNORM_OFF if len(sys.argv) > 1 and sys.argv[1] == "off" else capi.QNORM_ALL

@@ -21,6 +21,9 @@ b c5_8x4096_scraping_qnorm_off --no-cpu-baseline --objects 8 --modes 4096 --scen
 PBSO_SPLIT=0 b c2_1x512_one_wave_per_64_modes --no-cpu-baseline --objects 1 --modes 512 --steps 40 --warmup 2
 PBSO_FORCED_BLOCK=0 b c5_8x4096_scraping_per_sample_kernel --no-cpu-baseline --no-parity --objects 8 --modes 4096 --scenario scraping --steps 20 --warmup 2
 PBSO_AR_SERIAL=1 b c5_8x4096_scraping_serial_ar --no-cpu-baseline --no-parity --objects 8 --modes 4096 --scenario scraping --steps 20 --warmup 2
+PBSO_K2_ROWS=0 b c5_8x4096_scraping_chain_profile_kernel --no-cpu-baseline --no-parity --objects 8 --modes 4096 --scenario scraping --qnorm off --steps 20 --warmup 2
+PBSO_SPLIT=0 b c5_8x4096_scraping_one_wave_per_64_modes --no-cpu-baseline --no-parity --objects 8 --modes 4096 --scenario scraping --steps 20 --warmup 2
+PBSO_SPLIT=0 b c5_8x4096_scraping_qnorm_off_one_wave_per_64_modes --no-cpu-baseline --no-parity --objects 8 --modes 4096 --scenario scraping --qnorm off --steps 20 --warmup 2
 echo "== N > 1 path on one GPU"
 PBSO_BENCH_BACKEND=gloo b 2ranks_one_gpu_gloo --no-cpu-baseline --gpus 2 --steps 20 --warmup 2
 (PBSO_BENCH_GATHER_SELF=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29633 bench.py --gpus 1 --no-cpu-baseline --steps 40 --warmup 3 > $O/bench_1rank_torchrun_rccl_selfgather.json 2> $O/bench_1rank.err; echo "selfgather rc=$?")
@@ -61,6 +64,7 @@ echo "== census"
 PBSO_CENSUS=1 timeout 300 python scripts/census.py 1024 2>&1 | grep -v amdgpu.ids > $O/census_1024x512_block_f32.txt; tail -5 $O/census_1024x512_block_f32.txt
 timeout 300 python scripts/debug/census_scraping.py 2>&1 | grep -v amdgpu.ids > $O/census_8x4096_scraping.txt
 timeout 300 python scripts/debug/census_scraping.py off 2>&1 | grep -v amdgpu.ids >> $O/census_8x4096_scraping.txt
+(timeout 300 python scripts/debug/census_split.py; timeout 300 python scripts/debug/census_split.py off) 2>&1 | grep -v amdgpu.ids > $O/census_8x4096_scraping_time_split.txt
 make -C scripts/microbench mfma_valu_mix > /dev/null 2>&1; ./scripts/microbench/mfma_valu_mix > $O/mfma_valu_mix.txt 2>&1
 timeout 300 python scripts/latency.py > $O/realtime_latency.txt 2>&1
 ls $O | head -80
