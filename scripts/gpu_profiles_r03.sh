@@ -19,7 +19,7 @@ b c3_64x256_listener --no-cpu-baseline --objects 64 --modes 256 --scenario liste
 b c5_8x4096_scraping --no-cpu-baseline --objects 8 --modes 4096 --scenario scraping --steps 40 --warmup 2
 b c5_8x4096_scraping_qnorm_off --no-cpu-baseline --objects 8 --modes 4096 --scenario scraping --qnorm off --steps 40 --warmup 2
 PBSO_SPLIT=0 b c2_1x512_one_wave_per_64_modes --no-cpu-baseline --objects 1 --modes 512 --steps 40 --warmup 2
-PBSO_FORCED_BLOCK=0 b c5_8x4096_scraping_per_sample_kernel --no-cpu-baseline --no-parity --objects 8 --modes 4096 --scenario scraping --steps 20 --warmup 2
+PBSO_FORCED_BLOCK=0 PBSO_SPLIT=0 b c5_8x4096_scraping_per_sample_kernel --no-cpu-baseline --no-parity --objects 8 --modes 4096 --scenario scraping --steps 20 --warmup 2
 PBSO_AR_SERIAL=1 b c5_8x4096_scraping_serial_ar --no-cpu-baseline --no-parity --objects 8 --modes 4096 --scenario scraping --steps 20 --warmup 2
 PBSO_K2_ROWS=0 b c5_8x4096_scraping_chain_profile_kernel --no-cpu-baseline --no-parity --objects 8 --modes 4096 --scenario scraping --qnorm off --steps 20 --warmup 2
 PBSO_SPLIT=0 b c5_8x4096_scraping_one_wave_per_64_modes --no-cpu-baseline --no-parity --objects 8 --modes 4096 --scenario scraping --steps 20 --warmup 2
