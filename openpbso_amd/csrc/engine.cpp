@@ -370,6 +370,7 @@ int Engine::init() {
     if (const char *v = std::getenv("PBSO_DEVICE_PROFILES")) device_profiles_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_AR_SERIAL")) ar_serial_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_K2_ROWS")) k2_rows_ = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PBSO_SPLIT_KERNEL")) split_pipe_ = std::string(v) != "time";
     if (const char *v = std::getenv("PBSO_K2_MARGIN_PCT")) k2_margin_pct_ = std::min(400, std::max(1, std::atoi(v)));
     if (const char *v = std::getenv("PBSO_K2_PRIO")) { k2_prio_ = std::min(3, std::max(0, std::atoi(v))); k2_prio_auto_ = false; }
     if (const char *v = std::getenv("PBSO_DIRECT_HITS")) direct_hits_ = std::atoi(v) != 0;
@@ -1953,7 +1954,14 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     bool used[N_CLASS_STREAMS] = {false, false, false};
     if (split_launch) {
         kp.teams = d_ts_teams_.p;
-        LAUNCHTRY(iir_split::launch_iir_split(kp, n_ts_teams_, desc_.qnorm_mode, sk));
+        if (split_pipe_) {
+            // two consumers (one group each) also where that puts a second wave on some SIMDs: 8 x 4096 scraping -- 512 teams, 1536
+            // waves -- runs 3120 x against 2800 with one consumer (no qnorm rows) and 1700 x against 1590 (with them)
+            int nc = 2;
+            if (const char *v = std::getenv("PBSO_PIPE_CONSUMERS")) nc = std::atoi(v) == 1 ? 1 : 2;
+            LAUNCHTRY(iir_pipe::launch_iir_pipe(kp, n_ts_teams_, nc, desc_.qnorm_mode, sk));
+        }
+        else LAUNCHTRY(iir_split::launch_iir_split(kp, n_ts_teams_, desc_.qnorm_mode, sk));
     }
     const bool fork = !split_launch && classes_.size() > 1 && ev_fork_ && total_team_waves_ <= 16LL * n_cus_;
     if (fork) HIPTRY(hipEventRecord(ev_fork_, sk));

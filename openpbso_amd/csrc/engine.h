@@ -346,6 +346,7 @@ private:
     // K2, row-parallel form (the default; PBSO_K2_ROWS=0 or PBSO_AR_SERIAL=1: one workgroup walks an object's rows in order).
     // build_ar_tables() lists the launch's AR forces (streams), their uses and the candidate segments of their engines.
     bool k2_rows_ = true;
+    bool split_pipe_ = true;                             // small engines: K1p (producer / consumer waves); PBSO_SPLIT_KERNEL=time: K1s (two waves share the time axis)
     int k2_margin_pct_ = 100;                            // PBSO_K2_MARGIN_PCT: scales the candidate range (tests: < 100 forces the shortfall path)
     bool k2_rows_launch_ = false;                        // this launch takes the row-parallel form
     std::vector<ArStream> ar_streams_;

@@ -117,6 +117,11 @@ constexpr int MAX_WAVES_PER_BLOCK_TEAM = 8;
 constexpr double TRUNC_SPLIT_GAIN = 1.0 + 7.2e-6;
 // per wave: the staging area, two rings, and the landing area of a direct hit's three g32 rows ([3][R][64] floats)
 inline size_t block_lds_bytes(int W, int R) { return sizeof(float) * (size_t)W * (BLOCK_STAGE_FLOATS + 2 * BLOCK_RING_FLOATS + 3 * R * 64); }
+namespace iir_pipe {
+// K1p (kernels_pipe.hip): teams of one producer wave (steps, parks block-start states) and n_consumers (1 or 2) consumer waves
+// (project the previous buffer); teams as K1s: 64 modes each
+int launch_iir_pipe(const IirParams &p, int n_teams, int n_consumers, int qnorm_mode, hipStream_t stream);
+}
 namespace iir_block {
 // modes_per_lane in {1,2,4}; qnorm_mode 0 off, otherwise closed form (+ per-sample in literal buffers)
 // proj: 0 = f32 MFMA projection, 1 = split-bf16 projection (wtab holds the split table)

@@ -1,0 +1,463 @@
+// K1p: the block state-space oscillator bank for an UNDER-FILLED chip as a PIPELINE of waves (gfx950, wave64, f32 MFMA).
+//
+// Replaces the same reference code as K1 / K1b / K1s: the hot loop of ModalSolver::step (modal_solver.h:262-272) around
+// ModalIntegrator::Step (modal_integrator.h:103-113).  Same formulation as kernels_block.hip (read that first): a buffer
+// is sample 0 + 2 groups of 16 blocks of 16 samples; block-start states are parked in LDS and projected on the f32
+// matrix pipe with the per-mode table W = (a_j, b_j); a dense force profile adds a 16-tap FIR of the profile.
+//
+// A scene with fewer waves of oscillators than SIMDs is bound by the LATENCY of one buffer in one wave.  K1s
+// (kernels_split.hip) splits a buffer's two groups between two waves; its waves still alternate between stepping and
+// projecting, wait for each other at two barriers per buffer, and a dense profile needs a zero-state superposition and a
+// hand-over of the state.  Here the two kinds of work never share a wave: a team of 1 + NC waves owns 64 modes,
+//   wave 0          the PRODUCER: steps buffer b -- sample 0, the 32 coarse steps (a dense profile: a block at a time
+//                   with the increments F . T on the matrix pipe, or every sample when qnorm rows are asked for) -- from
+//                   the true state, parks the 32 block-start states in the staging area of parity b & 1, writes sample 0
+//                   and the qnorm row;
+//   waves 1 .. NC   the CONSUMERS: project buffer b - 1 from the staging area of the other parity (NC = 2: one group each;
+//                   NC = 1: both groups), add the profile's FIR, store 256 samples per group straight from the MFMA's
+//                   result registers.
+// One workgroup barrier per buffer; the buffer costs max(stepping, projection) instead of their sum, and the state never
+// changes hands.  The registers hold the state UNSCALED (the parked values carry the transfer weight), as in K1s.
+#include <type_traits>
+
+#include "kernels.h"
+#include "wave_ops.h"
+
+namespace pbso {
+namespace iir_pipe {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int BJ = BLOCK_J, BN = BLOCK_N, GROUP = BJ * BN;
+constexpr int ST_ROW = 130;                          // as K1b: [16 blocks][64 lanes][Q, D], row stride 130 floats
+constexpr int ST_AREA = BN * ST_ROW + 32 + 132;      // + a consumer's FIR taps h_0 .. h_15 + 64 floats of scratch for the taps' butterfly
+constexpr int U_ROW = 36;                            // increments: [64 modes][16 Q | 16 D] + 4 floats of padding (as K1b's FTM)
+
+struct PipeDims {
+    int nb, m_pad, b_pad, frames;
+    long long audio_stride, plane;
+    int qn_nb, qn_b0;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_mov<0xB1>(0.f, v);
+    v += dpp_mov<0x4E>(0.f, v);
+    v += dpp_mov<0x141>(0.f, v);
+    v += dpp_mov<0x140>(0.f, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+template <int K0, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (N > 0) {
+        f(std::integral_constant<int, K0>{});
+        static_for<K0 + 1, N - 1>(f);
+    }
+}
+
+template <int QNM>
+__global__ __launch_bounds__(192) void iir_pipe_kernel(
+    const float *__restrict__ p_ca, const float *__restrict__ p_cb, float *__restrict__ p_sq, float *__restrict__ p_sd,
+    float *__restrict__ p_ss, const BufDesc *__restrict__ p_desc, const float *__restrict__ p_grows,
+    const float *__restrict__ p_tprof, const double *__restrict__ p_xfer_rows, const int *__restrict__ p_xfer_init,
+    float *__restrict__ p_audio, float *__restrict__ p_qnorm, const float *__restrict__ p_gq, const float *__restrict__ p_pc,
+    const float *__restrict__ p_wtab, const TeamDesc *__restrict__ p_teams, float *__restrict__ p_audio_parts,
+    const float *__restrict__ p_ftab, unsigned long long *__restrict__ p_census, const PipeDims p) {
+    constexpr bool QN = QNM != 0;
+    __shared__ __attribute__((aligned(16))) float lds_stage[2][2][ST_AREA];       // [buffer parity][group]
+    __shared__ __attribute__((aligned(16))) float lds_incr[QN ? 4 : 64 * U_ROW];  // the producer's increments on their way back to lane = mode
+    // a dense buffer's profile for the producer's per-sample loop: [buffer parity][T_1 .. T_512 | T_0], staged by consumer 0 a buffer
+    // ahead (the loop's 16 values per block come from LDS in ~100 cycles whatever the memory system is busy with; one scalar
+    // load per block from L2 / HBM left 100 .. 250 of every block's 290 cycles waiting)
+    __shared__ __attribute__((aligned(16))) float lds_t[2][2 * GROUP + 8];
+    const TeamDesc team = p_teams[blockIdx.x];
+    const int obj = team.obj;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int NC = (int)(blockDim.x >> 6) - 1;                                    // consumers: 1 or 2
+    const bool producer = wave == 0;
+    const size_t ubase = (size_t)obj * p.m_pad + team.col0;
+    const unsigned ul = (unsigned)lane;
+    const BufDesc *__restrict__ dsc = p_desc + (size_t)obj * p.nb;
+    float *__restrict__ aout = team.part_row >= 0 ? p_audio_parts + (size_t)team.part_row * p.audio_stride
+                                                  : p_audio + (size_t)obj * p.audio_stride;
+    const int B = p.frames;
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // diagnostics (PBSO_CENSUS=1): words 0..5 the producer (head | stepping | wait), 6..11 consumer 0 (head + taps | projection | wait)
+    unsigned long long cy[3] = {0, 0, 0}, cy_mark = 0;
+    auto lap = [&](int k) {
+        if (p_census) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            cy[k] += now - cy_mark;
+            cy_mark = now;
+        }
+    };
+    const float nca = (p_ca + ubase)[ul], ncb = (p_cb + ubase)[ul];                // eps^2, -e  (velocity form, as K1)
+    const bool dead = nca == 0.f && ncb == 0.f;                                   // a padding column
+    // the transfer weight in force (both roles follow it: the producer parks t x state, a consumer's taps are sums of t g phi)
+    float t;
+    {
+        const int row0 = p_xfer_init[obj];
+        const float tr = row0 >= 0 ? (float)(p_xfer_rows + (size_t)row0 * p.m_pad + team.col0)[ul] : 1e7f;
+        t = dead ? 1.f : tr;
+    }
+    // a buffer's rows from memory -- force gain, new transfer weights -- are fetched a buffer ahead
+    float g_next = 0.f, t_next = 0.f;
+    auto fetch_rows = [&](const BufDesc &nd) {
+        if (nd.frow >= 0) g_next = (p_grows + (size_t)nd.frow * p.m_pad + team.col0)[ul];
+        if (nd.trow >= 0) t_next = (float)(p_xfer_rows + (size_t)nd.trow * p.m_pad + team.col0)[ul];
+    };
+    BufDesc next = dsc[0];
+    fetch_rows(next);
+    if (p_census) cy_mark = __builtin_amdgcn_s_memtime();
+
+    auto is_dense = [](const BufDesc &d) { return !(d.flags & DESC_SKIP) && d.frow >= 0 && !(d.flags & DESC_IMPULSE) && d.prow >= 0; };
+    auto stage_profile = [&](const BufDesc &d, int parity) {          // one wave: 2 KB, two 16-byte loads per lane
+        if (!is_dense(d)) return;
+        const float *__restrict__ row = p_tprof + (size_t)d.prow * p.b_pad;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = row[1 + 8 * lane + i];
+        float *dst = lds_t[parity] + 8 * lane;
+        *reinterpret_cast<f4 *>(dst) = f4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f4 *>(dst + 4) = f4{v[4], v[5], v[6], v[7]};
+    };
+    if (wave == 1) stage_profile(next, 0);
+    __syncthreads();
+    if (producer) {
+        // ================================================= PRODUCER =================================================
+        const float p11 = (p_pc + ubase)[ul], p12 = (p_pc + p.plane + ubase)[ul];     // P = A^16: P11 - 1, P12, P21, P22
+        const float p21 = (p_pc + 2 * p.plane + ubase)[ul], p22 = (p_pc + 3 * p.plane + ubase)[ul];
+        float g11 = 0.f, g12 = 0.f, g22 = 0.f;
+        if (QN) {
+            g11 = (p_gq + ubase)[ul];
+            g12 = (p_gq + p.plane + ubase)[ul];
+            g22 = (p_gq + 2 * p.plane + ubase)[ul];
+        }
+        // Dense profiles without qnorm rows: a block's state increment is F . T_n, F = [A^15 u .. A u, u] (the table of K1b's
+        // forced block path; absent -- PBSO_FORCED_BLOCK=0 -- every sample is stepped).  The increments of a group's 16 blocks
+        // are a [16 blocks x 16 taps] . [16 taps x 16 modes] product per tile of 16 modes and state component: 32 MFMAs whose
+        // A operand is the profile as the FIR's B operand holds it and whose B operand is F, resident here.
+        const bool ft = !QN && p_ftab != nullptr;
+        float fB[QN ? 1 : 4][2][4];
+        if (!QN && ft) {
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+                        fB[QN ? 0 : tl][c][ks] = (p_ftab + (size_t)(2 * (4 * ks + (lane >> 4)) + c) * p.plane + ubase)[16 * tl + (lane & 15)];
+        }
+        f2 x;                                        // state, unscaled (the arrays hold scale x state, kernels_iir.hip "scaled state")
+        {
+            const float s0 = (p_ss + ubase)[ul];
+            x.x = (p_sq + ubase)[ul] / s0;
+            x.y = (p_sd + ubase)[ul] / s0;
+        }
+        float *__restrict__ b_qn = p_qnorm + ((size_t)obj * p.qn_nb + p.qn_b0) * p.m_pad + team.col0;
+        auto coarse = [&](f2 v) {                    // v <- P v
+            const float qa = fmaf(p11, v.x, v.x);
+            const float da = p21 * v.x;
+            return f2{fmaf(p12, v.y, qa), fmaf(p22, v.y, da)};
+        };
+        for (int it = 0; it <= p.nb; ++it) {
+            if (it < p.nb) {
+                const int b = it;
+                const BufDesc cur = next;
+                next = dsc[b + 1 < p.nb ? b + 1 : b];
+                const float g_cur = g_next, t_cur = t_next;
+                fetch_rows(next);
+                float *__restrict__ ao = aout + (size_t)b * B;
+                if (cur.flags & DESC_SKIP) {
+                    // the reference's step() returned before stepping: no samples (the consumers write the zeros), state untouched
+                    if (QN) (b_qn + (size_t)b * p.m_pad)[ul] = 0.f;
+                } else {
+                    if (cur.trow != XFER_KEEP) {
+                        const float tr = cur.trow >= 0 ? t_cur : 1e7f;
+                        t = dead ? 1.f : tr;
+                    }
+                    const int frow = cur.frow;
+                    const float g = frow >= 0 ? g_cur : 0.f;
+                    const bool dense = frow >= 0 && !(cur.flags & DESC_IMPULSE);
+                    float *stage0 = lds_stage[b & 1][0], *stage1 = lds_stage[b & 1][1];
+                    const float *__restrict__ tprow = p_tprof + (size_t)(cur.prow >= 0 && dense ? cur.prow : 0) * p.b_pad;
+                    auto park = [&](float *st, int n, f2 v) { *reinterpret_cast<f2 *>(st + n * ST_ROW + 2 * lane) = f2{t * v.x, t * v.y}; };
+                    if (!dense) {
+                        // ---- force-free buffer (or an impulse at sample 0)
+                        const bool hit0 = frow >= 0 && (cur.tile_mask & 1u);
+                        float a = nca * x.y;
+                        a = fmaf(ncb, x.x, a);
+                        if (hit0) a = fmaf(g, cur.amp, a);
+                        x.y = a;
+                        x.x = x.x + a;
+                        if (QN) {
+                            // sum_{k=0}^{B-1} q_k^2 = x0' G x0, x0 = state after sample 0 (the rest of the buffer is force-free)
+                            float e = g22 * x.y * x.y;
+                            e = fmaf(g12 * x.x, x.y, e);
+                            e = fmaf(g11 * x.x, x.x, e);
+                            (b_qn + (size_t)b * p.m_pad)[ul] = __builtin_amdgcn_sqrtf(fmaxf(e, 0.f));
+                        }
+                        const float p0 = wave_sum(t * x.x);
+                        if (lane == 0) ao[0] = p0;
+                        lap(0);
+#pragma unroll
+                        for (int n = 0; n < BN; ++n) {
+                            park(stage0, n, x);
+                            x = coarse(x);
+                        }
+#pragma unroll
+                        for (int n = 0; n < BN; ++n) {
+                            park(stage1, n, x);
+                            x = coarse(x);
+                        }
+                    } else {
+                        // ---- dense force profile (Gaussian, AR: forces.h:92-128)
+                        // the profile as an MFMA operand, lane l: T[1 + 256 grp + 16 (l & 15) + 4 kk + (l >> 4)] (fetched under sample 0)
+                        float tb[2][4];
+                        if (ft) {
+#pragma unroll
+                            for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                                for (int kk = 0; kk < 4; ++kk) tb[gi][kk] = tprow[1 + GROUP * gi + BJ * (lane & 15) + 4 * kk + (lane >> 4)];
+                        }
+                        float qacc = 0.f;
+                        {
+                            float a = nca * x.y;
+                            a = fmaf(ncb, x.x, a);
+                            a = fmaf(g, tprow[0], a);
+                            x.y = a;
+                            x.x = x.x + a;
+                            if (QN) qacc = x.x * x.x;
+                            const float p0 = wave_sum(t * x.x);
+                            if (lane == 0) ao[0] = p0;
+                        }
+                        lap(0);
+                        if (!QN && ft) {
+                            // 16 blocks a block at a time: v_{n+1} = P v_n + g (F . T_n), parking every block-start state
+                            auto step_group_ft = [&](float *st, const float (&tbg)[4]) {
+                                if constexpr (!QN) {
+                                    static_for<0, 4>([&](auto tc) {
+                                        constexpr int tl = decltype(tc)::value;
+                                        f4 dq = f4{0.f, 0.f, 0.f, 0.f}, dd = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                                        for (int ks = 0; ks < 4; ++ks) {
+                                            dq = __builtin_amdgcn_mfma_f32_16x16x4f32(tbg[ks], fB[tl][0][ks], dq, 0, 0, 0);
+                                            dd = __builtin_amdgcn_mfma_f32_16x16x4f32(tbg[ks], fB[tl][1][ks], dd, 0, 0, 0);
+                                        }
+                                        float *dst = lds_incr + (16 * tl + (lane & 15)) * U_ROW + 4 * (lane >> 4);   // D[block 4 (l >> 4) + v][mode 16 tl + (l & 15)]
+                                        *reinterpret_cast<f4 *>(dst) = dq;
+                                        *reinterpret_cast<f4 *>(dst + BN) = dd;
+                                    });
+                                    wave_sync();
+                                    f4 uq[4], ud[4];
+                                    {
+                                        const f4 *src = reinterpret_cast<const f4 *>(lds_incr + lane * U_ROW);
+#pragma unroll
+                                        for (int i = 0; i < 4; ++i) { uq[i] = src[i]; ud[i] = src[4 + i]; }
+                                    }
+                                    wave_sync();                 // (the next group's tiles overwrite the area)
+                                    static_for<0, BN>([&](auto nc) {
+                                        constexpr int n = decltype(nc)::value;
+                                        park(st, n, x);
+                                        const f2 w = coarse(x);
+                                        x = f2{fmaf(g, uq[n / 4][n % 4], w.x), fmaf(g, ud[n / 4][n % 4], w.y)};
+                                    });
+                                }
+                            };
+                            step_group_ft(stage0, tb[0]);
+                            step_group_ft(stage1, tb[1]);
+                        } else {
+                            // every sample (qnorm rows need each sample's true state).  T values: one s_load_dwordx16 per block
+                            // issued a block ahead (scalar loads return out of order: first use, then the next load).  Unit-force
+                            // form (as K1b): with z = x / g the forcing term is the profile value itself -- an operand of the FMA --
+                            // while every lane's z stays well inside the floating-point range (a zero / tiny gain on some mode,
+                            // e.g. the dummy start message of a sustained contact, takes the general form).
+                            const float gi = __builtin_amdgcn_rcpf(g);
+                            const f2 z0 = f2{x.x * gi, x.y * gi};
+                            const bool z_ok = g != 0.f && fabsf(gi) < 0x1p100f && fabsf(z0.x) < 0x1p50f && fabsf(z0.y) < 0x1p50f;      // (NaN / inf fail)
+                            auto run = [&](auto unit_c) {
+                                constexpr bool unit = decltype(unit_c)::value;
+                                f2 w = unit ? z0 : x;
+                                const float tsc = unit ? t * g : t;
+                                float qz = 0.f;
+                                // 32 blocks of 16 samples; the profile values of a block: four broadcast ds_read_b128 (one address for
+                                // the whole wave), three blocks in flight in rotating registers (LDS operations return in order: a
+                                // block waits for ITS values only)
+                                const float *tl = lds_t[b & 1] + (ul >> 31);          // (+ 0, opaque: vector registers)
+                                f4 q0[4], q1[4], q2[4], q3[4];
+                                auto ld = [&](f4 (&d)[4], int n) {
+                                    const f4 *src = reinterpret_cast<const f4 *>(tl + BJ * (n < 2 * BN ? n : 2 * BN - 1));
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) d[i] = src[i];
+                                };
+                                auto runb = [&](const f4 (&d)[4], int n) {
+                                    float *st = n < BN ? stage0 : stage1;
+                                    *reinterpret_cast<f2 *>(st + (n & (BN - 1)) * ST_ROW + 2 * lane) = f2{tsc * w.x, tsc * w.y};
+                                    const float tv[BJ] = {d[0].x, d[0].y, d[0].z, d[0].w, d[1].x, d[1].y, d[1].z, d[1].w,
+                                                          d[2].x, d[2].y, d[2].z, d[2].w, d[3].x, d[3].y, d[3].z, d[3].w};
+#pragma unroll
+                                    for (int k = 0; k < BJ; ++k) {
+                                        const float in = unit ? fmaf(nca, w.y, tv[k]) : fmaf(nca, w.y, g * tv[k]);
+                                        w.y = fmaf(ncb, w.x, in);
+                                        w.x = w.x + w.y;
+                                        if (QN) qz = fmaf(w.x, w.x, qz);
+                                    }
+                                };
+                                ld(q0, 0); ld(q1, 1); ld(q2, 2);
+                                for (int n = 0; n < 2 * BN; n += 4) {
+                                    ld(q3, n + 3);
+                                    runb(q0, n);
+                                    ld(q0, n + 4);
+                                    runb(q1, n + 1);
+                                    ld(q1, n + 5);
+                                    runb(q2, n + 2);
+                                    ld(q2, n + 6);
+                                    runb(q3, n + 3);
+                                }
+                                x = unit ? f2{g * w.x, g * w.y} : w;
+                                if (QN) qacc = unit ? fmaf(g * g, qz, qacc) : qacc + qz;
+                            };
+                            if (__all(z_ok)) run(std::true_type{});
+                            else run(std::false_type{});
+                            if (QN) (b_qn + (size_t)b * p.m_pad)[ul] = sqrtf(qacc);
+                        }
+                    }
+                }
+                lap(1);
+            }
+            __syncthreads();                         // buffer `it` is parked; the consumers have projected buffer it - 1
+            lap(2);
+        }
+        (p_sq + ubase)[ul] = x.x;
+        (p_sd + ubase)[ul] = x.y;
+        (p_ss + ubase)[ul] = 1.f;
+    } else {
+        // ================================================= CONSUMERS =================================================
+        const int cidx = wave - 1;
+        float wreg[32];                              // the MFMA A operand of the 32 pairs of columns (as K1b)
+        {
+            const float *__restrict__ wsrc = p_wtab + (ubase / 2) * 64;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) wreg[s] = wsrc[s * 64 + lane];
+        }
+        // FIR taps of a dense profile (kernels_block.hip, "forced block path"): h_d = sum over modes of t g phi_d, phi_d = e1' A^d u
+        // the mode's response d samples after a unit force sample (u = (1, 1)': d += f, q += d).  phi: sixteen constants per
+        // mode, stepped here once per launch (fp64 from the f32 coefficients the per-sample kernels use); the sixteen sums over
+        // the wave are one butterfly (wave_ops.h).
+        float phi[16];
+        {
+            double vq = 1.0, vd = 1.0;
+            phi[0] = 1.f;
+#pragma unroll
+            for (int d = 1; d < 16; ++d) {
+                vd = (double)nca * vd + (double)ncb * vq;
+                vq = vq + vd;
+                phi[d] = dead ? 0.f : (float)vq;
+            }
+        }
+        const int ctid = (int)threadIdx.x - 64, cthreads = 64 * NC;
+        for (int it = 0; it <= p.nb; ++it) {
+            const BufDesc ahead = dsc[it + 1 < p.nb ? it + 1 : p.nb - 1];       // (fetched under the projection, used after it)
+            if (it >= 1) {
+                const int b = it - 1;
+                const BufDesc cur = next;
+                next = dsc[b + 1 < p.nb ? b + 1 : b];
+                const float g_cur = g_next, t_cur = t_next;
+                fetch_rows(next);
+                float *__restrict__ ao = aout + (size_t)b * B;
+                if (cur.flags & DESC_SKIP) {
+                    for (int i = ctid; i < B; i += cthreads) ao[i] = 0.f;
+                } else {
+                    if (cur.trow != XFER_KEEP) {
+                        const float tr = cur.trow >= 0 ? t_cur : 1e7f;
+                        t = dead ? 1.f : tr;
+                    }
+                    const int frow = cur.frow;
+                    const float g = frow >= 0 ? g_cur : 0.f;
+                    const bool dense = frow >= 0 && !(cur.flags & DESC_IMPULSE);
+                    const float *__restrict__ tprow = p_tprof + (size_t)(cur.prow >= 0 && dense ? cur.prow : 0) * p.b_pad;
+                    float fir_a[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (dense) {
+                        float *taps = lds_stage[b & 1][cidx] + BN * ST_ROW;       // (behind this consumer's first group's rows)
+                        const float tg = t * g;
+                        float pv[16];
+#pragma unroll
+                        for (int d = 0; d < 16; ++d) pv[d] = tg * phi[d];
+                        const float hd = wave_sum16(pv, lane, taps + 32, wave_sync);
+                        if (lane < 16) taps[taps_index(lane)] = hd;
+                        wave_sync();
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const int idx = (lane & 15) - 4 * kk - (lane >> 4);
+                            fir_a[kk] = idx >= 0 ? taps[idx] : 0.f;
+                        }
+                    }
+                    lap(0);
+                    for (int gi = cidx; gi < 2; gi += NC) {
+                        // projection of group gi from its parked block-start states (+ the profile's FIR): 256 samples, stored
+                        // straight from the MFMA's result registers
+                        const float *bs = lds_stage[b & 1][gi] + (lane & 15) * ST_ROW + 2 * (lane >> 5) + ((lane >> 4) & 1);
+                        float breg[32];
+#pragma unroll
+                        for (int s = 0; s < 32; ++s) breg[s] = bs[4 * s];
+                        f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = f4{0.f, 0.f, 0.f, 0.f};
+                        static_for<0, 32>([&](auto sc) {
+                            constexpr int s = decltype(sc)::value;
+                            if constexpr (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], breg[s], acc1, 0, 0, 0);
+                            else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], breg[s], acc0, 0, 0, 0);
+                        });
+                        if (dense) {
+#pragma unroll
+                            for (int kk = 0; kk < 4; ++kk) {
+                                const float fb = tprow[1 + GROUP * gi + BJ * (lane & 15) + 4 * kk + (lane >> 4)];
+                                if (kk & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fir_a[kk], fb, acc1, 0, 0, 0);
+                                else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fir_a[kk], fb, acc0, 0, 0, 0);
+                            }
+                        }
+                        const f4 acc = acc0 + acc1;  // D[i = 4 (l >> 4) + v][n = l & 15] = sample 16 n + i of the group
+                        float *o = ao + 1 + GROUP * gi + 16 * (lane & 15) + 4 * (lane >> 4);
+                        o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
+                    }
+                }
+                lap(1);
+            }
+            // the profile of the buffer the producer steps NEXT (it + 1), into the other parity's row
+            if (cidx == 0 && it + 1 < p.nb) stage_profile(ahead, (it + 1) & 1);
+            __syncthreads();
+            lap(2);
+        }
+    }
+    if (p_census && lane == 0 && wave < 2) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p_census[(size_t)blockIdx.x * CENSUS_WORDS + 6 * wave + k] = cy[k];
+#pragma unroll
+        for (int k = 3; k < 6; ++k) p_census[(size_t)blockIdx.x * CENSUS_WORDS + 6 * wave + k] = 0;
+    }
+}
+
+int launch_iir_pipe(const IirParams &p, int n_teams, int n_consumers, int qnorm_mode, hipStream_t stream) {
+    if (n_teams <= 0) return 0;
+    if (p.frames != 1 + 2 * GROUP || n_consumers < 1 || n_consumers > 2) return (int)hipErrorInvalidValue;
+    const PipeDims dims = {p.nb, p.m_pad, p.b_pad, p.frames, p.audio_stride, p.gq_plane, p.qn_nb, p.qn_b0};
+    const dim3 block(64 * (1 + n_consumers));
+    if (qnorm_mode != 0)
+        hipLaunchKernelGGL(iir_pipe_kernel<2>, dim3(n_teams), block, 0, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows, p.tprof,
+                           p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.ftab, p.census, dims);
+    else
+        hipLaunchKernelGGL(iir_pipe_kernel<0>, dim3(n_teams), block, 0, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows, p.tprof,
+                           p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.ftab, p.census, dims);
+    return (int)hipGetLastError();
+}
+
+}  // namespace iir_pipe
+}  // namespace pbso
