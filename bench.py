@@ -650,6 +650,9 @@ def main():
             # (a block-form engine may run launches that are mostly dense-profile buffers on the per-sample kernel)
             block = r["form_run"] in (0, 3) and info["total_block_launches"] >= info["total_sample_launches"]
             bf16 = block and r["form_run"] == 3
+            # an under-filled f32 engine runs on the pipeline kernel K1p (kernels_pipe.hip; PBSO_SPLIT_KERNEL=time: K1s)
+            small = block and 2 * info.get("total_split_launches", 0) > info["total_block_launches"]
+            small_kernel = "iir_split_kernel" if os.environ.get("PBSO_SPLIT_KERNEL") == "time" else "iir_pipe_kernel"
             dense = args.scenario == "scraping"
             per_s = 1.0 / (k_ms * 1e-3)
             if block and not bf16 and not dense:
@@ -686,7 +689,7 @@ def main():
             gbs = bytes_alg * per_s * 1e-9
             traffic, traffic_src = measured_traffic(args, form, r["n_local"])
             out = {
-                "bound": bound, "kernel": "iir_block_kernel" if block else "iir_bank_kernel",
+                "bound": bound, "kernel": small_kernel if small else ("iir_block_kernel" if block else "iir_bank_kernel"),
                 "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                 "min_work": {"flop_per_mode_sample_by_pipe": work, "mode_samples_per_launch": ms, "min_kernel_ms": min_ms,
                              "kernel_ms": k_ms, "note": note},

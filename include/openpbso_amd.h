@@ -308,8 +308,9 @@ typedef struct pbso_engine_info {
     int64_t total_timed_launches;     /* launches whose HIP-event times are in total_kernel_ms / total_device_ms: all of
                                        * them, or every n-th with env PBSO_TIMING_EVERY=n (an event pair costs the
                                        * stream ~8 us per launch; 0 = none)                                           */
-    int64_t total_split_launches;     /* of the block launches, those on the time-split kernel K1s (kernels_split.hip): engines
-                                       * with less than one wave of oscillators per SIMD, two waves per 64 modes            */
+    int64_t total_split_launches;     /* of the block launches, those on the kernel of under-filled engines (less than one wave
+                                       * of oscillators per SIMD): K1p, kernels_pipe.hip -- a producer wave and two consumer
+                                       * waves per 64 modes (PBSO_SPLIT_KERNEL=time: K1s, kernels_split.hip)                 */
 } pbso_engine_info;
 int pbso_get_info(pbso_engine *e, pbso_engine_info *out);
 /* diagnostics (engine created with env PBSO_CENSUS=1): for every object's

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""PBSO_CENSUS=1 with the time-split kernel K1s pinned (PBSO_SPLIT=2) on the 8 x 4096 sustained-scraping scene: where the two
+"""PBSO_CENSUS=1 with the kernel of under-filled engines pinned (PBSO_SPLIT=2: K1p; PBSO_SPLIT_KERNEL=time: K1s) on the 8 x 4096 sustained-scraping scene: where the two
 waves of a team spend their shader cycles (words 0..5 wave 0, 6..11 wave 1 of every team's census row)."""
 import os
 import sys
@@ -26,7 +26,14 @@ eng.sync()
 info = eng.info()
 c = eng.census().astype(np.float64)
 print(f"qnorm {'off' if qn == capi.QNORM_OFF else 'on'}: kernel_ms={info['last_step_kernel_ms']:.3f} split launches {info['total_split_launches']}; cycles per buffer (median over {c.shape[0]} teams)")
-names = ["head + taps", "first stepping phase", "wait at A", "second phase", "wait at B", "projection"]
-for w in (0, 1):
-    row = c[:, 6 * w:6 * w + 6]
-    print(f"  wave {w}: " + "; ".join(f"{n} {np.median(row[:, k]) / nb:.0f}" for k, n in enumerate(names)) + f"; total {np.median(row.sum(axis=1)) / nb:.0f}")
+pipe = os.environ.get("PBSO_SPLIT_KERNEL") != "time"
+if pipe:      # K1p: words 0..2 the producer, 6..8 consumer 0
+    for w, role, names in ((0, "producer  ", ["head + sample 0", "stepping + parks", "wait at the barrier"]),
+                           (1, "consumer 0", ["head + taps", "projection", "wait at the barrier"])):
+        row = c[:, 6 * w:6 * w + 3]
+        print(f"  {role}: " + "; ".join(f"{n} {np.median(row[:, k]) / nb:.0f}" for k, n in enumerate(names)) + f"; total {np.median(row.sum(axis=1)) / nb:.0f}")
+else:         # K1s: words 0..5 wave 0, 6..11 wave 1
+    names = ["head + taps", "first stepping phase", "wait at A", "second phase", "wait at B", "projection"]
+    for w in (0, 1):
+        row = c[:, 6 * w:6 * w + 6]
+        print(f"  wave {w}: " + "; ".join(f"{n} {np.median(row[:, k]) / nb:.0f}" for k, n in enumerate(names)) + f"; total {np.median(row.sum(axis=1)) / nb:.0f}")

@@ -64,7 +64,8 @@ echo "== census"
 PBSO_CENSUS=1 timeout 300 python scripts/census.py 1024 2>&1 | grep -v amdgpu.ids > $O/census_1024x512_block_f32.txt; tail -5 $O/census_1024x512_block_f32.txt
 timeout 300 python scripts/debug/census_scraping.py 2>&1 | grep -v amdgpu.ids > $O/census_8x4096_scraping.txt
 timeout 300 python scripts/debug/census_scraping.py off 2>&1 | grep -v amdgpu.ids >> $O/census_8x4096_scraping.txt
-(timeout 300 python scripts/debug/census_split.py; timeout 300 python scripts/debug/census_split.py off) 2>&1 | grep -v amdgpu.ids > $O/census_8x4096_scraping_time_split.txt
+(timeout 300 python scripts/debug/census_split.py; timeout 300 python scripts/debug/census_split.py off; timeout 300 python scripts/debug/census_split_free.py) 2>&1 | grep -v amdgpu.ids > $O/census_pipeline_kernel.txt
+(export PBSO_SPLIT_KERNEL=time; timeout 300 python scripts/debug/census_split.py; timeout 300 python scripts/debug/census_split.py off) 2>&1 | grep -v amdgpu.ids > $O/census_8x4096_scraping_time_split.txt
 make -C scripts/microbench mfma_valu_mix > /dev/null 2>&1; ./scripts/microbench/mfma_valu_mix > $O/mfma_valu_mix.txt 2>&1
 timeout 300 python scripts/latency.py > $O/realtime_latency.txt 2>&1
 ls $O | head -80

@@ -128,3 +128,27 @@ def test_split_kernel_generated_code(tmp_path):
         n_mfma = len(re.findall(r"\n\s+v_mfma_f32_16x16x4_f32", body))
         assert n_mfma == (32 + 4 + 2 * 32 if qnm == 0 else 2 * (32 + 4)), (qnm, n_mfma)
         assert "scratch_" not in body
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
+def test_pipe_kernel_generated_code(tmp_path):
+    """K1p (kernels_pipe.hip), both builds: no scratch, <= 256 VGPRs, static LDS under 64 KB; the consumers' projection + FIR
+    once (32 + 4 MFMAs: the loop over a consumer's groups is not unrolled), the producer's increment products F . T twice
+    (group 0, group 1) in the build without qnorm rows and not at all in the other; and the per-sample loop takes its
+    profile values from LDS (ds_read_b128), not from scalar loads."""
+    out = tmp_path / "kp.s"
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"),
+                    "-S", "--cuda-device-only", os.path.join(CSRC, "kernels_pipe.hip"), "-o", str(out)], check=True, capture_output=True)
+    asm = open(out).read()
+    meta = asm[asm.find(".amdgpu_metadata"):]
+    bodies = {int(re.search(r"iir_pipe_kernelILi(\d)E", k).group(1)): k.split("s_endpgm")[0]
+              for k in re.split(r"\n(?=_ZN4pbso8iir_pipe15iir_pipe_kernel\S*:)", asm)[1:]}
+    assert set(bodies) == {0, 2}
+    for qnm, body in bodies.items():
+        blk = [b for b in meta.split("- .agpr_count") if "iir_pipe_kernelILi%dE" % qnm in b][0]
+        lds, scratch, vgpr, spill = (int(re.search(r"\.%s:\s+(\d+)" % f, blk).group(1)) for f in
+                                     ("group_segment_fixed_size", "private_segment_fixed_size", "vgpr_count", "vgpr_spill_count"))
+        assert scratch == 0 and spill == 0 and vgpr <= 256 and lds <= 64 * 1024, (qnm, lds, scratch, vgpr, spill)
+        n_mfma = len(re.findall(r"\n\s+v_mfma_f32_16x16x4_f32", body))
+        assert n_mfma == (32 + 4 + 2 * 32 if qnm == 0 else 32 + 4), (qnm, n_mfma)
+        assert "s_load_dwordx16" not in body and "ds_read_b128" in body
