@@ -63,9 +63,11 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--settle", type=int, default=30,
+    ap.add_argument("--settle", type=int, default=40,
                     help="untimed steps run before the warm-up so that the shader clock has ramped (the first ~70 ms "
-                         "after idle run 10 %% slower, profiles/r01_clock_ramp.txt); reported as settle_steps")
+                         "after idle run 10 %% slower, profiles/r01_clock_ramp.txt) and the runtime's one-time work is behind "
+                         "(one or two asynchronous uploads among an engine's first ~30 block the caller for 6 - 7 ms: "
+                         "PBSO_TIMELINE=1, scripts/debug/r03_stalls.py); reported as settle_steps")
     ap.add_argument("--objects", type=int, default=1024, help="objects per GPU (weak scaling); the total for the strong leg")
     ap.add_argument("--modes", type=int, default=512)
     ap.add_argument("--buffers", type=int, default=86, help="audio buffers per step")

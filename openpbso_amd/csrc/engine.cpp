@@ -120,9 +120,11 @@ void free_retired_blocks() {
     (void)hipDeviceSynchronize();
     for (void *q : v) (void)hipFree(q);
 }
+std::atomic<long long> g_alloc_events{0};       // buffer (re)allocations so far (PBSO_TIMELINE diagnostics)
 template <class T>
 hipError_t DevBuf<T>::ensure(size_t n, bool keep, hipStream_t s) {
     if (n <= cap) return hipSuccess;
+    g_alloc_events += 1;
     // 25 % headroom: per-step demand (forced rows, slots) fluctuates by a few percent
     size_t ncap = std::max(n + n / 4, cap + cap / 2);
     T *np = nullptr;
@@ -165,6 +167,7 @@ hipError_t PinBuf<T>::ensure(size_t n) {
 template <class T>
 hipError_t PinBuf<T>::ensure_keep(size_t n, size_t keep) {
     if (n <= cap) return hipSuccess;
+    g_alloc_events += 1000;
     size_t ncap = std::max(n + n / 4, cap + cap / 2);
     T *np = nullptr;
     hipError_t e = hipHostMalloc((void **)&np, ncap * sizeof(T), hipHostMallocDefault);
@@ -249,8 +252,9 @@ Engine::~Engine() {
         while (!o.force_q.empty()) { std::free(o.force_q.front().ext); o.force_q.pop_front(); }
     if (std::getenv("PBSO_HOST_PROFILE") && tot_steps_ > 0)
         std::fprintf(stderr, "pbso host profile, ms per step over %lld steps: wait-for-set %.3f | plan: fill %.3f objects %.3f merge %.3f | "
-                             "submit (uploads + launches) %.3f | step total %.3f\n", (long long)tot_steps_, hprof_[0] / tot_steps_,
-                     hprof_[1] / tot_steps_, hprof_[2] / tot_steps_, hprof_[3] / tot_steps_, hprof_[4] / tot_steps_, hprof_[5] / tot_steps_);
+                             "submit (uploads + launches) %.3f = pack + upload %.3f, preparation launches %.3f, bank launches %.3f | step total %.3f\n",
+                     (long long)tot_steps_, hprof_[0] / tot_steps_, hprof_[1] / tot_steps_, hprof_[2] / tot_steps_, hprof_[3] / tot_steps_,
+                     hprof_[4] / tot_steps_, hprof_[6] / tot_steps_, hprof_[7] / tot_steps_, hprof_[8] / tot_steps_, hprof_[5] / tot_steps_);
     delete pool_;
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (prep_stream_) (void)hipStreamSynchronize(prep_stream_);
@@ -370,6 +374,7 @@ int Engine::init() {
     if (const char *v = std::getenv("PBSO_DEVICE_PROFILES")) device_profiles_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_AR_SERIAL")) ar_serial_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_K2_ROWS")) k2_rows_ = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PBSO_TIMELINE")) timeline_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_SPLIT_KERNEL")) split_pipe_ = std::string(v) != "time";
     if (const char *v = std::getenv("PBSO_K2_MARGIN_PCT")) k2_margin_pct_ = std::min(400, std::max(1, std::atoi(v)));
     if (const char *v = std::getenv("PBSO_K2_PRIO")) { k2_prio_ = std::min(3, std::max(0, std::atoi(v))); k2_prio_auto_ = false; }
@@ -853,7 +858,62 @@ int Engine::finalize() {
     // transfer rows: [0,N) _latest_transfer, [N,2N) the 1-slot transfer queue, then per-launch scratch
     HIPTRY(d_xfer_.ensure((size_t)2 * N * m_pad_));
     HIPTRY(hipMemset(d_xfer_.p, 0, (size_t)2 * N * m_pad_ * sizeof(double)));
+    {
+        int wrc = warm_copy_engines();
+        if (wrc != PBSO_OK) return wrc;
+    }
     finalized_ = true;
+    return PBSO_OK;
+}
+
+// One-time work of the runtime that would otherwise block a step's submission, done here, untimed (PBSO_WARM_COPIES=0: not).
+// Found with PBSO_TIMELINE=1 / scripts/debug/r03_stalls.py: an engine's first ~30 launches contained two hipMemcpyAsync calls
+// (the step's ONE upload) that took 6 - 7 ms each whatever their size, with no buffer growing -- in the middle of a real-time run,
+// or of a 20-step timed region (64 x 256 with a listener move per buffer measured 2800 x or 4900 x run to run, depending on
+// whether one fell into the 40 timed steps).  (1) The runtime opens its copy queues lazily: a few overlapping uploads and
+// read-backs on both streams remove the first.  (2) The other comes with the first upload whose stream is still WAITING for an
+// event of the other stream when the call is made -- which is what a step's upload looks like as soon as the host runs a whole
+// plan set ahead of the oscillator bank (the wait for ev_k1_done_ in front of it); it happened at a random launch, whenever the
+// host first got that far ahead.  Issuing exactly that pattern here removes it.
+int Engine::warm_copy_engines() {
+    if (const char *v = std::getenv("PBSO_WARM_COPIES")) if (std::atoi(v) == 0) return PBSO_OK;
+    const size_t chunk = (size_t)4 << 20;
+    const int n = 6;
+    PinBuf<unsigned char> h;
+    DevBuf<unsigned char> d;
+    HIPTRY(h.ensure(chunk * n));
+    HIPTRY(d.ensure(chunk * n));
+    std::memset(h.p, 0, chunk * n);
+    for (int rep = 0; rep < 2; ++rep) {               // (1)
+        for (int i = 0; i < n; ++i) {
+            hipStream_t s = (i & 1) ? stream_ : prep_stream_;
+            HIPTRY(hipMemcpyAsync(d.p + chunk * i, h.p + chunk * i, chunk, hipMemcpyHostToDevice, s));
+        }
+        for (int i = 0; i < n; ++i) {
+            hipStream_t s = (i & 1) ? prep_stream_ : stream_;
+            HIPTRY(hipMemcpyAsync(h.p + chunk * i, d.p + chunk * i, chunk, hipMemcpyDeviceToHost, s));
+        }
+    }
+    HIPTRY(hipStreamSynchronize(prep_stream_));
+    HIPTRY(hipStreamSynchronize(stream_));
+    // (2): uploads behind a wait for an event that has not happened yet
+    hipEvent_t ev = nullptr, ev2 = nullptr;
+    HIPTRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPTRY(hipEventCreateWithFlags(&ev2, hipEventDisableTiming));
+    for (int rep = 0; rep < 4; ++rep) {
+        for (int i = 0; i < n; ++i) HIPTRY(hipMemcpyAsync(d.p + chunk * i, h.p + chunk * i, chunk, hipMemcpyHostToDevice, stream_));
+        HIPTRY(hipEventRecord(ev, stream_));
+        HIPTRY(hipStreamWaitEvent(prep_stream_, ev, 0));
+        HIPTRY(hipMemcpyAsync(d.p, h.p, (size_t)384 << 10, hipMemcpyHostToDevice, prep_stream_));
+        HIPTRY(hipEventRecord(ev2, prep_stream_));
+        HIPTRY(hipStreamWaitEvent(stream_, ev2, 0));
+    }
+    HIPTRY(hipStreamSynchronize(prep_stream_));
+    HIPTRY(hipStreamSynchronize(stream_));
+    (void)hipEventDestroy(ev);
+    (void)hipEventDestroy(ev2);
+    h.release();
+    d.release();
     return PBSO_OK;
 }
 
@@ -1748,6 +1808,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     const int n_chains = (int)chain_ptr_.size();
     chain_ptr_.push_back((int)prof_rows_.size());
     last_plan_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const auto tsub0 = std::chrono::steady_clock::now();
 
     const int n_frows = n_frows_;
     last_frows_ = n_frows;
@@ -1777,12 +1838,15 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     }
     evq.step_id = step_id;
     evq.has_k2 = false;
+    auto host_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    evq.h_enter = std::chrono::duration<double, std::milli>(t0.time_since_epoch()).count();
     // (two timing events before and three after the bank cost the stream ~15 us per launch -- 2 % of a 0.7 ms step)
     const bool timed = timing_every_ > 0 && (launch_seq_ % (unsigned)timing_every_) == 0;
     // ---- preparation stream: this set's device buffers are free once the oscillator
     //      bank that last read them (two steps ago) has finished
     HIPTRY(hipStreamWaitEvent(sp, ev_k1_done_[cur_set_], 0));
     if (timed) HIPTRY(hipEventRecord(evq.p0, sp));
+    evq.h_prep = host_ms();
     // ---- ONE upload: everything the planner produced sits behind the descriptors in the set's pinned arena.
     // (Twelve separate copies cost the host 0.1 ms of API calls per step, and the small ones went through
     // blit kernels that cannot start while the oscillator bank fills the register file.)
@@ -1847,6 +1911,8 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     HIPTRY(ps.d_arena.ensure(off, false, sp));
     HIPTRY(hipMemcpyAsync(ps.d_arena.p, ha, off, hipMemcpyHostToDevice, sp));
     HIPTRY(hipEventRecord(ev_set_[cur_set_], sp));          // this set's pinned arena is reusable
+    evq.h_copy = host_ms();
+    const auto tsub1 = std::chrono::steady_clock::now();
     unsigned char *da = ps.d_arena.p;
     const BufDesc *d_desc = reinterpret_cast<const BufDesc *>(da);
     const int *d_xfer_init = reinterpret_cast<const int *>(da + ps.off_xfer_init);
@@ -1879,6 +1945,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     LAUNCHTRY(launch_force_combine(d_row_ptr, d_slot_idx, d_row_obj, n_frows, d_slots_.p, d_c3_.p, grows.p, d_projd, d_shapes_.p,
                                    d_shape_off_.p, d_n_modes_.p, m_pad_, sp));
     HIPTRY(hipEventRecord(ev_prep_done_[cur_set_], sp));
+    const auto tsub2 = std::chrono::steady_clock::now();
 
     // ---- compute stream: K1 after its preparation (and, stream order, after the previous K1)
     HIPTRY(hipStreamWaitEvent(sk, ev_prep_done_[cur_set_], 0));
@@ -1918,6 +1985,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.ftab = d_ftab_.p;
     kp.forced_block = (forced_block_ && n_prows_ > 0) ? 1 : 0;      // (the build with the forced block path only when a buffer needs it)
     if (timed) HIPTRY(hipEventRecord(evq.k0, sk));
+    evq.h_bank = host_ms();
     kp.audio_parts = d_audio_parts_.p ? d_audio_parts_.p + (size_t)b0 * B_ : nullptr;
     // Side by side only while everything is resident at once (largest teams first, on the engine's
     // stream); an engine that needs several rounds of workgroups runs its classes one after the other
@@ -1997,12 +2065,16 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     LAUNCHTRY(launch_copy_rows(d_copy, d_copy + (n_cl + n_cq), n_cl, d_xfer_.p, m_pad_, sk));
     LAUNCHTRY(launch_copy_rows(d_copy + n_cl, d_copy + (n_cl + n_cq) + n_cl, n_cq, d_xfer_.p, m_pad_, sk));
     if (timed) HIPTRY(hipEventRecord(evq.p1, sk));
+    evq.h_done = host_ms();
     HIPTRY(hipEventRecord(ev_k1_done_[cur_set_], sk));
     if (timed) ev_pending_.push_back(evq);
     else ev_free_.push_back(evq);
     buffers_done_ += nb;
     cur_set_ = (cur_set_ + 1) % N_SETS;
     hprof_[4] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - last_plan_ms_;
+    hprof_[6] += std::chrono::duration<double, std::milli>(tsub1 - tsub0).count();
+    hprof_[7] += std::chrono::duration<double, std::milli>(tsub2 - tsub1).count();
+    hprof_[8] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tsub2).count();
     hprof_[5] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
     return PBSO_OK;
 }
@@ -2312,6 +2384,18 @@ int Engine::harvest_timing(bool blocking) {
         float ms = 0, ms2 = 0;
         HIPTRY(hipEventElapsedTime(&ms, q.k0, q.k1));
         HIPTRY(hipEventElapsedTime(&ms2, q.p0, q.p1));
+        if (timeline_) {                            // PBSO_TIMELINE=1: where each timed launch's events fall (ms since the first one)
+            if (!timeline_base_) { HIPTRY(hipEventCreate(&timeline_base_)); timeline_have_base_ = false; }
+            float a = 0, b = 0, c = 0, d = 0;
+            if (!timeline_have_base_) { timeline_ref_ = q.p0; timeline_have_base_ = true; timeline_keep_ = true; timeline_h0_ = q.h_prep; }
+            HIPTRY(hipEventElapsedTime(&a, timeline_ref_, q.p0));
+            HIPTRY(hipEventElapsedTime(&b, timeline_ref_, q.k0));
+            HIPTRY(hipEventElapsedTime(&c, timeline_ref_, q.k1));
+            HIPTRY(hipEventElapsedTime(&d, timeline_ref_, q.p1));
+            std::fprintf(stderr, "pbso timeline: step %lld device: prep starts %.3f | bank starts %.3f ends %.3f | launch done %.3f || host: step entered %.3f, "
+                                 "prep submitted from %.3f (upload call returned %.3f), bank submitted at %.3f, all submitted %.3f\n", (long long)q.step_id, a, b, c, d,
+                         q.h_enter - timeline_h0_, q.h_prep - timeline_h0_, q.h_copy - timeline_h0_, q.h_bank - timeline_h0_, q.h_done - timeline_h0_);
+        }
         if (q.step_id != harvest_step_) {          // "last step" sums the launches of one step
             harvest_step_ = q.step_id;
             last_kernel_ms_ = 0;
@@ -2330,7 +2414,8 @@ int Engine::harvest_timing(bool blocking) {
         tot_timed_launches_ += 1;
         last_device_ms_ += ms2;
         tot_device_ms_ += ms2;
-        ev_free_.push_back(q);
+        if (timeline_keep_) timeline_keep_ = false;      // (the reference launch's events stay out of the free list)
+        else ev_free_.push_back(q);
     }
     ev_pending_.erase(ev_pending_.begin(), ev_pending_.begin() + (long)done);
     if (k2_prio_auto_ && k2_ms_n_ >= 2) {

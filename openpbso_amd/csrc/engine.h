@@ -243,7 +243,7 @@ private:
     hipEvent_t ev_fork_ = nullptr, ev_join_[N_CLASS_STREAMS] = {nullptr, nullptr, nullptr};
     int xfer_cap_ = 0;                                   // scratch transfer rows per plan set
     hipEvent_t ev_set_[N_SETS] = {};
-    struct EvQuad { hipEvent_t k0, k1, p0, p1, f0, f1; int64_t step_id; bool has_k2; };      // bank, pipeline, force-profile kernel
+    struct EvQuad { hipEvent_t k0, k1, p0, p1, f0, f1; int64_t step_id; bool has_k2; double h_enter, h_prep, h_copy, h_bank, h_done; };      // bank, pipeline, force-profile kernel
     std::vector<EvQuad> ev_free_, ev_pending_;           // one quad per step, harvested in info()
     int harvest_timing(bool blocking);
     double tot_kernel_ms_ = 0, tot_device_ms_ = 0, tot_plan_ms_ = 0, last_kernel_ms_ = 0, last_device_ms_ = 0;
@@ -346,6 +346,9 @@ private:
     // K2, row-parallel form (the default; PBSO_K2_ROWS=0 or PBSO_AR_SERIAL=1: one workgroup walks an object's rows in order).
     // build_ar_tables() lists the launch's AR forces (streams), their uses and the candidate segments of their engines.
     bool k2_rows_ = true;
+    bool timeline_ = false, timeline_have_base_ = false, timeline_keep_ = false;   // PBSO_TIMELINE=1 (diagnostics)
+    hipEvent_t timeline_base_ = nullptr, timeline_ref_ = nullptr;
+    double timeline_h0_ = 0;
     bool split_pipe_ = true;                             // small engines: K1p (producer / consumer waves); PBSO_SPLIT_KERNEL=time: K1s (two waves share the time axis)
     int k2_margin_pct_ = 100;                            // PBSO_K2_MARGIN_PCT: scales the candidate range (tests: < 100 forces the shortfall path)
     bool k2_rows_launch_ = false;                        // this launch takes the row-parallel form
@@ -360,6 +363,7 @@ private:
     DevBuf<ArRec> d_ar_recs_;
     DevBuf<ArFin> d_ar_fins_;
     void build_ar_tables();
+    int warm_copy_engines();
     std::vector<double> stage_;
     std::vector<ProjectEvent> proj_, proj_direct_;         // projections into pool rows / evaluated on the fly by the combine kernel
     BufDesc *plan_desc_ = nullptr;                       // the descriptor table being planned (front of the set's arena)
@@ -379,7 +383,7 @@ private:
     int chunk_buffers_ = 128;                            // longer steps are cut into launches of this many buffers
     int plan_b0_ = 0, plan_nb_total_ = 0;                // where the chunk being planned sits in the step
     int64_t harvest_step_ = -1;
-    double hprof_[6] = {0, 0, 0, 0, 0, 0};               // PBSO_HOST_PROFILE=1: host milliseconds by stage, printed at destruction
+    double hprof_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};               // PBSO_HOST_PROFILE=1: host milliseconds by stage, printed at destruction
     int64_t last_frows_ = 0, last_trows_ = 0;
 };
 
