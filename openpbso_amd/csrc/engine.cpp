@@ -619,7 +619,9 @@ int Engine::finalize() {
         const char *env = std::getenv("PBSO_SPLIT");
         long long chunks = 0;
         for (const Object &o : objs_) chunks += std::max(1, (o.n_modes + 63) / 64);
-        if (block && form_ == PBSO_FORM_BLOCK && R_ == 1 && 2 * chunks <= 4LL * n_cus_ && !(env && std::atoi(env) == 0)) {
+        long long max_chunks = 2LL * n_cus_;
+        if (const char *v = std::getenv("PBSO_SPLIT_MAX_CHUNKS")) max_chunks = std::atoll(v);
+        if (block && form_ == PBSO_FORM_BLOCK && R_ == 1 && chunks <= max_chunks && !(env && std::atoi(env) == 0)) {
             std::vector<TeamDesc> ts;
             std::vector<SplitObj> tsplit;
             n_ts_part_rows_ = 0;
