@@ -385,9 +385,15 @@ def measure(args, ctx, global_ids, want_parity):
     # leg "root": only rank 0 consumes the buffers: a gather to the root (send / receive) instead of the all-gather
     do_root = bool(do_gather and ctx.get("leg_root"))
     n_buf = 2 if do_gather else 1
-    audios = [torch.zeros((cmax, nb * B), dtype=torch.float32, device=dev) for _ in range(n_buf)]
-    gathered = ([torch.empty((world * cmax, nb * B), dtype=torch.float32, device=dev) for _ in range(n_buf)]
+    # All-gather IN PLACE: the engine writes this rank's buffers straight into its slice of the gather target (RCCL, like NCCL, skips
+    # the local copy when the send buffer IS that slice: sendbuff == recvbuff + rank * count) -- 181 MB less traffic per step and
+    # rank, and on a one-rank group nothing is left to do at all (the copy kernel used to fight the oscillator bank for CUs: 0.06 ms
+    # of every step exposed).  The gather-to-root and mix legs keep separate audio buffers.
+    in_place = bool(do_gather and not do_mix and not do_root and backend == "nccl")
+    gathered = ([(torch.zeros if in_place else torch.empty)((world * cmax, nb * B), dtype=torch.float32, device=dev) for _ in range(n_buf)]
                 if do_gather and not do_mix and (not do_root or rank == 0) else None)
+    audios = ([g[rank * cmax:(rank + 1) * cmax] for g in gathered] if in_place
+              else [torch.zeros((cmax, nb * B), dtype=torch.float32, device=dev) for _ in range(n_buf)])
     mixes = [torch.zeros(nb * B, dtype=torch.float32, device=dev) for _ in range(n_buf)] if do_mix else None
     ones_obj = torch.ones(n_obj, dtype=torch.float32, device=dev) if do_mix else None
     pending = [None] * n_buf
