@@ -2058,13 +2058,11 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         HIPTRY(hipStreamWaitEvent(sk, ev_join_[j], 0));
     }
     // objects stepped by several teams: the teams' partial sums of this launch's buffers, added in team order
-    if (split_launch)
-        LAUNCHTRY(launch_sum_parts(d_ts_split_.p, n_ts_split_, kp.audio_parts, audio + (size_t)b0 * B_, (long long)nb_total * B_, (long long)nb * B_, sk));
-    else
-        LAUNCHTRY(launch_sum_parts(d_split_.p, n_split_, kp.audio_parts, audio + (size_t)b0 * B_, (long long)nb_total * B_, (long long)nb * B_, sk));
+    // ... and _latest_transfer = trans (modal_solver.h:251) in the same launch; then re-park a still-queued transfer
+    LAUNCHTRY(launch_sum_parts_copy_rows(split_launch ? d_ts_split_.p : d_split_.p, split_launch ? n_ts_split_ : n_split_, kp.audio_parts,
+                                         audio + (size_t)b0 * B_, (long long)nb_total * B_, (long long)nb * B_, d_copy, d_copy + (n_cl + n_cq), n_cl,
+                                         d_xfer_.p, m_pad_, sk));
     if (timed) HIPTRY(hipEventRecord(evq.k1, sk));
-    // _latest_transfer = trans (modal_solver.h:251), then re-park a still-queued transfer
-    LAUNCHTRY(launch_copy_rows(d_copy, d_copy + (n_cl + n_cq), n_cl, d_xfer_.p, m_pad_, sk));
     LAUNCHTRY(launch_copy_rows(d_copy + n_cl, d_copy + (n_cl + n_cq) + n_cl, n_cq, d_xfer_.p, m_pad_, sk));
     if (timed) HIPTRY(hipEventRecord(evq.p1, sk));
     evq.h_done = host_ms();

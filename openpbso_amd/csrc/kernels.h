@@ -243,6 +243,9 @@ int launch_ffat_batch(const double *pos, int n_pos, const FfatGeom *geom_of_obje
 struct SplitObj { int obj, first_row, n_rows, pad; };
 int launch_sum_parts(const SplitObj *split, int n_split, const float *parts, float *audio, long long stride, long long n,
                      hipStream_t stream);
+// ... and, in the same launch, n_copy transfer rows copied (rows[dst_row[c]] = rows[src_row[c]]): the two jobs behind a bank launch
+int launch_sum_parts_copy_rows(const SplitObj *split, int n_split, const float *parts, float *audio, long long stride, long long n,
+                               const int *src_row, const int *dst_row, int n_copy, double *rows, int m_pad, hipStream_t stream);
 int launch_copy_rows(const int *src_row, const int *dst_row, int n, double *rows, int m_pad,
                      hipStream_t stream);
 

@@ -1024,4 +1024,36 @@ int launch_copy_rows(const int *src_row, const int *dst_row, int n, double *rows
     return (int)hipGetLastError();
 }
 
+// The two jobs that follow an oscillator-bank launch in its stream, in ONE launch (a launch hand-over costs the stream 5 - 8 us,
+// which is 3 - 4 % of a step of the small scenes): blockIdx.y < n_split adds an object's partial sums, the other rows of the
+// grid copy transfer rows (_latest_transfer = trans, modal_solver.h:251).  They touch different arrays.
+__global__ __launch_bounds__(256) void sum_parts_copy_rows_kernel(const SplitObj *__restrict__ split, int n_split,
+                                                                  const float *__restrict__ parts, float *__restrict__ audio,
+                                                                  long long stride, long long n, const int *__restrict__ src_row,
+                                                                  const int *__restrict__ dst_row, double *rows, int m_pad) {
+    if ((int)blockIdx.y < n_split) {
+        const SplitObj so = split[blockIdx.y];
+        const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= n) return;
+        float acc = parts[(size_t)so.first_row * stride + i];
+        for (int r = 1; r < so.n_rows; ++r) acc += parts[(size_t)(so.first_row + r) * stride + i];
+        audio[(size_t)so.obj * stride + i] = acc;
+    } else {
+        const int c = (int)blockIdx.y - n_split;
+        const int m = blockIdx.x * blockDim.x + threadIdx.x;
+        if (m >= m_pad) return;
+        rows[(size_t)dst_row[c] * m_pad + m] = rows[(size_t)src_row[c] * m_pad + m];
+    }
+}
+
+int launch_sum_parts_copy_rows(const SplitObj *split, int n_split, const float *parts, float *audio, long long stride, long long n,
+                               const int *src_row, const int *dst_row, int n_copy, double *rows, int m_pad, hipStream_t stream) {
+    if (n_split <= 0 || n <= 0) return launch_copy_rows(src_row, dst_row, n_copy, rows, m_pad, stream);
+    if (n_copy <= 0) return launch_sum_parts(split, n_split, parts, audio, stride, n, stream);
+    dim3 grid((unsigned)std::max<long long>((n + 255) / 256, (m_pad + 255) / 256), n_split + n_copy);
+    hipLaunchKernelGGL(sum_parts_copy_rows_kernel, grid, dim3(256), 0, stream, split, n_split, parts, audio, stride, n, src_row, dst_row,
+                       rows, m_pad);
+    return (int)hipGetLastError();
+}
+
 }  // namespace pbso
