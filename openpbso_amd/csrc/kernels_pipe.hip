@@ -70,7 +70,11 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
     const float *__restrict__ p_ftab, unsigned long long *__restrict__ p_census, const PipeDims p) {
     constexpr bool QN = QNM != 0;
     __shared__ __attribute__((aligned(16))) float lds_stage[2][2][ST_AREA];       // [buffer parity][group]
-    __shared__ __attribute__((aligned(16))) float lds_incr[QN ? 4 : 64 * U_ROW];  // the producer's increments on their way back to lane = mode
+    __shared__ __attribute__((aligned(16))) float lds_incr[64 * U_ROW];           // the producer's increments on their way back to lane = mode
+    // qnorm rows of dense buffers (block path): the UNWEIGHTED state at the start of blocks 0, 8 (group 0) and 16, 24 (group 1), from
+    // which the consumers re-step the samples for the sum of q^2 only; and consumer 1's half of the sum on its way to consumer 0
+    __shared__ f2 lds_raw[QN ? 2 : 1][4][64];
+    __shared__ float lds_qsum[QN ? 2 : 1][64];
     // a dense buffer's profile for the producer's per-sample loop: [buffer parity][T_1 .. T_512 | T_0], staged by consumer 0 a buffer
     // ahead (the loop's 16 values per block come from LDS in ~100 cycles whatever the memory system is busy with; one scalar
     // load per block from L2 / HBM left 100 .. 250 of every block's 290 cycles waiting)
@@ -131,6 +135,9 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
         *reinterpret_cast<f4 *>(dst) = f4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f4 *>(dst + 4) = f4{v[4], v[5], v[6], v[7]};
     };
+    float *__restrict__ b_qn = p_qnorm + ((size_t)obj * p.qn_nb + p.qn_b0) * p.m_pad + team.col0;
+    // qnorm rows of dense buffers come from the consumers when the producer takes the block path (the F table is there)
+    const bool qn_by_cons = QN && p_ftab != nullptr;
     if (wave == 1) stage_profile(next, 0);
     __syncthreads();
     if (producer) {
@@ -147,16 +154,16 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
         // forced block path; absent -- PBSO_FORCED_BLOCK=0 -- every sample is stepped).  The increments of a group's 16 blocks
         // are a [16 blocks x 16 taps] . [16 taps x 16 modes] product per tile of 16 modes and state component: 32 MFMAs whose
         // A operand is the profile as the FIR's B operand holds it and whose B operand is F, resident here.
-        const bool ft = !QN && p_ftab != nullptr;
-        float fB[QN ? 1 : 4][2][4];
-        if (!QN && ft) {
+        const bool ft = p_ftab != nullptr;
+        float fB[4][2][4];
+        if (ft) {
 #pragma unroll
             for (int tl = 0; tl < 4; ++tl)
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks)
-                        fB[QN ? 0 : tl][c][ks] = (p_ftab + (size_t)(2 * (4 * ks + (lane >> 4)) + c) * p.plane + ubase)[16 * tl + (lane & 15)];
+                        fB[tl][c][ks] = (p_ftab + (size_t)(2 * (4 * ks + (lane >> 4)) + c) * p.plane + ubase)[16 * tl + (lane & 15)];
         }
         f2 x;                                        // state, unscaled (the arrays hold scale x state, kernels_iir.hip "scaled state")
         {
@@ -164,7 +171,6 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
             x.x = (p_sq + ubase)[ul] / s0;
             x.y = (p_sd + ubase)[ul] / s0;
         }
-        float *__restrict__ b_qn = p_qnorm + ((size_t)obj * p.qn_nb + p.qn_b0) * p.m_pad + team.col0;
         auto coarse = [&](f2 v) {                    // v <- P v
             const float qa = fmaf(p11, v.x, v.x);
             const float da = p21 * v.x;
@@ -242,10 +248,11 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
                             if (lane == 0) ao[0] = p0;
                         }
                         lap(0);
-                        if (!QN && ft) {
-                            // 16 blocks a block at a time: v_{n+1} = P v_n + g (F . T_n), parking every block-start state
-                            auto step_group_ft = [&](float *st, const float (&tbg)[4]) {
-                                if constexpr (!QN) {
+                        if (ft) {
+                            // 16 blocks a block at a time: v_{n+1} = P v_n + g (F . T_n), parking every block-start state (with qnorm rows:
+                            // also the unweighted state every 8 blocks -- the consumers re-step the samples from there for the sum of q^2)
+                            auto step_group_ft = [&](float *st, const float (&tbg)[4], int gi) {
+                                {
                                     static_for<0, 4>([&](auto tc) {
                                         constexpr int tl = decltype(tc)::value;
                                         f4 dq = f4{0.f, 0.f, 0.f, 0.f}, dd = f4{0.f, 0.f, 0.f, 0.f};
@@ -269,13 +276,14 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
                                     static_for<0, BN>([&](auto nc) {
                                         constexpr int n = decltype(nc)::value;
                                         park(st, n, x);
+                                        if constexpr (QN && n % 8 == 0) lds_raw[QN ? (b & 1) : 0][2 * gi + n / 8][lane] = x;
                                         const f2 w = coarse(x);
                                         x = f2{fmaf(g, uq[n / 4][n % 4], w.x), fmaf(g, ud[n / 4][n % 4], w.y)};
                                     });
                                 }
                             };
-                            step_group_ft(stage0, tb[0]);
-                            step_group_ft(stage1, tb[1]);
+                            step_group_ft(stage0, tb[0], 0);
+                            step_group_ft(stage1, tb[1], 1);
                         } else {
                             // every sample (qnorm rows need each sample's true state).  T values: one s_load_dwordx16 per block
                             // issued a block ahead (scalar loads return out of order: first use, then the next load).  Unit-force
@@ -366,8 +374,18 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
             }
         }
         const int ctid = (int)threadIdx.x - 64, cthreads = 64 * NC;
+        float pend_sq = 0.f;                         // consumer 0: its share of a dense buffer's sum of q^2, until consumer 1's arrives
+        int pend_b = -1;
+        auto finish_row = [&]() {                    // (after the barrier that followed the buffer's projection)
+            if (QN && pend_b >= 0) {
+                const float tot = NC == 2 ? pend_sq + lds_qsum[QN ? (pend_b & 1) : 0][lane] : pend_sq;
+                (b_qn + (size_t)pend_b * p.m_pad)[ul] = sqrtf(tot);
+                pend_b = -1;
+            }
+        };
         for (int it = 0; it <= p.nb; ++it) {
             const BufDesc ahead = dsc[it + 1 < p.nb ? it + 1 : p.nb - 1];       // (fetched under the projection, used after it)
+            if (cidx == 0) finish_row();
             if (it >= 1) {
                 const int b = it - 1;
                 const BufDesc cur = next;
@@ -402,6 +420,62 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
                             fir_a[kk] = idx >= 0 ? taps[idx] : 0.f;
                         }
                     }
+                    if (QN && qn_by_cons && dense) {
+                        // The sum of q^2 over the buffer's samples, this consumer's groups: two chains of 128 samples per group, side by
+                        // side (independent: their instructions fill each other's dependency stalls), each from the unweighted state
+                        // the producer left at its first block; profile values from LDS (four broadcast ds_read_b128 per chain and
+                        // block, fetched a block ahead).  Unit-force form as everywhere (z = x / g) while the range allows.
+                        float sq = 0.f;
+                        for (int gi = cidx; gi < 2; gi += NC) {
+                            const float *tl = lds_t[b & 1] + GROUP * gi + (ul >> 31);      // (+ 0, opaque: vector registers)
+                            const f2 xa = lds_raw[QN ? (b & 1) : 0][2 * gi][lane], xb = lds_raw[QN ? (b & 1) : 0][2 * gi + 1][lane];
+                            if (gi == 0) sq = fmaf(xa.x, xa.x, sq);                   // sample 0 left the state block 0 starts from
+                            const float gr = __builtin_amdgcn_rcpf(g);
+                            const bool z_ok = g != 0.f && fabsf(gr) < 0x1p100f && fabsf(xa.x * gr) < 0x1p50f && fabsf(xa.y * gr) < 0x1p50f &&
+                                              fabsf(xb.x * gr) < 0x1p50f && fabsf(xb.y * gr) < 0x1p50f;      // (NaN / inf fail)
+                            auto run = [&](auto unit_c) {
+                                constexpr bool unit = decltype(unit_c)::value;
+                                f2 wa = unit ? f2{xa.x * gr, xa.y * gr} : xa, wb = unit ? f2{xb.x * gr, xb.y * gr} : xb;
+                                float qa = 0.f, qb = 0.f;
+                                f4 ca[4], cb[4], na[4], nb4[4];
+                                auto ld = [&](f4 (&da)[4], f4 (&db)[4], int blk) {
+                                    const f4 *sa = reinterpret_cast<const f4 *>(tl + BJ * (blk < 8 ? blk : 7));
+                                    const f4 *sb = reinterpret_cast<const f4 *>(tl + GROUP / 2 + BJ * (blk < 8 ? blk : 7));
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) { da[i] = sa[i]; db[i] = sb[i]; }
+                                };
+                                auto stepb = [&](const f4 (&da)[4], const f4 (&db)[4]) {
+                                    const float ta[BJ] = {da[0].x, da[0].y, da[0].z, da[0].w, da[1].x, da[1].y, da[1].z, da[1].w,
+                                                          da[2].x, da[2].y, da[2].z, da[2].w, da[3].x, da[3].y, da[3].z, da[3].w};
+                                    const float tb[BJ] = {db[0].x, db[0].y, db[0].z, db[0].w, db[1].x, db[1].y, db[1].z, db[1].w,
+                                                          db[2].x, db[2].y, db[2].z, db[2].w, db[3].x, db[3].y, db[3].z, db[3].w};
+#pragma unroll
+                                    for (int k = 0; k < BJ; ++k) {
+                                        const float ia = unit ? fmaf(nca, wa.y, ta[k]) : fmaf(nca, wa.y, g * ta[k]);
+                                        const float ib = unit ? fmaf(nca, wb.y, tb[k]) : fmaf(nca, wb.y, g * tb[k]);
+                                        wa.y = fmaf(ncb, wa.x, ia);
+                                        wb.y = fmaf(ncb, wb.x, ib);
+                                        wa.x = wa.x + wa.y;
+                                        wb.x = wb.x + wb.y;
+                                        qa = fmaf(wa.x, wa.x, qa);
+                                        qb = fmaf(wb.x, wb.x, qb);
+                                    }
+                                };
+                                ld(ca, cb, 0);
+                                for (int blk = 0; blk < 8; blk += 2) {
+                                    ld(na, nb4, blk + 1);
+                                    stepb(ca, cb);
+                                    ld(ca, cb, blk + 2);
+                                    stepb(na, nb4);
+                                }
+                                sq += unit ? g * g * (qa + qb) : qa + qb;
+                            };
+                            if (__all(z_ok)) run(std::true_type{});
+                            else run(std::false_type{});
+                        }
+                        if (NC == 2 && cidx == 1) lds_qsum[QN ? (b & 1) : 0][lane] = sq;
+                        else { pend_sq = sq; pend_b = b; }
+                    }
                     lap(0);
                     for (int gi = cidx; gi < 2; gi += NC) {
                         // projection of group gi from its parked block-start states (+ the profile's FIR): 256 samples, stored
@@ -431,11 +505,16 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
                 }
                 lap(1);
             }
-            // the profile of the buffer the producer steps NEXT (it + 1), into the other parity's row
-            if (cidx == 0 && it + 1 < p.nb) stage_profile(ahead, (it + 1) & 1);
+            // the profile of the buffer the producer steps NEXT (it + 1), into the other parity's row -- or, when the consumers are
+            // the ones that step samples (qnorm rows of dense buffers), of the buffer they take up next (it: the one being parked now)
+            if (cidx == 0) {
+                if (qn_by_cons) { if (it >= 1 && it < p.nb) stage_profile(next, it & 1); }
+                else if (it + 1 < p.nb) stage_profile(ahead, (it + 1) & 1);
+            }
             __syncthreads();
             lap(2);
         }
+        if (cidx == 0) finish_row();
     }
     if (p_census && lane == 0 && wave < 2) {
 #pragma unroll

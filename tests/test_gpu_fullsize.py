@@ -122,9 +122,9 @@ def test_config5_8x4096_sustained_scraping_full_size():
         evs.append(dict(t=30, obj=i, kind="arprm", a=[0.6, 0.2], sigma=0.002, mu=0.1))
         evs.append(force_ev(70, i, force_type=2, end=True))
     want = run_oracle(objs, evs, NB, threads=THREADS)
-    # (1) the f32 block form, dense-profile buffers in block form too (this scene runs on the pipeline kernel K1p: without qnorm
-    #     rows the producer steps a block at a time, increments on the matrix pipe -- measured 7e-6 of the peak; with them it
-    #     steps every sample in f32 like the per-sample kernel -- 8e-5); tolerance 1e-4 of the peak (the general one is 5e-4)
+    # (1) the f32 block form, dense-profile buffers in block form too (this scene runs on the pipeline kernel K1p: the producer
+    #     steps a block at a time, increments on the matrix pipe, with or without qnorm rows -- measured 7e-6 of the peak; the
+    #     consumers re-step the samples for the qnorm rows only); tolerance 1e-4 of the peak (the general one is 5e-4)
     for qn in (capi.QNORM_OFF, capi.QNORM_ALL):
         got = run_engine(objs, evs, NB, qnorm=qn, form=capi.FORM_BLOCK)
         assert got["info"]["recurrence_form"] == capi.FORM_BLOCK

@@ -134,8 +134,8 @@ def test_split_kernel_generated_code(tmp_path):
 def test_pipe_kernel_generated_code(tmp_path):
     """K1p (kernels_pipe.hip), both builds: no scratch, <= 256 VGPRs, static LDS under 64 KB; the consumers' projection + FIR
     once (32 + 4 MFMAs: the loop over a consumer's groups is not unrolled), the producer's increment products F . T twice
-    (group 0, group 1) in the build without qnorm rows and not at all in the other; and the per-sample loop takes its
-    profile values from LDS (ds_read_b128), not from scalar loads."""
+    (group 0, group 1) in both builds (with qnorm rows the consumers re-step the samples for the sums only); and the
+    per-sample loops take their profile values from LDS (ds_read_b128), not from scalar loads."""
     out = tmp_path / "kp.s"
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"),
                     "-S", "--cuda-device-only", os.path.join(CSRC, "kernels_pipe.hip"), "-o", str(out)], check=True, capture_output=True)
@@ -150,5 +150,5 @@ def test_pipe_kernel_generated_code(tmp_path):
                                      ("group_segment_fixed_size", "private_segment_fixed_size", "vgpr_count", "vgpr_spill_count"))
         assert scratch == 0 and spill == 0 and vgpr <= 256 and lds <= 64 * 1024, (qnm, lds, scratch, vgpr, spill)
         n_mfma = len(re.findall(r"\n\s+v_mfma_f32_16x16x4_f32", body))
-        assert n_mfma == (32 + 4 + 2 * 32 if qnm == 0 else 32 + 4), (qnm, n_mfma)
+        assert n_mfma == 32 + 4 + 2 * 32, (qnm, n_mfma)
         assert "s_load_dwordx16" not in body and "ds_read_b128" in body
