@@ -75,6 +75,7 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
     // which the consumers re-step the samples for the sum of q^2 only; and consumer 1's half of the sum on its way to consumer 0
     __shared__ f2 lds_raw[QN ? 2 : 1][4][64];
     __shared__ float lds_qsum[QN ? 2 : 1][64];
+    __shared__ float lds_taps[QN ? 2 : 1][16];       // (qnorm rows by the consumers: they are the longer stage there, and the producer computes the FIR taps)
     // a dense buffer's profile for the producer's per-sample loop: [buffer parity][T_1 .. T_512 | T_0], staged by consumer 0 a buffer
     // ahead (the loop's 16 values per block come from LDS in ~100 cycles whatever the memory system is busy with; one scalar
     // load per block from L2 / HBM left 100 .. 250 of every block's 290 cycles waiting)
@@ -84,7 +85,10 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NC = (int)(blockDim.x >> 6) - 1;                                    // consumers: 1 or 2
+    // (putting the producer LAST in the team that arrives second on its CU -- so that, with the dispatcher dealing waves to
+    //  consecutive SIMDs, no SIMD would carry two consumers -- ran slower: 8 x 4096 without qnorm rows 3180 -> 2870 x, 1 x 512 8000 -> 7200 x)
     const bool producer = wave == 0;
+    constexpr bool last_is_producer = false;
     const size_t ubase = (size_t)obj * p.m_pad + team.col0;
     const unsigned ul = (unsigned)lane;
     const BufDesc *__restrict__ dsc = p_desc + (size_t)obj * p.nb;
@@ -138,7 +142,23 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
     float *__restrict__ b_qn = p_qnorm + ((size_t)obj * p.qn_nb + p.qn_b0) * p.m_pad + team.col0;
     // qnorm rows of dense buffers come from the consumers when the producer takes the block path (the F table is there)
     const bool qn_by_cons = QN && p_ftab != nullptr;
-    if (wave == 1) stage_profile(next, 0);
+    // FIR taps of a dense profile (kernels_block.hip, "forced block path"): h_d = sum over modes of t g phi_d, phi_d = e1' A^d u
+    // the mode's response d samples after a unit force sample (u = (1, 1)': d += f, q += d).  phi: sixteen constants per
+    // mode, stepped here once per launch (fp64 from the f32 coefficients the per-sample kernels use); the sixteen sums over
+    // the wave are one butterfly (wave_ops.h).  The consumers compute them -- or, when they also re-step samples for qnorm rows
+    // and are the longer stage, the producer does.
+    float phi[16];
+    {
+        double vq = 1.0, vd = 1.0;
+        phi[0] = 1.f;
+#pragma unroll
+        for (int d = 1; d < 16; ++d) {
+            vd = (double)nca * vd + (double)ncb * vq;
+            vq = vq + vd;
+            phi[d] = dead ? 0.f : (float)vq;
+        }
+    }
+    if (wave == (last_is_producer ? 0 : 1)) stage_profile(next, 0);
     __syncthreads();
     if (producer) {
         // ================================================= PRODUCER =================================================
@@ -248,6 +268,15 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
                             if (lane == 0) ao[0] = p0;
                         }
                         lap(0);
+                        if (QN && qn_by_cons) {
+                            const float tg = t * g;
+                            float pv[16];
+#pragma unroll
+                            for (int d = 0; d < 16; ++d) pv[d] = tg * phi[d];
+                            const float hd = wave_sum16(pv, lane, lds_incr, wave_sync);      // (scratch: the increments' area, not yet in use)
+                            if (lane < 16) lds_taps[QN ? (b & 1) : 0][taps_index(lane)] = hd;
+                            wave_sync();
+                        }
                         if (ft) {
                             // 16 blocks a block at a time: v_{n+1} = P v_n + g (F . T_n), parking every block-start state (with qnorm rows:
                             // also the unweighted state every 8 blocks -- the consumers re-step the samples from there for the sum of q^2)
@@ -351,29 +380,14 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
         (p_ss + ubase)[ul] = 1.f;
     } else {
         // ================================================= CONSUMERS =================================================
-        const int cidx = wave - 1;
+        const int cidx = last_is_producer ? wave : wave - 1;
         float wreg[32];                              // the MFMA A operand of the 32 pairs of columns (as K1b)
         {
             const float *__restrict__ wsrc = p_wtab + (ubase / 2) * 64;
 #pragma unroll
             for (int s = 0; s < 32; ++s) wreg[s] = wsrc[s * 64 + lane];
         }
-        // FIR taps of a dense profile (kernels_block.hip, "forced block path"): h_d = sum over modes of t g phi_d, phi_d = e1' A^d u
-        // the mode's response d samples after a unit force sample (u = (1, 1)': d += f, q += d).  phi: sixteen constants per
-        // mode, stepped here once per launch (fp64 from the f32 coefficients the per-sample kernels use); the sixteen sums over
-        // the wave are one butterfly (wave_ops.h).
-        float phi[16];
-        {
-            double vq = 1.0, vd = 1.0;
-            phi[0] = 1.f;
-#pragma unroll
-            for (int d = 1; d < 16; ++d) {
-                vd = (double)nca * vd + (double)ncb * vq;
-                vq = vq + vd;
-                phi[d] = dead ? 0.f : (float)vq;
-            }
-        }
-        const int ctid = (int)threadIdx.x - 64, cthreads = 64 * NC;
+        const int ctid = (int)threadIdx.x - (last_is_producer ? 0 : 64), cthreads = 64 * NC;
         float pend_sq = 0.f;                         // consumer 0: its share of a dense buffer's sum of q^2, until consumer 1's arrives
         int pend_b = -1;
         auto finish_row = [&]() {                    // (after the barrier that followed the buffer's projection)
@@ -405,7 +419,13 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
                     const bool dense = frow >= 0 && !(cur.flags & DESC_IMPULSE);
                     const float *__restrict__ tprow = p_tprof + (size_t)(cur.prow >= 0 && dense ? cur.prow : 0) * p.b_pad;
                     float fir_a[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (dense) {
+                    if (dense && QN && qn_by_cons) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const int idx = (lane & 15) - 4 * kk - (lane >> 4);
+                            fir_a[kk] = idx >= 0 ? lds_taps[QN ? (b & 1) : 0][idx] : 0.f;
+                        }
+                    } else if (dense) {
                         float *taps = lds_stage[b & 1][cidx] + BN * ST_ROW;       // (behind this consumer's first group's rows)
                         const float tg = t * g;
                         float pv[16];
@@ -516,11 +536,12 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
         }
         if (cidx == 0) finish_row();
     }
-    if (p_census && lane == 0 && wave < 2) {
+    const int ridx = producer ? 0 : 1 + (last_is_producer ? wave : wave - 1);          // role: 0 producer, 1 consumer 0, 2 consumer 1
+    if (p_census && lane == 0 && ridx < 2) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) p_census[(size_t)blockIdx.x * CENSUS_WORDS + 6 * wave + k] = cy[k];
+        for (int k = 0; k < 3; ++k) p_census[(size_t)blockIdx.x * CENSUS_WORDS + 6 * ridx + k] = cy[k];
 #pragma unroll
-        for (int k = 3; k < 6; ++k) p_census[(size_t)blockIdx.x * CENSUS_WORDS + 6 * wave + k] = 0;
+        for (int k = 3; k < 6; ++k) p_census[(size_t)blockIdx.x * CENSUS_WORDS + 6 * ridx + k] = 0;
     }
 }
 
