@@ -88,7 +88,6 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
     // (putting the producer LAST in the team that arrives second on its CU -- so that, with the dispatcher dealing waves to
     //  consecutive SIMDs, no SIMD would carry two consumers -- ran slower: 8 x 4096 without qnorm rows 3180 -> 2870 x, 1 x 512 8000 -> 7200 x)
     const bool producer = wave == 0;
-    constexpr bool last_is_producer = false;
     const size_t ubase = (size_t)obj * p.m_pad + team.col0;
     const unsigned ul = (unsigned)lane;
     const BufDesc *__restrict__ dsc = p_desc + (size_t)obj * p.nb;
@@ -158,7 +157,7 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
             phi[d] = dead ? 0.f : (float)vq;
         }
     }
-    if (wave == (last_is_producer ? 0 : 1)) stage_profile(next, 0);
+    if (wave == 1) stage_profile(next, 0);
     __syncthreads();
     if (producer) {
         // ================================================= PRODUCER =================================================
@@ -380,14 +379,14 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
         (p_ss + ubase)[ul] = 1.f;
     } else {
         // ================================================= CONSUMERS =================================================
-        const int cidx = last_is_producer ? wave : wave - 1;
+        const int cidx = wave - 1;
         float wreg[32];                              // the MFMA A operand of the 32 pairs of columns (as K1b)
         {
             const float *__restrict__ wsrc = p_wtab + (ubase / 2) * 64;
 #pragma unroll
             for (int s = 0; s < 32; ++s) wreg[s] = wsrc[s * 64 + lane];
         }
-        const int ctid = (int)threadIdx.x - (last_is_producer ? 0 : 64), cthreads = 64 * NC;
+        const int ctid = (int)threadIdx.x - 64, cthreads = 64 * NC;
         float pend_sq = 0.f;                         // consumer 0: its share of a dense buffer's sum of q^2, until consumer 1's arrives
         int pend_b = -1;
         auto finish_row = [&]() {                    // (after the barrier that followed the buffer's projection)
@@ -536,12 +535,11 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
         }
         if (cidx == 0) finish_row();
     }
-    const int ridx = producer ? 0 : 1 + (last_is_producer ? wave : wave - 1);          // role: 0 producer, 1 consumer 0, 2 consumer 1
-    if (p_census && lane == 0 && ridx < 2) {
+    if (p_census && lane == 0 && wave < 2) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) p_census[(size_t)blockIdx.x * CENSUS_WORDS + 6 * ridx + k] = cy[k];
+        for (int k = 0; k < 3; ++k) p_census[(size_t)blockIdx.x * CENSUS_WORDS + 6 * wave + k] = cy[k];
 #pragma unroll
-        for (int k = 3; k < 6; ++k) p_census[(size_t)blockIdx.x * CENSUS_WORDS + 6 * ridx + k] = 0;
+        for (int k = 3; k < 6; ++k) p_census[(size_t)blockIdx.x * CENSUS_WORDS + 6 * wave + k] = 0;
     }
 }
 
