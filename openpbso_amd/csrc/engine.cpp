@@ -2099,7 +2099,9 @@ int Engine::read_audio(float *out, size_t n) {
 
 int Engine::read_census(unsigned long long *out, size_t n) {
     if (!census_ || !d_census_.p) return fail(PBSO_ERR_STATE, "census not enabled (PBSO_CENSUS=1) or no step yet");
-    if (n != (size_t)n_teams_ * CENSUS_WORDS) return fail(PBSO_ERR_INVALID, "read_census size mismatch (12 words per team)");
+    // (n_teams rows -- or, for an engine that also keeps the table of the kernel of under-filled scenes, that table's rows)
+    if (n != (size_t)n_teams_ * CENSUS_WORDS && !(use_split() && n == (size_t)n_ts_teams_ * CENSUS_WORDS))
+        return fail(PBSO_ERR_INVALID, "read_census size mismatch (12 words per team)");
     HIPTRY(hipMemcpyAsync(out, d_census_.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
     return sync();
 }

@@ -85,8 +85,11 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NC = (int)(blockDim.x >> 6) - 1;                                    // consumers: 1 or 2
-    // (putting the producer LAST in the team that arrives second on its CU -- so that, with the dispatcher dealing waves to
-    //  consecutive SIMDs, no SIMD would carry two consumers -- ran slower: 8 x 4096 without qnorm rows 3180 -> 2870 x, 1 x 512 8000 -> 7200 x)
+    // (A CU holds two teams -- six waves on four SIMDs -- and the dispatcher deals waves to the SIMDs in a fixed cyclic order that
+    //  continues from one workgroup to the next: one SIMD ends up with two consumers, one with a lone producer
+    //  (scripts/debug/census_placement.py).  Letting the other team of a CU put its producer last gives every SIMD at most one
+    //  consumer -- verified with the same census -- and is SLOWER: 8 x 4096 scraping 3220 -> 2890 x without qnorm rows (the
+    //  producer, the longer role there, now always shares its SIMD), 1980 -> 1940 x with them.  Not kept.)
     const bool producer = wave == 0;
     const size_t ubase = (size_t)obj * p.m_pad + team.col0;
     const unsigned ul = (unsigned)lane;
@@ -535,11 +538,14 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
         }
         if (cidx == 0) finish_row();
     }
+    if (p_census && lane == 0) {                     // where the team's waves sit: HW_ID (SIMD 5:4, CU 11:8, SH 12, SE 15:13) | XCC_ID << 32
+        const unsigned long long hw = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                      ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 32);
+        p_census[(size_t)blockIdx.x * CENSUS_WORDS + (wave == 0 ? 3 : 8 + wave)] = hw;
+    }
     if (p_census && lane == 0 && wave < 2) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) p_census[(size_t)blockIdx.x * CENSUS_WORDS + 6 * wave + k] = cy[k];
-#pragma unroll
-        for (int k = 3; k < 6; ++k) p_census[(size_t)blockIdx.x * CENSUS_WORDS + 6 * wave + k] = 0;
     }
 }
 

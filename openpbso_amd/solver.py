@@ -331,9 +331,10 @@ class Engine:
         assert a.size == b.size
         self._chk(self._l.pbso_write_state(self._h, obj, _dp(a), _dp(b), a.size))
 
-    def census(self):
-        """per-workgroup (start, end [100 MHz ticks], HW_ID, XCC_ID, clock start/end, block form: cycles in head / pipeline / barrier / combine) of the last launch (PBSO_CENSUS=1)."""
-        n = self.info()["n_teams"] * 12
+    def census(self, n_teams=None):
+        """per-workgroup (start, end [100 MHz ticks], HW_ID, XCC_ID, clock start/end, block form: cycles in head / pipeline / barrier / combine) of the last launch (PBSO_CENSUS=1).
+        n_teams: the number of rows to read when the launch ran on the kernel of under-filled scenes (one team per 64 modes)."""
+        n = (self.info()["n_teams"] if n_teams is None else n_teams) * 12
         out = np.empty(n, dtype=np.uint64)
         self._chk(self._l.pbso_read_census(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), n))
         return out.reshape(-1, 12)
