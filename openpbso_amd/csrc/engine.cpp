@@ -612,8 +612,9 @@ int Engine::finalize() {
         }
     }
 
-    // K1s: fewer than one wave of oscillators per SIMD even with one mode per lane -- two waves per 64 modes share the
-    // time axis instead (kernels_split.hip).  f32 block form only; PBSO_SPLIT=0 keeps the one-wave-per-64-modes kernel.
+    // K1p / K1s: fewer than one wave of oscillators per SIMD even with one mode per lane -- a team of several waves per 64
+    // modes instead (kernels_pipe.hip: a producer and two consumers; kernels_split.hip: two waves that share the time axis).
+    // f32 block form only; PBSO_SPLIT=0 keeps the one-wave-per-64-modes kernel.
     {
         split_ok_ = false;
         const char *env = std::getenv("PBSO_SPLIT");
@@ -1999,14 +2000,12 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     // rules are shared, so the two kernels hand over at any launch boundary.  (Audio then is bit-identical
     // across different cuts of a step only while both cuts pick the same kernel; always within tolerance.)
     // PBSO_DENSE_LAUNCHES=block keeps every launch on the block kernel (bit-identical audio for any cut of a step).
-    // K1s takes the launch unless most of its (object, buffer) pairs carry a dense force profile (sustained scraping): there the
-    // profile kernel K2 is the step's critical chain, and K1s -- one wave on EVERY SIMD -- slows it 2.7 x (1.28 ms against
-    // 0.48 for 8 chains of 86 rows beside K1b's 512 waves); K1b's forced block path takes those launches (state and teams
-    // hand over at any launch boundary)
-    // -- that was the chain form of K2; with the row-parallel form (a few tens of microseconds) K1s keeps those launches too:
-    // without qnorm rows its waves step a block at a time, increments on the matrix pipe (0.31 ms against K1b's 0.43 for
-    // 8 x 4096 x 86; needs the F table of the forced block path); with qnorm rows wave 0 steps every sample and wave 1 projects
-    // both groups behind it (0.66 ms against 0.74).
+    // The kernel of under-filled engines (K1p; PBSO_SPLIT_KERNEL=time: K1s) takes the launch -- also one whose (object, buffer)
+    // pairs mostly carry a dense force profile (sustained scraping) when the profiles come from K2's row-parallel form
+    // (8 x 4096 x 86: 0.30 ms against K1b's 0.43 without qnorm rows, 0.48 against 0.74 with).  Beside K2's CHAIN form -- then
+    // the step's critical chain, which a wave on every SIMD slows 2.7 x (1.28 ms against 0.48 for 8 chains of 86 rows beside
+    // K1b's 512 waves) -- K1b's forced block path keeps those launches (state and teams hand over at any launch boundary).
+    // Without the F table of the forced block path (PBSO_FORCED_BLOCK=0) and without qnorm rows they go to K1b as well.
     const bool dense_majority = (long long)n_prows_ * 2 > (long long)N * nb;
     const bool split_dense_ok = k2_rows_launch_ && (desc_.qnorm_mode != PBSO_QNORM_OFF || d_ftab_.p != nullptr);
     const bool split_launch = use_split() && (split_always_ || !dense_majority || split_dense_ok);      // (PBSO_SPLIT=2: always)

@@ -263,8 +263,8 @@ private:
     DevBuf<SplitObj> d_split_;                           // objects stepped by more than one team
     DevBuf<float> d_audio_parts_;                        // [n_part_rows_][nb * B] their partial sample sums
     int n_teams_ = 0, n_split_ = 0, n_part_rows_ = 0;
-    // K1s (kernels_split.hip): the team table of the time-split kernel -- one team of two waves per 64 columns -- for
-    // engines with less than a wave of oscillators per SIMD (f32 block form, one mode per lane; PBSO_SPLIT=0: never)
+    // K1p / K1s (kernels_pipe.hip, kernels_split.hip): the team table of the kernels of under-filled engines -- one team per 64
+    // columns -- for engines with less than a wave of oscillators per SIMD (f32 block form, one mode per lane; PBSO_SPLIT=0: never)
     bool split_ok_ = false, split_always_ = false;      // PBSO_SPLIT=2: also the launches that are mostly dense-profile buffers
     DevBuf<TeamDesc> d_ts_teams_;
     DevBuf<SplitObj> d_ts_split_;
