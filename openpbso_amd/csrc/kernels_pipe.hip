@@ -390,6 +390,7 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
             for (int s = 0; s < 32; ++s) wreg[s] = wsrc[s * 64 + lane];
         }
         const int ctid = (int)threadIdx.x - 64, cthreads = 64 * NC;
+        unsigned long long n_unit = 0;                // (census: groups whose qnorm chains took the unit-force form)
         float pend_sq = 0.f;                         // consumer 0: its share of a dense buffer's sum of q^2, until consumer 1's arrives
         int pend_b = -1;
         auto finish_row = [&]() {                    // (after the barrier that followed the buffer's projection)
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
                                 }
                                 sq += unit ? g * g * (qa + qb) : qa + qb;
                             };
-                            if (__all(z_ok)) run(std::true_type{});
+                            if (__all(z_ok)) { run(std::true_type{}); n_unit += 1; }
                             else run(std::false_type{});
                         }
                         if (NC == 2 && cidx == 1) lds_qsum[QN ? (b & 1) : 0][lane] = sq;
@@ -537,6 +538,7 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
             lap(2);
         }
         if (cidx == 0) finish_row();
+        if (p_census && lane == 0 && cidx == 0) p_census[(size_t)blockIdx.x * CENSUS_WORDS + 11] = n_unit;
     }
     if (p_census && lane == 0) {                     // where the team's waves sit: HW_ID (SIMD 5:4, CU 11:8, SH 12, SE 15:13) | XCC_ID << 32
         const unsigned long long hw = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
