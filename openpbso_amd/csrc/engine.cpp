@@ -2027,7 +2027,10 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
             // two consumers (one group each) also where that puts a second wave on some SIMDs: 8 x 4096 scraping -- 512 teams, 1536
             // waves -- runs 3120 x against 2800 with one consumer (no qnorm rows) and 1700 x against 1590 (with them)
             int nc = 2;
-            if (const char *v = std::getenv("PBSO_PIPE_CONSUMERS")) nc = std::atoi(v) == 1 ? 1 : 2;
+            // qnorm rows of a mostly-dense launch: the consumers re-step every sample for the sums and are the long stage -- a third
+            // consumer wave that only steps (half of the chains) when that still leaves at most two waves per SIMD
+            if (dense_majority && desc_.qnorm_mode != PBSO_QNORM_OFF && d_ftab_.p != nullptr && 4LL * n_ts_teams_ <= 8LL * n_cus_) nc = 3;
+            if (const char *v = std::getenv("PBSO_PIPE_CONSUMERS")) nc = std::min(3, std::max(1, std::atoi(v)));
             LAUNCHTRY(iir_pipe::launch_iir_pipe(kp, n_ts_teams_, nc, desc_.qnorm_mode, sk));
         }
         else LAUNCHTRY(iir_split::launch_iir_split(kp, n_ts_teams_, desc_.qnorm_mode, sk));

@@ -61,7 +61,7 @@ __device__ __forceinline__ void static_for(F &&f) {
 }
 
 template <int QNM>
-__global__ __launch_bounds__(192) void iir_pipe_kernel(
+__global__ __launch_bounds__(256) void iir_pipe_kernel(
     const float *__restrict__ p_ca, const float *__restrict__ p_cb, float *__restrict__ p_sq, float *__restrict__ p_sd,
     float *__restrict__ p_ss, const BufDesc *__restrict__ p_desc, const float *__restrict__ p_grows,
     const float *__restrict__ p_tprof, const double *__restrict__ p_xfer_rows, const int *__restrict__ p_xfer_init,
@@ -71,10 +71,10 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
     constexpr bool QN = QNM != 0;
     __shared__ __attribute__((aligned(16))) float lds_stage[2][2][ST_AREA];       // [buffer parity][group]
     __shared__ __attribute__((aligned(16))) float lds_incr[64 * U_ROW];           // the producer's increments on their way back to lane = mode
-    // qnorm rows of dense buffers (block path): the UNWEIGHTED state at the start of blocks 0, 8 (group 0) and 16, 24 (group 1), from
+    // qnorm rows of dense buffers (block path): the UNWEIGHTED state at the start of every fourth block (0, 4, 8, 12 | 16, 20, 24, 28), from
     // which the consumers re-step the samples for the sum of q^2 only; and consumer 1's half of the sum on its way to consumer 0
-    __shared__ f2 lds_raw[QN ? 2 : 1][4][64];
-    __shared__ float lds_qsum[QN ? 2 : 1][64];
+    __shared__ f2 lds_raw[QN ? 2 : 1][8][64];
+    __shared__ float lds_qsum[QN ? 2 : 1][4][64];    // [parity][group, pair of chains]: the same four partial sums whoever steps them
     __shared__ float lds_taps[QN ? 2 : 1][16];       // (qnorm rows by the consumers: they are the longer stage there, and the producer computes the FIR taps)
     // a dense buffer's profile for the producer's per-sample loop: [buffer parity][T_1 .. T_512 | T_0], staged by consumer 0 a buffer
     // ahead (the loop's 16 values per block come from LDS in ~100 cycles whatever the memory system is busy with; one scalar
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
     const int obj = team.obj;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int NC = (int)(blockDim.x >> 6) - 1;                                    // consumers: 1 or 2
+    const int NC = (int)(blockDim.x >> 6) - 1;                                    // consumers: 1 or 2; 3: two that project + a helper for the qnorm chains
     // (A CU holds two teams -- six waves on four SIMDs -- and the dispatcher deals waves to the SIMDs in a fixed cyclic order that
     //  continues from one workgroup to the next: one SIMD ends up with two consumers, one with a lone producer
     //  (scripts/debug/census_placement.py).  Letting the other team of a CU put its producer last gives every SIMD at most one
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
                         }
                         if (ft) {
                             // 16 blocks a block at a time: v_{n+1} = P v_n + g (F . T_n), parking every block-start state (with qnorm rows:
-                            // also the unweighted state every 8 blocks -- the consumers re-step the samples from there for the sum of q^2)
+                            // also the unweighted state every 4 blocks -- the consumers re-step the samples from there for the sum of q^2)
                             auto step_group_ft = [&](float *st, const float (&tbg)[4], int gi) {
                                 {
                                     static_for<0, 4>([&](auto tc) {
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
                                     static_for<0, BN>([&](auto nc) {
                                         constexpr int n = decltype(nc)::value;
                                         park(st, n, x);
-                                        if constexpr (QN && n % 8 == 0) lds_raw[QN ? (b & 1) : 0][2 * gi + n / 8][lane] = x;
+                                        if constexpr (QN && n % 4 == 0) lds_raw[QN ? (b & 1) : 0][4 * gi + n / 4][lane] = x;
                                         const f2 w = coarse(x);
                                         x = f2{fmaf(g, uq[n / 4][n % 4], w.x), fmaf(g, ud[n / 4][n % 4], w.y)};
                                     });
@@ -391,11 +391,12 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
         }
         const int ctid = (int)threadIdx.x - 64, cthreads = 64 * NC;
         unsigned long long n_unit = 0;                // (census: groups whose qnorm chains took the unit-force form)
-        float pend_sq = 0.f;                         // consumer 0: its share of a dense buffer's sum of q^2, until consumer 1's arrives
-        int pend_b = -1;
+        int pend_b = -1;                             // consumer 0: the dense buffer whose four partial sums of q^2 are on their way
         auto finish_row = [&]() {                    // (after the barrier that followed the buffer's projection)
             if (QN && pend_b >= 0) {
-                const float tot = NC == 2 ? pend_sq + lds_qsum[QN ? (pend_b & 1) : 0][lane] : pend_sq;
+                // (a fixed order: the row does not depend on how many waves shared the chains -- launches of one step may differ in that)
+                const float (*ps)[64] = lds_qsum[QN ? (pend_b & 1) : 0];
+                const float tot = (ps[0][lane] + ps[1][lane]) + (ps[2][lane] + ps[3][lane]);
                 (b_qn + (size_t)pend_b * p.m_pad)[ul] = sqrtf(tot);
                 pend_b = -1;
             }
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
                             const int idx = (lane & 15) - 4 * kk - (lane >> 4);
                             fir_a[kk] = idx >= 0 ? lds_taps[QN ? (b & 1) : 0][idx] : 0.f;
                         }
-                    } else if (dense) {
+                    } else if (dense && cidx < 2) {
                         float *taps = lds_stage[b & 1][cidx] + BN * ST_ROW;       // (behind this consumer's first group's rows)
                         const float tg = t * g;
                         float pv[16];
@@ -444,15 +445,17 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
                         }
                     }
                     if (QN && qn_by_cons && dense) {
-                        // The sum of q^2 over the buffer's samples, this consumer's groups: two chains of 128 samples per group, side by
-                        // side (independent: their instructions fill each other's dependency stalls), each from the unweighted state
-                        // the producer left at its first block; profile values from LDS (four broadcast ds_read_b128 per chain and
-                        // block, fetched a block ahead).  Unit-force form as everywhere (z = x / g) while the range allows.
-                        float sq = 0.f;
-                        for (int gi = cidx; gi < 2; gi += NC) {
-                            const float *tl = lds_t[b & 1] + GROUP * gi + (ul >> 31);      // (+ 0, opaque: vector registers)
-                            const f2 xa = lds_raw[QN ? (b & 1) : 0][2 * gi][lane], xb = lds_raw[QN ? (b & 1) : 0][2 * gi + 1][lane];
-                            if (gi == 0) sq = fmaf(xa.x, xa.x, sq);                   // sample 0 left the state block 0 starts from
+                        // The sum of q^2 over the buffer's samples: eight chains of 64 samples (four per group), each from the unweighted
+                        // state the producer left at its first block, stepped two at a time side by side (independent: their
+                        // instructions fill each other's dependency stalls); profile values from LDS (four broadcast ds_read_b128 per
+                        // chain and block, fetched a block ahead).  Unit-force form as everywhere (z = x / g) while the range allows.
+                        // Two consumers: each its group's two pairs.  Three: the projecting consumers their group's first pair, the
+                        // helper the second pair of both groups.
+                        auto chain_pair = [&](int gi, int ca_) {          // chains ca_, ca_ + 1 of group gi -> partial sum 2 gi + ca_ / 2
+                            float sq = 0.f;
+                            const float *tl = lds_t[b & 1] + GROUP * gi + 64 * ca_ + (ul >> 31);      // (+ 0, opaque: vector registers)
+                            const f2 xa = lds_raw[QN ? (b & 1) : 0][4 * gi + ca_][lane], xb = lds_raw[QN ? (b & 1) : 0][4 * gi + ca_ + 1][lane];
+                            if (gi == 0 && ca_ == 0) sq = fmaf(xa.x, xa.x, sq);       // sample 0 left the state block 0 starts from
                             const float gr = __builtin_amdgcn_rcpf(g);
                             const bool z_ok = g != 0.f && fabsf(gr) < 0x1p100f && fabsf(xa.x * gr) < 0x1p50f && fabsf(xa.y * gr) < 0x1p50f &&
                                               fabsf(xb.x * gr) < 0x1p50f && fabsf(xb.y * gr) < 0x1p50f;      // (NaN / inf fail)
@@ -462,8 +465,8 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
                                 float qa = 0.f, qb = 0.f;
                                 f4 ca[4], cb[4], na[4], nb4[4];
                                 auto ld = [&](f4 (&da)[4], f4 (&db)[4], int blk) {
-                                    const f4 *sa = reinterpret_cast<const f4 *>(tl + BJ * (blk < 8 ? blk : 7));
-                                    const f4 *sb = reinterpret_cast<const f4 *>(tl + GROUP / 2 + BJ * (blk < 8 ? blk : 7));
+                                    const f4 *sa = reinterpret_cast<const f4 *>(tl + BJ * (blk < 4 ? blk : 3));
+                                    const f4 *sb = reinterpret_cast<const f4 *>(tl + 64 + BJ * (blk < 4 ? blk : 3));
 #pragma unroll
                                     for (int i = 0; i < 4; ++i) { da[i] = sa[i]; db[i] = sb[i]; }
                                 };
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
                                     }
                                 };
                                 ld(ca, cb, 0);
-                                for (int blk = 0; blk < 8; blk += 2) {
+                                for (int blk = 0; blk < 4; blk += 2) {
                                     ld(na, nb4, blk + 1);
                                     stepb(ca, cb);
                                     ld(ca, cb, blk + 2);
@@ -495,9 +498,15 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
                             };
                             if (__all(z_ok)) { run(std::true_type{}); n_unit += 1; }
                             else run(std::false_type{});
+                            lds_qsum[QN ? (b & 1) : 0][2 * gi + ca_ / 2][lane] = sq;
+                        };
+                        if (NC == 3) {
+                            if (cidx < 2) chain_pair(cidx, 0);
+                            else { chain_pair(0, 2); chain_pair(1, 2); }
+                        } else {
+                            for (int gi = cidx; gi < 2; gi += NC) { chain_pair(gi, 0); chain_pair(gi, 2); }
                         }
-                        if (NC == 2 && cidx == 1) lds_qsum[QN ? (b & 1) : 0][lane] = sq;
-                        else { pend_sq = sq; pend_b = b; }
+                        if (cidx == 0) pend_b = b;
                     }
                     lap(0);
                     for (int gi = cidx; gi < 2; gi += NC) {
@@ -553,7 +562,8 @@ __global__ __launch_bounds__(192) void iir_pipe_kernel(
 
 int launch_iir_pipe(const IirParams &p, int n_teams, int n_consumers, int qnorm_mode, hipStream_t stream) {
     if (n_teams <= 0) return 0;
-    if (p.frames != 1 + 2 * GROUP || n_consumers < 1 || n_consumers > 2) return (int)hipErrorInvalidValue;
+    if (p.frames != 1 + 2 * GROUP || n_consumers < 1 || n_consumers > 3) return (int)hipErrorInvalidValue;
+    if (n_consumers == 3 && (qnorm_mode == 0 || p.ftab == nullptr)) n_consumers = 2;      // (the third only steps qnorm chains)
     const PipeDims dims = {p.nb, p.m_pad, p.b_pad, p.frames, p.audio_stride, p.gq_plane, p.qn_nb, p.qn_b0};
     const dim3 block(64 * (1 + n_consumers));
     if (qnorm_mode != 0)

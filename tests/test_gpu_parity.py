@@ -952,12 +952,12 @@ def test_state_restore_resumes_a_run(form):
     assert np.abs(resumed - w).max() <= tol * np.abs(want["audio"][0]).max()
 
 
-@pytest.mark.parametrize("kernel", ["pipe", "pipe1", "time"])
+@pytest.mark.parametrize("kernel", ["pipe", "pipe1", "pipe3", "time"])
 @pytest.mark.parametrize("qnorm", [capi.QNORM_ALL, capi.QNORM_OFF])
 def test_time_split_kernel_every_buffer_kind(qnorm, kernel, monkeypatch):
     """The kernels of under-filled engines, pinned for every launch (PBSO_SPLIT=2).  "pipe" (the default) / "pipe1": K1p
     (kernels_pipe.hip) -- a producer wave steps buffer b and parks its block-start states while two / one consumer waves
-    project buffer b - 1; the profile of a dense buffer reaches the producer's per-sample loop through LDS, staged by a
+    project buffer b - 1 ("pipe3": plus a third that shares the qnorm chains of dense buffers); the profile of a dense buffer reaches the producer's per-sample loop through LDS, staged by a
     consumer a buffer ahead.  "time": K1s (kernels_split.hip): two waves per 64 modes, wave g projects group g.
     Force-free and impulse buffers, a Gaussian over several buffers, sustained AR scraping with a parameter update (dense
     profiles: without qnorm rows wave 1 steps its half from a zero state and adds the free response of the state wave 0
@@ -966,8 +966,8 @@ def test_time_split_kernel_every_buffer_kind(qnorm, kernel, monkeypatch):
     modes (padding lanes, several teams per object)."""
     monkeypatch.setenv("PBSO_SPLIT", "2")
     monkeypatch.setenv("PBSO_SPLIT_KERNEL", "time" if kernel == "time" else "pipe")
-    if kernel == "pipe1":
-        monkeypatch.setenv("PBSO_PIPE_CONSUMERS", "1")
+    if kernel in ("pipe1", "pipe3"):              # (three: a helper wave that only re-steps samples for the qnorm rows of dense buffers)
+        monkeypatch.setenv("PBSO_PIPE_CONSUMERS", kernel[-1])
     nb = 16
     rng = np.random.default_rng(2024)
     sizes = [1, 64, 65, 300]
