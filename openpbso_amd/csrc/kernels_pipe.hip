@@ -402,7 +402,11 @@ __global__ __launch_bounds__(256) void iir_pipe_kernel(
             }
         };
         for (int it = 0; it <= p.nb; ++it) {
-            const BufDesc ahead = dsc[it + 1 < p.nb ? it + 1 : p.nb - 1];       // (fetched under the projection, used after it)
+            // (only a producer that steps every sample itself -- no F table -- wants the profile of ITS next buffer staged: the load
+            //  of that descriptor, fetched under the projection and used after it, is not made otherwise)
+            const bool stage_ahead = p_ftab == nullptr && cidx == 0;
+            BufDesc ahead = next;
+            if (stage_ahead) ahead = dsc[it + 1 < p.nb ? it + 1 : p.nb - 1];
             if (cidx == 0) finish_row();
             if (it >= 1) {
                 const int b = it - 1;
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(256) void iir_pipe_kernel(
             // the ones that step samples (qnorm rows of dense buffers), of the buffer they take up next (it: the one being parked now)
             if (cidx == 0) {
                 if (qn_by_cons) { if (it >= 1 && it < p.nb) stage_profile(next, it & 1); }
-                else if (it + 1 < p.nb) stage_profile(ahead, (it + 1) & 1);
+                else if (stage_ahead && it + 1 < p.nb) stage_profile(ahead, (it + 1) & 1);
             }
             __syncthreads();
             lap(2);
