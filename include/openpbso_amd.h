@@ -316,7 +316,11 @@ int pbso_get_info(pbso_engine *e, pbso_engine_info *out);
 /* diagnostics (engine created with env PBSO_CENSUS=1): for every object's
  * workgroup of the last oscillator-bank launch: start, end (100 MHz ticks),
  * HW_REG_HW_ID, HW_REG_XCC_ID, shader-clock count at start and end.
- * out[n_teams][12]; words 6..9 (block form): shader cycles of wave 0 spent in the buffer head, the MFMA pipeline, the barrier, the combine.                                                         */
+ * out[n_teams][12]; words 6..9 (block form): shader cycles of wave 0 spent in the buffer head, the MFMA pipeline, the barrier, the combine.
+ * A launch on the kernel of under-filled engines (total_split_launches) has one row per team of 64 modes -- n may then be that
+ * count x 12 --: words 0..2 the producer's cycles (head | stepping | wait at the barrier), 3 its HW_ID | XCC_ID << 32, 6..8
+ * consumer 0's (head + taps + qnorm chains | projection | wait), 9, 10 the consumers' HW_ID words, 11 qnorm chain groups stepped
+ * in unit-force form.                                                                                                            */
 int pbso_read_census(pbso_engine *e, unsigned long long *out, size_t n);
 
 #ifdef __cplusplus
