@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PBSO_ABI_VERSION 3
+#define PBSO_ABI_VERSION 4
 #define PBSO_SAMPLE_RATE 44100          /* config.h:13 */
 #define PBSO_FRAMES_PER_BUFFER 513      /* config.h:14 */
 
@@ -105,7 +105,37 @@ typedef struct pbso_engine_desc {
                                * legacy null stream cannot be selected: order other work on it with
                                * pbso_sync).  A second, engine-owned high-priority stream prepares the
                                * next launch (projection, FFAT lookup, force profiles).                */
+    /* ---- ABI 4: which kernels run and how.  Per ENGINE (two engines of one process may differ); 0 is the engine's
+     * own policy in every field, so a zeroed descriptor is the product's default.  None of them changes what is
+     * computed beyond the stated tolerance; tests and A/B runs use them to pin one path.                           */
+    int bank_kernel;          /* enum pbso_bank_kernel */
+    int time_chunks;          /* K5, launches cut along the time axis (a scan of the buffer-start states makes the buffers of a
+                               * launch independent): 0 = when the scene leaves SIMDs idle, < 0 = never, n > 0 = always, n buffers
+                               * per chunk */
+    int direct_hits;          /* < 0: plain vertex hits go through the fp64 projection / combine kernels instead of the bank's f32 table */
+    int forced_block;         /* < 0: dense-profile buffers are stepped per sample (no block form for them) */
+    int dense_launches;       /* launches that are mostly dense-profile buffers: 0 policy, 1 block kernel, 2 per-sample kernel */
+    int device_profiles;      /* < 0: force time profiles (forces.h:81-137) on the host in fp64, uploaded */
+    int profile_kernel;       /* K2: 0 row-parallel, 1 chain kernel (parallel AR scan), 2 chain kernel with the reference's serial AR loop */
+    int profile_margin_pct;   /* K2 row-parallel: candidate range in percent of the expected need (0 -> 100; tests: < 100 forces the shortfall path) */
+    int profile_priority;     /* K2 chain kernel's wave priority: 0 auto, 1..4 -> s_setprio 0..3 */
+    int team_waves;           /* > 0: waves per team (workgroup) of the oscillator bank; 0 = policy */
+    int pipe_consumers;       /* pipeline kernel: 0 policy, 1..3 consumer waves per team */
+    long long pipe_max_teams; /* pipeline kernel eligibility: at most this many 64-mode teams (0 -> 2 per CU) */
+    int chunk_buffers;        /* a step longer than this is cut into several launches (0 -> 128) */
+    int plan_threads;         /* host planner threads (0 -> 1: the caller's thread) */
+    int plan_pin;             /* != 0: pin the helper threads into the caller's core complex */
+    int timing_every;         /* HIP-event pairs around every n-th launch (0 -> 1; < 0: none) */
+    int warm_copies;          /* < 0: pbso_finalize does not warm the runtime's copy queues */
+    int reserved[3];
 } pbso_engine_desc;
+
+enum pbso_bank_kernel {
+    PBSO_BANK_AUTO = 0,       /* per launch: the block kernel K1b (chunked along time when the scene is small, K5), the pipeline
+                                 kernel K1p for small scenes whose launches are mostly dense-profile buffers */
+    PBSO_BANK_BLOCK = 1,      /* K1b always (never the pipeline kernel) */
+    PBSO_BANK_PIPE = 2        /* K1p whenever the engine is eligible for it (f32 block form, one mode per lane, few teams) */
+};
 
 /* --- lifetime ------------------------------------------------------------- */
 int pbso_engine_create(const pbso_engine_desc *desc, pbso_engine **out);
@@ -306,11 +336,12 @@ typedef struct pbso_engine_info {
                                        * forms, and launches of the block form in which more than half of the
                                        * (object, buffer) pairs carry a dense force profile (sustained contact) */
     int64_t total_timed_launches;     /* launches whose HIP-event times are in total_kernel_ms / total_device_ms: all of
-                                       * them, or every n-th with env PBSO_TIMING_EVERY=n (an event pair costs the
-                                       * stream ~8 us per launch; 0 = none)                                           */
-    int64_t total_split_launches;     /* of the block launches, those on the kernel of under-filled engines (less than one wave
-                                       * of oscillators per SIMD): K1p, kernels_pipe.hip -- a producer wave and two consumer
-                                       * waves per 64 modes (PBSO_SPLIT_KERNEL=time: K1s, kernels_split.hip)                 */
+                                       * them, or every n-th with pbso_engine_desc::timing_every = n (an event pair costs
+                                       * the stream ~8 us per launch)                                                 */
+    int64_t total_split_launches;     /* of the block launches, those on the pipeline kernel of small scenes (K1p, kernels_pipe.hip:
+                                       * a producer wave and two consumer waves per 64 modes)                               */
+    int64_t total_time_chunk_launches;/* of the block launches, those cut along the time axis (K5, kernels_scan.hip: a scan of the
+                                       * buffer-start states, then the block kernel over (team, chunk of buffers) workgroups) */
 } pbso_engine_info;
 int pbso_get_info(pbso_engine *e, pbso_engine_info *out);
 /* diagnostics (engine created with env PBSO_CENSUS=1): for every object's

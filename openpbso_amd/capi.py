@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBSO_LIB") or os.path.join(_HERE, "libopenpbso_amd.so")      # PBSO_LIB: A/B runs of two builds in one process tree
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_STATE, ERR_IO, ERR_MISSING_MAP, ERR_ASSERT, ERR_NOMEM = -1, -2, -3, -4, -5, -6, -7
 POINT_FORCE, GAUSSIAN_FORCE, AUTOREGRESSIVE_FORCE = 0, 1, 2
@@ -32,7 +32,15 @@ EXPORTS = [
 class EngineDesc(C.Structure):
     _fields_ = [("abi_version", C.c_int), ("device", C.c_int), ("frames_per_buffer", C.c_int),
                 ("sample_rate", C.c_int), ("recurrence_form", C.c_int), ("qnorm_mode", C.c_int),
-                ("modes_per_lane", C.c_int), ("stream", C.c_void_p)]
+                ("modes_per_lane", C.c_int), ("stream", C.c_void_p),
+                # ABI 4: kernel / path selection per engine (0 = the engine's policy)
+                ("bank_kernel", C.c_int), ("time_chunks", C.c_int), ("direct_hits", C.c_int), ("forced_block", C.c_int),
+                ("dense_launches", C.c_int), ("device_profiles", C.c_int), ("profile_kernel", C.c_int),
+                ("profile_margin_pct", C.c_int), ("profile_priority", C.c_int), ("team_waves", C.c_int),
+                ("pipe_consumers", C.c_int), ("pipe_max_teams", C.c_longlong), ("chunk_buffers", C.c_int),
+                ("plan_threads", C.c_int), ("plan_pin", C.c_int), ("timing_every", C.c_int), ("warm_copies", C.c_int),
+                ("reserved", C.c_int * 3)]
+BANK_AUTO, BANK_BLOCK, BANK_PIPE = 0, 1, 2
 
 
 class ObjectDesc(C.Structure):
@@ -67,7 +75,8 @@ class EngineInfo(C.Structure):
                 ("total_kernel_ms", C.c_double), ("total_device_ms", C.c_double),
                 ("total_host_plan_ms", C.c_double), ("total_steps", C.c_int64), ("n_teams", C.c_int),
                 ("recurrence_form", C.c_int), ("total_block_launches", C.c_int64), ("total_sample_launches", C.c_int64),
-                ("total_timed_launches", C.c_int64), ("total_split_launches", C.c_int64)]
+                ("total_timed_launches", C.c_int64), ("total_split_launches", C.c_int64),
+                ("total_time_chunk_launches", C.c_int64)]
 
 
 _lib = None

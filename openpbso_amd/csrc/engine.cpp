@@ -250,7 +250,7 @@ Engine::Engine(const pbso_engine_desc &d) : desc_(d) {}
 Engine::~Engine() {
     for (Object &o : objs_)
         while (!o.force_q.empty()) { std::free(o.force_q.front().ext); o.force_q.pop_front(); }
-    if (std::getenv("PBSO_HOST_PROFILE") && tot_steps_ > 0)
+    if (host_profile_ && tot_steps_ > 0)
         std::fprintf(stderr, "pbso host profile, ms per step over %lld steps: wait-for-set %.3f | plan: fill %.3f objects %.3f merge %.3f | "
                              "submit (uploads + launches) %.3f = pack + upload %.3f, preparation launches %.3f, bank launches %.3f | step total %.3f\n",
                      (long long)tot_steps_, hprof_[0] / tot_steps_, hprof_[1] / tot_steps_, hprof_[2] / tot_steps_, hprof_[3] / tot_steps_,
@@ -267,6 +267,8 @@ Engine::~Engine() {
     d_ar_recs_.release(); d_ar_fins_.release();
     d_arstate_.release(); d_board_.release(); d_teams_.release(); d_split_.release(); d_ts_teams_.release(); d_ts_split_.release(); d_audio_parts_.release();
     d_audio_.release(); d_qnorm_.release(); d_census_.release();
+    d_scan_.release(); d_xs_.release(); d_xtrow_.release();
+    for (TcSet &ts : tc_) { ts.d_teams.release(); ts.d_split.release(); }
     for (DevBuf<float> &g : d_grows_) g.release();
     for (int i = 0; i < N_SETS; ++i)
         for (hipEvent_t ev : {ev_prep_done_[i], ev_k1_done_[i], ev_set_[i]})
@@ -321,10 +323,14 @@ int Engine::init() {
     // itself (forced block path); the split-bf16 build has no such path and hands them to the per-sample kernel K1.
     // PBSO_DENSE_LAUNCHES=block|sample pins either; PBSO_FORCED_BLOCK=0 makes the block kernel step dense buffers per sample.
     dense_to_k1_ = form_ == PBSO_FORM_BLOCK_BF16;
-    if (const char *v = std::getenv("PBSO_FORCED_BLOCK")) forced_block_ = std::atoi(v) != 0;
+    forced_block_ = desc_.forced_block >= 0;
     if (!forced_block_) dense_to_k1_ = true;
-    if (const char *v = std::getenv("PBSO_DENSE_LAUNCHES")) dense_to_k1_ = std::string(v) != "block";
-    if (const char *v = std::getenv("PBSO_BLOCK_TEAM_WAVES")) block_team_waves_ = std::min(MAX_WAVES_PER_BLOCK_TEAM, std::max(1, std::atoi(v)));
+    if (desc_.dense_launches < 0 || desc_.dense_launches > 2) return fail(PBSO_ERR_INVALID, "dense_launches");
+    if (desc_.dense_launches) dense_to_k1_ = desc_.dense_launches == 2;
+    if (desc_.bank_kernel < PBSO_BANK_AUTO || desc_.bank_kernel > PBSO_BANK_PIPE) return fail(PBSO_ERR_INVALID, "bank_kernel");
+    if (desc_.profile_kernel < 0 || desc_.profile_kernel > 2) return fail(PBSO_ERR_INVALID, "profile_kernel");
+    if (desc_.pipe_consumers < 0 || desc_.pipe_consumers > 3) return fail(PBSO_ERR_INVALID, "pipe_consumers");
+    if (desc_.profile_priority < 0 || desc_.profile_priority > 4) return fail(PBSO_ERR_INVALID, "profile_priority");
     if (desc_.qnorm_mode < PBSO_QNORM_OFF || desc_.qnorm_mode > PBSO_QNORM_CLOSED)
         return fail(PBSO_ERR_INVALID, "qnorm_mode");
     {
@@ -364,23 +370,24 @@ int Engine::init() {
         HIPTRY(hipEventCreateWithFlags(&ev_prep_done_[i], hipEventDisableTiming));
         HIPTRY(hipEventCreateWithFlags(&ev_k1_done_[i], hipEventDisableTiming));
     }
-    if (const char *v = std::getenv("PBSO_PLAN_THREADS")) plan_threads_ = std::min(16, std::max(1, std::atoi(v)));
-    if (const char *v = std::getenv("PBSO_PLAN_GRAIN")) plan_grain_ = std::max(1, std::atoi(v));
+    plan_threads_ = std::min(16, std::max(1, desc_.plan_threads));
     ctx_.resize(plan_threads_);
     for (PlanCtx &c : ctx_) c.tbuf.assign(B_, 0.0);
     // which build of the oscillator bank to launch (see kernels_iir.hip)
     if (const char *v = std::getenv("PBSO_CENSUS")) census_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_ROTATE_PRIO")) rotate_prio_ = std::min(2, std::max(0, std::atoi(v)));
-    if (const char *v = std::getenv("PBSO_DEVICE_PROFILES")) device_profiles_ = std::atoi(v) != 0;
-    if (const char *v = std::getenv("PBSO_AR_SERIAL")) ar_serial_ = std::atoi(v) != 0;
-    if (const char *v = std::getenv("PBSO_K2_ROWS")) k2_rows_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_TIMELINE")) timeline_ = std::atoi(v) != 0;
-    if (const char *v = std::getenv("PBSO_SPLIT_KERNEL")) split_pipe_ = std::string(v) != "time";
-    if (const char *v = std::getenv("PBSO_K2_MARGIN_PCT")) k2_margin_pct_ = std::min(400, std::max(1, std::atoi(v)));
-    if (const char *v = std::getenv("PBSO_K2_PRIO")) { k2_prio_ = std::min(3, std::max(0, std::atoi(v))); k2_prio_auto_ = false; }
-    if (const char *v = std::getenv("PBSO_DIRECT_HITS")) direct_hits_ = std::atoi(v) != 0;
-    if (const char *v = std::getenv("PBSO_TIMING_EVERY")) timing_every_ = std::max(0, std::atoi(v));
-    if (const char *v = std::getenv("PBSO_CHUNK_BUFFERS")) chunk_buffers_ = std::max(1, std::atoi(v));
+    host_profile_ = std::getenv("PBSO_HOST_PROFILE") != nullptr;
+    // which kernels run and how: per engine, from the descriptor (ABI 4); the environment only switches diagnostics on
+    device_profiles_ = desc_.device_profiles >= 0;
+    k2_rows_ = desc_.profile_kernel == 0;
+    ar_serial_ = desc_.profile_kernel == 2;
+    if (desc_.profile_margin_pct > 0) k2_margin_pct_ = std::min(400, desc_.profile_margin_pct);
+    if (desc_.profile_priority > 0) { k2_prio_ = desc_.profile_priority - 1; k2_prio_auto_ = false; }
+    direct_hits_ = desc_.direct_hits >= 0;
+    timing_every_ = desc_.timing_every < 0 ? 0 : std::max(1, desc_.timing_every);
+    if (desc_.chunk_buffers > 0) chunk_buffers_ = desc_.chunk_buffers;
+    tc_mode_ = desc_.time_chunks;
     return PBSO_OK;
 }
 
@@ -549,6 +556,10 @@ int Engine::finalize() {
     for (const Object &o : objs_) wmax = std::max(wmax, waves_of(o, R));
     R_ = R;
     m_pad_ = 64 * R * wmax;
+    // K5 (kernels_scan.hip): launches cut along the time axis pick their team shape per launch, up to four modes per lane: rows
+    // padded to whole 256-column waves of that shape (padding columns are dead: zero coefficients, zero state)
+    tc_ok_ = block && tc_mode_ >= 0;
+    if (tc_ok_) m_pad_ = (m_pad_ + 255) / 256 * 256;
     // teams, grouped into size classes (one launch of the oscillator bank per team size, largest
     // first); the SoA rows stay m_pad wide and a team touches its own columns only
     {
@@ -559,8 +570,7 @@ int Engine::finalize() {
         // evenly over the 256 CUs.
         const int team_max = block ? (R == 8 ? 4 : MAX_WAVES_PER_BLOCK_TEAM) : MAX_WAVES_PER_TEAM;
         int team_cap = (int)std::min<long long>(team_max, std::max<long long>(1, (total_waves(R) + n_cus_ - 1) / n_cus_));
-        if (const char *v = std::getenv("PBSO_TEAM_WAVES")) team_cap = std::min(team_max, std::max(1, std::atoi(v)));
-        if (block && block_team_waves_ > 0) team_cap = block_team_waves_;
+        if (desc_.team_waves > 0) team_cap = std::min(team_max, desc_.team_waves);
         std::vector<std::vector<TeamDesc>> by_w(MAX_WAVES_PER_TEAM + 1);
         std::vector<SplitObj> split;
         n_part_rows_ = 0;
@@ -612,17 +622,68 @@ int Engine::finalize() {
         }
     }
 
+    if (tc_ok_) {
+        // team tables of the time-chunked launches, one per shape: whole objects as teams of up to 8 waves (an object that
+        // needs more is cut into several teams whose partial sums sum_parts adds, as above)
+        const int shapes[3] = {1, 2, 4};
+        for (int k = 0; k < 3; ++k) {
+            TcSet &ts = tc_[k];
+            ts.R = shapes[k];
+            std::vector<std::vector<TeamDesc>> by_w(MAX_WAVES_PER_BLOCK_TEAM + 1);
+            std::vector<SplitObj> split;
+            ts.n_part_rows = 0;
+            ts.waves = 0;
+            ts.cover = 0;
+            for (int i = 0; i < N; ++i) {
+                const int w = waves_of(objs_[i], ts.R);
+                const int parts = (w + MAX_WAVES_PER_BLOCK_TEAM - 1) / MAX_WAVES_PER_BLOCK_TEAM;
+                const int base = w / parts, rem = w % parts;
+                int w0 = 0;
+                if (parts > 1) {
+                    SplitObj so = {i, ts.n_part_rows, parts, 0};
+                    split.push_back(so);
+                }
+                for (int pi = 0; pi < parts; ++pi) {
+                    const int wp = base + (pi < rem ? 1 : 0);
+                    TeamDesc td = {i, 64 * ts.R * w0, parts > 1 ? ts.n_part_rows++ : -1, 0};
+                    by_w[wp].push_back(td);
+                    w0 += wp;
+                }
+                ts.waves += w;
+                ts.cover += (long long)w * 64 * ts.R;
+            }
+            ts.classes.clear();
+            std::vector<TeamDesc> flat;
+            for (int w = MAX_WAVES_PER_BLOCK_TEAM; w >= 1; --w) {
+                if (by_w[w].empty()) continue;
+                SizeClass c;
+                c.W = w;
+                c.first = (int)flat.size();
+                c.count = (int)by_w[w].size();
+                flat.insert(flat.end(), by_w[w].begin(), by_w[w].end());
+                ts.classes.push_back(c);
+            }
+            for (size_t j = 0; j < flat.size(); ++j) flat[j].id = (int)j;
+            ts.n_teams = (int)flat.size();
+            ts.n_split = (int)split.size();
+            HIPTRY(ts.d_teams.ensure(flat.size()));
+            HIPTRY(hipMemcpy(ts.d_teams.p, flat.data(), flat.size() * sizeof(TeamDesc), hipMemcpyHostToDevice));
+            if (ts.n_split) {
+                HIPTRY(ts.d_split.ensure(split.size()));
+                HIPTRY(hipMemcpy(ts.d_split.p, split.data(), split.size() * sizeof(SplitObj), hipMemcpyHostToDevice));
+            }
+        }
+    }
+
     // K1p / K1s: fewer than one wave of oscillators per SIMD even with one mode per lane -- a team of several waves per 64
     // modes instead (kernels_pipe.hip: a producer and two consumers; kernels_split.hip: two waves that share the time axis).
     // f32 block form only; PBSO_SPLIT=0 keeps the one-wave-per-64-modes kernel.
     {
         split_ok_ = false;
-        const char *env = std::getenv("PBSO_SPLIT");
         long long chunks = 0;
         for (const Object &o : objs_) chunks += std::max(1, (o.n_modes + 63) / 64);
-        long long max_chunks = 2LL * n_cus_;
-        if (const char *v = std::getenv("PBSO_SPLIT_MAX_CHUNKS")) max_chunks = std::atoll(v);
-        if (block && form_ == PBSO_FORM_BLOCK && R_ == 1 && chunks <= max_chunks && !(env && std::atoi(env) == 0)) {
+        const long long max_chunks = desc_.pipe_max_teams > 0 ? desc_.pipe_max_teams : 2LL * n_cus_;
+        if (block && form_ == PBSO_FORM_BLOCK && R_ == 1 && chunks <= max_chunks && desc_.bank_kernel != PBSO_BANK_BLOCK) {
             std::vector<TeamDesc> ts;
             std::vector<SplitObj> tsplit;
             n_ts_part_rows_ = 0;
@@ -646,7 +707,7 @@ int Engine::finalize() {
                 HIPTRY(hipMemcpy(d_ts_split_.p, tsplit.data(), tsplit.size() * sizeof(SplitObj), hipMemcpyHostToDevice));
             }
             split_ok_ = true;
-            split_always_ = env && std::atoi(env) == 2;
+            split_always_ = desc_.bank_kernel == PBSO_BANK_PIPE;
         }
     }
 
@@ -755,6 +816,35 @@ int Engine::finalize() {
         }
         HIPTRY(d_pc_.ensure(4 * nm));
         HIPTRY(hipMemcpy(d_pc_.p, pc.data(), 4 * nm * sizeof(float), hipMemcpyHostToDevice));
+        if (tc_ok_) {
+            // K5: a whole buffer as one step of the state -- A^B (first entry minus one, as P) and A^(B-1) u, u = (1, 1)': what a
+            // force sample at the buffer's first sample leaves at its end.  fp64, rounded once.
+            std::vector<float> sc(6 * nm, 0.f);
+            for (int i = 0; i < N; ++i) {
+                const Object &o = objs_[i];
+                for (int m = 0; m < o.n_modes; ++m) {
+                    const double eps2 = -o.c2[m], e = (1.0 - o.c1[m]) - o.c2[m];
+                    const double a00 = 1.0 - e, a01 = eps2, a10 = -e, a11 = eps2;
+                    double p00 = 1, p01 = 0, p10 = 0, p11 = 1;
+                    const size_t k = (size_t)i * m_pad_ + m;
+                    for (int j = 1; j <= B_; ++j) {
+                        if (j == B_) {                                   // A^(B-1) u
+                            sc[4 * nm + k] = (float)(p00 + p01);
+                            sc[5 * nm + k] = (float)(p10 + p11);
+                        }
+                        const double n00 = a00 * p00 + a01 * p10, n01 = a00 * p01 + a01 * p11;
+                        const double n10 = a10 * p00 + a11 * p10, n11 = a10 * p01 + a11 * p11;
+                        p00 = n00; p01 = n01; p10 = n10; p11 = n11;
+                    }
+                    sc[k] = (float)(p00 - 1.0);
+                    sc[nm + k] = (float)p01;
+                    sc[2 * nm + k] = (float)p10;
+                    sc[3 * nm + k] = (float)p11;
+                }
+            }
+            HIPTRY(d_scan_.ensure(6 * nm));
+            HIPTRY(hipMemcpy(d_scan_.p, sc.data(), 6 * nm * sizeof(float), hipMemcpyHostToDevice));
+        }
         if (form_ == PBSO_FORM_BLOCK && R_ <= 2 && forced_block_) {
             // Forced block path without qnorm rows (kernels_block.hip, FT): a force sample f enters the state as f u, u = (1, 1)'
             // (d += f, q += d), so the samples 16 n + i, i = 1..16, of a dense profile move the next block-start state by
@@ -879,7 +969,7 @@ int Engine::finalize() {
 // plan set ahead of the oscillator bank (the wait for ev_k1_done_ in front of it); it happened at a random launch, whenever the
 // host first got that far ahead.  Issuing exactly that pattern here removes it.
 int Engine::warm_copy_engines() {
-    if (const char *v = std::getenv("PBSO_WARM_COPIES")) if (std::atoi(v) == 0) return PBSO_OK;
+    if (desc_.warm_copies < 0) return PBSO_OK;
     const size_t chunk = (size_t)4 << 20;
     const int n = 6;
     PinBuf<unsigned char> h;
@@ -1045,7 +1135,7 @@ int Engine::consume_script(PlanCtx &c, int oi, int nb) {
     const bool idle = o.force_q.empty() && o.active.empty() && !o.sustained && o.pending.empty() && !o.trans_full &&
                       !(!o.use_transfer && o.latest_row != XFER_UNIT) && !o.arprm_full;
     int h = h0;
-    if (idle && device_profiles_ && direct_hits_ && !use_split()) {
+    if (idle && device_profiles_ && direct_hits_) {
         int next_b = 0;
         for (; h < h1; ++h) {
             const int64_t rel = script_.stamps[h] - buffers_done_;
@@ -1109,8 +1199,7 @@ int Engine::enqueue_force_batch(int n, const int *objs, const pbso_force_msg *ms
     };
     if (T > 1) {
         if (!pool_) {
-            const char *pin = std::getenv("PBSO_PLAN_PIN");
-            pool_ = new PlanPool(plan_threads_ - 1, pin && std::atoi(pin) ? sched_getcpu() : -1);
+            pool_ = new PlanPool(plan_threads_ - 1, desc_.plan_pin ? sched_getcpu() : -1);
         }
         pool_->run(T, job);
     } else {
@@ -1227,7 +1316,7 @@ int Engine::plan_object(PlanCtx &c, int oi, int b, int nb, int64_t t) {
         plain_hit = m0.force_type == PBSO_POINT_FORCE && !m0.clear_all && !m0.sustained_start && !m0.sustained_end &&
                     (m0.data_kind == PBSO_DATA_VERTEX || m0.data_kind == PBSO_DATA_FACE);
     }
-    if (plain_hit && direct_hits_ && !use_split() && o.force_q.front().data_kind == PBSO_DATA_VERTEX && 3 * o.force_q.front().vids[0] + 2 < o.n_dof) {
+    if (plain_hit && direct_hits_ && o.force_q.front().data_kind == PBSO_DATA_VERTEX && 3 * o.force_q.front().vids[0] + 2 < o.n_dof) {
         // ... and when the hit is at a vertex, not even a row: the oscillator bank dots the hit's normal with three rows
         // of the object's (float)(c3 * shape) table itself (DESC_DIRECT).  No work for any preparation kernel.
         const HostForceMsg &m0 = o.force_q.front();
@@ -1597,8 +1686,7 @@ int Engine::plan(int nb) {
     const auto tp1 = std::chrono::steady_clock::now();
     if (T > 1) {
         if (!pool_) {
-            const char *pin = std::getenv("PBSO_PLAN_PIN");
-            pool_ = new PlanPool(plan_threads_ - 1, pin && std::atoi(pin) ? sched_getcpu() : -1);
+            pool_ = new PlanPool(plan_threads_ - 1, desc_.plan_pin ? sched_getcpu() : -1);
         }
         pool_->run(T, job);
     } else {
@@ -1728,6 +1816,39 @@ void Engine::build_ar_tables() {
 // chunk_buffers_ buffers so that the host plans chunk c+1 while the device runs chunk c (the same
 // overlap consecutive steps have); results do not depend on the cut (state, force lists and queues
 // carry over exactly as between steps).
+// K5: does this launch run time-chunked, with which team shape and how many buffers per chunk?  Auto: only while the scene
+// leaves SIMDs idle (fewer than two waves per SIMD in its largest shape) and few of the launch's (object, buffer) pairs
+// carry a dense force profile (the scan steps those per sample, serially per object).  The shape: the most modes per lane
+// that still fills the chip when every buffer is its own chunk (a wave of four modes per lane amortises its operand table
+// over more work), unless the padding to whole waves wastes columns; the chunk length minimises rounds x (length + start-up).
+bool Engine::choose_time_chunks(int nb, int n_dense_rows, int *set, int *cb) const {
+    if (!tc_ok_ || !d_scan_.p || (nb < 2 && tc_mode_ <= 0)) return false;
+    const long long N = (long long)objs_.size();
+    const long long capacity = 8LL * n_cus_;             // two 256-register waves per SIMD
+    if (tc_mode_ == 0 && (long long)n_dense_rows * 8 > N * nb) return false;
+    int k = 0;
+    for (int c = 2; c >= 1; --c)
+        if (tc_[c].cover * 100 <= tc_[0].cover * 115 && tc_[c].waves * nb >= capacity) { k = c; break; }
+    const long long waves = tc_[k].waves;
+    int best = nb;
+    if (tc_mode_ > 0) {
+        best = std::min(tc_mode_, nb);
+    } else {
+        if (waves >= capacity) return false;              // the chip is full without cutting time
+        double best_cost = 0;
+        for (int c = nb; c >= 1; --c) {
+            const long long chunks = (nb + c - 1) / c;
+            const long long rounds = (waves * chunks + capacity - 1) / capacity;
+            const double cost = (double)rounds * (c + 0.3);
+            if (c == nb || cost < best_cost - 1e-9) { best = c; best_cost = cost; }
+        }
+    }
+    if ((nb + best - 1) / best < 2 && tc_mode_ <= 0) return false;       // (forced: every launch, so that any cut of a step runs the same arithmetic)
+    *set = k;
+    *cb = best;
+    return true;
+}
+
 int Engine::step(int nb, void *d_audio_user) {
     HIPTRY(hipSetDevice(desc_.device));      // the caller's thread may have another device current
     if (!finalized_) return fail(PBSO_ERR_STATE, "step before finalize");
@@ -1757,7 +1878,8 @@ int Engine::step(int nb, void *d_audio_user) {
     }
     {
         // (a step's launches may run on different kernels: room for either kind's partial rows)
-        const int rows = std::max(use_split() ? n_ts_part_rows_ : 0, n_part_rows_);
+        int rows = std::max(use_split() ? n_ts_part_rows_ : 0, n_part_rows_);
+        if (tc_ok_) for (const TcSet &ts : tc_) rows = std::max(rows, ts.n_part_rows);
         if (rows) HIPTRY(d_audio_parts_.ensure((size_t)rows * nb * B_, false, stream_));
     }
     emitted_.assign((size_t)N * nb, 1);
@@ -1973,7 +2095,9 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.gq_plane = (long long)N * m_pad_;
     kp.census = nullptr;
     if (census_) {
-        HIPTRY(d_census_.ensure((size_t)std::max(n_teams_, use_split() ? n_ts_teams_ : 0) * CENSUS_WORDS, false, sk));
+        size_t rows = (size_t)std::max(n_teams_, use_split() ? n_ts_teams_ : 0);
+        if (tc_ok_) for (const TcSet &ts : tc_) rows = std::max(rows, (size_t)ts.n_teams * nb);
+        HIPTRY(d_census_.ensure(rows * CENSUS_WORDS, false, sk));
         kp.census = d_census_.p;
     }
     kp.nb = nb; kp.n_tiles = n_tiles_; kp.m_pad = m_pad_; kp.b_pad = b_pad_;
@@ -2008,36 +2132,56 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     // Without the F table of the forced block path (PBSO_FORCED_BLOCK=0) and without qnorm rows they go to K1b as well.
     const bool dense_majority = (long long)n_prows_ * 2 > (long long)N * nb;
     const bool split_dense_ok = k2_rows_launch_ && (desc_.qnorm_mode != PBSO_QNORM_OFF || d_ftab_.p != nullptr);
-    const bool split_launch = use_split() && (split_always_ || !dense_majority || split_dense_ok);      // (PBSO_SPLIT=2: always)
-    (split_launch || !(dense_heavy || !is_block()) ? tot_block_launches_ : tot_sample_launches_) += 1;
+    // K5: a launch without (many) dense-profile buffers on a chip the scene cannot fill runs the block kernel as (team, chunk of
+    // buffers) workgroups behind a scan of the buffer-start states (kernels_scan.hip)
+    int tc_set = -1, tc_cb = 0;
+    const bool tc_launch = is_block() && !split_always_ && choose_time_chunks(nb, n_prows_, &tc_set, &tc_cb);
+    const bool split_launch = !tc_launch && use_split() && (split_always_ || !dense_majority || split_dense_ok);      // (PBSO_SPLIT=2: always)
+    (tc_launch || split_launch || !(dense_heavy || !is_block()) ? tot_block_launches_ : tot_sample_launches_) += 1;
     if (split_launch) tot_split_launches_ += 1;
+    if (tc_launch) tot_tc_launches_ += 1;
     if (n_dump_ > 0) {
         // the mix needs block states: a launch on the per-sample kernel leaves none, a dense-profile buffer neither
         for (int i = 0; i < N; ++i) {
             if (dump_row_[i] < 0) continue;
-            if (dense_heavy || !is_block()) { dump_valid_[i] = 0; continue; }
+            if (!tc_launch && (dense_heavy || !is_block())) { dump_valid_[i] = 0; continue; }
             for (int b = 0; b < nb; ++b)
                 if (!(plan_desc_[(size_t)i * nb + b].flags & DESC_DIRECT) && plan_desc_[(size_t)i * nb + b].prow >= 0) { dump_valid_[i] = 0; break; }
         }
     }
     bool used[N_CLASS_STREAMS] = {false, false, false};
+    if (tc_launch) {
+        TcSet &ts = tc_[tc_set];
+        const int n_chunks = (nb + tc_cb - 1) / tc_cb;
+        HIPTRY(d_xs_.ensure((size_t)N * n_chunks * m_pad_ * 2, false, sk));
+        HIPTRY(d_xtrow_.ensure((size_t)N * n_chunks, false, sk));
+        LAUNCHTRY(launch_iir_scan(kp, N, d_scan_.p, tc_cb, n_chunks, d_xs_.p, d_xtrow_.p, direct_hits_, sk));
+        kp.tc_cb = tc_cb;
+        kp.tc_xs = d_xs_.p;
+        kp.tc_xtrow = d_xtrow_.p;
+        kp.census_stride = ts.n_teams;
+        kp.rotate_prio = rotate_prio_ ? 1 : 0;
+        for (const SizeClass &c : ts.classes) {
+            kp.teams = ts.d_teams.p + c.first;
+            LAUNCHTRY(iir_block::launch_iir_block(kp, c.count, ts.R, c.W, desc_.qnorm_mode, form_ == PBSO_FORM_BLOCK_BF16 ? 1 : 0, sk));
+        }
+    }
     if (split_launch) {
         kp.teams = d_ts_teams_.p;
-        if (split_pipe_) {
+        {
             // two consumers (one group each) also where that puts a second wave on some SIMDs: 8 x 4096 scraping -- 512 teams, 1536
             // waves -- runs 3120 x against 2800 with one consumer (no qnorm rows) and 1700 x against 1590 (with them)
             int nc = 2;
             // qnorm rows of a mostly-dense launch: the consumers re-step every sample for the sums and are the long stage -- a third
             // consumer wave that only steps (half of the chains) when that still leaves at most two waves per SIMD
             if (dense_majority && desc_.qnorm_mode != PBSO_QNORM_OFF && d_ftab_.p != nullptr && 4LL * n_ts_teams_ <= 8LL * n_cus_) nc = 3;
-            if (const char *v = std::getenv("PBSO_PIPE_CONSUMERS")) nc = std::min(3, std::max(1, std::atoi(v)));
+            if (desc_.pipe_consumers > 0) nc = desc_.pipe_consumers;
             LAUNCHTRY(iir_pipe::launch_iir_pipe(kp, n_ts_teams_, nc, desc_.qnorm_mode, sk));
         }
-        else LAUNCHTRY(iir_split::launch_iir_split(kp, n_ts_teams_, desc_.qnorm_mode, sk));
     }
-    const bool fork = !split_launch && classes_.size() > 1 && ev_fork_ && total_team_waves_ <= 16LL * n_cus_;
+    const bool fork = !tc_launch && !split_launch && classes_.size() > 1 && ev_fork_ && total_team_waves_ <= 16LL * n_cus_;
     if (fork) HIPTRY(hipEventRecord(ev_fork_, sk));
-    for (size_t ci = 0; ci < (split_launch ? 0 : classes_.size()); ++ci) {
+    for (size_t ci = 0; ci < (tc_launch || split_launch ? 0 : classes_.size()); ++ci) {
         const SizeClass &c = classes_[ci];
         hipStream_t s = sk;
         if (fork && ci > 0) {
@@ -2061,7 +2205,8 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     }
     // objects stepped by several teams: the teams' partial sums of this launch's buffers, added in team order
     // ... and _latest_transfer = trans (modal_solver.h:251) in the same launch; then re-park a still-queued transfer
-    LAUNCHTRY(launch_sum_parts_copy_rows(split_launch ? d_ts_split_.p : d_split_.p, split_launch ? n_ts_split_ : n_split_, kp.audio_parts,
+    LAUNCHTRY(launch_sum_parts_copy_rows(tc_launch ? tc_[tc_set].d_split.p : split_launch ? d_ts_split_.p : d_split_.p,
+                                         tc_launch ? tc_[tc_set].n_split : split_launch ? n_ts_split_ : n_split_, kp.audio_parts,
                                          audio + (size_t)b0 * B_, (long long)nb_total * B_, (long long)nb * B_, d_copy, d_copy + (n_cl + n_cq), n_cl,
                                          d_xfer_.p, m_pad_, sk));
     if (timed) HIPTRY(hipEventRecord(evq.k1, sk));
@@ -2356,6 +2501,7 @@ int Engine::info(pbso_engine_info *out) {
     out->total_block_launches = tot_block_launches_;
     out->total_sample_launches = tot_sample_launches_;
     out->total_split_launches = tot_split_launches_;
+    out->total_time_chunk_launches = tot_tc_launches_;
     out->buffers_done = buffers_done_;
     out->last_step_host_plan_ms = last_plan_ms_;
     out->last_step_forced_rows = last_frows_;
@@ -2425,7 +2571,7 @@ int Engine::harvest_timing(bool blocking) {
     if (k2_prio_auto_ && k2_ms_n_ >= 2) {
         // the longer of the two kernels that run side by side gets the SIMDs they share (with hysteresis)
         const int want = k2_ms_avg_ > (k2_prio_ ? 0.85 : 0.95) * k2_bank_ms_avg_ ? 3 : 0;
-        if (want != k2_prio_ && std::getenv("PBSO_HOST_PROFILE"))
+        if (want != k2_prio_ && host_profile_)
             std::fprintf(stderr, "pbso: force-profile kernel %.3f ms, oscillator bank %.3f ms per timed launch: K2 wave priority %d -> %d\n",
                          k2_ms_avg_, k2_bank_ms_avg_, k2_prio_, want);
         k2_prio_ = want;

@@ -271,6 +271,25 @@ private:
     int n_ts_teams_ = 0, n_ts_split_ = 0, n_ts_part_rows_ = 0;
     int64_t tot_split_launches_ = 0;
     bool use_split() const { return split_ok_ && n_dump_ == 0; }
+    // K5 (kernels_scan.hip): launches whose buffers are made independent by a scan of the buffer-start states run the block
+    // kernel K1b as (team, chunk of buffers) workgroups.  The chunked launches pick their team shape per launch -- R modes per
+    // lane, whole objects as teams of up to 8 waves -- from three tables (the state arrays are indexed by column: any shape
+    // reads them), so a short launch of a small scene takes many small teams and a long one few large ones.
+    struct TcSet {
+        int R = 0;
+        std::vector<SizeClass> classes;
+        DevBuf<TeamDesc> d_teams;
+        DevBuf<SplitObj> d_split;
+        int n_teams = 0, n_split = 0, n_part_rows = 0;
+        long long waves = 0, cover = 0;                  // waves of all teams; columns they cover (padding included)
+    } tc_[3];                                            // R = 1, 2, 4
+    bool tc_ok_ = false;
+    int tc_mode_ = 0;                                    // pbso_engine_desc::time_chunks: 0 auto, < 0 never, n > 0 chunks of n buffers always
+    DevBuf<float> d_scan_;                               // 6 planes [n_obj][m_pad]: A^513 (P11 - 1, P12, P21, P22), A^512 u
+    DevBuf<float> d_xs_;                                 // [n_obj][n_chunks][m_pad] pairs: the state at the first buffer of every chunk
+    DevBuf<int> d_xtrow_;                                // [n_obj][n_chunks] the transfer row in force there
+    int64_t tot_tc_launches_ = 0;
+    bool choose_time_chunks(int nb, int n_dense_rows, int *set, int *cb) const;
     int n_cus_ = 256;                                     // hipDeviceProp_t::multiProcessorCount of the engine's device
     long long total_team_waves_ = 0;
     DevBuf<float> d_gq_;                                 // closed-form qnorm: G11, 2 G12, G22 planes
@@ -288,7 +307,6 @@ private:
     int form_ = PBSO_FORM_BLOCK;                         // the form that runs (block falls back to velocity for odd buffer lengths)
     bool dense_to_k1_ = true;                            // dense-heavy launches run on the per-sample kernel K1 (split-bf16 form; PBSO_DENSE_LAUNCHES)
     bool forced_block_ = true;                           // f32 block kernel: dense-profile buffers in block form (PBSO_FORCED_BLOCK=0: per sample)
-    int block_team_waves_ = 0;                           // PBSO_BLOCK_TEAM_WAVES: waves per team of the block form (0 = policy)
     DevBuf<double> d_shapes_;
     DevBuf<long long> d_shape_off_;
     std::vector<long long> geom_off_h_;                  // host copy of d_geom_off_ (first FfatGeom of every object)
@@ -347,9 +365,9 @@ private:
     // build_ar_tables() lists the launch's AR forces (streams), their uses and the candidate segments of their engines.
     bool k2_rows_ = true;
     bool timeline_ = false, timeline_have_base_ = false, timeline_keep_ = false;   // PBSO_TIMELINE=1 (diagnostics)
+    bool host_profile_ = false;                          // PBSO_HOST_PROFILE=1 (diagnostics): host milliseconds by stage at destruction
     hipEvent_t timeline_base_ = nullptr, timeline_ref_ = nullptr;
     double timeline_h0_ = 0;
-    bool split_pipe_ = true;                             // small engines: K1p (producer / consumer waves); PBSO_SPLIT_KERNEL=time: K1s (two waves share the time axis)
     int k2_margin_pct_ = 100;                            // PBSO_K2_MARGIN_PCT: scales the candidate range (tests: < 100 forces the shortfall path)
     bool k2_rows_launch_ = false;                        // this launch takes the row-parallel form
     std::vector<ArStream> ar_streams_;

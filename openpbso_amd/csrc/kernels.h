@@ -87,6 +87,12 @@ struct IirParams {
     float *xdump;                // [n_dump][qn_nb][32][m_pad] pairs (Q, D), scaled as the registers hold them
     float *xscale;               // [n_dump][qn_nb][m_pad] the scale (transfer weight) of that buffer; 0: stepped per sample
     const int *dump_row;         // [n_obj]
+    // time-chunked launch of the block form (kernels_scan.hip): tc_cb > 0 buffers per chunk, grid (team, chunk); the states at
+    // the chunks' first buffers [n_obj][n_chunks][m_pad] pairs (q, d), unscaled, and the transfer rows in force there
+    int tc_cb = 0;
+    const float *tc_xs = nullptr;
+    const int *tc_xtrow = nullptr;
+    int census_stride = 0;       // census rows per chunk (= the launch's teams, all size classes)
 };
 
 // launches the oscillator bank for n_teams teams of waves_per_team waves; returns hipError_t as int.
@@ -119,7 +125,7 @@ constexpr double TRUNC_SPLIT_GAIN = 1.0 + 7.2e-6;
 inline size_t block_lds_bytes(int W, int R) { return sizeof(float) * (size_t)W * (BLOCK_STAGE_FLOATS + 2 * BLOCK_RING_FLOATS + 3 * R * 64); }
 namespace iir_pipe {
 // K1p (kernels_pipe.hip): teams of one producer wave (steps, parks block-start states) and n_consumers (1 or 2) consumer waves
-// (project the previous buffer); teams as K1s: 64 modes each
+// (project the previous buffer); one team per 64 modes
 int launch_iir_pipe(const IirParams &p, int n_teams, int n_consumers, int qnorm_mode, hipStream_t stream);
 }
 namespace iir_block {
@@ -135,11 +141,11 @@ int launch_listener_mix(const float *xdump, const float *xscale, const float *wt
                         int nb, int m_pad, int n_modes, int n_listeners, long long out_stride, hipStream_t stream);
 }
 
-// ---- K1s: the block form for an under-filled chip (kernels_split.hip): teams of TWO waves that own the same 64 modes
-// (one mode per lane, f32 projection), wave g projecting group g of every buffer; p.teams lists one team per 64 columns
-namespace iir_split {
-int launch_iir_split(const IirParams &p, int n_teams, int qnorm_mode, hipStream_t stream);
-}
+// ---- K5: the scan of buffer-start states that makes a launch's buffers independent (kernels_scan.hip).  sc: 6 planes
+// [n_obj][m_pad] (stride gq_plane): A^513 as (P11 - 1, P12, P21, P22), then A^512 u.  Writes the state at the first buffer of
+// every chunk of cb buffers to xs, the transfer row in force there to xtrow, and the launch's end state to sq / sd / ss.
+int launch_iir_scan(const IirParams &p, int n_obj, const float *sc, int cb, int n_chunks, float *xs, int *xtrow, bool direct,
+                    hipStream_t stream);
 
 // ---- exact fp64 helper kernels (kernels_exact.hip, built with -ffp-contract=off)
 struct ProjectEvent {

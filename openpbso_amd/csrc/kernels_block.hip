@@ -67,6 +67,10 @@ struct BlkDims {
     int qn_nb, qn_b0;
     int rotate;                  // != 0: the teams of a CU take turns at the highest wave priority, one buffer each
     int forced_block;            // != 0 (f32 projection only): buffers with a dense force profile run in block form too
+    // time-chunked launch (kernels_scan.hip): grid (team, chunk); workgroup (t, c) runs buffers c * cb .. of its team from the
+    // state the scan left at p_xs[obj][c] (unscaled) under the transfer row p_xtrow[obj][c]; it does NOT write the state back
+    // (the scan has).  cb == 0: one workgroup per team walks all nb buffers from the state arrays.
+    int cb, n_chunks, census_stride;
 };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -113,9 +117,13 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     const float *__restrict__ p_gq, const float *__restrict__ p_pc, const float *__restrict__ p_wtab,
     const TeamDesc *__restrict__ p_teams, float *__restrict__ p_audio_parts, unsigned long long *__restrict__ p_census,
     float *__restrict__ p_xdump, float *__restrict__ p_xscale, const int *__restrict__ p_dump_row, unsigned *__restrict__ p_board,
-    const float *__restrict__ p_ftab, const BlkDims p) {
+    const float *__restrict__ p_ftab, const float *__restrict__ p_xs, const int *__restrict__ p_xtrow, const BlkDims p) {
     constexpr bool QN = QNM != 0;
     constexpr int NG = 2;                              // groups per buffer (513 = 1 + 2 * 256; checked at launch)
+    const bool chunked = p.cb > 0;
+    const int chunk = chunked ? (int)blockIdx.y : 0;
+    const int b_begin = chunk * p.cb;
+    const int b_end = chunked ? (b_begin + p.cb < p.nb ? b_begin + p.cb : p.nb) : p.nb;
     constexpr int U = NG * R;                          // slices per buffer: (group, r)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const TeamDesc team = p_teams[blockIdx.x];
@@ -150,8 +158,13 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const unsigned k = r * rowlen + utid;
-        x2[r].x = (p_sq + ubase)[k];
-        x2[r].y = (p_sd + ubase)[k];
+        if (chunked) {
+            const float *__restrict__ xsrc = p_xs + 2 * (((size_t)obj * p.n_chunks + chunk) * p.m_pad + team.col0);
+            x2[r] = reinterpret_cast<const f2 *>(xsrc)[k];
+        } else {
+            x2[r].x = (p_sq + ubase)[k];
+            x2[r].y = (p_sd + ubase)[k];
+        }
         c1[r].x = (p_pc + ubase)[k];
         c2[r].x = (p_pc + p.plane + ubase)[k];
         c1[r].y = (p_pc + 2 * p.plane + ubase)[k];
@@ -258,11 +271,11 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
         scaled = ok;
     };
     {
-        const int row0 = p_xfer_init[obj];
+        const int row0 = chunked ? p_xtrow[(size_t)obj * p.n_chunks + chunk] : p_xfer_init[obj];
         float s0[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            s0[r] = (p_ss + ubase)[r * rowlen + utid];
+            s0[r] = chunked ? 1.f : (p_ss + ubase)[r * rowlen + utid];
             const float tr = row0 >= 0 ? (float)(p_xfer_rows + (size_t)row0 * p.m_pad + team.col0)[r * rowlen + utid] : 1e7f;
             t[r] = dead[r] ? 1.f : tr;
         }
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
             cy_mark = now;
         }
     };
-    BufDesc next = dsc[0];
+    BufDesc next = dsc[b_begin];
     prefetch(next);
     prefetch_direct(next);
     if (p_census) cy_mark = __builtin_amdgcn_s_memtime();
@@ -412,7 +425,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
         // (starting the teams of a CU half a slice period apart -- one wave's vector burst under its SIMD partner's matrix
         //  burst -- changed nothing: 0.948 ms with any stagger of 1, 2 or 4 K cycles on either rank bit, 0.948 without)
     }
-    for (int b = 0; b < p.nb; ++b) {
+    for (int b = b_begin; b < b_end; ++b) {
         const BufDesc cur = next;
         next = dsc[b + 1 < p.nb ? b + 1 : b];
         if (p.rotate) {
@@ -1020,19 +1033,21 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
 
     if (p_census && tid == 0) {
         // where and when this workgroup ran, and the shader clock it held (diagnostics, PBSO_CENSUS=1)
-        p_census[(size_t)team.id * CENSUS_WORDS + 0] = census_t0;
-        p_census[(size_t)team.id * CENSUS_WORDS + 1] = __builtin_amdgcn_s_memrealtime();
-        p_census[(size_t)team.id * CENSUS_WORDS + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
-        p_census[(size_t)team.id * CENSUS_WORDS + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
-        p_census[(size_t)team.id * CENSUS_WORDS + 4] = census_c0;
-        p_census[(size_t)team.id * CENSUS_WORDS + 5] = __builtin_amdgcn_s_memtime();
-        p_census[(size_t)team.id * CENSUS_WORDS + 6] = cy_head;
-        p_census[(size_t)team.id * CENSUS_WORDS + 7] = cy_pipe;
-        p_census[(size_t)team.id * CENSUS_WORDS + 8] = cy_bar;
-        p_census[(size_t)team.id * CENSUS_WORDS + 9] = cy_comb;
-        p_census[(size_t)team.id * CENSUS_WORDS + 10] = cy_taps;       // forced block path: sample 0 + FIR taps
-        p_census[(size_t)team.id * CENSUS_WORDS + 11] = cy_step;       // forced block path: per-sample state stepping
+        const size_t census_row = (size_t)team.id + (size_t)chunk * p.census_stride;
+        p_census[census_row * CENSUS_WORDS + 0] = census_t0;
+        p_census[census_row * CENSUS_WORDS + 1] = __builtin_amdgcn_s_memrealtime();
+        p_census[census_row * CENSUS_WORDS + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        p_census[census_row * CENSUS_WORDS + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+        p_census[census_row * CENSUS_WORDS + 4] = census_c0;
+        p_census[census_row * CENSUS_WORDS + 5] = __builtin_amdgcn_s_memtime();
+        p_census[census_row * CENSUS_WORDS + 6] = cy_head;
+        p_census[census_row * CENSUS_WORDS + 7] = cy_pipe;
+        p_census[census_row * CENSUS_WORDS + 8] = cy_bar;
+        p_census[census_row * CENSUS_WORDS + 9] = cy_comb;
+        p_census[census_row * CENSUS_WORDS + 10] = cy_taps;       // forced block path: sample 0 + FIR taps
+        p_census[census_row * CENSUS_WORDS + 11] = cy_step;       // forced block path: per-sample state stepping
     }
+    if (chunked) return;                               // (the scan wrote the launch's end state)
     const unsigned utid_end = lane_off();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -1057,9 +1072,12 @@ static int launch_one(const IirParams &p, int n_teams, int W, hipStream_t stream
         if (e != hipSuccess) return (int)e;
     }
     const int frames = p.frames;
-    const BlkDims dims = {p.nb, p.m_pad, p.b_pad, frames, (frames - 1) / GROUP, p.audio_stride, p.gq_plane, p.qn_nb, p.qn_b0, p.rotate_prio, p.forced_block};
-    hipLaunchKernelGGL(kern, dim3(n_teams), dim3(64 * W), lds, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows, p.g32, p.g32_off,
-                       p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.census, p.xdump, p.xscale, p.dump_row, p.board, p.ftab, dims);
+    const int n_chunks = p.tc_cb > 0 ? (p.nb + p.tc_cb - 1) / p.tc_cb : 1;
+    const BlkDims dims = {p.nb, p.m_pad, p.b_pad, frames, (frames - 1) / GROUP, p.audio_stride, p.gq_plane, p.qn_nb, p.qn_b0, p.rotate_prio, p.forced_block,
+                          p.tc_cb, n_chunks, p.census_stride};
+    hipLaunchKernelGGL(kern, dim3(n_teams, n_chunks), dim3(64 * W), lds, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows, p.g32, p.g32_off,
+                       p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.census, p.xdump, p.xscale, p.dump_row, p.board, p.ftab,
+                       p.tc_xs, p.tc_xtrow, dims);
     return (int)hipGetLastError();
 }
 

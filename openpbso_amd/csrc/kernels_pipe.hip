@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256) void iir_pipe_kernel(
     const float *__restrict__ p_tprof, const double *__restrict__ p_xfer_rows, const int *__restrict__ p_xfer_init,
     float *__restrict__ p_audio, float *__restrict__ p_qnorm, const float *__restrict__ p_gq, const float *__restrict__ p_pc,
     const float *__restrict__ p_wtab, const TeamDesc *__restrict__ p_teams, float *__restrict__ p_audio_parts,
-    const float *__restrict__ p_ftab, unsigned long long *__restrict__ p_census, const PipeDims p) {
+    const float *__restrict__ p_ftab, unsigned long long *__restrict__ p_census, const float *__restrict__ p_g32,
+    const long long *__restrict__ p_g32_off, const PipeDims p) {
     constexpr bool QN = QNM != 0;
     __shared__ __attribute__((aligned(16))) float lds_stage[2][2][ST_AREA];       // [buffer parity][group]
     __shared__ __attribute__((aligned(16))) float lds_incr[64 * U_ROW];           // the producer's increments on their way back to lane = mode
@@ -122,8 +123,15 @@ __global__ __launch_bounds__(256) void iir_pipe_kernel(
     }
     // a buffer's rows from memory -- force gain, new transfer weights -- are fetched a buffer ahead
     float g_next = 0.f, t_next = 0.f;
+    const float *__restrict__ g32_obj = p_g32 + (size_t)p_g32_off[obj] * p.m_pad + team.col0;
     auto fetch_rows = [&](const BufDesc &nd) {
-        if (nd.frow >= 0) g_next = (p_grows + (size_t)nd.frow * p.m_pad + team.col0)[ul];
+        if (nd.frow >= 0 && (nd.flags & DESC_DIRECT)) {
+            // the hit of a plain PointForce at a vertex (kernels.h): g = n . (three rows of the object's (float)(c3 * shape) table)
+            const float *__restrict__ r0 = g32_obj + (size_t)nd.frow * p.m_pad;
+            float gv = __builtin_bit_cast(float, nd.prow) * r0[ul];
+            gv = fmaf(__builtin_bit_cast(float, nd.tile_mask), (r0 + p.m_pad)[ul], gv);
+            g_next = fmaf(__builtin_bit_cast(float, nd.pad[0]), (r0 + 2 * (size_t)p.m_pad)[ul], gv);
+        } else if (nd.frow >= 0) g_next = (p_grows + (size_t)nd.frow * p.m_pad + team.col0)[ul];
         if (nd.trow >= 0) t_next = (float)(p_xfer_rows + (size_t)nd.trow * p.m_pad + team.col0)[ul];
     };
     BufDesc next = dsc[0];
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(256) void iir_pipe_kernel(
                     auto park = [&](float *st, int n, f2 v) { *reinterpret_cast<f2 *>(st + n * ST_ROW + 2 * lane) = f2{t * v.x, t * v.y}; };
                     if (!dense) {
                         // ---- force-free buffer (or an impulse at sample 0)
-                        const bool hit0 = frow >= 0 && (cur.tile_mask & 1u);
+                        const bool hit0 = frow >= 0 && ((cur.flags & DESC_DIRECT) || (cur.tile_mask & 1u));
                         float a = nca * x.y;
                         a = fmaf(ncb, x.x, a);
                         if (hit0) a = fmaf(g, cur.amp, a);
@@ -572,10 +580,10 @@ int launch_iir_pipe(const IirParams &p, int n_teams, int n_consumers, int qnorm_
     const dim3 block(64 * (1 + n_consumers));
     if (qnorm_mode != 0)
         hipLaunchKernelGGL(iir_pipe_kernel<2>, dim3(n_teams), block, 0, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows, p.tprof,
-                           p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.ftab, p.census, dims);
+                           p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.ftab, p.census, p.g32, p.g32_off, dims);
     else
         hipLaunchKernelGGL(iir_pipe_kernel<0>, dim3(n_teams), block, 0, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows, p.tprof,
-                           p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.ftab, p.census, dims);
+                           p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.ftab, p.census, p.g32, p.g32_off, dims);
     return (int)hipGetLastError();
 }
 

@@ -84,9 +84,60 @@ class ForceMessage:
         return m
 
 
+def _select_from_env():
+    """Test / A-B convenience of THIS wrapper (the library reads no such variables): the kernel- and path-selection fields of
+    pbso_engine_desc (ABI 4) from the environment, so that a whole pytest / bench run can pin one path.
+    PBSO_ENGINE_OPTS="field=value,..." names descriptor fields directly; the older switches map onto them."""
+    env = os.environ
+    sel = {}
+    split = env.get("PBSO_SPLIT")
+    if split == "0":                                  # the block kernel K1b for every launch, walked buffer by buffer
+        sel.update(bank_kernel=capi.BANK_BLOCK, time_chunks=-1)
+    elif split == "2":                                # the pipeline kernel K1p for every launch
+        sel.update(bank_kernel=capi.BANK_PIPE)
+    if "PBSO_TIME_CHUNKS" in env:
+        sel["time_chunks"] = int(env["PBSO_TIME_CHUNKS"])
+    if env.get("PBSO_DIRECT_HITS") == "0":
+        sel["direct_hits"] = -1
+    if env.get("PBSO_FORCED_BLOCK") == "0":
+        sel["forced_block"] = -1
+    if "PBSO_DENSE_LAUNCHES" in env:
+        sel["dense_launches"] = {"block": 1, "sample": 2}[env["PBSO_DENSE_LAUNCHES"]]
+    if env.get("PBSO_DEVICE_PROFILES") == "0":
+        sel["device_profiles"] = -1
+    if env.get("PBSO_AR_SERIAL") == "1":
+        sel["profile_kernel"] = 2
+    elif env.get("PBSO_K2_ROWS") == "0":
+        sel["profile_kernel"] = 1
+    for name, field in (("PBSO_K2_MARGIN_PCT", "profile_margin_pct"), ("PBSO_TEAM_WAVES", "team_waves"),
+                        ("PBSO_PIPE_CONSUMERS", "pipe_consumers"), ("PBSO_SPLIT_MAX_CHUNKS", "pipe_max_teams"),
+                        ("PBSO_CHUNK_BUFFERS", "chunk_buffers"), ("PBSO_PLAN_THREADS", "plan_threads"),
+                        ("PBSO_PLAN_PIN", "plan_pin")):
+        if name in env:
+            sel[field] = int(env[name])
+    if "PBSO_K2_PRIO" in env:
+        sel["profile_priority"] = int(env["PBSO_K2_PRIO"]) + 1
+    if "PBSO_TIMING_EVERY" in env:
+        n = int(env["PBSO_TIMING_EVERY"])
+        sel["timing_every"] = n if n > 0 else -1
+    if env.get("PBSO_WARM_COPIES") == "0":
+        sel["warm_copies"] = -1
+    for item in filter(None, env.get("PBSO_ENGINE_OPTS", "").split(",")):
+        k, v = item.split("=")
+        sel[k.strip()] = int(v)
+    return sel
+
+
+SELECT_FIELDS = ("bank_kernel", "time_chunks", "direct_hits", "forced_block", "dense_launches", "device_profiles",
+                 "profile_kernel", "profile_margin_pct", "profile_priority", "team_waves", "pipe_consumers",
+                 "pipe_max_teams", "chunk_buffers", "plan_threads", "plan_pin", "timing_every", "warm_copies")
+
+
 class Engine:
     def __init__(self, device=0, form=None, qnorm=capi.QNORM_ALL, modes_per_lane=0,
-                 stream=None, frames_per_buffer=0):
+                 stream=None, frames_per_buffer=0, **select):
+        """select: the ABI-4 fields of pbso_engine_desc that pick kernels and paths for THIS engine (bank_kernel,
+        time_chunks, direct_hits, ...; include/openpbso_amd.h).  0 / absent = the engine's policy."""
         if form is None:
             # the C ABI's default (a zeroed pbso_engine_desc): the block form with the exact f32 projection.
             # PBSO_FORM=block|block_bf16|velocity|direct lets a whole test / bench run pick the oscillator-bank kernel
@@ -102,6 +153,13 @@ class Engine:
         d.qnorm_mode = qnorm
         d.modes_per_lane = modes_per_lane
         d.stream = stream
+        sel = _select_from_env()
+        sel.update(select)
+        for k, v in sel.items():
+            if k not in SELECT_FIELDS:
+                raise TypeError(f"unknown engine option {k!r}")
+            setattr(d, k, int(v))
+        self.select = sel
         h = C.c_void_p()
         rc = self._l.pbso_engine_create(C.byref(d), C.byref(h))
         self._h = h

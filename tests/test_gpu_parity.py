@@ -952,20 +952,17 @@ def test_state_restore_resumes_a_run(form):
     assert np.abs(resumed - w).max() <= tol * np.abs(want["audio"][0]).max()
 
 
-@pytest.mark.parametrize("kernel", ["pipe", "pipe1", "pipe3", "time"])
+@pytest.mark.parametrize("kernel", ["pipe", "pipe1", "pipe3"])
 @pytest.mark.parametrize("qnorm", [capi.QNORM_ALL, capi.QNORM_OFF])
-def test_time_split_kernel_every_buffer_kind(qnorm, kernel, monkeypatch):
-    """The kernels of under-filled engines, pinned for every launch (PBSO_SPLIT=2).  "pipe" (the default) / "pipe1": K1p
+def test_pipeline_kernel_every_buffer_kind(qnorm, kernel, monkeypatch):
+    """The pipeline kernel of small scenes, pinned for every launch (bank_kernel = PBSO_BANK_PIPE).  "pipe" (the default) / "pipe1": K1p
     (kernels_pipe.hip) -- a producer wave steps buffer b and parks its block-start states while two / one consumer waves
     project buffer b - 1 ("pipe3": plus a third that shares the qnorm chains of dense buffers); the profile of a dense buffer reaches the producer's per-sample loop through LDS, staged by a
-    consumer a buffer ahead.  "time": K1s (kernels_split.hip): two waves per 64 modes, wave g projects group g.
-    Force-free and impulse buffers, a Gaussian over several buffers, sustained AR scraping with a parameter update (dense
-    profiles: without qnorm rows wave 1 steps its half from a zero state and adds the free response of the state wave 0
-    hands over; with qnorm rows wave 0 steps all 512 samples), a clearAllForces hole, a listener moving through FFAT maps
+    consumer a buffer ahead.
+    Force-free and impulse buffers, a Gaussian over several buffers, sustained AR scraping with a parameter update, a clearAllForces hole, a listener moving through FFAT maps
     with a zero weight on one mode (the registers hold the state unscaled: no fallback path), objects of 1, 64, 65 and 300
     modes (padding lanes, several teams per object)."""
     monkeypatch.setenv("PBSO_SPLIT", "2")
-    monkeypatch.setenv("PBSO_SPLIT_KERNEL", "time" if kernel == "time" else "pipe")
     if kernel in ("pipe1", "pipe3"):              # (three: a helper wave that only re-steps samples for the qnorm rows of dense buffers)
         monkeypatch.setenv("PBSO_PIPE_CONSUMERS", kernel[-1])
     nb = 16

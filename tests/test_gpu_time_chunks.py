@@ -1,0 +1,186 @@
+"""K5 (kernels_scan.hip + the chunked launches of kernels_block.hip): a launch cut along the TIME axis.
+
+The reference admits forces only at the first sample of a buffer (modal_solver.h:184-205) and a mode's recurrence is
+linear (modal_integrator.h:103-113): a per-mode scan x_{b+1} = A^513 x_b + impulse_b gives the state at the start of
+every buffer, after which the block kernel runs (team, chunk of buffers) workgroups side by side.  Checked here against
+the fp64 oracle for every buffer kind, every team shape the engine picks from, both projections, any chunk length and
+any cut of the step into launches; plus the policy (when the engine chooses it by itself) and the two claims the design
+makes about it: one buffer per chunk makes the audio independent of how a step is cut, and two engines of one process
+may differ in their settings (pbso_engine_desc, ABI 4).
+"""
+import numpy as np
+import pytest
+
+from openpbso_amd import capi, synth
+from tests.scenarios import B, ObjSpec, force_ev, rel_errors, run_engine, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(got, want, tol_max=5e-4, tol_l2=1e-3, qnorm=True):
+    assert np.isfinite(got["audio"]).all()
+    assert np.array_equal(got["emitted"], want["emitted"])
+    mx, l2 = rel_errors(got["audio"], want["audio"])
+    assert (mx <= tol_max).all() and (l2 <= tol_l2).all(), (mx.max(), l2.max())
+    if qnorm:
+        for key, w in want["qnorm"].items():
+            assert np.abs(got["qnorm"][key] - w).max() <= 5e-4 * max(np.abs(w).max(), 1e-30) + 2e-6 * np.abs(want["audio"][key[0]]).max(), key
+    for i, (g, w) in enumerate(zip(got["state"], want["state"])):
+        np.testing.assert_allclose(g[0], w[0], rtol=0, atol=5e-4 * max(np.abs(w[0]).max(), 1e-30))
+    return mx.max()
+
+
+def _every_kind_scene(nb=16, sizes=(1, 64, 65, 300, 600)):
+    """force-free and impulse buffers (explicit data, vertex hits on an idle object: DESC_DIRECT, a face hit), a Gaussian over
+    several buffers, sustained AR scraping with a parameter update, a clearAllForces hole, a listener moving through FFAT
+    maps with a zero weight on one mode, objects of 1 .. 600 modes (padding lanes, one to three waves at four modes per lane)"""
+    rng = np.random.default_rng(4242)
+    objs, evs = [], []
+    for i, m in enumerate(sizes):
+        lam = synth.eigenvalues(m, 1900 + i)
+        shapes = synth.mode_shapes(m, 1900 + i)
+        maps = synth.ffat_maps(lam, 1900 + i, dim=4, cell_size=0.01) if i == 3 else None
+        if maps is not None:
+            for mm in maps:
+                mm["psi"] = np.array(mm["psi"], dtype=np.float64)
+            maps[7]["psi"][:] = 0.0
+        objs.append(ObjSpec(lam, shapes=shapes, maps=maps))
+        nv = shapes.shape[1] // 3
+        vns = synth.unit_normals(nb, 1900 + i)
+        evs += [force_ev(0, i, vid=int(rng.integers(0, nv)), vn=vns[0]),
+                force_ev(1, i, vid=int(rng.integers(0, nv)), vn=vns[1]),
+                force_ev(2, i, data=rng.standard_normal(m) * 1e-3, force_type=1, width=1500.0),
+                force_ev(5, i, clear=True),
+                force_ev(6, i, data=rng.standard_normal(m) * 1e-3, force_type=2, start=True),
+                force_ev(8, i, data=rng.standard_normal(m) * 1e-3, force_type=2),
+                dict(t=9, obj=i, kind="arprm", a=[0.5, 0.3], sigma=0.004, mu=0.2),
+                force_ev(10, i, force_type=2, end=True),
+                force_ev(12, i, vids=[0, 1, 2], coords=[0.2, 0.3, 0.5], vn=vns[2]),
+                force_ev(13, i, vid=int(rng.integers(0, nv)), vn=vns[3]),
+                force_ev(14, i, data=rng.standard_normal(m) * 1e-3)]
+        if maps is None:
+            evs.append(dict(t=0, obj=i, kind="use_transfer", use=False))
+        else:
+            dirs = np.array([[1, .2, .3], [.2, 1, .3], [.2, .3, 1], [-1, .2, .3]], dtype=float)
+            evs += [dict(t=b, obj=i, kind="listener", pos=0.5 * dirs[b % 4] / np.linalg.norm(dirs[b % 4])) for b in range(0, nb, 3)]
+    return objs, evs
+
+
+@pytest.mark.parametrize("form", [capi.FORM_BLOCK, capi.FORM_BLOCK_BF16])
+@pytest.mark.parametrize("qnorm", [capi.QNORM_ALL, capi.QNORM_OFF])
+@pytest.mark.parametrize("cb", [1, 3, 16])
+def test_time_chunks_every_buffer_kind(cb, qnorm, form):
+    nb = 16
+    objs, evs = _every_kind_scene(nb)
+    want = run_oracle(objs, evs, nb)
+    for split in (None, [1, 4, 11]):
+        got = run_engine(objs, evs, nb, split=split, form=form, qnorm=qnorm, time_chunks=cb)
+        info = got["info"]
+        n_launch = 1 if split is None else 3
+        assert info["total_time_chunk_launches"] == info["total_block_launches"] == n_launch and info["total_sample_launches"] == 0
+        _check(got, want, qnorm=qnorm != capi.QNORM_OFF)
+        assert not got["emitted"][:, 5].any()
+
+
+@pytest.mark.parametrize("mpl_scene", ["small", "large"])
+def test_one_buffer_per_chunk_is_independent_of_the_cut(mpl_scene):
+    """time_chunks = 1: every buffer starts from the scan's state, and the scan is one sequential pass whose arithmetic does
+    not depend on where a step is cut into launches -- bit-identical audio, qnorm rows and state for any cut"""
+    nb = 16
+    objs, evs = _every_kind_scene(nb, sizes=(64, 300) if mpl_scene == "small" else (600, 1100))
+    a = run_engine(objs, evs, nb, time_chunks=1)
+    for split in ([1, 4, 11], [8, 8], [1] * 16):
+        b = run_engine(objs, evs, nb, split=split, time_chunks=1)
+        assert np.array_equal(a["audio"], b["audio"]), split
+        for key in a["qnorm"]:
+            assert np.array_equal(a["qnorm"][key], b["qnorm"][key]), (split, key)
+        for sa, sb in zip(a["state"], b["state"]):
+            assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])
+
+
+def _poisson_scene(n_obj, n_modes, nb, p_hit=0.233, seed=31):
+    rng = np.random.default_rng(seed)
+    objs, evs = [], []
+    for i in range(n_obj):
+        s = synth.seed_for(2, i)
+        objs.append(ObjSpec(synth.eigenvalues(n_modes, s), shapes=synth.mode_shapes(n_modes, s)))
+        nv = objs[-1].shapes.shape[1] // 3
+        vns = synth.unit_normals(nb, s)
+        for b in range(nb):
+            if rng.random() < p_hit:
+                evs.append(force_ev(b, i, vid=int(rng.integers(0, nv)), vn=vns[b]))
+        evs.append(dict(t=0, obj=i, kind="use_transfer", use=False))
+    return objs, evs
+
+
+def test_policy_small_scenes_take_it_full_chips_and_single_buffers_do_not():
+    """auto (time_chunks = 0): BASELINE configs[1] (1 x 512, 86 buffers) runs time-chunked; the same engine stepping ONE buffer
+    (the real-time facade's call) does not; an engine pinned to the buffer-by-buffer walk (time_chunks < 0) never does; a launch
+    that is mostly dense-profile buffers (sustained scraping) keeps the kernels that walk the buffers in order"""
+    nb = 86
+    objs, evs = _poisson_scene(1, 512, nb)
+    want = run_oracle(objs, evs, nb)
+    got = run_engine(objs, evs, nb)
+    assert got["info"]["total_time_chunk_launches"] == 1 and got["info"]["total_split_launches"] == 0
+    err_tc = _check(got, want)
+    one = run_engine(objs, evs, nb, split=[1] * nb)
+    assert one["info"]["total_time_chunk_launches"] == 0
+    _check(one, want)
+    off = run_engine(objs, evs, nb, time_chunks=-1)
+    assert off["info"]["total_time_chunk_launches"] == 0
+    err_walk = _check(off, want)
+    print(f"1 x 512 x 86: time-chunked {err_tc:.2e}, buffer-by-buffer {err_walk:.2e} of peak")
+    # sustained scraping: every buffer dense
+    rng = np.random.default_rng(5)
+    sevs = [force_ev(0, 0, data=rng.standard_normal(512) * 1e-3, force_type=2, start=True), dict(t=0, obj=0, kind="use_transfer", use=False)]
+    sevs += [force_ev(b, 0, data=rng.standard_normal(512) * 1e-3, force_type=2) for b in range(1, 12)]
+    scr = run_engine(objs, sevs, 12)
+    assert scr["info"]["total_time_chunk_launches"] == 0
+    _check(scr, run_oracle(objs, sevs, 12))
+
+
+def test_two_engines_of_one_process_with_different_settings():
+    """pbso_engine_desc (ABI 4) selects kernels per ENGINE: a time-chunked engine, a pipeline-kernel engine and a
+    buffer-by-buffer block engine side by side in one process, all inside the tolerance of the same oracle run"""
+    from openpbso_amd import Engine, ForceMessage
+    nb = 20
+    objs, evs = _poisson_scene(3, 300, nb, p_hit=0.4)
+    want = run_oracle(objs, evs, nb)
+    engines = [Engine(time_chunks=2), Engine(bank_kernel=capi.BANK_PIPE), Engine(bank_kernel=capi.BANK_BLOCK, time_chunks=-1, direct_hits=-1)]
+    try:
+        for e in engines:
+            for o in objs:
+                e.add_object(o.lam, o.rho, o.alpha, o.beta, o.n_modes, o.shapes)
+            e.finalize()
+            for ev in sorted(evs, key=lambda x: x["t"]):
+                if ev["kind"] == "force":
+                    assert e.enqueue_force(ev["obj"], ForceMessage(vid=ev["vid"], vn=ev["vn"]), ev["t"])
+                else:
+                    e.set_use_transfer(ev["obj"], ev["use"], ev["t"])
+        for e in engines:                            # interleaved: all three have work in flight at once
+            e.step(nb)
+        outs = [e.audio().copy() for e in engines]
+        infos = [e.info() for e in engines]
+    finally:
+        for e in engines:
+            e.close()
+    assert infos[0]["total_time_chunk_launches"] == 1 and infos[1]["total_split_launches"] == 1
+    assert infos[2]["total_time_chunk_launches"] == 0 and infos[2]["total_split_launches"] == 0 and infos[2]["last_step_forced_rows"] > 0
+    for a in outs:
+        mx, l2 = rel_errors(a, want["audio"])
+        assert (mx <= 5e-4).all() and (l2 <= 1e-3).all()
+    assert not np.array_equal(outs[0], outs[1])      # (different arithmetic: they are different kernels)
+
+
+@pytest.mark.parametrize("n_obj,n_modes", [(128, 512), (64, 256)])
+def test_strong_scaling_shares_full_size(n_obj, n_modes):
+    """the per-GPU share of BASELINE configs[3] on 8 GPUs (128 x 512) and configs[2]'s shape, 86 buffers, auto policy:
+    time-chunked, sampled objects against the oracle"""
+    nb = 86
+    objs, evs = _poisson_scene(n_obj, n_modes, nb)
+    got = run_engine(objs, evs, nb)
+    assert got["info"]["total_time_chunk_launches"] == 1
+    pick = list(range(0, n_obj, max(1, n_obj // 6)))
+    want = run_oracle(objs, evs, nb, only=pick, threads=4)
+    mx, l2 = rel_errors(got["audio"][pick], want["audio"])
+    assert (mx <= 1e-4).all() and (l2 <= 1e-3).all(), (mx.max(), l2.max())
