@@ -20,14 +20,21 @@
 //
 // A^513 and A^512 u are per-mode constants, fp64 on the host, rounded once (Engine::finalize); A^513's first entry is
 // stored minus one, as K1b's coarse step P = A^16.  One wave = 64 consecutive columns of one object, one mode per lane.
-// Two passes per 64 buffers.  (1) lane = BUFFER: every lane decodes one descriptor (two coalesced 16-byte loads per 64
-// buffers) into what the step needs -- the address of the row(s) the hit's gain comes from (g, or the three g32 rows of a
-// DESC_DIRECT hit; a buffer without a hit points at a finite dummy row), their weights (0 without a hit), kind bits.
-// (2) lane = MODE: the buffers in order, eight at a time; their fields reach scalar registers by v_readlane, their rows
-// are loaded UNCONDITIONALLY and one group ahead, so the compiler counts the loads exactly and a step never waits for a
-// round trip to L2 / HBM.  A group that holds a dense buffer (or the ragged tail) takes a generic loop that exists once:
-// the first version unrolled all 64 buffer positions with the dense loop inside each -- 90 KB of code per kernel, 45 us
-// per launch in instruction fetches alone.
+// The only part that has to be sequential is the state update itself, so everything else is taken out of it -- per 64
+// buffers:
+//   (1) lane = BUFFER: every lane decodes one descriptor (two coalesced 16-byte loads per 64 buffers, fetched a batch
+//       ahead) into what its step needs: the address of the row(s) its gain comes from (g, or the three g32 rows of a
+//       DESC_DIRECT hit), their weights, kind bits; wave ballots turn those into 64-bit masks (hit / skip / dense), and the
+//       transfer row in force at every chunk start is a lane-parallel "last row set before me" (no walk);
+//   (2) lane = MODE, buffers with a hit only (a quarter of them in a Poisson train), sixteen at a time: rows loaded back to
+//       back, gain g amp written to LDS [buffer][mode] (zero-filled first);
+//   (3) lane = MODE, the scan: per buffer one LDS read (issued eight buffers ahead) and eight vector instructions two
+//       dependent operations deep; a scalar bit test sends chunk starts to their store and skipped / dense buffers to a
+//       generic path that exists once.
+// The first version walked descriptors, loads and bookkeeping inside the sequential loop: 45 us per launch (90 KB of
+// unrolled code), 22 us after compaction, 13 us in this form (scripts/debug/r04_scan_abl.sh times its stages) -- and since
+// only the scan itself hands the state from launch to launch, the engine runs it on the PREPARATION stream, beside the
+// previous launch's oscillator bank.
 #include <type_traits>
 
 #include "kernels.h"
@@ -36,9 +43,12 @@ namespace pbso {
 namespace iir_scan {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 typedef int i4 __attribute__((ext_vector_type(4)));
 
-constexpr int G = 8;             // buffers per group of prefetched rows
+constexpr int G = 8;             // buffers per unrolled group of the scan
+constexpr int HB = 16;           // hits whose rows are in flight together
+typedef const __attribute__((address_space(1))) float *gptr;      // (a pointer rebuilt from two scalar halves stays a GLOBAL pointer)
 
 template <int K0, int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {
@@ -53,10 +63,9 @@ struct ScanDims {
     long long plane;             // elements between the planes of p_sc / p_pc
 };
 
-#ifndef PBSO_SCAN_FAST
-#define PBSO_SCAN_FAST 1
+#ifndef PBSO_SCAN_STOP
+#define PBSO_SCAN_STOP 9         // (ablation builds for timing only: scripts/debug/r04_scan_abl.sh)
 #endif
-constexpr unsigned K_SKIP = 1u, K_DENSE = 2u;
 
 template <bool DIRECT>
 __global__ __launch_bounds__(64) void iir_scan_kernel(
@@ -65,6 +74,7 @@ __global__ __launch_bounds__(64) void iir_scan_kernel(
     const float *__restrict__ p_grows, const float *__restrict__ p_g32, const long long *__restrict__ p_g32_off,
     const float *__restrict__ p_tprof, const int *__restrict__ p_xfer_init, float *__restrict__ p_xs,
     int *__restrict__ p_xtrow, const ScanDims p) {
+    __shared__ __attribute__((aligned(16))) float lds_g[64][64];          // [buffer of the batch][mode]: the hit's gain g amp (0: no hit)
     const int obj = blockIdx.y;
     const int col0 = 64 * blockIdx.x;
     const unsigned lane = threadIdx.x;
@@ -80,156 +90,185 @@ __global__ __launch_bounds__(64) void iir_scan_kernel(
         x.y = (p_sd + ubase)[lane] / s0;
     }
     const BufDesc *__restrict__ dsc = p_desc + (size_t)obj * p.nb;
-    const float *__restrict__ dummy = p_ca + ubase;                                   // a finite row for buffers without a hit
     const float *__restrict__ g32_obj = DIRECT ? p_g32 + (size_t)p_g32_off[obj] * p.m_pad + col0 : nullptr;
     int cur_row = p_xfer_init[obj];
     f2 *__restrict__ xs = reinterpret_cast<f2 *>(p_xs) + (size_t)obj * p.n_chunks * p.m_pad + col0;
     constexpr int NR = DIRECT ? 3 : 1;
-    int next_mark = 0, chunk_i = 0;
     auto rl = [](int v, int j) { return __builtin_amdgcn_readlane(v, j); };
     auto rlf = [](float v, int j) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j)); };
     auto rlp = [&](unsigned long long v, int j) {
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, j), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), j);
-        return reinterpret_cast<const float *>(((unsigned long long)hi << 32) | lo);
+        const unsigned lo = (unsigned)rl((int)(unsigned)v, j), hi = (unsigned)rl((int)(unsigned)(v >> 32), j);
+        return (gptr)(((unsigned long long)hi << 32) | lo);
     };
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // the descriptors of a batch, one per lane, fetched a batch ahead
+    auto load_descs = [&](int base, i4 &lo, i4 &hi) {
+        const int bi = base + (int)lane;
+        const i4 *src = reinterpret_cast<const i4 *>(dsc + (bi < p.nb ? bi : p.nb - 1));
+        lo = src[0];                                 // frow, prow, tile_mask, amp
+        hi = src[1];                                 // trow, flags, pad[0], pad[1]
+    };
+    i4 nlo, nhi;
+    load_descs(0, nlo, nhi);
+    f2 *__restrict__ xs_next = xs;                   // where the next chunk's start state goes (chunks start in order)
 
-    for (int base = 0; base < p.nb; base += 64) {
-        // ---- pass 1, lane = buffer base + lane: what its step needs
-        unsigned long long ptr[NR];
+    for (int base = 0; base < p.nb && PBSO_SCAN_STOP > 1; base += 64) {
+        const int nd = p.nb - base < 64 ? p.nb - base : 64;
+        // ---- (1) lane = buffer base + lane
+        unsigned long long ptr[NR];                  // address of its row(s), this wave's columns
         float w[NR];
-        unsigned kind;
         int trow, prow;
+        unsigned long long hit_mask, skip_mask, dense_mask, mark_mask = 0;
         {
             const int bi = base + (int)lane;
             const bool in = bi < p.nb;
-            const i4 *src = reinterpret_cast<const i4 *>(dsc + (in ? bi : p.nb - 1));
-            const i4 dlo = src[0];                   // frow, prow, tile_mask, amp
-            const i4 dhi = src[1];                   // trow, flags, pad[0], pad[1]
+            const i4 dlo = nlo, dhi = nhi;
+            if (base + 64 < p.nb) load_descs(base + 64, nlo, nhi);
             // (scalars first: __builtin_bit_cast of a vector ELEMENT expression reads element 0 with this compiler)
             const int frow = dlo.x, w_prow = dlo.y, w_mask = dlo.z, w_amp = dlo.w, w_pad0 = dhi.z;
             const unsigned flags = (unsigned)dhi.y;
-            const bool skip = (flags & DESC_SKIP) != 0;
-            const bool live = in && frow >= 0 && !skip;
+            const bool skip = in && (flags & DESC_SKIP) != 0;
+            const bool live = in && frow >= 0 && !(flags & DESC_SKIP);
             const bool impulse = (flags & DESC_IMPULSE) != 0;
             const bool direct = DIRECT && (flags & DESC_DIRECT) != 0;
             const bool hit0 = direct || (w_mask & 1);
-            const float a = !live ? 0.f : (impulse ? (hit0 ? __builtin_bit_cast(float, w_amp) : 0.f) : 1.f);      // (a dense buffer wants g itself)
+            const float a = impulse ? (hit0 ? __builtin_bit_cast(float, w_amp) : 0.f) : 1.f;      // (a dense buffer wants g itself)
             const bool dl = live && direct;
             // a DESC_DIRECT hit: g = n . (three rows of the object's (float)(c3 * shape) table), the normal in the descriptor's
-            // spare words (kernels.h)
-            const float *r0 = dl ? g32_obj + (size_t)frow * p.m_pad : (live ? p_grows + (size_t)frow * p.m_pad + col0 : dummy);
+            // spare words (kernels.h); any other hit has ONE row, g = c3 * S from the combine kernel (its other two reads repeat
+            // it with weight 0)
+            const float *r0 = dl ? g32_obj + (size_t)frow * p.m_pad : p_grows + (size_t)(live ? frow : 0) * p.m_pad + col0;
             ptr[0] = (unsigned long long)r0;
             w[0] = dl ? a * __builtin_bit_cast(float, w_prow) : a;
             if constexpr (DIRECT) {
-                ptr[1] = (unsigned long long)(dl ? g32_obj + (size_t)(frow + 1) * p.m_pad : dummy);
-                ptr[2] = (unsigned long long)(dl ? g32_obj + (size_t)(frow + 2) * p.m_pad : dummy);
+                ptr[1] = (unsigned long long)(dl ? r0 + p.m_pad : r0);
+                ptr[2] = (unsigned long long)(dl ? r0 + 2 * (size_t)p.m_pad : r0);
                 w[1] = dl ? a * __builtin_bit_cast(float, w_mask) : 0.f;
                 w[2] = dl ? a * __builtin_bit_cast(float, w_pad0) : 0.f;
             }
-            kind = (skip ? K_SKIP : 0u) | (live && !impulse ? K_DENSE : 0u);
             trow = dhi.x;
             prow = direct ? -1 : w_prow;
+            hit_mask = __ballot(live && (a != 0.f || !impulse));
+            skip_mask = __ballot(skip);
+            dense_mask = __ballot(live && !impulse);
+            // chunk starts in this batch (a handful: scalar), and the transfer row in force when one starts: the last row a
+            // non-skipped buffer before it switched to
+            const int c0 = (base + p.cb - 1) / p.cb;                  // the first chunk that starts at or behind `base`
+            for (int b = c0 * p.cb; b < base + nd; b += p.cb) mark_mask |= 1ull << (b - base);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const unsigned long long set_mask = __ballot(in && !skip && trow != XFER_KEEP);
+            const unsigned long long before = set_mask & below;
+            const int src_lane = before ? 63 - __builtin_clzll(before) : 0;
+            const int got = __shfl(trow, src_lane, 64);
+            if (((mark_mask >> lane) & 1) && col0 == 0)
+                p_xtrow[(size_t)obj * p.n_chunks + c0 + __builtin_popcountll(mark_mask & below)] = before ? got : cur_row;
+            if (set_mask) cur_row = rl(trow, 63 - __builtin_clzll(set_mask));
         }
-        const unsigned long long slow_mask = __ballot((kind & K_DENSE) != 0);
-        const int nd = p.nb - base < 64 ? p.nb - base : 64;
-
-        // ---- pass 2, lane = mode
-        struct Rows { float r[G][NR]; };
-        auto fetch = [&](Rows &R, int j0) {          // rows of buffers j0 .. j0 + G - 1 (lanes beyond the launch hold the last buffer's)
-            static_for<0, G>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                const int j = j0 + i < 64 ? j0 + i : 63;
+        if (PBSO_SCAN_STOP <= 2) { x.x += (float)(hit_mask ^ skip_mask ^ dense_mask ^ mark_mask) + w[0] + (float)trow + (float)prow + (float)ptr[0]; continue; }
+        // ---- (2) the gains of the batch's hits, [buffer][mode] in LDS
+        wave_sync();                                 // (the previous batch's reads are done)
+        {
+            f4 *z = reinterpret_cast<f4 *>(&lds_g[0][0]) + lane;
+            const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < (nd + 3) / 4; ++i) z[64 * i] = zero;
+        }
+        wave_sync();
+        for (unsigned long long m = hit_mask; m;) {
+            int jj[HB];
+#pragma unroll
+            for (int h = 0; h < HB; ++h) {           // the next HB hits (the last one repeated when fewer are left)
+                jj[h] = __builtin_ctzll(m);
+                const unsigned long long rest = m & (m - 1);
+                if (rest) m = rest;
+                else if (h == HB - 1) m = 0;
+            }
+            float r[HB][NR];
+#pragma unroll
+            for (int h = 0; h < HB; ++h)
                 static_for<0, NR>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
-                    R.r[i][k] = rlp(ptr[k], j)[lane];
+                    r[h][k] = rlp(ptr[k], jj[h])[lane];
                 });
-            });
-        };
-        auto mark = [&](int b) {                     // the first buffer of a chunk: its start state and the transfer row in force
-            if (b == next_mark) {
-                (xs + (size_t)chunk_i * p.m_pad)[lane] = x;
-                if (col0 == 0 && lane == 0) p_xtrow[(size_t)obj * p.n_chunks + chunk_i] = cur_row;
-                next_mark += p.cb;
-                chunk_i += 1;
-            }
-        };
-        auto coarse = [&](float gv) {                // x <- A^513 x (+ the impulse's share): q' = q + (P11 - 1) q + P12 d, the small terms last
-            const float qa = fmaf(s11, x.x, x.x);
-            const float da = s21 * x.x;
-            float qn = fmaf(s12, x.y, qa);
-            float dn = fmaf(s22, x.y, da);
-            qn = fmaf(gv, hq, qn);
-            dn = fmaf(gv, hd, dn);
-            x.x = qn;
-            x.y = dn;
-        };
-        auto step_fast = [&](const Rows &R, int j0) {    // a full group without a dense buffer
-            static_for<0, G>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                const int j = j0 + i;
-                mark(base + j);
-                const unsigned kd = (unsigned)rl((int)kind, j);
-                if (kd & K_SKIP) return;             // step() returned before stepping: state (and transfer) untouched
-                const int tr = rl(trow, j);
-                if (tr != XFER_KEEP) cur_row = tr;
-                float gv = rlf(w[0], j) * R.r[i][0];
+#pragma unroll
+            for (int h = 0; h < HB; ++h) {
+                const int j = jj[h];
+                float gv = rlf(w[0], j) * r[h][0];
                 if constexpr (DIRECT) {
-                    gv = fmaf(rlf(w[NR > 1 ? 1 : 0], j), R.r[i][NR > 1 ? 1 : 0], gv);
-                    gv = fmaf(rlf(w[NR > 2 ? 2 : 0], j), R.r[i][NR > 2 ? 2 : 0], gv);
+                    gv = fmaf(rlf(w[NR > 1 ? 1 : 0], j), r[h][NR > 1 ? 1 : 0], gv);
+                    gv = fmaf(rlf(w[NR > 2 ? 2 : 0], j), r[h][NR > 2 ? 2 : 0], gv);
                 }
-                coarse(gv);
-            });
-        };
-        auto step_slow = [&](int j0, int n) {        // any buffers, one at a time (rows loaded on demand)
-            for (int j = j0; j < j0 + n; ++j) {
-                mark(base + j);
-                const unsigned kd = (unsigned)rl((int)kind, j);
-                if (kd & K_SKIP) continue;
-                const int tr = rl(trow, j);
-                if (tr != XFER_KEEP) cur_row = tr;
-                float gv = rlf(w[0], j) * rlp(ptr[0], j)[lane];
-                if constexpr (DIRECT) {
-                    gv = fmaf(rlf(w[NR > 1 ? 1 : 0], j), rlp(ptr[NR > 1 ? 1 : 0], j)[lane], gv);
-                    gv = fmaf(rlf(w[NR > 2 ? 2 : 0], j), rlp(ptr[NR > 2 ? 2 : 0], j)[lane], gv);
-                }
-                if (kd & K_DENSE) {
-                    // dense force profile: every sample, literally (d = eps^2 d - e q + g T_k ; q += d); the row 64 samples at a
-                    // time, one per lane and a batch ahead; sample k reaches the FMA as a scalar operand
-                    const int pr = rl(prow, j);
-                    const float *__restrict__ tprow = p_tprof + (size_t)(pr >= 0 ? pr : 0) * p.b_pad;
-                    auto ldt = [&](int kb) { const int k = kb + (int)lane; return tprow[k < p.frames ? k : p.frames - 1]; };
-                    float tv = ldt(0);
-                    for (int kb = 0; kb < p.frames; kb += 64) {
-                        const float tn = ldt(kb + 64 < p.frames ? kb + 64 : kb);
-                        const int nk = p.frames - kb < 64 ? p.frames - kb : 64;
-                        for (int k = 0; k < nk; ++k) {
-                            const float tk = rlf(tv, k);
-                            float a = nca * x.y;
-                            a = fmaf(ncb, x.x, a);
-                            a = fmaf(gv, tk, a);
-                            x.y = a;
-                            x.x = x.x + a;
-                        }
-                        tv = tn;
-                    }
-                } else {
-                    coarse(gv);
-                }
+                lds_g[j][lane] = gv;
             }
+        }
+        wave_sync();
+        if (PBSO_SCAN_STOP <= 3) { x.x += lds_g[lane][lane]; continue; }
+
+        // ---- (3) the scan, lane = mode
+        // x <- A^513 x + gv A^512 u, two dependent operations deep (a lone wave issues a dependent instruction every ~8 cycles):
+        // q' = (q + (P11 - 1) q) + (P12 d + gv hq), d' = P21 q + (P22 d + gv hd); the impulse's share is off the chain
+        auto coarse = [&](float gv) {
+            const float gq = gv * hq, gd = gv * hd;
+            const float qa = fmaf(s11, x.x, x.x), qb = fmaf(s12, x.y, gq);
+            const float da = s21 * x.x, db = fmaf(s22, x.y, gd);
+            x.x = qa + qb;
+            x.y = da + db;
         };
-        auto step = [&](const Rows &R, int j0) {
-            if (j0 >= nd) return;
+        auto mark = [&]() {                          // the first buffer of a chunk: its start state
+            xs_next[lane] = x;
+            xs_next += p.m_pad;
+        };
+        const unsigned long long slow_mask = skip_mask | dense_mask;
+        for (int j0 = 0; j0 < nd; j0 += G) {
             const int n = nd - j0 < G ? nd - j0 : G;
-            if (PBSO_SCAN_FAST && n == G && ((slow_mask >> j0) & ((1ull << G) - 1)) == 0) step_fast(R, j0);
-            else step_slow(j0, n);
-        };
-        Rows Ra, Rb;
-        fetch(Ra, 0);
-        for (int j0 = 0; j0 < nd; j0 += 2 * G) {
-            fetch(Rb, j0 + G);
-            step(Ra, j0);
-            fetch(Ra, j0 + 2 * G);
-            step(Rb, j0 + G);
+            if (n == G && ((slow_mask >> j0) & ((1ull << G) - 1)) == 0) {
+                float gv[G];
+#pragma unroll
+                for (int i = 0; i < G; ++i) gv[i] = lds_g[j0 + i][lane];
+                const unsigned mm = (unsigned)(mark_mask >> j0) & ((1u << G) - 1u);
+                if (mm == 0) {
+#pragma unroll
+                    for (int i = 0; i < G; ++i) coarse(gv[i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < G; ++i) {
+                        if (mm & (1u << i)) mark();
+                        coarse(gv[i]);
+                    }
+                }
+            } else {
+                for (int j = j0; j < j0 + n; ++j) {
+                    if ((mark_mask >> j) & 1) mark();
+                    if ((skip_mask >> j) & 1) continue;      // step() returned before stepping: state untouched
+                    const float gv = lds_g[j][lane];
+                    if ((dense_mask >> j) & 1) {
+                        // dense force profile: every sample, literally (d = eps^2 d - e q + g T_k ; q += d); the row 64 samples at a
+                        // time, one per lane and a batch ahead; sample k reaches the FMA as a scalar operand
+                        const int pr = rl(prow, j);
+                        const float *__restrict__ tprow = p_tprof + (size_t)(pr >= 0 ? pr : 0) * p.b_pad;
+                        auto ldt = [&](int kb) { const int k = kb + (int)lane; return tprow[k < p.frames ? k : p.frames - 1]; };
+                        float tv = ldt(0);
+                        for (int kb = 0; kb < p.frames; kb += 64) {
+                            const float tn = ldt(kb + 64 < p.frames ? kb + 64 : kb);
+                            const int nk = p.frames - kb < 64 ? p.frames - kb : 64;
+                            for (int k = 0; k < nk; ++k) {
+                                const float tk = rlf(tv, k);
+                                float a = nca * x.y;
+                                a = fmaf(ncb, x.x, a);
+                                a = fmaf(gv, tk, a);
+                                x.y = a;
+                                x.x = x.x + a;
+                            }
+                            tv = tn;
+                        }
+                    } else {
+                        coarse(gv);
+                    }
+                }
+            }
         }
     }
     (p_sq + ubase)[lane] = x.x;
