@@ -265,9 +265,11 @@ Engine::~Engine() {
     d_pc_.release(); d_wtab_.release(); d_ftab_.release(); d_dump_row_.release(); d_xdump_.release(); d_xscale_.release(); d_wtab32_.release();
     d_ar_snaps_.release(); d_ar_vnorm_.release(); d_ar_cbuf_.release(); d_ar_vstate_.release(); d_ar_segcount_.release();
     d_ar_recs_.release(); d_ar_fins_.release();
-    d_arstate_.release(); d_board_.release(); d_teams_.release(); d_split_.release(); d_ts_teams_.release(); d_ts_split_.release(); d_audio_parts_.release();
-    d_audio_.release(); d_qnorm_.release(); d_census_.release();
-    d_scan_.release(); d_xs_.release(); d_xtrow_.release();
+    d_arstate_.release(); d_board_.release(); d_teams_.release(); d_split_.release(); d_ts_teams_.release(); d_ts_split_.release();
+    d_audio_parts_.release(); d_audio_.release(); d_qnorm_.release();
+    d_census_.release();
+    d_scan_.release();
+    for (int i = 0; i < N_SETS; ++i) { d_xs_[i].release(); d_xtrow_[i].release(); }
     for (TcSet &ts : tc_) { ts.d_teams.release(); ts.d_split.release(); }
     for (DevBuf<float> &g : d_grows_) g.release();
     for (int i = 0; i < N_SETS; ++i)
@@ -1823,6 +1825,7 @@ void Engine::build_ar_tables() {
 // over more work), unless the padding to whole waves wastes columns; the chunk length minimises rounds x (length + start-up).
 bool Engine::choose_time_chunks(int nb, int n_dense_rows, int *set, int *cb) const {
     if (!tc_ok_ || !d_scan_.p || (nb < 2 && tc_mode_ <= 0)) return false;
+    if (n_dump_ > 0) return false;                       // (objects that keep their block-start states for a listener mix: the walk in buffer order, as K1p)
     const long long N = (long long)objs_.size();
     const long long capacity = 8LL * n_cus_;             // two 256-register waves per SIMD
     if (tc_mode_ == 0 && (long long)n_dense_rows * 8 > N * nb) return false;
@@ -2051,29 +2054,6 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     const ProjectEvent *d_proj = reinterpret_cast<const ProjectEvent *>(da + o_proj), *d_projd = reinterpret_cast<const ProjectEvent *>(da + o_projd);
     const FfatEvent *d_ffat = reinterpret_cast<const FfatEvent *>(da + o_ffat);
 
-    // K2 -> time-profile rows ; K3 / scatter -> data slots ; K4 -> transfer rows ; combine -> g rows
-    if (device_profiles_ && timed && n_chains > 0) { HIPTRY(hipEventRecord(evq.f0, sp)); evq.has_k2 = true; }
-    if (device_profiles_ && k2_rows_launch_)
-        LAUNCHTRY(launch_force_rows(d_prow, (int)prof_rows_.size(), d_pent, reinterpret_cast<const ArUse *>(da + o_aruse), (int)ar_uses_.size(),
-                                    reinterpret_cast<const ArStream *>(da + o_arstream), reinterpret_cast<const int *>(da + o_arseg),
-                                    (int)seg_stream_.size(), ar_max_segs_, d_arstate_.p, d_ar_snaps_.p, d_ar_vnorm_.p, d_ar_vstate_.p,
-                                    d_ar_segcount_.p, d_ar_cbuf_.p, d_ar_recs_.p, d_ar_fins_.p, ps.d_tprof.p, B_, b_pad_, b_pad_, sp));
-    else if (device_profiles_)
-        LAUNCHTRY(launch_force_profiles(d_chain, n_chains, d_prow, d_pent, d_arstate_.p, ps.d_tprof.p, B_, b_pad_, ar_serial_ ? 1 : 0, k2_prio_, sp));
-    if (evq.has_k2) HIPTRY(hipEventRecord(evq.f1, sp));
-    LAUNCHTRY(launch_scatter_rows(d_stage, d_stage_slot, (int)stage_slot_.size(), d_slots_.p, m_pad_, sp));
-    LAUNCHTRY(launch_modal_project(d_proj, (int)proj_.size(), d_shapes_.p, d_shape_off_.p, d_n_modes_.p, d_slots_.p, m_pad_, sp));
-    LAUNCHTRY(launch_ffat_lookup(d_ffat, (int)ffat_.size(), d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p, d_xfer_.p, m_pad_, sp));
-    // (the combine stays on the preparation stream even when the bank fills the register file: its workgroups
-    //  move in as the bank's retire, so most of it is done when the last one leaves -- queued behind the bank in
-    //  the bank's own stream it would start only then: 0.785 instead of 0.735 ms per step at 1024 x 512)
-    LAUNCHTRY(launch_force_combine(d_row_ptr, d_slot_idx, d_row_obj, n_frows, d_slots_.p, d_c3_.p, grows.p, d_projd, d_shapes_.p,
-                                   d_shape_off_.p, d_n_modes_.p, m_pad_, sp));
-    HIPTRY(hipEventRecord(ev_prep_done_[cur_set_], sp));
-    const auto tsub2 = std::chrono::steady_clock::now();
-
-    // ---- compute stream: K1 after its preparation (and, stream order, after the previous K1)
-    HIPTRY(hipStreamWaitEvent(sk, ev_prep_done_[cur_set_], 0));
     const bool dense_heavy = is_block() && dense_to_k1_ && (long long)n_prows_ * 2 > (long long)N * nb;
     IirParams kp;
     kp.ca = d_ca_.p; kp.cb = d_cb_.p; kp.sq = d_sq_.p; kp.sd = d_sd_.p; kp.ss = d_ss_.p;
@@ -2111,6 +2091,43 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.frames = B_;
     kp.ftab = d_ftab_.p;
     kp.forced_block = (forced_block_ && n_prows_ > 0) ? 1 : 0;      // (the build with the forced block path only when a buffer needs it)
+    // K5: a launch without (many) dense-profile buffers on a chip the scene cannot fill runs the block kernel as (team, chunk of
+    // buffers) workgroups behind a scan of the buffer-start states (kernels_scan.hip)
+    int tc_set = -1, tc_cb = 0;
+    const bool tc_launch = is_block() && !split_always_ && choose_time_chunks(nb, n_prows_, &tc_set, &tc_cb);
+    // K2 -> time-profile rows ; K3 / scatter -> data slots ; K4 -> transfer rows ; combine -> g rows
+    if (device_profiles_ && timed && n_chains > 0) { HIPTRY(hipEventRecord(evq.f0, sp)); evq.has_k2 = true; }
+    if (device_profiles_ && k2_rows_launch_)
+        LAUNCHTRY(launch_force_rows(d_prow, (int)prof_rows_.size(), d_pent, reinterpret_cast<const ArUse *>(da + o_aruse), (int)ar_uses_.size(),
+                                    reinterpret_cast<const ArStream *>(da + o_arstream), reinterpret_cast<const int *>(da + o_arseg),
+                                    (int)seg_stream_.size(), ar_max_segs_, d_arstate_.p, d_ar_snaps_.p, d_ar_vnorm_.p, d_ar_vstate_.p,
+                                    d_ar_segcount_.p, d_ar_cbuf_.p, d_ar_recs_.p, d_ar_fins_.p, ps.d_tprof.p, B_, b_pad_, b_pad_, sp));
+    else if (device_profiles_)
+        LAUNCHTRY(launch_force_profiles(d_chain, n_chains, d_prow, d_pent, d_arstate_.p, ps.d_tprof.p, B_, b_pad_, ar_serial_ ? 1 : 0, k2_prio_, sp));
+    if (evq.has_k2) HIPTRY(hipEventRecord(evq.f1, sp));
+    LAUNCHTRY(launch_scatter_rows(d_stage, d_stage_slot, (int)stage_slot_.size(), d_slots_.p, m_pad_, sp));
+    LAUNCHTRY(launch_modal_project(d_proj, (int)proj_.size(), d_shapes_.p, d_shape_off_.p, d_n_modes_.p, d_slots_.p, m_pad_, sp));
+    LAUNCHTRY(launch_ffat_lookup(d_ffat, (int)ffat_.size(), d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p, d_xfer_.p, m_pad_, sp));
+    // (the combine stays on the preparation stream even when the bank fills the register file: its workgroups
+    //  move in as the bank's retire, so most of it is done when the last one leaves -- queued behind the bank in
+    //  the bank's own stream it would start only then: 0.785 instead of 0.735 ms per step at 1024 x 512)
+    LAUNCHTRY(launch_force_combine(d_row_ptr, d_slot_idx, d_row_obj, n_frows, d_slots_.p, d_c3_.p, grows.p, d_projd, d_shapes_.p,
+                                   d_shape_off_.p, d_n_modes_.p, m_pad_, sp));
+    if (tc_launch) {
+        // The scan hands the state from launch to launch by itself (the chunked bank launches never write it), so it runs HERE, on
+        // the preparation stream, beside the previous launch's oscillator bank -- behind a launch of another kind it waits for
+        // that launch's bank, which wrote the state it starts from.
+        const int n_chunks = (nb + tc_cb - 1) / tc_cb;
+        HIPTRY(d_xs_[cur_set_].ensure((size_t)N * n_chunks * m_pad_ * 2, false, sp));
+        HIPTRY(d_xtrow_[cur_set_].ensure((size_t)N * n_chunks, false, sp));
+        if (!last_launch_tc_ && last_set_ >= 0) HIPTRY(hipStreamWaitEvent(sp, ev_k1_done_[last_set_], 0));
+        LAUNCHTRY(launch_iir_scan(kp, N, d_scan_.p, tc_cb, n_chunks, d_xs_[cur_set_].p, d_xtrow_[cur_set_].p, direct_hits_, sp));
+    }
+    HIPTRY(hipEventRecord(ev_prep_done_[cur_set_], sp));
+    const auto tsub2 = std::chrono::steady_clock::now();
+
+    // ---- compute stream: K1 after its preparation (and, stream order, after the previous K1)
+    HIPTRY(hipStreamWaitEvent(sk, ev_prep_done_[cur_set_], 0));
     if (timed) HIPTRY(hipEventRecord(evq.k0, sk));
     evq.h_bank = host_ms();
     kp.audio_parts = d_audio_parts_.p ? d_audio_parts_.p + (size_t)b0 * B_ : nullptr;
@@ -2132,10 +2149,6 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     // Without the F table of the forced block path (PBSO_FORCED_BLOCK=0) and without qnorm rows they go to K1b as well.
     const bool dense_majority = (long long)n_prows_ * 2 > (long long)N * nb;
     const bool split_dense_ok = k2_rows_launch_ && (desc_.qnorm_mode != PBSO_QNORM_OFF || d_ftab_.p != nullptr);
-    // K5: a launch without (many) dense-profile buffers on a chip the scene cannot fill runs the block kernel as (team, chunk of
-    // buffers) workgroups behind a scan of the buffer-start states (kernels_scan.hip)
-    int tc_set = -1, tc_cb = 0;
-    const bool tc_launch = is_block() && !split_always_ && choose_time_chunks(nb, n_prows_, &tc_set, &tc_cb);
     const bool split_launch = !tc_launch && use_split() && (split_always_ || !dense_majority || split_dense_ok);      // (PBSO_SPLIT=2: always)
     (tc_launch || split_launch || !(dense_heavy || !is_block()) ? tot_block_launches_ : tot_sample_launches_) += 1;
     if (split_launch) tot_split_launches_ += 1;
@@ -2152,13 +2165,9 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     bool used[N_CLASS_STREAMS] = {false, false, false};
     if (tc_launch) {
         TcSet &ts = tc_[tc_set];
-        const int n_chunks = (nb + tc_cb - 1) / tc_cb;
-        HIPTRY(d_xs_.ensure((size_t)N * n_chunks * m_pad_ * 2, false, sk));
-        HIPTRY(d_xtrow_.ensure((size_t)N * n_chunks, false, sk));
-        LAUNCHTRY(launch_iir_scan(kp, N, d_scan_.p, tc_cb, n_chunks, d_xs_.p, d_xtrow_.p, direct_hits_, sk));
         kp.tc_cb = tc_cb;
-        kp.tc_xs = d_xs_.p;
-        kp.tc_xtrow = d_xtrow_.p;
+        kp.tc_xs = d_xs_[cur_set_].p;
+        kp.tc_xtrow = d_xtrow_[cur_set_].p;
         kp.census_stride = ts.n_teams;
         kp.rotate_prio = rotate_prio_ ? 1 : 0;
         for (const SizeClass &c : ts.classes) {
@@ -2217,6 +2226,8 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     if (timed) ev_pending_.push_back(evq);
     else ev_free_.push_back(evq);
     buffers_done_ += nb;
+    last_launch_tc_ = tc_launch;
+    last_set_ = cur_set_;
     cur_set_ = (cur_set_ + 1) % N_SETS;
     hprof_[4] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - last_plan_ms_;
     hprof_[6] += std::chrono::duration<double, std::milli>(tsub1 - tsub0).count();
@@ -2237,6 +2248,7 @@ int Engine::sync() {
 }
 
 int Engine::read_audio(float *out, size_t n) {
+    { int src = sync(); if (src != PBSO_OK) return src; }      // (results come from two streams: the bank's, and the scan's state on the preparation stream)
     if (!last_audio_) return fail(PBSO_ERR_STATE, "no step yet");
     const size_t total = (size_t)objs_.size() * last_nb_ * B_;
     if (n != total) return fail(PBSO_ERR_INVALID, "read_audio size mismatch");
@@ -2245,6 +2257,7 @@ int Engine::read_audio(float *out, size_t n) {
 }
 
 int Engine::read_census(unsigned long long *out, size_t n) {
+    { int src = sync(); if (src != PBSO_OK) return src; }      // (results come from two streams: the bank's, and the scan's state on the preparation stream)
     if (!census_ || !d_census_.p) return fail(PBSO_ERR_STATE, "census not enabled (PBSO_CENSUS=1) or no step yet");
     // (n_teams rows -- or, for an engine that also keeps the table of the kernel of under-filled scenes, that table's rows)
     if (n != (size_t)n_teams_ * CENSUS_WORDS && !(use_split() && n == (size_t)n_ts_teams_ * CENSUS_WORDS))
@@ -2260,6 +2273,7 @@ int Engine::read_emitted(unsigned char *out, size_t n) {
 }
 
 int Engine::read_qnorm(int obj, int buffer, float *out, int n) {
+    { int src = sync(); if (src != PBSO_OK) return src; }      // (results come from two streams: the bank's, and the scan's state on the preparation stream)
     if (desc_.qnorm_mode == PBSO_QNORM_OFF) return fail(PBSO_ERR_STATE, "qnorm_mode is OFF");
     if (!valid_obj(obj) || buffer < 0 || buffer >= last_nb_ || n < 0 || n > m_pad_)
         return fail(PBSO_ERR_INVALID, "read_qnorm arguments");
@@ -2269,6 +2283,7 @@ int Engine::read_qnorm(int obj, int buffer, float *out, int n) {
 }
 
 int Engine::read_state(int obj, double *q1, double *q2, int n) {
+    { int src = sync(); if (src != PBSO_OK) return src; }      // (results come from two streams: the bank's, and the scan's state on the preparation stream)
     if (!finalized_) return fail(PBSO_ERR_STATE, "read_state before finalize");
     if (!valid_obj(obj) || n < 0 || n > m_pad_) return fail(PBSO_ERR_INVALID, "read_state arguments");
     // the arrays hold (scale x state) and the scale (kernels_iir.hip, "scaled state")
@@ -2309,6 +2324,7 @@ int Engine::write_state(int obj, const double *q1, const double *q2, int n) {
 
 // ModalSolver::getLatestTransfer, modal_solver.h:145-147
 int Engine::get_latest_transfer(int obj, double *out) {
+    { int src = sync(); if (src != PBSO_OK) return src; }      // (results come from two streams: the bank's, and the scan's state on the preparation stream)
     if (!finalized_) return fail(PBSO_ERR_STATE, "get_latest_transfer before finalize");
     if (!valid_obj(obj)) return fail(PBSO_ERR_INVALID, "object id");
     const Object &o = objs_[obj];
@@ -2364,6 +2380,7 @@ int Engine::listeners_enable(int obj) {
 
 // out[n_listeners][last_nb * frames]: the last step's audio of `obj` as heard at each position
 int Engine::mix_listeners(int obj, const double *pos, int n_listeners, float *out, size_t n_out) {
+    { int src = sync(); if (src != PBSO_OK) return src; }      // (results come from two streams: the bank's, and the scan's state on the preparation stream)
     HIPTRY(hipSetDevice(desc_.device));
     if (!finalized_) return fail(PBSO_ERR_STATE, "mix_listeners before finalize");
     if (!valid_obj(obj) || n_listeners <= 0 || !pos || !out) return fail(PBSO_ERR_INVALID, "mix_listeners arguments");

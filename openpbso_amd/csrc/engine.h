@@ -286,8 +286,11 @@ private:
     bool tc_ok_ = false;
     int tc_mode_ = 0;                                    // pbso_engine_desc::time_chunks: 0 auto, < 0 never, n > 0 chunks of n buffers always
     DevBuf<float> d_scan_;                               // 6 planes [n_obj][m_pad]: A^513 (P11 - 1, P12, P21, P22), A^512 u
-    DevBuf<float> d_xs_;                                 // [n_obj][n_chunks][m_pad] pairs: the state at the first buffer of every chunk
-    DevBuf<int> d_xtrow_;                                // [n_obj][n_chunks] the transfer row in force there
+    // per plan set (the scan of launch k + 1 runs beside the bank of launch k):
+    DevBuf<float> d_xs_[N_SETS];                         // [n_obj][n_chunks][m_pad] pairs: the state at the first buffer of every chunk
+    DevBuf<int> d_xtrow_[N_SETS];                        // [n_obj][n_chunks] the transfer row in force there
+    bool last_launch_tc_ = false;                        // the previous launch was time-chunked (its bank did not write the state)
+    int last_set_ = -1;
     int64_t tot_tc_launches_ = 0;
     bool choose_time_chunks(int nb, int n_dense_rows, int *set, int *cb) const;
     int n_cus_ = 256;                                     // hipDeviceProp_t::multiProcessorCount of the engine's device

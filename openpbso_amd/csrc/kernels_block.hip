@@ -1135,7 +1135,7 @@ __global__ __launch_bounds__(64) void listener_mix_kernel(
             acc[l] = f4{0.f, 0.f, 0.f, 0.f};
             y0[l] = 0.f;
         }
-        for (int slab = 0; slab < m_pad / 64; ++slab) {
+        for (int slab = 0; slab < (n_modes + 63) / 64; ++slab) {     // (columns behind the object's waves are never written: m_pad may be wider than its teams)
             const int m = slab * 64 + lane;
             __syncthreads();
             // scale < 0: the buffer was skipped (clearAllForces, modal_solver.h:186-189): silence, and the state rows were

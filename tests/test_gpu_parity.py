@@ -500,9 +500,13 @@ def test_projection_bit_exact_through_state(monkeypatch, direct_hits):
         assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max()         # f32 rounding of three products, through 4 buffers of recurrence
 
 
-def test_size_independent_properties_full_size_object():
+@pytest.mark.parametrize("time_chunks", [-1, 1])
+def test_size_independent_properties_full_size_object(time_chunks, monkeypatch):
     """Properties that need no oracle: determinism, batch-split invariance,
-    time-shift invariance (bit-exact) and exact power-of-two linearity."""
+    time-shift invariance (bit-exact) and exact power-of-two linearity.  With the walk in buffer order (time_chunks = -1) and
+    with one buffer per chunk (1): both run the same arithmetic however a step is cut (the engine's own choice cuts time only
+    where that pays, so a one-buffer launch and a 16-buffer launch differ in the last bits)."""
+    monkeypatch.setenv("PBSO_TIME_CHUNKS", str(time_chunks))
     n_obj, n_modes, nb = 8, 512, 16
     rng = np.random.default_rng(77)
     objs = [ObjSpec(synth.eigenvalues(n_modes, synth.seed_for(4, i))) for i in range(n_obj)]
