@@ -87,6 +87,11 @@ def parse(argv=None):
                     help="impulses: Poisson PointForce hits (headline, configs[1]/[3]); scraping: sustained "
                          "AutoregressiveForce with one face hit per buffer (configs[4]); listener: impulses + FFAT maps "
                          "and a new listener position every buffer (configs[2])")
+    ap.add_argument("--weak", action="store_true",
+                    help="N > 1: make the weak-scaling run (--objects per GPU) the headline; default for N > 1 is the configuration as written "
+                         "(--objects in total, BASELINE configs[3]) with the weak run as the side leg")
+    ap.add_argument("--no-strong-share", action="store_true",
+                    help="one GPU: skip the strong-scaling proxy (the per-rank shares objects / 2, 4, 8 measured on this GPU)")
     ap.add_argument("--strong", action="store_true",
                     help="make the strong-scaling leg the headline: --objects is the TOTAL, split over the ranks")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the nested strong-scaling measurement")
@@ -305,17 +310,36 @@ def measure(args, ctx, global_ids, want_parity):
     total_buffers = n_steps_all * args.buffers
     lam, shapes, scripts = build_inputs(args, global_ids, total_buffers)
     stream = ctx["stream"].cuda_stream
-    eng = Engine(device=ctx["dev_index"],
-                 form={"block": capi.FORM_BLOCK, "block_bf16": capi.FORM_BLOCK_BF16, "velocity": capi.FORM_VELOCITY,
-                       "direct": capi.FORM_DIRECT}[args.form],
-                 qnorm={"sample": capi.QNORM_ALL, "closed": capi.QNORM_CLOSED, "off": capi.QNORM_OFF}[
-                     "off" if args.no_qnorm else args.qnorm],
-                 modes_per_lane=args.modes_per_lane, stream=stream)
-    for i, gid in enumerate(global_ids):
-        eng.add_object(lam[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
-        if args.scenario == "listener":
+    form_c = {"block": capi.FORM_BLOCK, "block_bf16": capi.FORM_BLOCK_BF16, "velocity": capi.FORM_VELOCITY, "direct": capi.FORM_DIRECT}[args.form]
+    qnorm_c = {"sample": capi.QNORM_ALL, "closed": capi.QNORM_CLOSED, "off": capi.QNORM_OFF}["off" if args.no_qnorm else args.qnorm]
+    # A leg with an RCCL collective runs through the C ABI's DEVICE GROUP (include/openpbso_amd.h: one engine per rank, the
+    # gather called from C++ on its own stream, double-buffered); torch.distributed only starts the ranks, carries the
+    # group's unique id and the barrier around the timed region.  Legs without a collective, and the gloo stand-in of the
+    # one-GPU tests, use the engine directly.
+    use_group = bool(ctx["use_dist"] and backend == "nccl" and (world > 1 or os.environ.get("PBSO_BENCH_GATHER_SELF") == "1")
+                     and not args.no_gather and not ctx.get("leg_without_gather"))
+    grp = None
+    if use_group:
+        from openpbso_amd.group import Group, unique_id
+        ident = [unique_id() if (rank == 0 and world > 1) else None]
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0, device=ctx["coll_dev"])
+        counts_all = ctx.get("counts") or [n_obj]
+        grp = Group([ctx["dev_index"]], world_size=world, first_rank=rank, unique_id=ident[0], form=form_c, qnorm=qnorm_c,
+                    modes_per_lane=args.modes_per_lane)
+        grp.plan([args.modes] * int(sum(counts_all)))
+        assert grp.span(rank) == (global_ids[0], global_ids[-1] + 1), (grp.span(rank), global_ids[0], global_ids[-1])
+        for i, gid in enumerate(global_ids):
+            grp.add_object(gid, lam[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
+        eng = grp.engine(rank)
+    else:
+        eng = Engine(device=ctx["dev_index"], form=form_c, qnorm=qnorm_c, modes_per_lane=args.modes_per_lane, stream=stream)
+        for i, gid in enumerate(global_ids):
+            eng.add_object(lam[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
+    if args.scenario == "listener":
+        for i, gid in enumerate(global_ids):
             eng.set_ffat_maps(i, scripts[i]["maps"])
-    eng.finalize()
+    (grp or eng).finalize()
     n_hits = 0
     feed_obj, feed_vid, feed_vn, feed_t, feed_bary = [], [], [], [], []
     for i, gid in enumerate(global_ids):
@@ -390,8 +414,9 @@ def measure(args, ctx, global_ids, want_parity):
     # rank, and on a one-rank group nothing is left to do at all (the copy kernel used to fight the oscillator bank for CUs: 0.06 ms
     # of every step exposed).  The gather-to-root and mix legs keep separate audio buffers.
     in_place = bool(do_gather and not do_mix and not do_root and backend == "nccl")
+    in_place = in_place and not use_group
     gathered = ([(torch.zeros if in_place else torch.empty)((world * cmax, nb * B), dtype=torch.float32, device=dev) for _ in range(n_buf)]
-                if do_gather and not do_mix and (not do_root or rank == 0) else None)
+                if do_gather and not use_group and not do_mix and (not do_root or rank == 0) else None)
     audios = ([g[rank * cmax:(rank + 1) * cmax] for g in gathered] if in_place
               else [torch.zeros((cmax, nb * B), dtype=torch.float32, device=dev) for _ in range(n_buf)])
     mixes = [torch.zeros(nb * B, dtype=torch.float32, device=dev) for _ in range(n_buf)] if do_mix else None
@@ -414,7 +439,17 @@ def measure(args, ctx, global_ids, want_parity):
 
     feed(0)
 
+    gather_mode = capi.GATHER_MIX if do_mix else (capi.GATHER_ROOT if do_root else capi.GATHER_ALL)
+
     def one_step(k, capture=False):
+        if use_group:
+            n_calls[0] += 1
+            grp.step(nb)                               # (waits, on the device, for the collective that last read this target)
+            feed(k + 1)
+            if capture:
+                captured[0] = torch.from_numpy(eng.audio_rows(rows))
+            grp.gather(gather_mode)                    # asynchronous: runs beside the next step's oscillator bank
+            return
         slot = n_calls[0] % n_buf
         n_calls[0] += 1
         if pending[slot] is not None:
@@ -448,6 +483,8 @@ def measure(args, ctx, global_ids, want_parity):
                 gathered[slot].copy_(gather_audio(audios[slot].cpu()))
 
     def drain():
+        if use_group:
+            grp.sync()
         for i, w in enumerate(pending):
             if w is not None:
                 w.wait()
@@ -476,6 +513,15 @@ def measure(args, ctx, global_ids, want_parity):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     info1 = eng.info()
+    if use_group:
+        # the gathered result holds this rank's rows where the engine wrote them, and finite values everywhere
+        p_res, r_rows, r_row = grp.result_ptr(rank)
+        assert p_res and r_row == nb * B and r_rows == (1 if do_mix else (world * cmax if (not do_root or rank == 0) else cmax))
+        sample = grp.result(rank)
+        assert np.isfinite(sample).all()
+        if not do_mix:
+            mine = sample[rank * cmax:rank * cmax + n_obj] if (not do_root or rank == 0) else sample[:n_obj]
+            assert np.array_equal(mine[[0, n_obj - 1]], eng.audio_rows([0, n_obj - 1]))
     assert all(torch.isfinite(a).all() for a in audios)
     if do_mix:
         assert all(torch.isfinite(x).all() for x in mixes)
@@ -525,7 +571,8 @@ def measure(args, ctx, global_ids, want_parity):
             "pass": bool((mx <= TOL_MAX).all() and (l2 <= TOL_L2).all()),
         }
     res["_cpu_inputs"] = (lam, shapes, scripts)
-    eng.close()
+    res["collective_by"] = "pbso_group (C ABI: RCCL called from C++)" if use_group else ("torch.distributed" if do_gather else None)
+    (grp or eng).close()
     return res
 
 
@@ -598,7 +645,9 @@ def main():
     weak_ids = list(range(rank * args.objects, (rank + 1) * args.objects))
     spans = [shard_by_modes([args.modes] * args.objects, world, r) for r in range(world)]
     strong_ids = list(range(*spans[rank]))
-    order = ["strong", "weak"] if args.strong else ["weak", "strong"]
+    # N > 1: the headline is the configuration AS WRITTEN -- --objects in total, sharded (BASELINE configs[3]: "strong") -- and the
+    # run with --objects per GPU is the side leg ("weak"); --weak swaps them
+    order = ["weak", "strong"] if args.weak and not args.strong else ["strong", "weak"]
     if world == 1:
         order = ["weak"]                               # one rank: the two legs are the same run
     elif args.no_strong:
@@ -620,6 +669,20 @@ def main():
         a2.form = second_form = "block_bf16" if args.form == "block" else "block"
         ctx["counts"] = [args.objects]
         second = measure(a2, ctx, weak_ids, want_parity=(not args.no_parity and rank == 0))
+    # one GPU: the strong-scaling PROXY.  Objects are independent (modal_solver.h:100-126), so the per-rank compute of the
+    # 2 / 4 / 8-GPU run of this configuration IS this GPU stepping objects / N of them: measured here, each with its own
+    # oracle check, next to the efficiency it implies (this run's ms_per_step / N / the share's ms_per_step; the gather is extra)
+    shares = []
+    if world == 1 and not args.no_strong_share and args.scenario == "impulses" and args.objects >= 16:
+        import copy
+        for n_ranks in (2, 4, 8):
+            if args.objects % n_ranks:
+                continue
+            a3 = copy.copy(args)
+            a3.objects = args.objects // n_ranks
+            ctx["counts"] = [a3.objects]
+            shares.append((n_ranks, a3.objects, measure(a3, ctx, list(range(a3.objects)), want_parity=(not args.no_parity and rank == 0))))
+        ctx["counts"] = [args.objects]
     # what the collective costs: the head leg once more with the all-gather left out, with a gather to rank 0 only
     # (send / receive) and with the reduce a consumer of ONE mixed stream needs (reported beside it, never as `value`)
     bare = mixed = rooted = None
@@ -658,9 +721,10 @@ def main():
             # (a block-form engine may run launches that are mostly dense-profile buffers on the per-sample kernel)
             block = r["form_run"] in (0, 3) and info["total_block_launches"] >= info["total_sample_launches"]
             bf16 = block and r["form_run"] == 3
-            # an under-filled f32 engine runs on the pipeline kernel K1p (kernels_pipe.hip; PBSO_SPLIT_KERNEL=time: K1s)
+            # a small scene whose launches are mostly dense-profile buffers runs on the pipeline kernel K1p (kernels_pipe.hip); other
+            # small scenes run the block kernel cut along the time axis behind a scan of buffer-start states (K5, kernels_scan.hip)
             small = block and 2 * info.get("total_split_launches", 0) > info["total_block_launches"]
-            small_kernel = "iir_split_kernel" if os.environ.get("PBSO_SPLIT_KERNEL") == "time" else "iir_pipe_kernel"
+            small_kernel = "iir_pipe_kernel"
             dense = args.scenario == "scraping"
             per_s = 1.0 / (k_ms * 1e-3)
             if block and not bf16 and not dense:
@@ -754,8 +818,11 @@ def main():
                             + (f", {coll_txt} all-gather of the audio buffers inside the timed region" if m["gather"] else ""),
                 "scenario": args.scenario, "objects_per_gpu": m["n_local"], "modes": M, "buffers_per_step": nb, "frames_per_buffer": B,
                 "hits": m["n_hits"], "modes_per_lane": info["modes_per_lane"], "waves_per_object": info["waves_per_object"],
+                "objects_total": hn["objects_total"],
+                "time_chunked_launches": info.get("total_time_chunk_launches", 0), "bank_launches": info["total_block_launches"] + info["total_sample_launches"],
                 "recurrence_form": args.form, "gather": m["gather"], "group_ranks": rccl_ranks, "rccl_ranks": rccl_ranks if backend == "nccl" else None,
                 "backend": backend if use_dist else None,
+                "collective_by": m.get("collective_by"),
                 "host_planner_threads": int(os.environ["PBSO_PLAN_THREADS"]), "host_cores": host_cores(), "parallelism": f"object-sharded x{world}",
                 "launched_by": "bench.py" if os.environ.get("PBSO_BENCH_SPAWNED") else ("torch.distributed.run" if use_dist else "single process"),
             },
@@ -814,6 +881,24 @@ def main():
             }
             if "parity" in second and not second["parity"]["pass"]:
                 rc = 3
+        if shares:
+            rows_s = []
+            for n_ranks, n_o, r in shares:
+                ln = leg_numbers("strong", r)
+                rows_s.append({"n_gpus": n_ranks, "objects": n_o, "ms_per_step": ln["ms_per_step"], "kernel_ms": r["kernel_ms"],
+                               "realtime_x": ln["realtime_x"],
+                               "implied_efficiency_at_N": hn["ms_per_step"] / n_ranks / ln["ms_per_step"],
+                               "time_chunked_launches": r["info"].get("total_time_chunk_launches", 0),
+                               "bank_launches": r["info"]["total_block_launches"] + r["info"]["total_sample_launches"],
+                               "max_err": r.get("parity", {}).get("max_err"), "parity_pass": r.get("parity", {}).get("pass")})
+                if "parity" in r and not r["parity"]["pass"]:
+                    rc = 3
+            out["strong_share"] = {
+                "shares": rows_s,
+                "note": "strong-scaling proxy measured on THIS GPU: objects are independent, so a rank of the N-GPU run of this configuration "
+                        "steps objects / N of them -- this is that rank's compute, gather not included; implied_efficiency_at_N = "
+                        "(this line's ms_per_step / N) / the share's ms_per_step.  Shares that leave SIMDs idle run the block kernel cut "
+                        "along the time axis (K5: time_chunked_launches)"}
         if mixed is not None:
             out["mix"] = dict(leg_numbers(head, mixed), scaling=head, collective="all_reduce(sum) of one mixed row per rank",
                               bytes_per_rank=nb * B * 4,

@@ -291,6 +291,8 @@ int pbso_sync(pbso_engine *e);
  * the reference's step() returned early without a buffer (clearAllForces,
  * modal_solver.h:186-189); those samples are 0.                               */
 int pbso_read_audio(pbso_engine *e, float *host_out, size_t n_floats);
+/* the rows of some objects only: host_out[n_rows][n_buffers * frames_per_buffer] */
+int pbso_read_audio_rows(pbso_engine *e, const int *object_ids, int n_rows, float *host_out);
 int pbso_read_emitted(pbso_engine *e, unsigned char *host_out, size_t n);
 /* getQBufferNorm (modal_solver.h:153-159) for (object, buffer) of the last step */
 int pbso_read_qnorm(pbso_engine *e, int object_id, int buffer, float *host_out, int n);
@@ -302,6 +304,68 @@ int pbso_read_state(pbso_engine *e, int object_id, double *q1, double *q2, int n
  * a resumed run re-sends its pending messages.  Waits for the launches in flight.                              */
 int pbso_write_state(pbso_engine *e, int object_id, const double *q1, const double *q2, int n);
 void *pbso_audio_device_ptr(pbso_engine *e);
+
+/* Sum over the engine's objects of the LAST step's audio, on the device, in object order (deterministic):
+ * d_out[n_buffers * frames_per_buffer] fp32 (a device pointer).  What a consumer of ONE mixed stream plays when the
+ * scene's objects sound together (the reference mixes nothing: one ModalSolver, one PortAudio stream,
+ * tools/real_time_modal_sound.cpp:192-212); also the per-rank half of PBSO_GATHER_MIX below.  Asynchronous on the engine's stream. */
+int pbso_mix_objects(pbso_engine *e, void *d_out);
+
+/* --- device group ("create/destroy engine (sample rate, buffer size 513, device list)", 8(e)) -------------
+ * Objects are independent -- every ModalSolver owns its integrator state, force list and maps, modal_solver.h:100-126 -- so
+ * a job of many objects shards over the GPUs of a node with no exchange while stepping: each RANK (one GPU, one engine) owns a
+ * contiguous block of objects, balanced by the sum of modes.  RCCL over xGMI is used only to gather finished audio buffers,
+ * called from here (C++), not from a Python launcher: one process may drive several GPUs (devices[]), or one process per GPU
+ * joins a job of world_size ranks through a shared unique id (ncclCommInitRank).  librccl is loaded when the first group
+ * with more than one rank is created; an engine alone never needs it.                                                    */
+typedef struct pbso_group pbso_group;
+enum pbso_gather_mode {
+    PBSO_GATHER_ALL = 1,      /* every rank receives every object's buffers: ncclAllGather, in place (each engine writes its buffers
+                                 straight into its slice of the gather target) */
+    PBSO_GATHER_ROOT = 2,     /* only rank 0 receives them: ncclSend / ncclRecv */
+    PBSO_GATHER_MIX = 3       /* the consumer wants ONE mixed stream: every rank sums its objects' buffers on the device
+                                 (pbso_mix_objects) and the ranks all-reduce n_buffers * 513 floats */
+};
+#define PBSO_GROUP_ID_BYTES 128
+typedef struct pbso_group_desc {
+    int abi_version;          /* PBSO_ABI_VERSION */
+    const int *devices;       /* HIP ordinals THIS process drives: one rank (engine) each */
+    int n_devices;
+    int world_size;           /* ranks of the whole job; 0 -> n_devices (a single process) */
+    int first_rank;           /* rank of devices[0]; this process owns ranks first_rank .. first_rank + n_devices - 1 */
+    const void *unique_id;    /* world_size > n_devices: the PBSO_GROUP_ID_BYTES bytes pbso_group_unique_id() gave ONE process,
+                                 handed to all of them by the launcher (a file, an environment variable, a store) */
+    pbso_engine_desc engine;  /* settings of every engine; `device` and `stream` are the group's */
+} pbso_group_desc;
+int pbso_group_unique_id(void *out_bytes);
+int pbso_group_create(const pbso_group_desc *d, pbso_group **out);
+void pbso_group_destroy(pbso_group *g);
+const char *pbso_group_last_error(const pbso_group *g);
+/* the job: mode counts of ALL its objects, the same list in every process.  Computes the shards -- contiguous blocks whose cut
+ * points are the object boundaries nearest to the ideal prefix sums of the mode counts.                                    */
+int pbso_group_plan(pbso_group *g, const int *modes_per_object, int n_objects);
+/* the rule by itself (no group, no GPU): cuts[world_size + 1], rank r owns ids [cuts[r], cuts[r + 1]) */
+int pbso_shard_by_modes(const int *modes_per_object, int n_objects, int world_size, int *cuts);
+int pbso_group_rank_span(pbso_group *g, int rank, int *lo, int *hi);          /* global ids [lo, hi) of a rank */
+int pbso_group_owner(pbso_group *g, int global_id, int *rank, int *local_id);
+/* BuildSolver for object global_id (pbso_add_object on its owner), in ascending id order; ids of ranks in OTHER processes are
+ * accepted and ignored, so every process may run the same loop over the job's objects.                                    */
+int pbso_group_add_object(pbso_group *g, int global_id, const pbso_object_desc *d);
+int pbso_group_finalize(pbso_group *g);
+pbso_engine *pbso_group_engine(pbso_group *g, int rank);                      /* NULL for a rank of another process */
+/* pbso_enqueue_force on the object's owner (1 / 0 / < 0); an object of another process: 1, nothing done (its owner does it) */
+int pbso_group_enqueue_force(pbso_group *g, int global_id, const pbso_force_msg *m, int64_t not_before);
+/* ModalSolver::step n_buffers times on every local rank; each engine writes into its slice of the group's gather target
+ * (two targets used in turn: the gather of step k runs beside the oscillator bank of step k + 1)                          */
+int pbso_group_step(pbso_group *g, int n_buffers);
+/* the collective for the LAST step, asynchronous (its own stream per rank, ordered behind the step); enum pbso_gather_mode  */
+int pbso_group_gather(pbso_group *g, int mode);
+int pbso_group_sync(pbso_group *g);
+/* the last gather's result on a local rank, a device pointer: ALL -> [world_size * rows_per_rank][n_buffers * 513] (rank r's
+ * objects from row r * rows_per_rank; shards smaller than the largest are padded with silent rows), ROOT -> the same on rank 0
+ * and the rank's own rows elsewhere, MIX -> [n_buffers * 513].  rows / row_floats (may be NULL) receive the shape.          */
+void *pbso_group_result_device_ptr(pbso_group *g, int rank, size_t *rows, size_t *row_floats);
+int pbso_group_read_result(pbso_group *g, int rank, float *host_out, size_t n_floats);   /* that buffer, synchronously */
 
 /* PaModalCallback body (tools/real_time_modal_sound.cpp:207-210): mono sound
  * -> interleaved stereo float32 scaled by 1e-10.                              */

@@ -26,7 +26,19 @@ EXPORTS = [
     "pbso_read_audio", "pbso_read_emitted", "pbso_read_qnorm", "pbso_read_state", "pbso_write_state",
     "pbso_audio_device_ptr", "pbso_pa_convert", "pbso_get_info",
     "pbso_modes_read", "pbso_num_modes_audible", "pbso_material_read", "pbso_free", "pbso_read_census", "pbso_obj_read",
+    "pbso_mix_objects", "pbso_read_audio_rows",
+    # the device group (one engine per GPU, RCCL gather called from C++)
+    "pbso_group_unique_id", "pbso_group_create", "pbso_group_destroy", "pbso_group_last_error", "pbso_group_plan",
+    "pbso_group_rank_span", "pbso_group_owner", "pbso_group_add_object", "pbso_group_finalize", "pbso_group_engine",
+    "pbso_group_enqueue_force", "pbso_group_step", "pbso_group_gather", "pbso_group_sync", "pbso_group_result_device_ptr",
+    "pbso_group_read_result", "pbso_shard_by_modes",
 ]
+GATHER_ALL, GATHER_ROOT, GATHER_MIX = 1, 2, 3
+GROUP_ID_BYTES = 128
+
+
+class GroupDesc(C.Structure):
+    pass          # (fields follow EngineDesc: set below)
 
 
 class EngineDesc(C.Structure):
@@ -78,6 +90,9 @@ class EngineInfo(C.Structure):
                 ("total_timed_launches", C.c_int64), ("total_split_launches", C.c_int64),
                 ("total_time_chunk_launches", C.c_int64)]
 
+
+GroupDesc._fields_ = [("abi_version", C.c_int), ("devices", C.POINTER(C.c_int)), ("n_devices", C.c_int), ("world_size", C.c_int),
+                      ("first_rank", C.c_int), ("unique_id", C.c_void_p), ("engine", EngineDesc)]
 
 _lib = None
 
@@ -141,5 +156,28 @@ def lib():
     l.pbso_read_census.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t]
     l.pbso_free.argtypes = [vp]
     l.pbso_free.restype = None
+    l.pbso_mix_objects.argtypes = [vp, vp]
+    l.pbso_read_audio_rows.argtypes = [vp, ip, C.c_int, C.POINTER(C.c_float)]
+    l.pbso_shard_by_modes.argtypes = [ip, C.c_int, C.c_int, ip]
+    l.pbso_group_unique_id.argtypes = [vp]
+    l.pbso_group_create.argtypes = [C.POINTER(GroupDesc), C.POINTER(vp)]
+    l.pbso_group_destroy.argtypes = [vp]
+    l.pbso_group_destroy.restype = None
+    l.pbso_group_last_error.argtypes = [vp]
+    l.pbso_group_last_error.restype = C.c_char_p
+    l.pbso_group_plan.argtypes = [vp, ip, C.c_int]
+    l.pbso_group_rank_span.argtypes = [vp, C.c_int, ip, ip]
+    l.pbso_group_owner.argtypes = [vp, C.c_int, ip, ip]
+    l.pbso_group_add_object.argtypes = [vp, C.c_int, C.POINTER(ObjectDesc)]
+    l.pbso_group_finalize.argtypes = [vp]
+    l.pbso_group_engine.argtypes = [vp, C.c_int]
+    l.pbso_group_engine.restype = vp
+    l.pbso_group_enqueue_force.argtypes = [vp, C.c_int, C.POINTER(ForceMsg), C.c_int64]
+    l.pbso_group_step.argtypes = [vp, C.c_int]
+    l.pbso_group_gather.argtypes = [vp, C.c_int]
+    l.pbso_group_sync.argtypes = [vp]
+    l.pbso_group_result_device_ptr.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    l.pbso_group_result_device_ptr.restype = vp
+    l.pbso_group_read_result.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_size_t]
     _lib = l
     return l

@@ -363,6 +363,20 @@ int pbso_step_into(pbso_engine *e, int n_buffers, void *d_audio) {
     GUARD_END(e)
 }
 
+int pbso_read_audio_rows(pbso_engine *e, const int *object_ids, int n_rows, float *host_out) {
+    NEED(e);
+    GUARD_BEGIN
+    return e->impl->read_audio_rows(object_ids, n_rows, host_out);
+    GUARD_END(e)
+}
+
+int pbso_mix_objects(pbso_engine *e, void *d_out) {
+    NEED(e);
+    GUARD_BEGIN
+    return e->impl->mix_objects(d_out);
+    GUARD_END(e)
+}
+
 int pbso_sync(pbso_engine *e) {
     NEED(e);
     GUARD_BEGIN

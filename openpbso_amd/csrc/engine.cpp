@@ -266,7 +266,7 @@ Engine::~Engine() {
     d_ar_snaps_.release(); d_ar_vnorm_.release(); d_ar_cbuf_.release(); d_ar_vstate_.release(); d_ar_segcount_.release();
     d_ar_recs_.release(); d_ar_fins_.release();
     d_arstate_.release(); d_board_.release(); d_teams_.release(); d_split_.release(); d_ts_teams_.release(); d_ts_split_.release();
-    d_audio_parts_.release(); d_audio_.release(); d_qnorm_.release();
+    d_audio_parts_.release(); d_audio_.release(); d_qnorm_.release(); d_mix_parts_.release();
     d_census_.release();
     d_scan_.release();
     for (int i = 0; i < N_SETS; ++i) { d_xs_[i].release(); d_xtrow_[i].release(); }
@@ -2256,6 +2256,19 @@ int Engine::read_audio(float *out, size_t n) {
     return sync();
 }
 
+// some objects' rows of the last step's audio: out[n_rows][n_buffers * B]
+int Engine::read_audio_rows(const int *rows, int n_rows, float *out) {
+    if (!last_audio_) return fail(PBSO_ERR_STATE, "no step yet");
+    if (n_rows < 0 || (n_rows > 0 && (!rows || !out))) return fail(PBSO_ERR_INVALID, "read_audio_rows arguments");
+    { int src = sync(); if (src != PBSO_OK) return src; }
+    const size_t row = (size_t)last_nb_ * B_;
+    for (int i = 0; i < n_rows; ++i) {
+        if (!valid_obj(rows[i])) return fail(PBSO_ERR_INVALID, "read_audio_rows: object id out of range");
+        HIPTRY(hipMemcpy(out + (size_t)i * row, last_audio_ + (size_t)rows[i] * row, row * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return PBSO_OK;
+}
+
 int Engine::read_census(unsigned long long *out, size_t n) {
     { int src = sync(); if (src != PBSO_OK) return src; }      // (results come from two streams: the bank's, and the scan's state on the preparation stream)
     if (!census_ || !d_census_.p) return fail(PBSO_ERR_STATE, "census not enabled (PBSO_CENSUS=1) or no step yet");
@@ -2447,6 +2460,18 @@ int Engine::mix_listeners(int obj, const double *pos, int n_listeners, float *ou
     rows.release();
     dout.release();
     return rc;
+}
+
+// The step's audio summed over the objects, on the device, in a fixed order (what one output stream plays when the scene's
+// objects sound together; the per-rank half of the device group's PBSO_GATHER_MIX).  Asynchronous on the engine's stream.
+int Engine::mix_objects(void *d_out) {
+    if (!last_audio_ || !d_out) return fail(PBSO_ERR_STATE, "mix_objects: no step yet (or a null output)");
+    HIPTRY(hipSetDevice(desc_.device));
+    const int N = (int)objs_.size();
+    const long long n = (long long)last_nb_ * B_;
+    HIPTRY(d_mix_parts_.ensure((size_t)mix_objects_groups(N) * n, false, stream_));
+    LAUNCHTRY(launch_mix_objects(last_audio_, N, n, n, d_mix_parts_.p, (float *)d_out, stream_));
+    return PBSO_OK;
 }
 
 int Engine::object_n_maps(int obj) {

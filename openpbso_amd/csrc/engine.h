@@ -183,6 +183,7 @@ public:
     int compute_transfer_batch(int obj, const double *pos, int n_pos, double *out, int out_cols);
     int listeners_enable(int obj);
     int mix_listeners(int obj, const double *pos, int n_listeners, float *out, size_t n_out);
+    int mix_objects(void *d_out);
     int object_n_maps(int obj);
     int set_use_transfer(int obj, int use, int64_t not_before);
     int get_latest_transfer(int obj, double *out);
@@ -190,6 +191,7 @@ public:
     int step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_id);   // one launch of at most chunk_buffers_ buffers
     int sync();
     int read_audio(float *out, size_t n);
+    int read_audio_rows(const int *rows, int n_rows, float *out);
     int read_emitted(unsigned char *out, size_t n);
     int read_qnorm(int obj, int buffer, float *out, int n);
     int read_state(int obj, double *q1, double *q2, int n);
@@ -325,6 +327,7 @@ private:
     DevBuf<double> d_slots_;                             // [n_slots][m_pad] ForceMessage::data rows
     DevBuf<double> d_xfer_;                              // [n_obj + scratch][m_pad]
     DevBuf<float> d_audio_, d_qnorm_;
+    DevBuf<float> d_mix_parts_;                          // pbso_mix_objects: partial rows of the object groups
     DevBuf<unsigned long long> d_census_;                // PBSO_CENSUS=1: per-workgroup placement/timing
     bool census_ = false;
     int rotate_prio_ = 2;                                // PBSO_ROTATE_PRIO: 0 off, 1 rotation, 2 rotation + per-CU progress feedback

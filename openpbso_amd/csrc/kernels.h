@@ -255,4 +255,8 @@ int launch_sum_parts_copy_rows(const SplitObj *split, int n_split, const float *
 int launch_copy_rows(const int *src_row, const int *dst_row, int n, double *rows, int m_pad,
                      hipStream_t stream);
 
+// pbso_mix_objects: out[i] = sum over the n_obj rows of audio, i < n (rows `stride` apart); parts: mix_objects_groups(n_obj) x n floats
+int mix_objects_groups(int n_obj);
+int launch_mix_objects(const float *audio, int n_obj, long long stride, long long n, float *parts, float *out, hipStream_t stream);
+
 }  // namespace pbso

@@ -1056,4 +1056,41 @@ int launch_sum_parts_copy_rows(const SplitObj *split, int n_split, const float *
     return (int)hipGetLastError();
 }
 
+// ---- sum over objects of a step's audio (pbso_mix_objects): out[i] = sum_o audio[o][i], two stages of fixed order --
+// groups of MIX_GROUP consecutive objects are summed side by side (one workgroup per group and 1024 samples), then the
+// groups' partial rows in group order: the result does not depend on the launch shape.  HBM-bound: reads the step's audio once.
+constexpr int MIX_GROUP = 32;
+__global__ __launch_bounds__(256) void mix_objects_stage1(const float *__restrict__ audio, int n_obj, long long stride, long long n,
+                                                         float *__restrict__ parts) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const int o0 = blockIdx.y * MIX_GROUP, o1 = o0 + MIX_GROUP < n_obj ? o0 + MIX_GROUP : n_obj;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int o = o0; o < o1; ++o) {
+        const float *row = audio + (long long)o * stride + i;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + k < n) acc[k] += row[k];
+    }
+    float *dst = parts + (long long)blockIdx.y * n + i;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i + k < n) dst[k] = acc[k];
+}
+__global__ __launch_bounds__(256) void mix_objects_stage2(const float *__restrict__ parts, int n_groups, long long n, float *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (int g = 0; g < n_groups; ++g) acc += parts[(long long)g * n + i];
+    out[i] = acc;
+}
+int mix_objects_groups(int n_obj) { return (n_obj + MIX_GROUP - 1) / MIX_GROUP; }
+int launch_mix_objects(const float *audio, int n_obj, long long stride, long long n, float *parts, float *out, hipStream_t stream) {
+    if (n_obj <= 0 || n <= 0) return 0;
+    const int groups = mix_objects_groups(n_obj);
+    hipLaunchKernelGGL(mix_objects_stage1, dim3((unsigned)((n + 1023) / 1024), groups), dim3(256), 0, stream, audio, n_obj, stride, n, parts);
+    hipLaunchKernelGGL(mix_objects_stage2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, parts, groups, n, out);
+    return (int)hipGetLastError();
+}
+
 }  // namespace pbso

@@ -133,7 +133,45 @@ SELECT_FIELDS = ("bank_kernel", "time_chunks", "direct_hits", "forced_block", "d
                  "pipe_max_teams", "chunk_buffers", "plan_threads", "plan_pin", "timing_every", "warm_copies")
 
 
+def fill_engine_desc(d, device, form, qnorm, modes_per_lane, stream, frames_per_buffer, select):
+    """a capi.EngineDesc from the wrapper's arguments; returns the kernel / path selection that went into it"""
+    d.abi_version = capi.ABI_VERSION
+    d.device = device
+    d.frames_per_buffer = frames_per_buffer
+    d.recurrence_form = form
+    d.qnorm_mode = qnorm
+    d.modes_per_lane = modes_per_lane
+    d.stream = stream
+    sel = _select_from_env()
+    sel.update(select)
+    for k, v in sel.items():
+        if k not in SELECT_FIELDS:
+            raise TypeError(f"unknown engine option {k!r}")
+        setattr(d, k, int(v))
+    return sel
+
+
+def default_form():
+    return {"block": capi.FORM_BLOCK, "velocity": capi.FORM_VELOCITY, "direct": capi.FORM_DIRECT,
+            "block_bf16": capi.FORM_BLOCK_BF16}[os.environ.get("PBSO_FORM", "block")]
+
+
 class Engine:
+    @classmethod
+    def from_handle(cls, handle, n_modes, qnorm, frames_per_buffer=0):
+        """a view of an engine somebody else owns (a device group's rank): same methods, close() leaves it alone"""
+        self = cls.__new__(cls)
+        self._l = capi.lib()
+        self._h = C.c_void_p(handle)
+        self._owned = False
+        self.n_modes = list(n_modes)
+        self.B = frames_per_buffer or 513
+        self.qnorm_mode = qnorm
+        self._last_nb = 0
+        self._borrowed = None
+        self.select = {}
+        return self
+
     def __init__(self, device=0, form=None, qnorm=capi.QNORM_ALL, modes_per_lane=0,
                  stream=None, frames_per_buffer=0, **select):
         """select: the ABI-4 fields of pbso_engine_desc that pick kernels and paths for THIS engine (bank_kernel,
@@ -141,25 +179,12 @@ class Engine:
         if form is None:
             # the C ABI's default (a zeroed pbso_engine_desc): the block form with the exact f32 projection.
             # PBSO_FORM=block|block_bf16|velocity|direct lets a whole test / bench run pick the oscillator-bank kernel
-            form = {"block": capi.FORM_BLOCK, "velocity": capi.FORM_VELOCITY, "direct": capi.FORM_DIRECT,
-                    "block_bf16": capi.FORM_BLOCK_BF16}[os.environ.get("PBSO_FORM", "block")]
+            form = default_form()
         self.form = form
         self._l = capi.lib()
         d = capi.EngineDesc()
-        d.abi_version = capi.ABI_VERSION
-        d.device = device
-        d.frames_per_buffer = frames_per_buffer
-        d.recurrence_form = form
-        d.qnorm_mode = qnorm
-        d.modes_per_lane = modes_per_lane
-        d.stream = stream
-        sel = _select_from_env()
-        sel.update(select)
-        for k, v in sel.items():
-            if k not in SELECT_FIELDS:
-                raise TypeError(f"unknown engine option {k!r}")
-            setattr(d, k, int(v))
-        self.select = sel
+        self.select = fill_engine_desc(d, device, form, qnorm, modes_per_lane, stream, frames_per_buffer, select)
+        self._owned = True
         h = C.c_void_p()
         rc = self._l.pbso_engine_create(C.byref(d), C.byref(h))
         self._h = h
@@ -183,7 +208,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._l.pbso_engine_destroy(self._h)
+            if self._owned:
+                self._l.pbso_engine_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -297,10 +323,13 @@ class Engine:
         n = np.ascontiguousarray(vns, dtype=np.float64).reshape(-1, 3)
         t = np.ascontiguousarray(not_before, dtype=np.int64)
         assert o.size == v.size == t.size == n.shape[0]
-        self._borrowed = (o, v, n, t)
-        return self._chk(self._l.pbso_enqueue_vertex_hits(
+        rc = self._chk(self._l.pbso_enqueue_vertex_hits(
             self._h, o.size, o.ctypes.data_as(C.POINTER(C.c_int)), v.ctypes.data_as(C.POINTER(C.c_int)), _dp(n),
             t.ctypes.data_as(C.POINTER(C.c_int64))))
+        # (only a script the engine TOOK is held here: a refused call -- a script already pending, bad ids -- leaves the
+        #  arrays of the pending one, which the engine still points at, alive)
+        self._borrowed = (o, v, n, t)
+        return rc
 
     def enqueue_arprm(self, obj, a, sigma, mu, not_before=0):
         a = np.ascontiguousarray(a, dtype=np.float64)
@@ -364,6 +393,13 @@ class Engine:
         self._chk(self._l.pbso_read_audio(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), n))
         return out.reshape(len(self.n_modes), self._last_nb * self.B)
 
+    def audio_rows(self, rows):
+        """the last step's audio of some objects only: [len(rows)][n_buffers * 513] float32"""
+        r = np.ascontiguousarray(rows, dtype=np.int32)
+        out = np.empty((r.size, self._last_nb * self.B), dtype=np.float32)
+        self._chk(self._l.pbso_read_audio_rows(self._h, r.ctypes.data_as(C.POINTER(C.c_int)), r.size, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
     def emitted(self):
         n = len(self.n_modes) * self._last_nb
         out = np.empty(n, dtype=np.uint8)
@@ -399,6 +435,10 @@ class Engine:
 
     def audio_device_ptr(self):
         return self._l.pbso_audio_device_ptr(self._h)
+
+    def mix_objects(self, d_out):
+        """pbso_mix_objects: the last step's audio summed over the objects, into the device buffer d_out [n_buffers * 513] f32"""
+        self._chk(self._l.pbso_mix_objects(self._h, C.c_void_p(d_out)))
 
     def info(self):
         i = capi.EngineInfo()

@@ -1,6 +1,8 @@
 """bench.py --gpus 2 on ONE GPU: the ranks are started by bench.py itself (a torch.distributed.run child), share the
-GPU under PBSO_BENCH_BACKEND=gloo, and the line carries the gather, its cost leg and the strong (configs[3] as
-written) leg.  The data path is the one N GPUs run; only the collective's transport differs (gloo through the host)."""
+GPU under PBSO_BENCH_BACKEND=gloo, and the line's headline is the configuration AS WRITTEN (--objects in total, sharded:
+BASELINE configs[3]) with the gather, its cost legs and the weak (--objects per GPU) side leg.  The data path is the one
+N GPUs run; only the collective's transport differs (gloo through the host stands in for the device group's RCCL calls,
+which need one GPU per rank)."""
 import json
 import os
 import subprocess
@@ -21,26 +23,28 @@ def test_two_ranks_on_one_gpu_print_one_line_with_gather_and_strong_leg():
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout                     # ONE JSON line, from rank 0
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["gather"] is True and d["config"]["group_ranks"] == 2
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["gather"] is True and d["config"]["group_ranks"] == 2
+    assert d["config"]["objects_total"] == 96                # --objects is the JOB's object count (BASELINE configs[3] as written)
     # the transport is named for what it is: gloo here, never "RCCL"
     assert d["config"]["rccl_ranks"] is None and d["config"]["backend"] == "gloo" and "gloo" in d["config"]["workload"] and "RCCL all-gather" not in d["config"]["workload"]
     assert d["dtype"] == "f32" and d["config"]["recurrence_form"] == "block"
-    assert d["config"]["launched_by"] == "bench.py" and d["config"]["objects_per_gpu"] == 96
+    assert d["config"]["launched_by"] == "bench.py" and d["config"]["objects_per_gpu"] == 48
+    assert d["config"]["collective_by"] == "torch.distributed"
     assert d["parity"]["pass"] and d["parity_checked_objects"] == 8
     g = d["gather_cost"]
-    assert g["bytes_sent_per_rank"] == 96 * 86 * 513 * 4 and g["bytes_received_per_rank"] == g["bytes_sent_per_rank"]
+    assert g["bytes_sent_per_rank"] == 48 * 86 * 513 * 4 and g["bytes_received_per_rank"] == g["bytes_sent_per_rank"]
     assert g["ms_per_step_without_gather"] > 0 and g["value_without_gather"] > 0
     mx = d["mix"]
-    assert mx["bytes_per_rank"] == 86 * 513 * 4 and mx["value"] > 0 and mx["objects_total"] == 192
+    assert mx["bytes_per_rank"] == 86 * 513 * 4 and mx["value"] > 0 and mx["objects_total"] == 96
     gr = d["gather_to_root"]
-    assert gr["bytes_received_by_root"] == 96 * 86 * 513 * 4 and gr["value"] > 0 and gr["objects_total"] == 192
+    assert gr["bytes_received_by_root"] == 48 * 86 * 513 * 4 and gr["value"] > 0 and gr["objects_total"] == 96
     # every rank got its share of the host's cores for planning, and says whether the host was the bottleneck
     assert 1 <= d["config"]["host_planner_threads"] <= max(1, d["config"]["host_cores"] // 2 - 1)
     assert isinstance(d["timing"]["host_bound"], bool)
-    s = d["strong"]
-    assert s["scaling"] == "strong" and s["objects_total"] == 96 and s["objects_rank0"] == 48 and s["gather"] is True
-    # whole-job value: both ranks' objects over the slowest rank's time
-    assert abs(d["value"] - 2 * 96 * 86 * 513 * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]
+    s = d["weak"]
+    assert s["scaling"] == "weak" and s["objects_total"] == 192 and s["objects_rank0"] == 96 and s["gather"] is True
+    # whole-job value: the job's objects over the slowest rank's time
+    assert abs(d["value"] - 96 * 86 * 513 * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]
 
 
 @pytest.mark.gpu
@@ -60,5 +64,6 @@ def test_one_rank_under_torchrun_runs_the_rccl_gather_path():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["gather"] is True and d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 1
     assert d["config"]["launched_by"] == "torch.distributed.run" and d["parity"]["pass"]
+    assert d["config"]["collective_by"].startswith("pbso_group")          # the collective was issued by the C++ device group
     assert d["gather_cost"]["bytes_sent_per_rank"] == 256 * 86 * 513 * 4 and d["gather_cost"]["bytes_received_per_rank"] == 0
     assert "RCCL all-gather" in d["config"]["workload"] and d["gather_to_root"]["value"] > 0 and d["mix"]["value"] > 0

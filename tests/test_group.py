@@ -1,0 +1,123 @@
+"""The device group (include/openpbso_amd.h "device group"; SURVEY.md 8(b) device list, 8(e)): one engine per GPU, objects
+sharded by the sum of their modes, RCCL called from the C++ library.  CPU part: the entry points exist and fail cleanly
+without a GPU.  GPU part (one device, all this pool has): the group's three gather modes equal the single engine bit for
+bit (in-place self-gather, root, on-device object mix), the shards equal the Python rule the gloo tests use, the error paths."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from openpbso_amd import capi, synth
+from openpbso_amd.distributed import shard_by_modes
+
+
+def test_group_symbols_and_clean_failure_without_a_gpu():
+    lib = capi.lib()
+    for name in capi.EXPORTS:
+        assert name.startswith("pbso_") and getattr(lib, name)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the failure path is the no-device one")
+    from openpbso_amd.group import Group
+    from openpbso_amd.solver import PbsoError
+    with pytest.raises(PbsoError) as ei:
+        Group([0])
+    assert ei.value.status == capi.ERR_HIP                   # no CPU fallback, and no crash
+    d = capi.GroupDesc()
+    h = C.c_void_p()
+    assert lib.pbso_group_create(C.byref(d), C.byref(h)) == capi.ERR_INVALID      # abi_version 0
+    assert b"abi_version" in lib.pbso_group_last_error(h)
+    lib.pbso_group_destroy(h)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8, 13])
+def test_c_sharding_rule_equals_the_python_one(world):
+    """pbso_shard_by_modes (what pbso_group_plan uses) is a port of openpbso_amd.distributed.shard_by_modes (what the gloo tests
+    and bench.py's launcher-less fallback use): the same cuts for equal, ragged and degenerate jobs"""
+    lib = capi.lib()
+    rng = np.random.default_rng(world)
+    for modes in ([512] * 1024, list(rng.integers(1, 4096, 37)), [5], [0, 0, 7, 0], list(rng.integers(0, 3, 11)), [], [4096] * 8,
+                  list(rng.integers(64, 600, 1000))):
+        m = np.ascontiguousarray(modes, dtype=np.int32)
+        cuts = np.zeros(world + 1, dtype=np.int32)
+        assert lib.pbso_shard_by_modes(m.ctypes.data_as(C.POINTER(C.c_int)), m.size, world, cuts.ctypes.data_as(C.POINTER(C.c_int))) == capi.OK
+        want = [shard_by_modes(modes, world, r) for r in range(world)]
+        assert [(int(cuts[r]), int(cuts[r + 1])) for r in range(world)] == [tuple(w) for w in want], (world, modes[:8])
+    bad = np.array([3, -1], dtype=np.int32)
+    cuts = np.zeros(3, dtype=np.int32)
+    assert lib.pbso_shard_by_modes(bad.ctypes.data_as(C.POINTER(C.c_int)), 2, 2, cuts.ctypes.data_as(C.POINTER(C.c_int))) == capi.ERR_INVALID
+
+
+@pytest.mark.gpu
+def test_group_of_one_device_equals_the_engine_bit_for_bit():
+    """in-place all-gather on a one-rank group is the engine's own buffer (nothing to send), gather-to-root likewise, and the
+    mix is the object sum of the engine's audio in object order -- against pbso_step on a second engine fed the same messages"""
+    from openpbso_amd import Engine, ForceMessage
+    from openpbso_amd.group import Group
+    n_obj, n_modes, nb = 12, 200, 6
+    rng = np.random.default_rng(12)
+    lams = [synth.eigenvalues(n_modes, 700 + i) for i in range(n_obj)]
+    shapes = [synth.mode_shapes(n_modes, 700 + i) for i in range(n_obj)]
+    nv = shapes[0].shape[1] // 3
+    hits = [(int(rng.integers(0, n_obj)), int(rng.integers(0, nv)), int(rng.integers(0, 2 * nb))) for _ in range(40)]
+    vns = synth.unit_normals(len(hits), 3)
+    with Engine() as eng, Group([0]) as grp:
+        grp.plan([n_modes] * n_obj)
+        assert grp.span(0) == (0, n_obj)
+        for i in range(n_obj):
+            eng.add_object(lams[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
+            grp.add_object(i, lams[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
+        eng.finalize()
+        grp.finalize()
+        ge = grp.engine(0)
+        for i in range(n_obj):
+            eng.set_use_transfer(i, False)
+            ge.set_use_transfer(i, False)
+        for (o, v, t), vn in zip(sorted(hits, key=lambda h: h[2]), vns):
+            m = ForceMessage(vid=v, vn=vn)
+            assert eng.enqueue_force(o, m, t) and grp.enqueue_force(o, m, t)
+        for k in range(2):                                    # two steps: both gather targets are used
+            eng.step(nb)
+            want = eng.audio()
+            grp.step(nb)
+            grp.gather(capi.GATHER_ALL)
+            got = grp.result(0)
+            assert got.shape == (n_obj, nb * 513) and np.array_equal(got, want), k
+            grp.gather(capi.GATHER_ROOT)
+            assert np.array_equal(grp.result(0), want)
+            grp.gather(capi.GATHER_MIX)
+            mix = grp.result(0)
+            assert mix.shape == (1, nb * 513)
+            ref = want.astype(np.float64).sum(axis=0)
+            assert np.abs(mix[0] - ref).max() <= 4e-6 * np.abs(ref).max()         # f32 sum of 12 rows
+            assert np.abs(want).max() > 0
+        assert ge.info()["buffers_done"] == 2 * nb
+
+
+@pytest.mark.gpu
+def test_group_error_paths():
+    from openpbso_amd.group import Group
+    from openpbso_amd.solver import PbsoError
+    with pytest.raises(PbsoError):
+        Group([0, 0])                                        # one rank per GPU
+    with pytest.raises(PbsoError):
+        Group([0], world_size=2)                             # a job of several processes needs the shared id
+    with Group([0]) as g:
+        with pytest.raises(PbsoError):
+            g.finalize()                                     # before plan
+        g.plan([64, 64])
+        lam = synth.eigenvalues(64, 1)
+        with pytest.raises(PbsoError):
+            g.add_object(1, lam, synth.RHO, synth.ALPHA, synth.BETA)      # ascending order within a rank
+        g.add_object(0, lam, synth.RHO, synth.ALPHA, synth.BETA)
+        with pytest.raises(PbsoError):
+            g.finalize()                                     # object 1 missing
+        g.add_object(1, lam, synth.RHO, synth.ALPHA, synth.BETA)
+        g.finalize()
+        with pytest.raises(PbsoError):
+            g.gather(capi.GATHER_ALL)                        # before a step
+        g.step(2)
+        with pytest.raises(PbsoError):
+            g.gather(7)
+        g.gather(capi.GATHER_ALL)
+        assert g.result(0).shape == (2, 2 * 513)

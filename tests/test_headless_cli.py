@@ -124,3 +124,34 @@ def test_headless_dof_mismatch_is_reported(tmp_path):
         f.write("v 0 0 0\n")
     r = subprocess.run([EXE, "-d", str(d), "--buffers", "1", "--out", str(tmp_path / "o.wav")], capture_output=True, text=True)
     assert r.returncode != 0 and "DOFs mismatch" in r.stderr
+
+
+@pytest.mark.gpu
+def test_headless_devices_flag_runs_the_scene_through_the_device_group(tmp_path):
+    """--devices 0 --copies 3: three instances of the object on a group of one GPU (include/openpbso_amd.h "device group"),
+    copy c one buffer later than copy c - 1, the WAV their on-device MIX -- equal to the sum of three single-engine runs of the
+    tool with the scripts shifted by hand"""
+    d = tmp_path / "data"
+    d.mkdir()
+    make_data_dir(d)
+    nb = 7
+    hits = [(0, 3, (0.2, -0.5, 1.0)), (2, 7, (1.0, 0.0, 0.3)), (3, 1, (0.0, 1.0, 0.0))]
+    path = synth.listener_path(nb)
+
+    def scripts(shift, tag):
+        (tmp_path / f"h{tag}.txt").write_text("".join(f"{b + shift} {v} {n[0]} {n[1]} {n[2]} point\n" for b, v, n in hits))
+        (tmp_path / f"l{tag}.txt").write_text("".join(f"{b + shift} {float(p[0])!r} {float(p[1])!r} {float(p[2])!r}\n" for b, p in enumerate(path)))
+        return ["--hits", str(tmp_path / f"h{tag}.txt"), "--listener", str(tmp_path / f"l{tag}.txt")]
+
+    r = subprocess.run([EXE, "-d", str(d)] + scripts(0, "g") + ["--buffers", str(nb), "--devices", "0", "--copies", "3",
+                        "--out", str(tmp_path / "g.wav"), "--raw", str(tmp_path / "g.raw")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "3 copies x" in r.stdout and "ranks own [0, 3)" in r.stdout
+    got = np.fromfile(tmp_path / "g.raw", dtype=np.float32).astype(np.float64)
+    want = np.zeros(nb * B)
+    for c in range(3):
+        r1 = subprocess.run([EXE, "-d", str(d)] + scripts(c, f"s{c}") + ["--buffers", str(nb), "--out", str(tmp_path / "s.wav"),
+                             "--raw", str(tmp_path / f"s{c}.raw")], capture_output=True, text=True)
+        assert r1.returncode == 0, r1.stderr
+        want += np.fromfile(tmp_path / f"s{c}.raw", dtype=np.float32).astype(np.float64)
+    assert np.abs(want).max() > 0 and np.abs(got - want).max() <= 2e-6 * np.abs(want).max()

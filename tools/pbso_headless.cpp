@@ -13,6 +13,10 @@
 //   --listener FILE  lines: <buffer> <x> <y> <z>          (computeTransfer at that buffer)
 //   --buffers N      number of 513-sample buffers (default 86 ~ 1 s)
 //   --out FILE       output WAV (default out.wav);  --raw FILE also dumps the fp32 sound values
+//   --devices 0,1,.. several GPUs through the C ABI's device group (one engine per GPU, objects sharded by the sum of their
+//                    modes, RCCL only for the final collective): the scene is --copies K instances of the object (default: one
+//                    per device), copy c hears the hit and listener scripts c * --copy-shift buffers later (default 1), and
+//                    the WAV is their MIX (PBSO_GATHER_MIX: every GPU sums its objects, the GPUs all-reduce one row)
 #include <dirent.h>
 
 #include <cmath>
@@ -63,9 +67,84 @@ static void write_wav_f32(const std::string &path, const std::vector<float> &mon
     std::fclose(f);
 }
 
+struct Hit { long b; pbso_force_msg m; };
+struct Pos { long b; double p[3]; };
+
+// the scene on several GPUs (include/openpbso_amd.h "device group")
+static int run_group(const std::vector<int> &devices, int copies, int shift, const std::string &modes, const std::string &material,
+                     const std::string &ffat, const std::vector<Hit> &hits, const std::vector<Pos> &path, int n_buffers,
+                     std::vector<float> &sound) {
+    auto gcheck = [](pbso_group *g, int rc, const char *what) {
+        if (rc < 0) die(std::string(what) + ": " + pbso_status_string(rc) + ": " + (g ? pbso_group_last_error(g) : ""));
+    };
+    // BuildSolver's inputs (tools/...:309-345), read once: the audible mode count is what the shards are balanced by
+    double mat[5];
+    if (pbso_material_read(material.c_str(), mat) != PBSO_OK) die("cannot read material file " + material);
+    int n_dof = 0, n_modes = 0;
+    double *om = nullptr, *md = nullptr;
+    if (pbso_modes_read(modes.c_str(), &n_dof, &n_modes, &om, &md) != PBSO_OK) die("cannot read modes " + modes);
+    double max_freq = 20000.;                            // tools/...:316-329
+    if (!ffat.empty()) {
+        std::ifstream f((ffat + "/freq_threshold.txt").c_str());
+        if (f) f >> max_freq;
+    }
+    const int n_aud = pbso_num_modes_audible(om, n_modes, mat[0], max_freq);
+    pbso_group_desc gd;
+    std::memset(&gd, 0, sizeof(gd));
+    gd.abi_version = PBSO_ABI_VERSION;
+    gd.devices = devices.data();
+    gd.n_devices = (int)devices.size();
+    gd.engine.abi_version = PBSO_ABI_VERSION;
+    gd.engine.qnorm_mode = PBSO_QNORM_OFF;
+    pbso_group *g = nullptr;
+    gcheck(g, pbso_group_create(&gd, &g), "group_create");
+    std::vector<int> mc(copies, n_aud);
+    gcheck(g, pbso_group_plan(g, mc.data(), copies), "group_plan");
+    pbso_object_desc od;
+    std::memset(&od, 0, sizeof(od));
+    od.n_modes = n_aud; od.n_omega = n_modes; od.omega_squared = om;
+    od.density = mat[0]; od.alpha = mat[3]; od.beta = mat[4];
+    od.n_dof = n_dof; od.mode_shapes = md;
+    for (int c = 0; c < copies; ++c) {
+        gcheck(g, pbso_group_add_object(g, c, &od), "group_add_object");
+        int rank = 0, local = 0;
+        gcheck(g, pbso_group_owner(g, c, &rank, &local), "group_owner");
+        pbso_engine *e = pbso_group_engine(g, rank);
+        if (e && !ffat.empty()) check(e, pbso_object_read_ffat_maps(e, local, ffat.c_str()), "read_ffat_maps");
+    }
+    pbso_free(om);
+    pbso_free(md);
+    gcheck(g, pbso_group_finalize(g), "group_finalize");
+    for (int c = 0; c < copies; ++c) {
+        int rank = 0, local = 0;
+        gcheck(g, pbso_group_owner(g, c, &rank, &local), "group_owner");
+        pbso_engine *e = pbso_group_engine(g, rank);
+        if (path.empty()) check(e, pbso_set_use_transfer(e, local, 0, 0), "set_use_transfer");
+        for (const Pos &p : path) check(e, pbso_compute_transfer(e, local, p.p, p.b + (long)c * shift), "compute_transfer");
+        for (const Hit &h : hits) {
+            const int rc = pbso_group_enqueue_force(g, c, &h.m, h.b + (long)c * shift);
+            gcheck(g, rc, "group_enqueue_force");
+            if (rc == 0) die("force queue full");
+        }
+    }
+    gcheck(g, pbso_group_step(g, n_buffers), "group_step");
+    gcheck(g, pbso_group_gather(g, PBSO_GATHER_MIX), "group_gather");
+    sound.resize((size_t)n_buffers * PBSO_FRAMES_PER_BUFFER);
+    gcheck(g, pbso_group_read_result(g, 0, sound.data(), sound.size()), "group_read_result");
+    std::printf("%d copies x %d audible modes on %d device(s): ranks own", copies, n_aud, (int)devices.size());
+    for (int r = 0; r < (int)devices.size(); ++r) {
+        int lo = 0, hi = 0;
+        pbso_group_rank_span(g, r, &lo, &hi);
+        std::printf(" [%d, %d)", lo, hi);
+    }
+    std::printf("\n");
+    pbso_group_destroy(g);
+    return 0;
+}
+
 int main(int argc, char **argv) {
-    std::string d, name, mesh, modes, material, ffat, hits, listener, out = "out.wav", raw;
-    int n_buffers = 86;
+    std::string d, name, mesh, modes, material, ffat, hits, listener, out = "out.wav", raw, devices_arg;
+    int n_buffers = 86, copies = 0, copy_shift = 1;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto val = [&]() -> std::string { if (i + 1 >= argc) die("missing value for " + a); return argv[++i]; };
@@ -80,6 +159,9 @@ int main(int argc, char **argv) {
         else if (a == "--buffers") n_buffers = std::atoi(val().c_str());
         else if (a == "--out") out = val();
         else if (a == "--raw") raw = val();
+        else if (a == "--devices") devices_arg = val();
+        else if (a == "--copies") copies = std::atoi(val().c_str());
+        else if (a == "--copy-shift") copy_shift = std::atoi(val().c_str());
         else die("unknown flag " + a);
     }
     if (!d.empty()) {                                   // fixed directory structure, tools/...:480-495
@@ -92,22 +174,15 @@ int main(int argc, char **argv) {
     }
     if (modes.empty() || material.empty()) die("need -d <dir> or -s <modes> -t <material> [-m <obj>] [-p <ffat dir>]");
 
-    pbso_engine_desc desc;
-    std::memset(&desc, 0, sizeof(desc));
-    desc.abi_version = PBSO_ABI_VERSION;
-    desc.qnorm_mode = PBSO_QNORM_OFF;
-    pbso_engine *e = nullptr;
-    int rc = pbso_engine_create(&desc, &e);
-    check(e, rc, "engine_create");
-    int obj = -1, n_aud = 0;
-    check(e, pbso_add_object_from_files(e, modes.c_str(), material.c_str(), ffat.empty() ? nullptr : ffat.c_str(), &obj, &n_aud),
-          "add_object_from_files");
     // assert(modes->numDOF() == V.rows()*3), tools/...:515
     int n_dof = 0, n_modes = 0;
-    double *om = nullptr, *md = nullptr;
-    check(e, pbso_modes_read(modes.c_str(), &n_dof, &n_modes, &om, &md), "modes_read");
-    pbso_free(om);
-    pbso_free(md);
+    {
+        double *om = nullptr, *md = nullptr;
+        const int mrc = pbso_modes_read(modes.c_str(), &n_dof, &n_modes, &om, &md);
+        if (mrc != PBSO_OK) die(std::string("modes_read: ") + pbso_status_string(mrc) + ": " + modes);
+        pbso_free(om);
+        pbso_free(md);
+    }
     // igl::read_triangle_mesh(obj_file, V, F); igl::per_vertex_normals(V, F, VN);   tools/...:508-509
     std::vector<double> VN;
     if (!mesh.empty()) {
@@ -126,10 +201,8 @@ int main(int argc, char **argv) {
             die("cannot read mesh " + mesh);
         }
     }
-    std::printf("modes: %d of %d audible, nDOF %d\n", n_aud, n_modes, n_dof);
-    check(e, pbso_finalize(e), "finalize");
-
-    bool any_listener = false;
+    // the scripts that stand in for the camera and the mouse
+    std::vector<Pos> path;
     if (!listener.empty()) {
         std::ifstream f(listener);
         if (!f) die("cannot read " + listener);
@@ -137,13 +210,12 @@ int main(int argc, char **argv) {
         while (std::getline(f, line)) {
             if (line.empty() || line[0] == '#') continue;
             std::istringstream iss(line);
-            long b; double p[3];
-            if (!(iss >> b >> p[0] >> p[1] >> p[2])) die("bad listener line: " + line);
-            check(e, pbso_compute_transfer(e, obj, p, b), "compute_transfer");
-            any_listener = true;
+            Pos p;
+            if (!(iss >> p.b >> p.p[0] >> p.p[1] >> p.p[2])) die("bad listener line: " + line);
+            path.push_back(p);
         }
     }
-    if (!any_listener) check(e, pbso_set_use_transfer(e, obj, 0, 0), "set_use_transfer");   // unit transfer
+    std::vector<Hit> hit_list;
     if (!hits.empty()) {
         std::ifstream f(hits);
         if (!f) die("cannot read " + hits);
@@ -162,23 +234,57 @@ int main(int argc, char **argv) {
                 if (!(iss >> n[1] >> n[2])) die("bad hit line: " + line);
             }
             iss >> type;
-            pbso_force_msg m;
-            std::memset(&m, 0, sizeof(m));
-            m.data_kind = PBSO_DATA_VERTEX;
-            m.vids[0] = vid;
+            Hit h;
+            h.b = b;
+            std::memset(&h.m, 0, sizeof(h.m));
+            h.m.data_kind = PBSO_DATA_VERTEX;
+            h.m.vids[0] = vid;
             const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);   // VN.row(vid).normalized(), tools/...:607
-            for (int j = 0; j < 3; ++j) m.vn[j] = n[j] / len;
-            if (type == "gauss") { m.force_type = PBSO_GAUSSIAN_FORCE; iss >> m.gaussian_width_us; }
-            else if (type == "ar") m.force_type = PBSO_AUTOREGRESSIVE_FORCE;
-            else m.force_type = PBSO_POINT_FORCE;
-            rc = pbso_enqueue_force(e, obj, &m, b);
+            for (int j = 0; j < 3; ++j) h.m.vn[j] = n[j] / len;
+            if (type == "gauss") { h.m.force_type = PBSO_GAUSSIAN_FORCE; iss >> h.m.gaussian_width_us; }
+            else if (type == "ar") h.m.force_type = PBSO_AUTOREGRESSIVE_FORCE;
+            else h.m.force_type = PBSO_POINT_FORCE;
+            hit_list.push_back(h);
+        }
+    }
+
+    std::vector<float> sound((size_t)n_buffers * PBSO_FRAMES_PER_BUFFER);
+    double device_ms = 0;
+    if (!devices_arg.empty()) {
+        std::vector<int> devices;
+        std::istringstream ds(devices_arg);
+        std::string tok;
+        while (std::getline(ds, tok, ',')) devices.push_back(std::atoi(tok.c_str()));
+        if (devices.empty()) die("--devices needs a list of HIP ordinals");
+        run_group(devices, copies > 0 ? copies : (int)devices.size(), copy_shift, modes, material, ffat, hit_list, path, n_buffers, sound);
+    } else {
+        pbso_engine_desc desc;
+        std::memset(&desc, 0, sizeof(desc));
+        desc.abi_version = PBSO_ABI_VERSION;
+        desc.qnorm_mode = PBSO_QNORM_OFF;
+        pbso_engine *e = nullptr;
+        int rc = pbso_engine_create(&desc, &e);
+        check(e, rc, "engine_create");
+        int obj = -1, n_aud = 0;
+        check(e, pbso_add_object_from_files(e, modes.c_str(), material.c_str(), ffat.empty() ? nullptr : ffat.c_str(), &obj, &n_aud),
+              "add_object_from_files");
+        std::printf("modes: %d of %d audible, nDOF %d\n", n_aud, n_modes, n_dof);
+        check(e, pbso_finalize(e), "finalize");
+        for (const Pos &p : path) check(e, pbso_compute_transfer(e, obj, p.p, p.b), "compute_transfer");
+        if (path.empty()) check(e, pbso_set_use_transfer(e, obj, 0, 0), "set_use_transfer");   // unit transfer
+        for (const Hit &h : hit_list) {
+            rc = pbso_enqueue_force(e, obj, &h.m, h.b);
             check(e, rc, "enqueue_force");
             if (rc == 0) die("force queue full");
         }
+        check(e, pbso_step(e, n_buffers), "step");
+        check(e, pbso_read_audio(e, sound.data(), sound.size()), "read_audio");
+        pbso_engine_info info;
+        check(e, pbso_get_info(e, &info), "get_info");
+        device_ms = info.last_step_device_ms;
+        pbso_engine_destroy(e);
     }
-    check(e, pbso_step(e, n_buffers), "step");
-    std::vector<float> sound((size_t)n_buffers * PBSO_FRAMES_PER_BUFFER), mono(sound.size());
-    check(e, pbso_read_audio(e, sound.data(), sound.size()), "read_audio");
+    std::vector<float> mono(sound.size());
     for (size_t i = 0; i < sound.size(); ++i) mono[i] = (float)((double)sound[i] / 1E10);   // tools/...:208
     write_wav_f32(out, mono, PBSO_SAMPLE_RATE);
     if (!raw.empty()) {
@@ -187,10 +293,8 @@ int main(int argc, char **argv) {
         std::fwrite(sound.data(), 4, sound.size(), f);
         std::fclose(f);
     }
-    pbso_engine_info info;
-    check(e, pbso_get_info(e, &info), "get_info");
     std::printf("%d buffers (%.3f s of audio) in %.3f ms on the device -> %s\n", n_buffers,
-                n_buffers * (double)PBSO_FRAMES_PER_BUFFER / PBSO_SAMPLE_RATE, info.last_step_device_ms, out.c_str());
-    pbso_engine_destroy(e);
+                n_buffers * (double)PBSO_FRAMES_PER_BUFFER / PBSO_SAMPLE_RATE, device_ms, out.c_str());
     return 0;
 }
+
