@@ -245,7 +245,8 @@ int pbso_enqueue_force_batch(pbso_engine *e, int n, const int *object_ids, const
  * pbso_enqueue_force in that order, except that nothing is copied: the arrays are BORROWED until the next pbso_step
  * returns.  That step consumes them -- the hits of an idle object with an empty queue go straight into the step's
  * descriptors (no queue round trip), the others, and the hits stamped beyond the step, enter the object's queue as if
- * enqueued one by one (a queue that cannot take them, 1023 slots, fails that step: PBSO_ERR_STATE).  One script may be
+ * enqueued one by one (a full queue, 1023 slots, rejects a hit exactly as enqueueForceMessage returns false for it,
+ * modal_solver.h:329-333: the hit is dropped and counted in pbso_engine_info::total_dropped_hits).  One script may be
  * pending at a time; any other enqueue call for the engine first moves a pending script into the queues (order is kept).
  * Returns n, or PBSO_ERR_INVALID (ids / vertex ids out of range, object order) / PBSO_ERR_STATE (a script is pending). */
 int pbso_enqueue_vertex_hits(pbso_engine *e, int n, const int *object_ids, const int *vids, const double *vn,
@@ -406,6 +407,8 @@ typedef struct pbso_engine_info {
                                        * a producer wave and two consumer waves per 64 modes)                               */
     int64_t total_time_chunk_launches;/* of the block launches, those cut along the time axis (K5, kernels_scan.hip: a scan of the
                                        * buffer-start states, then the block kernel over (team, chunk of buffers) workgroups) */
+    int64_t total_dropped_hits;       /* hits of pbso_enqueue_vertex_hits scripts that found their object's 1023-slot queue full:
+                                       * rejected, as enqueueForceMessage would have been (modal_solver.h:329-333)              */
 } pbso_engine_info;
 int pbso_get_info(pbso_engine *e, pbso_engine_info *out);
 /* diagnostics (engine created with env PBSO_CENSUS=1): for every object's

@@ -88,7 +88,7 @@ class EngineInfo(C.Structure):
                 ("total_host_plan_ms", C.c_double), ("total_steps", C.c_int64), ("n_teams", C.c_int),
                 ("recurrence_form", C.c_int), ("total_block_launches", C.c_int64), ("total_sample_launches", C.c_int64),
                 ("total_timed_launches", C.c_int64), ("total_split_launches", C.c_int64),
-                ("total_time_chunk_launches", C.c_int64)]
+                ("total_time_chunk_launches", C.c_int64), ("total_dropped_hits", C.c_int64)]
 
 
 GroupDesc._fields_ = [("abi_version", C.c_int), ("devices", C.POINTER(C.c_int)), ("n_devices", C.c_int), ("world_size", C.c_int),

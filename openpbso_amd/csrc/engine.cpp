@@ -1096,11 +1096,14 @@ int Engine::enqueue_vertex_hits(int n, const int *objs, const int *vids, const d
     return n;
 }
 
-// hits h0 .. h1 - 1 of the script (all of object oi) enter the object's queue exactly as pbso_enqueue_force would put them
+// hits h0 .. h1 - 1 of the script (all of object oi) enter the object's queue exactly as pbso_enqueue_force would put them: a
+// full queue (1023 slots, modal_solver.h:105) REJECTS a message -- try_enqueue returns false, modal_solver.h:329-333, and the tool
+// ignores it (tools/real_time_modal_sound.cpp:610) -- so the hits that do not fit are dropped and counted, nothing fails
 int Engine::script_to_queue(int oi, int h0, int h1, const char **why) {
+    (void)why;
     Object &o = objs_[oi];
     for (int h = h0; h < h1; ++h) {
-        if (o.force_q.size() >= 1023) { *why = "force queue overflow while taking a hit script (1023 slots, modal_solver.h:105)"; return PBSO_ERR_STATE; }
+        if (o.force_q.size() >= 1023) { dropped_hits_.fetch_add(h1 - h); break; }
         HostForceMsg m;
         m.force_type = PBSO_POINT_FORCE;
         m.data_kind = PBSO_DATA_VERTEX;
@@ -2544,6 +2547,7 @@ int Engine::info(pbso_engine_info *out) {
     out->total_sample_launches = tot_sample_launches_;
     out->total_split_launches = tot_split_launches_;
     out->total_time_chunk_launches = tot_tc_launches_;
+    out->total_dropped_hits = dropped_hits_.load();
     out->buffers_done = buffers_done_;
     out->last_step_host_plan_ms = last_plan_ms_;
     out->last_step_forced_rows = last_frows_;

@@ -217,6 +217,7 @@ private:
     // has planned; hit_off_[o] .. hit_off_[o + 1] are object o's hits
     struct HitScript { int n = 0; const int *objs = nullptr, *vids = nullptr; const double *vn = nullptr; const int64_t *stamps = nullptr; } script_;
     std::vector<int> hit_off_;
+    std::atomic<int64_t> dropped_hits_{0};               // hits of a script that found their object's queue full (rejected as try_enqueue would)
     int script_to_queue(int oi, int h0, int h1, const char **why);     // hits h0 .. h1 - 1 of object oi enter its queue, in order
     int flush_script();                                                 // all of it (another enqueue call came before the step)
     int consume_script(PlanCtx &c, int oi, int nb);                     // planner: the object's hits of this launch

@@ -101,3 +101,38 @@ def test_vertex_hits_on_large_teams(form, mpl, monkeypatch):
     mx, l2 = rel_errors(got["audio"], want["audio"])
     assert (mx <= 5e-4).all() and (l2 <= 1e-3).all(), (mx.max(), l2.max())
     assert got["info"]["last_step_forced_rows"] == 0 and got["info"]["waves_per_object"] >= 8
+
+
+def test_hit_script_overflow_is_rejected_like_try_enqueue_not_fatal():
+    """a script that brings more hits than a BUSY object's 1023-slot queue can take: the surplus is rejected the way
+    enqueueForceMessage returns false for a full queue (modal_solver.h:329-333; the tool ignores the bool,
+    tools/real_time_modal_sound.cpp:610) -- counted in pbso_engine_info::total_dropped_hits, the step succeeds and the engine
+    stays usable (round 3: PBSO_ERR_STATE, and the engine refused every later step)"""
+    from openpbso_amd import Engine, ForceMessage
+    n_modes, nb = 96, 4
+    s = synth.seed_for(9, 0)
+    lam, shapes = synth.eigenvalues(n_modes, s), synth.mode_shapes(n_modes, s)
+    nv = shapes.shape[1] // 3
+    n_hits = 1100
+    vns = synth.unit_normals(n_hits, s)
+    with Engine() as eng:
+        for _ in range(2):
+            eng.add_object(lam, synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes)
+        eng.finalize()
+        for i in range(2):
+            eng.set_use_transfer(i, False)
+        # object 1 is busy (a Gaussian force is alive), so its hits take the queue: stamped far ahead, they pile up
+        assert eng.enqueue_force(1, ForceMessage(data=np.full(n_modes, 1e-3), forceType=1, gaussianWidth=5000.0), 0)
+        o = np.concatenate([np.zeros(2, np.int32), np.ones(n_hits, np.int32)])
+        v = (np.arange(2 + n_hits) % nv).astype(np.int32)
+        t = np.concatenate([np.array([0, 1]), np.full(n_hits, 1000)]).astype(np.int64)
+        assert eng.enqueue_vertex_hits(o, v, np.concatenate([vns[:2], vns]), t) == 2 + n_hits
+        eng.step(nb)
+        a = eng.audio()
+        info = eng.info()
+        # (the Gaussian message still sat in object 1's queue when the script arrived: 1022 free slots)
+        assert info["total_dropped_hits"] == n_hits - 1022 and np.isfinite(a).all() and np.abs(a[0]).max() > 0
+        eng.step(nb)                                         # still usable
+        assert eng.enqueue_force(0, ForceMessage(vid=1, vn=vns[0]), 2 * nb)
+        eng.step(nb)
+        assert np.abs(eng.audio()[0]).max() > 0 and eng.info()["total_dropped_hits"] == n_hits - 1022
