@@ -357,9 +357,10 @@ def measure(args, ctx, global_ids, want_parity):
             n_hits += total_buffers - 1
             continue
         if args.scenario == "listener":
-            path = sc["path"]
-            for b in range(total_buffers):
-                eng.compute_transfer(i, path[b], int(b))
+            # one computeTransfer per buffer (the camera moves every frame): the whole path in one call
+            took = eng.compute_transfer_path(np.full(total_buffers, i, dtype=np.int32), sc["path"][:total_buffers],
+                                             np.arange(total_buffers, dtype=np.int64))
+            assert took.all()
         else:
             eng.set_use_transfer(i, False)             # no FFAT maps in this config: unit transfer
         hb = np.nonzero(hits >= 0)[0]

@@ -258,6 +258,13 @@ int pbso_enqueue_arprm(pbso_engine *e, int object_id, const double a[2], double 
  * every mode on the device, result offered to the 1-slot transfer queue.
  * 1 = enqueued, 0 = no maps / queue still full.                               */
 int pbso_compute_transfer(pbso_engine *e, int object_id, const double pos[3], int64_t not_before);
+/* A listener PATH, the twin of pbso_enqueue_force_batch for ModalSolver::computeTransfer(pos) (modal_solver.h:286-300; the
+ * tool calls it from its camera callback, tools/real_time_modal_sound.cpp:844, 1172): n positions, position i for object
+ * object_ids[i] at stamp not_before[i], issued in order -- semantically n calls of pbso_compute_transfer, one entry into the
+ * library.  accepted[i] (may be NULL) receives each call's result; returns the number accepted, or a negative pbso_status on
+ * the first hard error (bad id, PBSO_ERR_MISSING_MAP).  The arrays are read before the call returns.                        */
+int pbso_compute_transfer_path(pbso_engine *e, int n, const int *object_ids, const double *pos, const int64_t *not_before,
+                               unsigned char *accepted);
 /* ModalSolver::computeTransfer(pos, T *trans) (modal_solver.h:302-315), batched over n_pos listener
  * positions.  Like the reference it writes _ffat_maps->size() (= pbso_object_n_maps) entries per position:
  * out[n_pos][out_cols] doubles, columns [0, n_maps) of every row are written, the others left alone;

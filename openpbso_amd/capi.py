@@ -26,7 +26,7 @@ EXPORTS = [
     "pbso_read_audio", "pbso_read_emitted", "pbso_read_qnorm", "pbso_read_state", "pbso_write_state",
     "pbso_audio_device_ptr", "pbso_pa_convert", "pbso_get_info",
     "pbso_modes_read", "pbso_num_modes_audible", "pbso_material_read", "pbso_free", "pbso_read_census", "pbso_obj_read",
-    "pbso_mix_objects", "pbso_read_audio_rows",
+    "pbso_mix_objects", "pbso_read_audio_rows", "pbso_compute_transfer_path",
     # the device group (one engine per GPU, RCCL gather called from C++)
     "pbso_group_unique_id", "pbso_group_create", "pbso_group_destroy", "pbso_group_last_error", "pbso_group_plan",
     "pbso_group_rank_span", "pbso_group_owner", "pbso_group_add_object", "pbso_group_finalize", "pbso_group_engine",
@@ -157,6 +157,7 @@ def lib():
     l.pbso_free.argtypes = [vp]
     l.pbso_free.restype = None
     l.pbso_mix_objects.argtypes = [vp, vp]
+    l.pbso_compute_transfer_path.argtypes = [vp, C.c_int, ip, dp, C.POINTER(C.c_int64), C.POINTER(C.c_ubyte)]
     l.pbso_read_audio_rows.argtypes = [vp, ip, C.c_int, C.POINTER(C.c_float)]
     l.pbso_shard_by_modes.argtypes = [ip, C.c_int, C.c_int, ip]
     l.pbso_group_unique_id.argtypes = [vp]

@@ -370,6 +370,14 @@ int pbso_read_audio_rows(pbso_engine *e, const int *object_ids, int n_rows, floa
     GUARD_END(e)
 }
 
+int pbso_compute_transfer_path(pbso_engine *e, int n, const int *object_ids, const double *pos, const int64_t *not_before,
+                               unsigned char *accepted) {
+    NEED(e);
+    GUARD_BEGIN
+    return e->impl->compute_transfer_path(n, object_ids, pos, not_before, accepted);
+    GUARD_END(e)
+}
+
 int pbso_mix_objects(pbso_engine *e, void *d_out) {
     NEED(e);
     GUARD_BEGIN

@@ -918,6 +918,9 @@ int Engine::finalize() {
         std::vector<double> psi;
         for (int i = 0; i < N; ++i) {
             Object &o = objs_[i];
+            o.maps_cover_modes = true;
+            for (int m = 0; m < o.n_modes; ++m)
+                if (m >= (int)o.geom.size() || !o.geom[m].valid) { o.maps_cover_modes = false; break; }
             goff[i] = (long long)geom.size();
             const int ng = std::min((int)o.geom.size(), m_pad_);
             nmodes[i] = o.n_modes;
@@ -1243,9 +1246,8 @@ int Engine::compute_transfer(int obj, const double pos[3], int64_t not_before) {
     if (!valid_obj(obj)) return fail(PBSO_ERR_INVALID, "object id");
     Object &o = objs_[obj];
     if (!o.have_maps) return 0;                                   // :290-291
-    for (int m = 0; m < o.n_modes; ++m)
-        if (m >= (int)o.geom.size() || !o.geom[m].valid)
-            return fail(PBSO_ERR_MISSING_MAP, "FFAT map for a modeId in 0..N_modes-1 is missing (std::map::at throws)");
+    if (!o.maps_cover_modes)                                      // (the maps are fixed at finalize: checked once, there)
+        return fail(PBSO_ERR_MISSING_MAP, "FFAT map for a modeId in 0..N_modes-1 is missing (std::map::at throws)");
     if (not_before <= buffers_done_ && o.pending.empty() && o.trans_full) return 0;   // try_enqueue on a full 1-slot queue
     TimedEvent ev;
     ev.kind = TimedEvent::TRANSFER;
@@ -1254,6 +1256,20 @@ int Engine::compute_transfer(int obj, const double pos[3], int64_t not_before) {
     ev.flag = 0;
     push_timed(o.pending, ev);
     return 1;
+}
+
+// a listener PATH: n computeTransfer(pos) calls (modal_solver.h:286-300) in one -- what the tool's camera callback issues frame
+// after frame (tools/real_time_modal_sound.cpp:844, 1172), pre-scheduled as the throughput harness has it
+int Engine::compute_transfer_path(int n, const int *objs, const double *pos, const int64_t *stamps, unsigned char *accepted) {
+    if (n < 0 || (n > 0 && (!objs || !pos || !stamps))) return fail(PBSO_ERR_INVALID, "compute_transfer_path arguments");
+    int taken = 0;
+    for (int i = 0; i < n; ++i) {
+        const int rc = compute_transfer(objs[i], pos + 3 * (size_t)i, stamps[i]);
+        if (rc < 0) return rc;
+        if (accepted) accepted[i] = rc ? 1 : 0;
+        taken += rc ? 1 : 0;
+    }
+    return taken;
 }
 
 // ModalSolver::setUseTransfer, modal_solver.h:148-152

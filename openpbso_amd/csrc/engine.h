@@ -127,6 +127,7 @@ struct Object {
     int n_dof = 0;
     std::vector<double> shapes;                          // mode-major until finalize
     bool have_maps = false;                              // _ffat_maps non-null
+    bool maps_cover_modes = false;                       // ... and holds a map for every modeId 0 .. n_modes - 1 (set by finalize)
     int n_maps = 0;
     std::vector<FfatGeom> geom;                          // index = modeId
     std::vector<double> psi;
@@ -180,6 +181,7 @@ public:
     int enqueue_vertex_hits(int n, const int *objs, const int *vids, const double *vn, const int64_t *stamps);
     int enqueue_arprm(int obj, const double a[2], double sigma, double mu, int64_t not_before);
     int compute_transfer(int obj, const double pos[3], int64_t not_before);
+    int compute_transfer_path(int n, const int *objs, const double *pos, const int64_t *stamps, unsigned char *accepted);
     int compute_transfer_batch(int obj, const double *pos, int n_pos, double *out, int out_cols);
     int listeners_enable(int obj);
     int mix_listeners(int obj, const double *pos, int n_listeners, float *out, size_t n_out);

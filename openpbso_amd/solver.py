@@ -339,6 +339,17 @@ class Engine:
         p = np.ascontiguousarray(pos, dtype=np.float64)
         return bool(self._chk(self._l.pbso_compute_transfer(self._h, obj, _dp(p), not_before)))
 
+    def compute_transfer_path(self, objs, pos, not_before):
+        """pbso_compute_transfer_path: n computeTransfer(pos) calls in one; returns the accepted flags [n]"""
+        o = np.ascontiguousarray(objs, dtype=np.int32)
+        p = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+        t = np.ascontiguousarray(not_before, dtype=np.int64)
+        assert o.size == t.size == p.shape[0]
+        acc = np.zeros(o.size, dtype=np.uint8)
+        self._chk(self._l.pbso_compute_transfer_path(self._h, o.size, o.ctypes.data_as(C.POINTER(C.c_int)), _dp(p),
+                                                     t.ctypes.data_as(C.POINTER(C.c_int64)), acc.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        return acc.astype(bool)
+
     def listeners_enable(self, obj):
         """from the next step on, keep this object's block-start states for mix_listeners"""
         self._chk(self._l.pbso_listeners_enable(self._h, obj))

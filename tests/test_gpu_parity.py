@@ -1176,3 +1176,43 @@ def test_block_kernel_forced_path_every_buffer_kind(qnorm, mpl, monkeypatch):
                 assert np.abs(got["qnorm"][key] - w).max() <= 5e-4 * max(np.abs(w).max(), 1e-30) + 2e-6 * np.abs(want["audio"][key[0]]).max(), key
         for i in range(len(sizes)):
             np.testing.assert_allclose(got["state"][i][0], want["state"][i][0], rtol=0, atol=5e-4 * max(np.abs(want["state"][i][0]).max(), 1e-30))
+
+
+def test_listener_path_call_equals_call_by_call():
+    """pbso_compute_transfer_path (n computeTransfer(pos) calls in one entry into the library) == the same calls one by one,
+    bit for bit: audio, the rows getLatestTransfer returns, the accepted flags -- including a second position stamped for the
+    same buffer (the 1-slot queue still holds the first: modal_solver.h:286-300 returns false for it) and an object without
+    maps (returns false, modal_solver.h:290-291)"""
+    from openpbso_amd import Engine
+    nb, n_modes = 10, 96
+    lams = [synth.eigenvalues(n_modes, 40 + i) for i in range(3)]
+    maps = [synth.ffat_maps(lams[i], 40 + i, dim=4, cell_size=0.01) for i in range(2)] + [None]
+    rng = np.random.default_rng(3)
+    hits = [rng.standard_normal(n_modes) * 1e-3 for _ in range(3)]
+    objs = np.array([0] * nb + [0] + [1] * (nb // 2) + [2], dtype=np.int32)
+    stamps = np.array(list(range(nb)) + [4] + list(range(0, nb, 2)) + [1], dtype=np.int64)
+    dirs = rng.standard_normal((objs.size, 3))
+    pos = 0.5 * dirs / np.linalg.norm(dirs, axis=1, keepdims=True)
+
+    def run(batch):
+        with Engine() as eng:
+            for i in range(3):
+                eng.add_object(lams[i], synth.RHO, synth.ALPHA, synth.BETA)
+                if maps[i] is not None:
+                    eng.set_ffat_maps(i, maps[i])
+            eng.finalize()
+            for i in range(3):
+                assert eng.enqueue_force(i, ForceMessage(data=hits[i]), 0)
+            if batch:
+                acc = eng.compute_transfer_path(objs, pos, stamps)
+            else:
+                acc = np.array([eng.compute_transfer(int(o), p, int(t)) for o, p, t in zip(objs, pos, stamps)])
+            eng.step(nb)
+            return acc, eng.audio().copy(), [eng.latest_transfer(i).copy() for i in range(3)]
+
+    a_acc, a_audio, a_latest = run(True)
+    b_acc, b_audio, b_latest = run(False)
+    assert np.array_equal(a_acc, b_acc) and not a_acc[-1] and a_acc[:nb].all()       # (object 2 has no maps)
+    assert np.array_equal(a_audio, b_audio) and np.abs(a_audio[:2]).max() > 0
+    for x, y in zip(a_latest, b_latest):
+        assert np.array_equal(x, y)
