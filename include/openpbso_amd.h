@@ -291,6 +291,17 @@ int pbso_get_latest_transfer(pbso_engine *e, int object_id, double *out);
 int pbso_step(pbso_engine *e, int n_buffers);
 /* same, audio written to a caller-owned device buffer [n_objects][n_buffers*B] fp32 */
 int pbso_step_into(pbso_engine *e, int n_buffers, void *d_audio);
+/* ... and delivered to the HOST, where the reference's consumer lives (the PortAudio callback takes SoundMessages from a host
+ * queue, modal_solver.h:79-82, 346-363; tools/real_time_modal_sound.cpp:192-212): host_out[n_objects][n_buffers * B] fp32.
+ * host_out from pbso_host_alloc (or any pinned, device-mapped host memory): the oscillator bank writes its samples straight
+ * into it over PCIe -- no copy pass; the step then runs at the link's rate.  Pageable memory: the bank writes device memory
+ * and a copy follows on its own stream (two device buffers in turn).  Asynchronous either way: pbso_host_wait blocks until the
+ * LAST pbso_step_to_host's samples are in host_out; a caller that alternates two host buffers consumes step k while step
+ * k + 1 runs.                                                                                                              */
+int pbso_step_to_host(pbso_engine *e, int n_buffers, float *host_out, size_t n_floats);
+int pbso_host_wait(pbso_engine *e);
+int pbso_host_alloc(size_t bytes, void **out);      /* pinned host memory (hipHostMalloc) for callers that do not link HIP */
+void pbso_host_free(void *p);
 int pbso_sync(pbso_engine *e);
 
 /* results of the LAST step.  audio is the reference's SoundMessage::data

@@ -27,6 +27,7 @@ EXPORTS = [
     "pbso_audio_device_ptr", "pbso_pa_convert", "pbso_get_info",
     "pbso_modes_read", "pbso_num_modes_audible", "pbso_material_read", "pbso_free", "pbso_read_census", "pbso_obj_read",
     "pbso_mix_objects", "pbso_read_audio_rows", "pbso_compute_transfer_path",
+    "pbso_step_to_host", "pbso_host_wait", "pbso_host_alloc", "pbso_host_free",
     # the device group (one engine per GPU, RCCL gather called from C++)
     "pbso_group_unique_id", "pbso_group_create", "pbso_group_destroy", "pbso_group_last_error", "pbso_group_plan",
     "pbso_group_rank_span", "pbso_group_owner", "pbso_group_add_object", "pbso_group_finalize", "pbso_group_engine",
@@ -157,6 +158,11 @@ def lib():
     l.pbso_free.argtypes = [vp]
     l.pbso_free.restype = None
     l.pbso_mix_objects.argtypes = [vp, vp]
+    l.pbso_step_to_host.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_size_t]
+    l.pbso_host_wait.argtypes = [vp]
+    l.pbso_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    l.pbso_host_free.argtypes = [vp]
+    l.pbso_host_free.restype = None
     l.pbso_compute_transfer_path.argtypes = [vp, C.c_int, ip, dp, C.POINTER(C.c_int64), C.POINTER(C.c_ubyte)]
     l.pbso_read_audio_rows.argtypes = [vp, ip, C.c_int, C.POINTER(C.c_float)]
     l.pbso_shard_by_modes.argtypes = [ip, C.c_int, C.c_int, ip]

@@ -385,6 +385,30 @@ int pbso_mix_objects(pbso_engine *e, void *d_out) {
     GUARD_END(e)
 }
 
+int pbso_step_to_host(pbso_engine *e, int n_buffers, float *host_out, size_t n_floats) {
+    NEED(e);
+    GUARD_BEGIN
+    return e->impl->step_to_host(n_buffers, host_out, n_floats);
+    GUARD_END(e)
+}
+
+int pbso_host_wait(pbso_engine *e) {
+    NEED(e);
+    GUARD_BEGIN
+    return e->impl->host_wait();
+    GUARD_END(e)
+}
+
+int pbso_host_alloc(size_t bytes, void **out) {
+    if (!out) return PBSO_ERR_INVALID;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? PBSO_OK : PBSO_ERR_NOMEM;
+}
+
+void pbso_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int pbso_sync(pbso_engine *e) {
     NEED(e);
     GUARD_BEGIN

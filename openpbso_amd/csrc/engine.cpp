@@ -257,6 +257,10 @@ Engine::~Engine() {
                      hprof_[4] / tot_steps_, hprof_[6] / tot_steps_, hprof_[7] / tot_steps_, hprof_[8] / tot_steps_, hprof_[5] / tot_steps_);
     delete pool_;
     if (stream_) (void)hipStreamSynchronize(stream_);
+    if (timeline_have_base_) {                         // (the reference launch's quad was kept out of the free list)
+        for (hipEvent_t ev : {timeline_quad_.k0, timeline_quad_.k1, timeline_quad_.p0, timeline_quad_.p1, timeline_quad_.f0, timeline_quad_.f1})
+            if (ev) (void)hipEventDestroy(ev);
+    }
     if (prep_stream_) (void)hipStreamSynchronize(prep_stream_);
     free_retired_blocks();
     d_ca_.release(); d_cb_.release(); d_sq_.release(); d_sd_.release(); d_ss_.release(); d_c3_.release(); d_gq_.release();
@@ -267,6 +271,12 @@ Engine::~Engine() {
     d_ar_recs_.release(); d_ar_fins_.release();
     d_arstate_.release(); d_board_.release(); d_teams_.release(); d_split_.release(); d_ts_teams_.release(); d_ts_split_.release();
     d_audio_parts_.release(); d_audio_.release(); d_qnorm_.release(); d_mix_parts_.release();
+    d_audio_host_[0].release(); d_audio_host_[1].release();
+    if (copy_stream_) {
+        (void)hipStreamSynchronize(copy_stream_);
+        (void)hipStreamDestroy(copy_stream_);
+        for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(ev_host_bank_[i]); (void)hipEventDestroy(ev_host_copy_[i]); }
+    }
     d_census_.release();
     d_scan_.release();
     for (int i = 0; i < N_SETS; ++i) { d_xs_[i].release(); d_xtrow_[i].release(); }
@@ -956,10 +966,7 @@ int Engine::finalize() {
     // transfer rows: [0,N) _latest_transfer, [N,2N) the 1-slot transfer queue, then per-launch scratch
     HIPTRY(d_xfer_.ensure((size_t)2 * N * m_pad_));
     HIPTRY(hipMemset(d_xfer_.p, 0, (size_t)2 * N * m_pad_ * sizeof(double)));
-    {
-        int wrc = warm_copy_engines();
-        if (wrc != PBSO_OK) return wrc;
-    }
+    (void)warm_copy_engines();
     finalized_ = true;
     return PBSO_OK;
 }
@@ -975,41 +982,50 @@ int Engine::finalize() {
 // host first got that far ahead.  Issuing exactly that pattern here removes it.
 int Engine::warm_copy_engines() {
     if (desc_.warm_copies < 0) return PBSO_OK;
-    const size_t chunk = (size_t)4 << 20;
+    // Best effort: a failure here costs a slow first launch, never the engine (errors are swallowed, everything is released).
+    // A caller's stream is not touched: the second pattern only needs SOME stream the preparation stream waits for.
+    const size_t chunk = (size_t)1 << 20;
     const int n = 6;
     PinBuf<unsigned char> h;
     DevBuf<unsigned char> d;
-    HIPTRY(h.ensure(chunk * n));
-    HIPTRY(d.ensure(chunk * n));
-    std::memset(h.p, 0, chunk * n);
-    for (int rep = 0; rep < 2; ++rep) {               // (1)
-        for (int i = 0; i < n; ++i) {
-            hipStream_t s = (i & 1) ? stream_ : prep_stream_;
-            HIPTRY(hipMemcpyAsync(d.p + chunk * i, h.p + chunk * i, chunk, hipMemcpyHostToDevice, s));
-        }
-        for (int i = 0; i < n; ++i) {
-            hipStream_t s = (i & 1) ? prep_stream_ : stream_;
-            HIPTRY(hipMemcpyAsync(h.p + chunk * i, d.p + chunk * i, chunk, hipMemcpyDeviceToHost, s));
-        }
-    }
-    HIPTRY(hipStreamSynchronize(prep_stream_));
-    HIPTRY(hipStreamSynchronize(stream_));
-    // (2): uploads behind a wait for an event that has not happened yet
+    hipStream_t other = own_stream_ ? stream_ : nullptr;
     hipEvent_t ev = nullptr, ev2 = nullptr;
-    HIPTRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    HIPTRY(hipEventCreateWithFlags(&ev2, hipEventDisableTiming));
-    for (int rep = 0; rep < 4; ++rep) {
-        for (int i = 0; i < n; ++i) HIPTRY(hipMemcpyAsync(d.p + chunk * i, h.p + chunk * i, chunk, hipMemcpyHostToDevice, stream_));
-        HIPTRY(hipEventRecord(ev, stream_));
-        HIPTRY(hipStreamWaitEvent(prep_stream_, ev, 0));
-        HIPTRY(hipMemcpyAsync(d.p, h.p, (size_t)384 << 10, hipMemcpyHostToDevice, prep_stream_));
-        HIPTRY(hipEventRecord(ev2, prep_stream_));
-        HIPTRY(hipStreamWaitEvent(stream_, ev2, 0));
-    }
-    HIPTRY(hipStreamSynchronize(prep_stream_));
-    HIPTRY(hipStreamSynchronize(stream_));
-    (void)hipEventDestroy(ev);
-    (void)hipEventDestroy(ev2);
+    auto body = [&]() -> hipError_t {
+        hipError_t e;
+        if (!other && (e = hipStreamCreateWithFlags(&other, hipStreamNonBlocking)) != hipSuccess) return e;
+        if ((e = h.ensure(chunk * n)) != hipSuccess) return e;
+        if ((e = d.ensure(chunk * n)) != hipSuccess) return e;
+        std::memset(h.p, 0, chunk * n);
+        for (int rep = 0; rep < 2; ++rep) {           // (1) the copy queues, both directions, both streams
+            for (int i = 0; i < n; ++i)
+                if ((e = hipMemcpyAsync(d.p + chunk * i, h.p + chunk * i, chunk, hipMemcpyHostToDevice, (i & 1) ? other : prep_stream_)) != hipSuccess) return e;
+            for (int i = 0; i < n; ++i)
+                if ((e = hipMemcpyAsync(h.p + chunk * i, d.p + chunk * i, chunk, hipMemcpyDeviceToHost, (i & 1) ? prep_stream_ : other)) != hipSuccess) return e;
+        }
+        if ((e = hipStreamSynchronize(prep_stream_)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(other)) != hipSuccess) return e;
+        // (2) uploads behind a wait for an event that has not happened yet
+        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&ev2, hipEventDisableTiming)) != hipSuccess) return e;
+        for (int rep = 0; rep < 4; ++rep) {
+            for (int i = 0; i < n; ++i)
+                if ((e = hipMemcpyAsync(d.p + chunk * i, h.p + chunk * i, chunk, hipMemcpyHostToDevice, other)) != hipSuccess) return e;
+            if ((e = hipEventRecord(ev, other)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(prep_stream_, ev, 0)) != hipSuccess) return e;
+            if ((e = hipMemcpyAsync(d.p, h.p, (size_t)384 << 10, hipMemcpyHostToDevice, prep_stream_)) != hipSuccess) return e;
+            if ((e = hipEventRecord(ev2, prep_stream_)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(other, ev2, 0)) != hipSuccess) return e;
+        }
+        if ((e = hipStreamSynchronize(prep_stream_)) != hipSuccess) return e;
+        return hipStreamSynchronize(other);
+    };
+    (void)body();
+    (void)hipGetLastError();
+    if (prep_stream_) (void)hipStreamSynchronize(prep_stream_);
+    if (other) (void)hipStreamSynchronize(other);
+    if (ev) (void)hipEventDestroy(ev);
+    if (ev2) (void)hipEventDestroy(ev2);
+    if (other && other != stream_) (void)hipStreamDestroy(other);
     h.release();
     d.release();
     return PBSO_OK;
@@ -2260,6 +2276,7 @@ int Engine::sync() {
     HIPTRY(hipSetDevice(desc_.device));      // the caller's thread may have another device current
     if (prep_stream_) HIPTRY(hipStreamSynchronize(prep_stream_));
     if (stream_) HIPTRY(hipStreamSynchronize(stream_));
+    if (copy_stream_) HIPTRY(hipStreamSynchronize(copy_stream_));
     for (hipStream_t cs : class_stream_)
         if (cs) HIPTRY(hipStreamSynchronize(cs));
     free_retired_blocks();                   // nothing of this engine is in flight any more
@@ -2481,6 +2498,66 @@ int Engine::mix_listeners(int obj, const double *pos, int n_listeners, float *ou
     return rc;
 }
 
+// Host delivery (the reference's consumer is a host queue of SoundMessages, modal_solver.h:79-82, 346-363): a step whose audio
+// of ALL objects lands in caller memory.  Pinned host memory (pbso_host_alloc, hipHostMalloc, hipHostRegister) is mapped into
+// the device's address space: the oscillator bank writes its samples STRAIGHT into it over PCIe -- every sample is stored
+// exactly once, coalesced -- so delivery needs no second pass and the step runs at the link's rate (1024 x 512 x 86: 3.5 ms per
+// step against 3.2 ms for the bare copy of the same 181 MB; scripts/debug/r04_d2h.py).  What was tried first -- the bank into
+// device memory, then hipMemcpyAsync on a copy stream beside the next step's bank -- does NOT overlap on this stack: the runtime
+// runs the device-to-host copy as a blit KERNEL, which finds no free registers while the bank's two 256-register waves per SIMD
+// are resident (4.35 ms per step waited one by one, 4.65 ms "pipelined").  That staged path remains for pageable memory.
+int Engine::step_to_host(int nb, float *host_out, size_t n) {
+    HIPTRY(hipSetDevice(desc_.device));
+    if (!finalized_) return fail(PBSO_ERR_STATE, "step before finalize");
+    const size_t total = (size_t)objs_.size() * (size_t)std::max(nb, 0) * B_;
+    if (!host_out || nb <= 0 || n != total) return fail(PBSO_ERR_INVALID, "step_to_host arguments (n_floats = n_objects * n_buffers * frames_per_buffer)");
+    if (!copy_stream_) {
+        {
+            // (highest priority: should the runtime run the copy as a blit kernel, its workgroups take the CUs the retiring
+            //  bank frees before the next bank's do)
+            int least = 0, greatest = 0;
+            HIPTRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIPTRY(hipStreamCreateWithPriority(&copy_stream_, hipStreamNonBlocking, greatest));
+        }
+        for (int i = 0; i < 2; ++i) {
+            HIPTRY(hipEventCreateWithFlags(&ev_host_bank_[i], hipEventDisableTiming));
+            HIPTRY(hipEventCreateWithFlags(&ev_host_copy_[i], hipEventDisableTiming));
+        }
+    }
+    const int slot = host_slot_;
+    {
+        hipPointerAttribute_t attr;
+        std::memset(&attr, 0, sizeof(attr));
+        if (hipPointerGetAttributes(&attr, host_out) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer) {
+            int rc = step(nb, attr.devicePointer);
+            if (rc != PBSO_OK) return rc;
+            HIPTRY(hipEventRecord(ev_host_copy_[slot], stream_));      // "delivered" = the bank (and what follows it) has finished
+            host_last_ = slot;
+            host_slot_ ^= 1;
+            return PBSO_OK;
+        }
+        (void)hipGetLastError();                         // (a pageable pointer is not an error here)
+    }
+    HIPTRY(d_audio_host_[slot].ensure(total, false, stream_));
+    HIPTRY(hipStreamWaitEvent(stream_, ev_host_copy_[slot], 0));          // the copy that last read this buffer is done
+    int rc = step(nb, d_audio_host_[slot].p);
+    if (rc != PBSO_OK) return rc;
+    HIPTRY(hipEventRecord(ev_host_bank_[slot], stream_));
+    HIPTRY(hipStreamWaitEvent(copy_stream_, ev_host_bank_[slot], 0));
+    HIPTRY(hipMemcpyAsync(host_out, d_audio_host_[slot].p, total * sizeof(float), hipMemcpyDeviceToHost, copy_stream_));
+    HIPTRY(hipEventRecord(ev_host_copy_[slot], copy_stream_));
+    host_last_ = slot;
+    host_slot_ ^= 1;
+    return PBSO_OK;
+}
+
+int Engine::host_wait() {
+    if (host_last_ < 0) return PBSO_OK;
+    HIPTRY(hipSetDevice(desc_.device));
+    HIPTRY(hipEventSynchronize(ev_host_copy_[host_last_]));
+    return PBSO_OK;
+}
+
 // The step's audio summed over the objects, on the device, in a fixed order (what one output stream plays when the scene's
 // objects sound together; the per-rank half of the device group's PBSO_GATHER_MIX).  Asynchronous on the engine's stream.
 int Engine::mix_objects(void *d_out) {
@@ -2597,9 +2674,8 @@ int Engine::harvest_timing(bool blocking) {
         HIPTRY(hipEventElapsedTime(&ms, q.k0, q.k1));
         HIPTRY(hipEventElapsedTime(&ms2, q.p0, q.p1));
         if (timeline_) {                            // PBSO_TIMELINE=1: where each timed launch's events fall (ms since the first one)
-            if (!timeline_base_) { HIPTRY(hipEventCreate(&timeline_base_)); timeline_have_base_ = false; }
             float a = 0, b = 0, c = 0, d = 0;
-            if (!timeline_have_base_) { timeline_ref_ = q.p0; timeline_have_base_ = true; timeline_keep_ = true; timeline_h0_ = q.h_prep; }
+            if (!timeline_have_base_) { timeline_ref_ = q.p0; timeline_quad_ = q; timeline_have_base_ = true; timeline_keep_ = true; timeline_h0_ = q.h_prep; }
             HIPTRY(hipEventElapsedTime(&a, timeline_ref_, q.p0));
             HIPTRY(hipEventElapsedTime(&b, timeline_ref_, q.k0));
             HIPTRY(hipEventElapsedTime(&c, timeline_ref_, q.k1));

@@ -190,6 +190,8 @@ public:
     int set_use_transfer(int obj, int use, int64_t not_before);
     int get_latest_transfer(int obj, double *out);
     int step(int n_buffers, void *d_audio);
+    int step_to_host(int n_buffers, float *host_out, size_t n);
+    int host_wait();
     int step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_id);   // one launch of at most chunk_buffers_ buffers
     int sync();
     int read_audio(float *out, size_t n);
@@ -331,6 +333,11 @@ private:
     DevBuf<double> d_xfer_;                              // [n_obj + scratch][m_pad]
     DevBuf<float> d_audio_, d_qnorm_;
     DevBuf<float> d_mix_parts_;                          // pbso_mix_objects: partial rows of the object groups
+    // pbso_step_to_host: two device audio buffers used in turn, a copy stream, events both ways
+    DevBuf<float> d_audio_host_[2];
+    hipStream_t copy_stream_ = nullptr;
+    hipEvent_t ev_host_bank_[2] = {nullptr, nullptr}, ev_host_copy_[2] = {nullptr, nullptr};
+    int host_slot_ = 0, host_last_ = -1;
     DevBuf<unsigned long long> d_census_;                // PBSO_CENSUS=1: per-workgroup placement/timing
     bool census_ = false;
     int rotate_prio_ = 2;                                // PBSO_ROTATE_PRIO: 0 off, 1 rotation, 2 rotation + per-CU progress feedback
@@ -375,7 +382,8 @@ private:
     bool k2_rows_ = true;
     bool timeline_ = false, timeline_have_base_ = false, timeline_keep_ = false;   // PBSO_TIMELINE=1 (diagnostics)
     bool host_profile_ = false;                          // PBSO_HOST_PROFILE=1 (diagnostics): host milliseconds by stage at destruction
-    hipEvent_t timeline_base_ = nullptr, timeline_ref_ = nullptr;
+    hipEvent_t timeline_ref_ = nullptr;
+    EvQuad timeline_quad_ = {};                          // the launch the timeline's device times are relative to (its events live until the engine dies)
     double timeline_h0_ = 0;
     int k2_margin_pct_ = 100;                            // PBSO_K2_MARGIN_PCT: scales the candidate range (tests: < 100 forces the shortfall path)
     bool k2_rows_launch_ = false;                        // this launch takes the row-parallel form

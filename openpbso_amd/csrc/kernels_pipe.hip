@@ -564,7 +564,8 @@ __global__ __launch_bounds__(256) void iir_pipe_kernel(
     if (p_census && lane == 0) {                     // where the team's waves sit: HW_ID (SIMD 5:4, CU 11:8, SH 12, SE 15:13) | XCC_ID << 32
         const unsigned long long hw = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
                                       ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 32);
-        p_census[(size_t)blockIdx.x * CENSUS_WORDS + (wave == 0 ? 3 : 8 + wave)] = hw;
+        // (words 3, 9, 10: the producer's and the two projecting consumers'; word 11 is consumer 0's n_unit: a helper wave keeps quiet)
+        if (wave < 3) p_census[(size_t)blockIdx.x * CENSUS_WORDS + (wave == 0 ? 3 : 8 + wave)] = hw;
     }
     if (p_census && lane == 0 && wave < 2) {
 #pragma unroll

@@ -211,6 +211,9 @@ class Engine:
             if self._owned:
                 self._l.pbso_engine_destroy(self._h)
             self._h = None
+            for p in getattr(self, "_pinned", []):
+                self._l.pbso_host_free(p)
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -397,6 +400,29 @@ class Engine:
 
     def sync(self):
         self._chk(self._l.pbso_sync(self._h))
+
+    def host_buffer(self, n_buffers):
+        """a pinned numpy array [n_objects][n_buffers * 513] float32 for step_to_host (freed with the engine)"""
+        n = len(self.n_modes) * n_buffers * self.B
+        p = C.c_void_p()
+        rc = self._l.pbso_host_alloc(n * 4, C.byref(p))
+        if rc != capi.OK:
+            raise PbsoError(rc, "pbso_host_alloc failed")
+        if not hasattr(self, "_pinned"):
+            self._pinned = []
+        self._pinned.append(p)
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n,))
+        return arr.reshape(len(self.n_modes), n_buffers * self.B)
+
+    def step_to_host(self, n_buffers, out):
+        """pbso_step_to_host: the step's audio of all objects into `out` (a host_buffer), asynchronously"""
+        assert out.dtype == np.float32 and out.flags.c_contiguous and out.size == len(self.n_modes) * n_buffers * self.B
+        self._chk(self._l.pbso_step_to_host(self._h, n_buffers, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+        self._last_nb = n_buffers
+        self._borrowed = None
+
+    def host_wait(self):
+        self._chk(self._l.pbso_host_wait(self._h))
 
     def audio(self):
         n = len(self.n_modes) * self._last_nb * self.B

@@ -184,3 +184,38 @@ def test_strong_scaling_shares_full_size(n_obj, n_modes):
     want = run_oracle(objs, evs, nb, only=pick, threads=4)
     mx, l2 = rel_errors(got["audio"][pick], want["audio"])
     assert (mx <= 1e-4).all() and (l2 <= 1e-3).all(), (mx.max(), l2.max())
+
+
+def test_step_to_host_delivers_what_read_audio_returns():
+    """pbso_step_to_host: the step's audio of all objects in pinned host memory, double-buffered on the device so that the copy
+    of step k runs beside the bank of step k + 1 -- three steps into two alternating host buffers, each equal to what a second
+    engine's pbso_read_audio returns for the same step, bit for bit"""
+    from openpbso_amd import Engine, ForceMessage
+    nb = 6
+    objs, evs = _poisson_scene(5, 200, 3 * nb, p_hit=0.5)
+    with Engine() as a, Engine() as b:
+        for e in (a, b):
+            for o in objs:
+                e.add_object(o.lam, o.rho, o.alpha, o.beta, o.n_modes, o.shapes)
+            e.finalize()
+            for ev in sorted(evs, key=lambda x: x["t"]):
+                if ev["kind"] == "force":
+                    assert e.enqueue_force(ev["obj"], ForceMessage(vid=ev["vid"], vn=ev["vn"]), ev["t"])
+                else:
+                    e.set_use_transfer(ev["obj"], ev["use"], ev["t"])
+        bufs = [a.host_buffer(nb), a.host_buffer(nb)]
+        want = []
+        for k in range(3):
+            b.step(nb)
+            want.append(b.audio().copy())
+        got = []
+        a.step_to_host(nb, bufs[0])
+        a.step_to_host(nb, bufs[1])                  # (step 1's bank runs while step 0's samples travel)
+        a.host_wait()
+        got.append(bufs[0].copy())
+        got.append(bufs[1].copy())
+        a.step_to_host(nb, bufs[0])
+        a.host_wait()
+        got.append(bufs[0].copy())
+        for k in range(3):
+            assert np.array_equal(got[k], want[k]) and np.abs(want[k]).max() > 0, k
