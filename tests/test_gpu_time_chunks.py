@@ -219,3 +219,9 @@ def test_step_to_host_delivers_what_read_audio_returns():
         got.append(bufs[0].copy())
         for k in range(3):
             assert np.array_equal(got[k], want[k]) and np.abs(want[k]).max() > 0, k
+        # a PAGEABLE target takes the staged path (device buffer, then a copy on its own stream): same samples
+        b.step(nb)
+        plain = np.empty_like(got[0])
+        a.step_to_host(nb, plain)
+        a.host_wait()
+        assert np.array_equal(plain, b.audio())
