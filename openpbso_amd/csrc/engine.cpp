@@ -2033,7 +2033,14 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     const size_t o_tprof = place(device_profiles_ ? 0 : tprof_.size() * sizeof(float));
     const size_t o_stage = place(stage_.size() * sizeof(double)), o_stage_slot = place(stage_slot_.size() * sizeof(int));
     const size_t o_proj = place(proj_.size() * sizeof(ProjectEvent)), o_projd = place(proj_direct_.size() * sizeof(ProjectEvent));
+    // the listener events as runs of one object each (the planner lists them object by object): one geometry read per (run, mode)
+    ffat_runs_.clear();
+    for (size_t i = 0; i < ffat_.size(); ++i) {
+        if (ffat_runs_.empty() || ffat_runs_.back().obj != ffat_[i].obj) ffat_runs_.push_back(FfatRun{ffat_[i].obj, (int)i, 0, 0});
+        ffat_runs_.back().count += 1;
+    }
     const size_t o_ffat = place(ffat_.size() * sizeof(FfatEvent)), o_copy = place(cp.size() * sizeof(int));
+    const size_t o_ffat_runs = place(ffat_runs_.size() * sizeof(FfatRun));
     HIPTRY(ps.h_arena.ensure_keep(off, ps.front_bytes));
     plan_desc_ = reinterpret_cast<BufDesc *>(ps.h_arena.p);      // (the arena may have moved)
     ps.last_bytes = off;
@@ -2070,6 +2077,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     put(o_proj, proj_.data(), proj_.size() * sizeof(ProjectEvent));
     put(o_projd, proj_direct_.data(), proj_direct_.size() * sizeof(ProjectEvent));
     put(o_ffat, ffat_.data(), ffat_.size() * sizeof(FfatEvent));
+    put(o_ffat_runs, ffat_runs_.data(), ffat_runs_.size() * sizeof(FfatRun));
     put(o_copy, cp.data(), cp.size() * sizeof(int));
     HIPTRY(ps.d_arena.ensure(off, false, sp));
     HIPTRY(hipMemcpyAsync(ps.d_arena.p, ha, off, hipMemcpyHostToDevice, sp));
@@ -2142,7 +2150,12 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     if (evq.has_k2) HIPTRY(hipEventRecord(evq.f1, sp));
     LAUNCHTRY(launch_scatter_rows(d_stage, d_stage_slot, (int)stage_slot_.size(), d_slots_.p, m_pad_, sp));
     LAUNCHTRY(launch_modal_project(d_proj, (int)proj_.size(), d_shapes_.p, d_shape_off_.p, d_n_modes_.p, d_slots_.p, m_pad_, sp));
-    LAUNCHTRY(launch_ffat_lookup(d_ffat, (int)ffat_.size(), d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p, d_xfer_.p, m_pad_, sp));
+    // (a few events: one thread per (event, mode); listener paths -- many events per object -- by runs)
+    if (ffat_.size() >= 4 * ffat_runs_.size() && !ffat_runs_.empty())
+        LAUNCHTRY(launch_ffat_lookup_runs(d_ffat, reinterpret_cast<const FfatRun *>(da + o_ffat_runs), (int)ffat_runs_.size(), d_geom_.p,
+                                          d_geom_off_.p, d_n_modes_.p, d_psi_.p, d_xfer_.p, m_pad_, sp));
+    else
+        LAUNCHTRY(launch_ffat_lookup(d_ffat, (int)ffat_.size(), d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p, d_xfer_.p, m_pad_, sp));
     // (the combine stays on the preparation stream even when the bank fills the register file: its workgroups
     //  move in as the bank's retire, so most of it is done when the last one leaves -- queued behind the bank in
     //  the bank's own stream it would start only then: 0.785 instead of 0.735 ms per step at 1024 x 512)

@@ -403,6 +403,7 @@ private:
     std::vector<ProjectEvent> proj_, proj_direct_;         // projections into pool rows / evaluated on the fly by the combine kernel
     BufDesc *plan_desc_ = nullptr;                       // the descriptor table being planned (front of the set's arena)
     std::vector<FfatEvent> ffat_;
+    std::vector<FfatRun> ffat_runs_;
     std::vector<unsigned char> emitted_;
     // planner threads (PBSO_PLAN_THREADS, default 1): ctx_[t] plans a contiguous share of the busy objects.
     // More than one only pays when the threads share a last-level cache with the caller: on the 2-socket

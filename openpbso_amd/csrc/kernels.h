@@ -238,6 +238,10 @@ struct FfatEvent {
     int row;             // destination transfer row
     double pos[3];
 };
+struct FfatRun { int obj, first, count, pad; };          // consecutive events of one object in the launch's list
+int launch_ffat_lookup_runs(const FfatEvent *events, const FfatRun *runs, int n_runs, const FfatGeom *geom,
+                            const long long *geom_off, const int *n_modes, const double *psi,
+                            double *rows, int m_pad, hipStream_t stream);
 int launch_ffat_lookup(const FfatEvent *events, int n_events, const FfatGeom *geom,
                        const long long *geom_off, const int *n_modes, const double *psi,
                        double *rows, int m_pad, hipStream_t stream);

@@ -950,6 +950,36 @@ int launch_ffat_lookup(const FfatEvent *events, int n_events, const FfatGeom *ge
     return (int)hipGetLastError();
 }
 
+// K4 for a launch's listener events, the planner's list cut into RUNS of consecutive events of one object (it lists them
+// object by object).  One workgroup per (run, mode): the mode's geometry is workgroup-uniform -- scalar loads, once -- and the
+// threads are the run's events.  The per-event kernel above reads the mode's 232-byte geometry per LOOKUP: 325 MB through L2
+// for the 1.4 M lookups of 64 x 256 x 86 with a listener move per buffer, 75 us, the longest kernel of that step.  Same
+// arithmetic (ffat_get_map_val), bit-exact with the oracle.
+__global__ __launch_bounds__(128) void ffat_lookup_runs_kernel(
+    const FfatEvent *__restrict__ events, const FfatRun *__restrict__ runs, const FfatGeom *__restrict__ geom,
+    const long long *__restrict__ geom_off, const int *__restrict__ n_modes,
+    const double *__restrict__ psi, double *__restrict__ rows, int m_pad) {
+    const FfatRun run = runs[blockIdx.y];
+    const int m = blockIdx.x;
+    const bool live = m < n_modes[run.obj];
+    const FfatGeom &g = geom[geom_off[run.obj] + (live ? m : 0)];
+    const bool on = live && g.valid;
+    for (int i = threadIdx.x; i < run.count; i += blockDim.x) {
+        const FfatEvent ev = events[run.first + i];
+        // computeTransfer wraps GetMapVal in another std::abs (modal_solver.h:295)
+        rows[(size_t)ev.row * m_pad + m] = on ? fabs(ffat_get_map_val(g, psi + g.psi_off, ev.pos)) : 0.0;
+    }
+}
+
+int launch_ffat_lookup_runs(const FfatEvent *events, const FfatRun *runs, int n_runs, const FfatGeom *geom,
+                            const long long *geom_off, const int *n_modes, const double *psi,
+                            double *rows, int m_pad, hipStream_t stream) {
+    if (n_runs <= 0) return 0;
+    hipLaunchKernelGGL(ffat_lookup_runs_kernel, dim3(m_pad, n_runs), dim3(128), 0, stream, events, runs, geom, geom_off,
+                       n_modes, psi, rows, m_pad);
+    return (int)hipGetLastError();
+}
+
 // K4, many positions of ONE object (computeTransfer(pos, T*), modal_solver.h:302-315; the HUD sphere of the tool,
 // tools/real_time_modal_sound.cpp:916-927).  One workgroup per (mode, chunk of positions): the mode's map -- all six
 // faces of Psi -- is staged in LDS once and every bilinear interpolation of the chunk gathers from there; the mode's

@@ -1,0 +1,11 @@
+#!/bin/bash
+# quick bench numbers of the BASELINE configurations (no cpu baseline, no second form)
+cd "$GRAFT_REPO_ROOT"
+run() { python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-second-form --no-strong-share "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['realtime_x']), 'x', round(d['ms_per_step'],4), 'ms kernel', round(d['roofline']['kernel_ms'],4), 'host', round(d['timing']['host_ms'],3), 'err', d.get('max_err'))"; }
+for rep in 1 2; do
+echo "1x512     $(run --objects 1 --modes 512)"
+echo "listener  $(run --objects 64 --modes 256 --scenario listener)"
+echo "scraping  $(run --objects 8 --modes 4096 --scenario scraping)"
+echo "128x512   $(run --objects 128 --modes 512)"
+done
+echo "default   $(run)"
