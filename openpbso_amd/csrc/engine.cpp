@@ -1642,6 +1642,26 @@ int Engine::plan_object_span(PlanCtx &c, int oi, int nb) {
     int b = 0;
     while (b < nb) {
         const int64_t t = buffers_done_ + b;
+        // The buffer of a listener PATH in one step: nothing is due but one computeTransfer (a camera move per frame,
+        // tools/real_time_modal_sound.cpp:844, 1172), no force is alive, the 1-slot queue is free -- what plan_object does for it
+        // (try_enqueue into _queue_trans, modal_solver.h:286-300; dequeued at :242-256 in the same step) comes to one lookup event
+        // and this buffer's transfer row.
+        if (!o.pending.empty() && o.pending.front().kind == TimedEvent::TRANSFER && o.pending.front().not_before <= t &&
+            o.active.empty() && !o.sustained && o.use_transfer && !o.trans_full &&
+            (o.force_q.empty() || o.force_q.front().not_before > t) && (o.pending.size() == 1 || o.pending[1].not_before > t)) {
+            const TimedEvent &ev = o.pending.front();
+            FfatEvent fe;
+            fe.obj = oi;
+            fe.row = c.xfer_base + c.n_xfer++;
+            fe.pos[0] = ev.v[0]; fe.pos[1] = ev.v[1]; fe.pos[2] = ev.v[2];
+            c.ffat.push_back(fe);
+            o.pending.pop_front();
+            o.trans_row = fe.row;
+            o.latest_row = fe.row;
+            plan_desc_[(size_t)oi * nb + b].trow = fe.row;
+            ++b;
+            continue;
+        }
         const bool due = (!o.pending.empty() && o.pending.front().not_before <= t) ||
                          (!o.force_q.empty() && o.force_q.front().not_before <= t);
         const bool live = !o.active.empty() || o.sustained || (o.trans_full && o.use_transfer) ||
