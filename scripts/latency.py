@@ -35,3 +35,31 @@ for n_modes in (128, 512, 2048):
           f"p99 {np.percentile(ts, 99):7.1f} us; with audio D2H median {np.median(ts_read):7.1f} us p99 {np.percentile(ts_read, 99):7.1f} us; "
           f"kernel {info['last_step_kernel_ms'] * 1e3:6.1f} us  (deadline 11 630 us)")
     eng.close()
+
+
+# Sustained contact in real-time mode (the facade's use: ONE buffer per step, an AutoregressiveForce alive, a new face hit every
+# buffer: tools/real_time_modal_sound.cpp:754-776, 1127-1160): the force-profile kernels (K2) and the oscillator bank of every
+# buffer are on the critical path here -- nothing runs a step ahead.
+for n_modes in (512, 2048):
+    eng = Engine(qnorm=capi.QNORM_ALL)
+    shapes = synth.mode_shapes(n_modes, 6)
+    eng.add_object(synth.eigenvalues(n_modes, 6), synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes)
+    eng.finalize()
+    eng.set_use_transfer(0, False)
+    assert eng.enqueue_force(0, ForceMessage(forceType=capi.AUTOREGRESSIVE_FORCE, sustainedForceStart=True), 0)
+    vns = synth.unit_normals(400, 6)
+    ts, ks, ds = [], [], []
+    for i in range(400):
+        if i > 0:
+            eng.enqueue_force(0, ForceMessage(vids=[0, 1, 2], coords=[0.2, 0.3, 0.5], vn=vns[i], forceType=capi.AUTOREGRESSIVE_FORCE), i)
+        t0 = time.perf_counter()
+        eng.step(1)
+        eng.sync()
+        ts.append(time.perf_counter() - t0)
+        info = eng.info()
+        ks.append(info["last_step_kernel_ms"] * 1e3)
+        ds.append(info["last_step_device_ms"] * 1e3)
+    ts = np.array(ts[50:]) * 1e6
+    print(f"sustained AR scraping, modes={n_modes:5d}: step+sync median {np.median(ts):7.1f} us p99 {np.percentile(ts, 99):7.1f} us; "
+          f"device pipeline (K2 + projection + combine + bank) median {np.median(ds[50:]):6.1f} us, bank alone {np.median(ks[50:]):6.1f} us  (deadline 11 630 us)")
+    eng.close()
