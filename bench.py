@@ -90,6 +90,10 @@ def parse(argv=None):
     ap.add_argument("--weak", action="store_true",
                     help="N > 1: make the weak-scaling run (--objects per GPU) the headline; default for N > 1 is the configuration as written "
                          "(--objects in total, BASELINE configs[3]) with the weak run as the side leg")
+    ap.add_argument("--host-delivery", action="store_true",
+                    help="one GPU: also time pbso_step_to_host (the oscillator bank writing straight into pinned host memory) in a loop of "
+                         "its own behind the timed region.  Off by default: its launches are the headline kernel at the PCIe link's pace "
+                         "(3.5 ms instead of 0.94), which would skew a profiler's per-kernel average over the default command")
     ap.add_argument("--no-strong-share", action="store_true",
                     help="one GPU: skip the strong-scaling proxy (the per-rank shares objects / 2, 4, 8 measured on this GPU)")
     ap.add_argument("--strong", action="store_true",
@@ -319,16 +323,34 @@ def measure(args, ctx, global_ids, want_parity):
     use_group = bool(ctx["use_dist"] and backend == "nccl" and (world > 1 or os.environ.get("PBSO_BENCH_GATHER_SELF") == "1")
                      and not args.no_gather and not ctx.get("leg_without_gather"))
     grp = None
+    group_note = None
     if use_group:
-        from openpbso_amd.group import Group, unique_id
-        ident = [unique_id() if (rank == 0 and world > 1) else None]
+        # (should the group not come up on some rank -- librccl missing, a communicator error -- every rank falls back to the
+        #  torch.distributed collectives together: the ranks agree on it with one all-reduce, and the JSON line says so)
+        try:
+            from openpbso_amd.group import Group, unique_id
+            ident = [unique_id() if (rank == 0 and world > 1) else None]
+            if world > 1:
+                dist.broadcast_object_list(ident, src=0, device=ctx["coll_dev"])
+            counts_all = ctx.get("counts") or [n_obj]
+            grp = Group([ctx["dev_index"]], world_size=world, first_rank=rank, unique_id=ident[0], form=form_c, qnorm=qnorm_c,
+                        modes_per_lane=args.modes_per_lane)
+            grp.plan([args.modes] * int(sum(counts_all)))
+            assert grp.span(rank) == (global_ids[0], global_ids[-1] + 1), (grp.span(rank), global_ids[0], global_ids[-1])
+        except Exception as ex:
+            group_note = repr(ex)
+            if grp is not None:
+                grp.close()
+            grp = None
+        ok = torch.tensor([1.0 if grp is not None else 0.0], device=ctx["coll_dev"])
         if world > 1:
-            dist.broadcast_object_list(ident, src=0, device=ctx["coll_dev"])
-        counts_all = ctx.get("counts") or [n_obj]
-        grp = Group([ctx["dev_index"]], world_size=world, first_rank=rank, unique_id=ident[0], form=form_c, qnorm=qnorm_c,
-                    modes_per_lane=args.modes_per_lane)
-        grp.plan([args.modes] * int(sum(counts_all)))
-        assert grp.span(rank) == (global_ids[0], global_ids[-1] + 1), (grp.span(rank), global_ids[0], global_ids[-1])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) < 1.0:
+            if grp is not None:
+                grp.close()
+            grp, use_group = None, False
+            group_note = group_note or "the device group failed on another rank"
+    if use_group:
         for i, gid in enumerate(global_ids):
             grp.add_object(gid, lam[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
         eng = grp.engine(rank)
@@ -556,19 +578,20 @@ def measure(args, ctx, global_ids, want_parity):
             reps.append(time.perf_counter() - td)
         res["d2h_ms"] = float(np.median(reps)) * 1e3
         res["d2h_bytes"] = n_obj * nb * B * 4
-        # ... and MEASURED with the product's own delivery path: pbso_step_to_host into two pinned buffers in turn (the copy of
-        # step k beside the bank of step k + 1), a short timed loop of its own behind the timed region
-        hb = [eng.host_buffer(nb), eng.host_buffer(nb)]
-        for w in range(2):
-            eng.step_to_host(nb, hb[w])
-        eng.host_wait()
         k2 = max(4, min(10, args.steps))
-        td = time.perf_counter()
-        for k in range(k2):
-            eng.step_to_host(nb, hb[k % 2])
-        eng.host_wait()
-        res["to_host_ms_per_step"] = (time.perf_counter() - td) / k2 * 1e3
-        assert np.isfinite(hb[0]).all() and np.isfinite(hb[1]).all()
+        if args.host_delivery:
+            # ... and MEASURED with the product's own delivery path: pbso_step_to_host into two pinned host buffers in turn (the
+            # bank stores its samples straight into them over PCIe), a short timed loop of its own behind the timed region
+            hb = [eng.host_buffer(nb), eng.host_buffer(nb)]
+            for w in range(2):
+                eng.step_to_host(nb, hb[w])
+            eng.host_wait()
+            td = time.perf_counter()
+            for k in range(k2):
+                eng.step_to_host(nb, hb[k % 2])
+            eng.host_wait()
+            res["to_host_ms_per_step"] = (time.perf_counter() - td) / k2 * 1e3
+            assert np.isfinite(hb[0]).all() and np.isfinite(hb[1]).all()
         # ... and the one-stream consumer: the object mix on the device (pbso_mix_objects) behind every step
         mix_row = torch.zeros(nb * B, dtype=torch.float32, device=dev)
         for w in range(2):
@@ -599,7 +622,8 @@ def measure(args, ctx, global_ids, want_parity):
             "pass": bool((mx <= TOL_MAX).all() and (l2 <= TOL_L2).all()),
         }
     res["_cpu_inputs"] = (lam, shapes, scripts)
-    res["collective_by"] = "pbso_group (C ABI: RCCL called from C++)" if use_group else ("torch.distributed" if do_gather else None)
+    res["collective_by"] = "pbso_group (C ABI: RCCL called from C++)" if use_group else (
+        ("torch.distributed" + (" (pbso_group not used: %s)" % group_note if group_note else "")) if do_gather else None)
     (grp or eng).close()
     return res
 
@@ -866,6 +890,8 @@ def main():
                 "realtime_x_if_copied_after_each_step": step_s / ((hn["ms_per_step"] + m["d2h_ms"]) * 1e-3),
                 "realtime_x_if_copy_overlaps_compute": step_s / (max(hn["ms_per_step"], m["d2h_ms"]) * 1e-3),
                 "to_host_ms_per_step_measured": m.get("to_host_ms_per_step"),
+                "to_host_measured_by": "this run (--host-delivery)" if m.get("to_host_ms_per_step") else
+                                       "python bench.py --host-delivery (profiles/r04_bench_host_delivery.json): not part of the default command",
                 "realtime_x_overlapped_measured": step_s / (m["to_host_ms_per_step"] * 1e-3) if m.get("to_host_ms_per_step") else None,
                 "overlapped_path": "pbso_step_to_host into pinned host memory: the oscillator bank stores its samples straight into the (device-"
                                    "mapped) host buffer over PCIe, no copy pass (PCIe-bound: bytes_per_step / to_host_ms_per_step_measured; a "

@@ -107,7 +107,9 @@ __device__ __forceinline__ void static_for(F &&f) {
 // (scaled, as the registers hold it) and the scale of the buffer to memory; other builds carry no trace of it.
 // FORCED (f32 projection only): buffers with a dense force profile run in block form too ("forced block path" below); a
 // launch without such buffers uses the build without it (its registers are the kernel's peak at R = 4).
-template <int R, int QNM, int PROJ, bool DUMP, int MAXT, bool FORCED>
+// CHUNKED: the launch is cut along the time axis (kernels_scan.hip): grid (team, chunk), start states from the scan.  A build of
+// its own -- the walk in buffer order keeps the code it had, and a profile tells the two apart by the kernel's name.
+template <int R, int QNM, int PROJ, bool DUMP, int MAXT, bool FORCED, bool CHUNKED = false>
 __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     const float *__restrict__ p_ca, const float *__restrict__ p_cb, float *__restrict__ p_sq,
     float *__restrict__ p_sd, float *__restrict__ p_ss, const BufDesc *__restrict__ p_desc,
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     const float *__restrict__ p_ftab, const float *__restrict__ p_xs, const int *__restrict__ p_xtrow, const BlkDims p) {
     constexpr bool QN = QNM != 0;
     constexpr int NG = 2;                              // groups per buffer (513 = 1 + 2 * 256; checked at launch)
-    const bool chunked = p.cb > 0;
+    constexpr bool chunked = CHUNKED;
     const int chunk = chunked ? (int)blockIdx.y : 0;
     const int b_begin = chunk * p.cb;
     const int b_end = chunked ? (b_begin + p.cb < p.nb ? b_begin + p.cb : p.nb) : p.nb;
@@ -1058,14 +1060,18 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     }
 }
 
-template <int R, int QNM, int PROJ, bool DUMP, bool FORCED = false>
+template <int R, int QNM, int PROJ, bool DUMP, bool FORCED = false, bool CHUNKED = false>
 static int launch_one(const IirParams &p, int n_teams, int W, hipStream_t stream) {
+    if constexpr (!CHUNKED && !DUMP && R != 8) {
+        if (p.tc_cb > 0) return launch_one<R, QNM, PROJ, DUMP, FORCED, true>(p, n_teams, W, stream);
+    }
+    if (!CHUNKED && p.tc_cb > 0) return (int)hipErrorInvalidValue;       // (no chunked build of this shape: the engine never asks)
     // (the forced block path of a one-mode-per-lane engine without qnorm rows transposes its increments through LDS: FTM)
     const size_t lds = block_lds_bytes(W, R) + (FORCED && PROJ == 0 && QNM == 0 && R == 1 ? sizeof(float) * (size_t)W * 64 * FTM_U_ROW : 0);
     // R = 8 is the one-wave-per-SIMD build (512 registers: the 256 W-table operands go to AGPRs): teams of <= 4 waves
     constexpr int MAXT = R == 8 ? 256 : 64 * MAX_WAVES_PER_BLOCK_TEAM;
     if (64 * W > MAXT) return (int)hipErrorInvalidValue;
-    auto kern = iir_block_kernel<R, QNM, PROJ, DUMP, MAXT, FORCED>;
+    auto kern = iir_block_kernel<R, QNM, PROJ, DUMP, MAXT, FORCED, CHUNKED>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -11,6 +11,7 @@ b default
 b driver_flags_steps20_warmup5 --steps 20 --warmup 5
 b form_block_bf16 --no-cpu-baseline --form block_bf16 --no-strong-share
 b qnorm_off --no-cpu-baseline --qnorm off --no-second-form --no-strong-share
+b host_delivery --host-delivery --no-cpu-baseline --no-second-form --no-strong-share
 echo "== other BASELINE configurations"
 b c2_1x512 --no-cpu-baseline --objects 1 --modes 512 --steps 40 --warmup 2
 b c3_64x256_listener --no-cpu-baseline --objects 64 --modes 256 --scenario listener --steps 40 --warmup 2
@@ -29,7 +30,7 @@ PBSO_BENCH_BACKEND=gloo b 2ranks_one_gpu_gloo --no-cpu-baseline --gpus 2 --steps
 (PBSO_BENCH_GATHER_SELF=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29633 bench.py --gpus 1 --no-cpu-baseline --steps 40 --warmup 3 > $O/bench_1rank_torchrun_device_group_selfgather.json 2> $O/bench_1rank.err; echo "selfgather rc=$?")
 echo "== rocprofv3 kernel trace + stats"
 st() { name=$1; shift; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/st_$name -- python3 $R/bench.py --no-cpu-baseline --no-second-form "$@" > $O/st_$name.log 2>&1); f=$(find $O/st_$name -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats_$name.csv; [ $name = default ] && python scripts/trace_gaps.py $O/st_$name > $O/trace_gaps.txt 2>&1; rm -rf $O/st_$name; echo "stats $name: $(sed -n 2p $O/kernel_stats_$name.csv | cut -c1-70 | tr -d '\n') ... $(sed -n 2p $O/kernel_stats_$name.csv | awk -F, '{print $(NF-5), $(NF-4)}')"; }
-st default --no-strong-share
+st default
 st c2_1x512 --objects 1 --modes 512 --steps 40
 st c3_64x256_listener --objects 64 --modes 256 --scenario listener --steps 40
 st c5_8x4096_scraping --objects 8 --modes 4096 --scenario scraping --steps 40

@@ -50,9 +50,9 @@ def block_asm(tmp_path_factory):
     asm = open(out).read()
     kernels = {}
     for k in re.split(r"\n(?=_ZN4pbso9iir_block16iir_block_kernel\S*:)", asm)[1:]:
-        t = re.search(r"ILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)ELb(\d)E", k.split(":")[0])
-        # key: (R, QNM, PROJ, DUMP, FORCED)
-        kernels[tuple(int(t.group(i)) for i in (1, 2, 3, 4, 6))] = k.split("s_endpgm")[0]
+        t = re.search(r"ILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)ELb(\d)ELb(\d)E", k.split(":")[0])
+        # key: (R, QNM, PROJ, DUMP, FORCED, CHUNKED)
+        kernels[tuple(int(t.group(i)) for i in (1, 2, 3, 4, 6, 7))] = k.split("s_endpgm")[0]
     return asm, kernels
 
 
@@ -70,11 +70,17 @@ def test_block_kernel_generated_code(block_asm):
     (8 slices x 32 = 256 v_mfma_f32_16x16x4_f32; 8 x 12 = 96 v_mfma_f32_16x16x32_bf16), the LDS-DMA of a direct hit sets M0 right
     before every global_load_lds_dword and nothing else touches M0, and the coarse step stays on full-rate instructions."""
     asm, kernels = block_asm
-    assert len(kernels) == 8
-    f32 = kernels[(4, 2, 0, 0, 0)]
-    f32_noqn = kernels[(4, 0, 0, 0, 0)]
-    bf16 = kernels[(4, 2, 1, 0, 0)]
-    for part in ("ILi4ELi2ELi0ELb0ELi512ELb0E", "ILi4ELi0ELi0ELb0ELi512ELb0E", "ILi4ELi2ELi1ELb0ELi512ELb0E", "ILi4ELi0ELi1ELb0ELi512ELb0E"):
+    # 8 builds that walk the buffers in order + their 6 time-chunked twins (K5; the builds that keep block states for a listener
+    # mix have none)
+    assert len(kernels) == 14 and sum(1 for k in kernels if k[5]) == 6
+    f32 = kernels[(4, 2, 0, 0, 0, 0)]
+    f32_noqn = kernels[(4, 0, 0, 0, 0, 0)]
+    bf16 = kernels[(4, 2, 1, 0, 0, 0)]
+    # the chunked twin of the headline build: the same matrix work per buffer body, no scratch, the same register budget
+    f32_tc = kernels[(4, 2, 0, 0, 0, 1)]
+    assert len(re.findall(r"\bv_mfma_f32_16x16x4_f32\b", f32_tc)) == 256 and "scratch_" not in f32_tc
+    for part in ("ILi4ELi2ELi0ELb0ELi512ELb0ELb0E", "ILi4ELi0ELi0ELb0ELi512ELb0ELb0E", "ILi4ELi2ELi1ELb0ELi512ELb0ELb0E",
+                 "ILi4ELi0ELi1ELb0ELi512ELb0ELb0E", "ILi4ELi2ELi0ELb0ELi512ELb0ELb1E", "ILi4ELi2ELi1ELb0ELi512ELb0ELb1E"):
         scratch, vgprs, spilled = _meta(asm, part)
         assert scratch == 0 and spilled == 0 and vgprs <= 256, (part, scratch, vgprs, spilled)
     for body in (f32, f32_noqn, bf16):
@@ -83,7 +89,7 @@ def test_block_kernel_generated_code(block_asm):
     assert len(re.findall(r"\bv_mfma_f32_16x16x4_f32\b", f32)) == 256 and "v_mfma_f32_16x16x32_bf16" not in f32
     assert len(re.findall(r"\bv_mfma_f32_16x16x32_bf16\b", bf16)) == 96 and "v_mfma_f32_16x16x4_f32" not in bf16
     # the forced block path (dense force profiles) adds its own: per group R x 32 + 4 (FIR), + R x 32 for the taps
-    forced = kernels[(4, 2, 0, 0, 1)]
+    forced = kernels[(4, 2, 0, 0, 1, 0)]
     assert len(re.findall(r"\bv_mfma_f32_16x16x4_f32\b", forced)) == 256 + 2 * (4 * 32 + 4) + 4 * 32
     for body in kernels.values():
         lines = body.splitlines()
