@@ -857,7 +857,7 @@ int Engine::finalize() {
             HIPTRY(d_scan_.ensure(6 * nm));
             HIPTRY(hipMemcpy(d_scan_.p, sc.data(), 6 * nm * sizeof(float), hipMemcpyHostToDevice));
         }
-        if (form_ == PBSO_FORM_BLOCK && R_ <= 2 && forced_block_) {
+        if (form_ == PBSO_FORM_BLOCK && (R_ <= 2 || tc_ok_) && forced_block_) {      // (a time-chunked launch picks its own team shape: one or two modes per lane use the table)
             // Forced block path without qnorm rows (kernels_block.hip, FT): a force sample f enters the state as f u, u = (1, 1)'
             // (d += f, q += d), so the samples 16 n + i, i = 1..16, of a dense profile move the next block-start state by
             // sum_i A^(16 - i) u f_i.  Plane 2 i' + c holds component c of A^(15 - i') u, i' = 0..15, per mode (fp64, rounded once).

@@ -11,6 +11,10 @@ from openpbso_amd import Engine, ForceMessage, capi, synth
 from tests.scenarios import ObjSpec, force_ev, rel_errors, run_engine, run_oracle
 
 pytestmark = pytest.mark.gpu
+# PBSO_TIME_CHUNKS=n pytest tests/test_gpu_fullsize.py runs every full-size configuration with K5 forced on (launches cut into
+# chunks of n buffers behind the scan, whatever the launch holds): the numerics are checked as always, the assertions about WHICH
+# kernel took a launch are the policy's and are skipped
+K5_FORCED = int(__import__("os").environ.get("PBSO_TIME_CHUNKS", "0")) > 0
 NB = 86
 TOL_MAX, TOL_L2 = 5e-4, 1e-3
 THREADS = max(1, min(8, len(os.sched_getaffinity(0))))
@@ -142,10 +146,12 @@ def test_config5_8x4096_sustained_scraping_full_size():
     #     inside it for those ten, starting from the state the other kernel left
     got = run_engine(objs, evs, NB, qnorm=capi.QNORM_OFF, split=[60, 26], form=capi.FORM_BLOCK_BF16)
     assert got["info"]["recurrence_form"] == capi.FORM_BLOCK_BF16
-    assert got["info"]["total_sample_launches"] == 1 and got["info"]["total_block_launches"] == 1
+    if not K5_FORCED:
+        assert got["info"]["total_sample_launches"] == 1 and got["info"]["total_block_launches"] == 1
     assert np.array_equal(got["emitted"], want["emitted"])
     mx, l2 = _assert_parity(got["audio"], want["audio"], "8x4096 scraping")
     one = run_engine(objs, evs, NB, qnorm=capi.QNORM_OFF, form=capi.FORM_BLOCK_BF16)      # one launch: per-sample kernel throughout
-    assert one["info"]["total_sample_launches"] == 1 and one["info"]["total_block_launches"] == 0
+    if not K5_FORCED:
+        assert one["info"]["total_sample_launches"] == 1 and one["info"]["total_block_launches"] == 0
     _assert_parity(one["audio"], want["audio"], "8x4096 scraping, one launch")
     print(f"C5 full size: max/peak {mx:.2e} relL2 {l2:.2e}")

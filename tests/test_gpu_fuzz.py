@@ -121,7 +121,15 @@ def test_random_scripts_match_oracle(seed, monkeypatch):
         monkeypatch.setenv("PBSO_TEAM_WAVES", "16")     # whole objects as teams, as on a full chip
     # seeds 2, 3 of every four on the block kernel with the split-bf16 projection, the others on the default form
     # (PBSO_FORM; the block kernel with the f32 projection unless the run says otherwise)
-    _run_seed(seed, [3, 40, 64, 100, 129, 300], dict(form=capi.FORM_BLOCK_BF16) if seed % 4 >= 2 else {})
+    kw = dict(form=capi.FORM_BLOCK_BF16) if seed % 4 >= 2 else {}
+    # K5 (launches cut along the time axis behind a scan of buffer-start states): forced on with 1, 2 or 7 buffers per chunk for
+    # a third of the seeds -- whatever the script holds: dense profiles, clears, listener moves --, forced off for another third
+    # (the walk in buffer order: K1b, or the pipeline kernel K1p for these small scenes), the engine's own choice for the rest
+    if seed % 3 == 0:
+        kw["time_chunks"] = [1, 2, 7][(seed // 3) % 3]
+    elif seed % 3 == 1:
+        kw["time_chunks"] = -1
+    _run_seed(seed, [3, 40, 64, 100, 129, 300], kw)
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PBSO_FUZZ_SHAPE_SEEDS", "60"))))
@@ -136,5 +144,6 @@ def test_random_scripts_random_engine_shapes(seed, monkeypatch):
     # both oscillator-bank kernels: the block state-space form (K1b, the default) and the per-sample form (K1)
     form = int(rng.choice([capi.FORM_BLOCK, capi.FORM_BLOCK_BF16, capi.FORM_VELOCITY]))
     mpl = [0, 1, 2, 4, 8] if form != capi.FORM_VELOCITY else [0, 1, 2, 3, 4, 8]
-    kw = dict(form=form, modes_per_lane=int(rng.choice(mpl)), qnorm=int(rng.choice([capi.QNORM_ALL, capi.QNORM_CLOSED])))
+    kw = dict(form=form, modes_per_lane=int(rng.choice(mpl)), qnorm=int(rng.choice([capi.QNORM_ALL, capi.QNORM_CLOSED])),
+              time_chunks=int(rng.choice([0, -1, 1, 3])))
     _run_seed(seed + 100000, [5, 64, 200, 1100, 2100], kw, projected_hits=True)
