@@ -513,6 +513,12 @@ def measure(args, ctx, global_ids, want_parity):
                 w.wait()
                 pending[i] = None
 
+    # (the interpreter's cyclic collector is kept out of the measured loops: with the run's inputs on the heap -- hit scripts, mode
+    #  shapes, feeds -- a full collection takes 40 ms, and it used to fire inside a feed call around step 90 of every run: 128 x 512
+    #  measured 0.57-1.0 ms per step for --steps >= 50 and 0.157 for --steps 40, scripts/debug/r04_steps.sh)
+    import gc
+    gc.collect()
+    gc.disable()
     for k in range(args.settle + args.warmup):
         one_step(k, capture=(k == 0 and want_parity))     # (loads the copy kernel's code object outside the timed region)
     drain()
@@ -531,6 +537,7 @@ def measure(args, ctx, global_ids, want_parity):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if ctx["use_dist"]:
         t = torch.tensor([elapsed], dtype=torch.float64, device=ctx["coll_dev"])
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
