@@ -984,7 +984,10 @@ int Engine::warm_copy_engines() {
     if (desc_.warm_copies < 0) return PBSO_OK;
     // Best effort: a failure here costs a slow first launch, never the engine (errors are swallowed, everything is released).
     // A caller's stream is not touched: the second pattern only needs SOME stream the preparation stream waits for.
-    const size_t chunk = (size_t)1 << 20;
+#ifndef PBSO_WARM_CHUNK_MB
+#define PBSO_WARM_CHUNK_MB 1
+#endif
+    const size_t chunk = (size_t)PBSO_WARM_CHUNK_MB << 20;
     const int n = 6;
     PinBuf<unsigned char> h;
     DevBuf<unsigned char> d;
