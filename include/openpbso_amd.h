@@ -127,7 +127,10 @@ typedef struct pbso_engine_desc {
     int plan_pin;             /* != 0: pin the helper threads into the caller's core complex */
     int timing_every;         /* HIP-event pairs around every n-th launch (0 -> 1; < 0: none) */
     int warm_copies;          /* < 0: pbso_finalize does not warm the runtime's copy queues */
-    int reserved[3];
+    int stream_sync;          /* how the preparation stream hands a launch to the bank stream: 0 policy (= 1), 1 events, 2 a value in
+                               * signal memory and hipStreamWaitValue64 (a beta interface of the runtime: half the latency of an
+                               * event, 1 % per step on small scenes; creation fails where the device does not support it) */
+    int reserved[2];
 } pbso_engine_desc;
 
 enum pbso_bank_kernel {

@@ -286,6 +286,7 @@ Engine::~Engine() {
         for (hipEvent_t ev : {ev_prep_done_[i], ev_k1_done_[i], ev_set_[i]})
             if (ev) (void)hipEventDestroy(ev);
     if (prep_stream_) (void)hipStreamDestroy(prep_stream_);
+    if (sig_prep_) (void)hipFree(sig_prep_);
     for (hipStream_t cs : class_stream_)
         if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
@@ -343,6 +344,7 @@ int Engine::init() {
     if (desc_.profile_kernel < 0 || desc_.profile_kernel > 2) return fail(PBSO_ERR_INVALID, "profile_kernel");
     if (desc_.pipe_consumers < 0 || desc_.pipe_consumers > 3) return fail(PBSO_ERR_INVALID, "pipe_consumers");
     if (desc_.profile_priority < 0 || desc_.profile_priority > 4) return fail(PBSO_ERR_INVALID, "profile_priority");
+    if (desc_.stream_sync < 0 || desc_.stream_sync > 2) return fail(PBSO_ERR_INVALID, "stream_sync");
     if (desc_.qnorm_mode < PBSO_QNORM_OFF || desc_.qnorm_mode > PBSO_QNORM_CLOSED)
         return fail(PBSO_ERR_INVALID, "qnorm_mode");
     {
@@ -378,9 +380,25 @@ int Engine::init() {
         HIPTRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPTRY(hipStreamCreateWithPriority(&prep_stream_, hipStreamNonBlocking, greatest));
     }
+    if (desc_.stream_sync == 2) {
+        int can = 0;
+        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, desc_.device) == hipSuccess && can &&
+            hipExtMallocWithFlags((void **)&sig_prep_, sizeof(unsigned long long), hipMallocSignalMemory) == hipSuccess) {
+            HIPTRY(hipMemset(sig_prep_, 0, sizeof(unsigned long long)));
+            HIPTRY(hipDeviceSynchronize());
+            sync_values_ = true;
+        }
+        (void)hipGetLastError();
+        if (!sync_values_) return fail(PBSO_ERR_HIP, "stream_sync = values: the device has no hipStreamWaitValue64");
+    }
     for (int i = 0; i < N_SETS; ++i) {
-        HIPTRY(hipEventCreateWithFlags(&ev_prep_done_[i], hipEventDisableTiming));
-        HIPTRY(hipEventCreateWithFlags(&ev_k1_done_[i], hipEventDisableTiming));
+        // (waited for by the engine's own streams only, never by the host or another device: without the system-scope fence
+        //  a record costs the stream nothing -- 4 us with it, scripts/microbench/wait_value.hip; +0.4 % per step at 1024 x 512)
+#ifndef PBSO_DEVICE_EVENT_FLAGS
+#define PBSO_DEVICE_EVENT_FLAGS (hipEventDisableTiming | hipEventDisableSystemFence)
+#endif
+        HIPTRY(hipEventCreateWithFlags(&ev_prep_done_[i], PBSO_DEVICE_EVENT_FLAGS));
+        HIPTRY(hipEventCreateWithFlags(&ev_k1_done_[i], PBSO_DEVICE_EVENT_FLAGS));
     }
     plan_threads_ = std::min(16, std::max(1, desc_.plan_threads));
     ctx_.resize(plan_threads_);
@@ -687,9 +705,9 @@ int Engine::finalize() {
         }
     }
 
-    // K1p / K1s: fewer than one wave of oscillators per SIMD even with one mode per lane -- a team of several waves per 64
-    // modes instead (kernels_pipe.hip: a producer and two consumers; kernels_split.hip: two waves that share the time axis).
-    // f32 block form only; PBSO_SPLIT=0 keeps the one-wave-per-64-modes kernel.
+    // K1p: fewer than one wave of oscillators per SIMD even with one mode per lane -- a team of several waves per 64
+    // modes instead (kernels_pipe.hip: a producer and two consumers).  f32 block form only; desc.bank_kernel = BLOCK keeps
+    // the one-wave-per-64-modes kernel (and its time chunks, K5) for every launch.
     {
         split_ok_ = false;
         long long chunks = 0;
@@ -2028,8 +2046,10 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     evq.h_enter = std::chrono::duration<double, std::milli>(t0.time_since_epoch()).count();
     // (two timing events before and three after the bank cost the stream ~15 us per launch -- 2 % of a 0.7 ms step)
     const bool timed = timing_every_ > 0 && (launch_seq_ % (unsigned)timing_every_) == 0;
-    // ---- preparation stream: this set's device buffers are free once the oscillator
-    //      bank that last read them (two steps ago) has finished
+    // ---- preparation stream: this set's device buffers are free once the oscillator bank that last read them (N_SETS
+    //      launches ago) has finished.  (The upload stays on this stream: on one of its own the next launch's scan starts as soon
+    //      as this launch's has finished -- beside the START of a bank, whose workgroups then wait for the slots it holds:
+    //      512 x 512 x 86 0.51 -> 0.59 ms per step, scripts/debug/r04_sync.sh.)
     HIPTRY(hipStreamWaitEvent(sp, ev_k1_done_[cur_set_], 0));
     if (timed) HIPTRY(hipEventRecord(evq.p0, sp));
     evq.h_prep = host_ms();
@@ -2194,11 +2214,15 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         if (!last_launch_tc_ && last_set_ >= 0) HIPTRY(hipStreamWaitEvent(sp, ev_k1_done_[last_set_], 0));
         LAUNCHTRY(launch_iir_scan(kp, N, d_scan_.p, tc_cb, n_chunks, d_xs_[cur_set_].p, d_xtrow_[cur_set_].p, direct_hits_, sp));
     }
-    HIPTRY(hipEventRecord(ev_prep_done_[cur_set_], sp));
+    // ---- compute stream: the bank after its preparation (and, stream order, after the previous bank)
+    if (sync_values_) {
+        LAUNCHTRY(launch_signal_value(sig_prep_, ++prep_seq_, sp));
+        HIPTRY(hipStreamWaitValue64(sk, sig_prep_, prep_seq_, hipStreamWaitValueGte, ~0ull));
+    } else {
+        HIPTRY(hipEventRecord(ev_prep_done_[cur_set_], sp));
+        HIPTRY(hipStreamWaitEvent(sk, ev_prep_done_[cur_set_], 0));
+    }
     const auto tsub2 = std::chrono::steady_clock::now();
-
-    // ---- compute stream: K1 after its preparation (and, stream order, after the previous K1)
-    HIPTRY(hipStreamWaitEvent(sk, ev_prep_done_[cur_set_], 0));
     if (timed) HIPTRY(hipEventRecord(evq.k0, sk));
     evq.h_bank = host_ms();
     kp.audio_parts = d_audio_parts_.p ? d_audio_parts_.p + (size_t)b0 * B_ : nullptr;
@@ -2212,7 +2236,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     // rules are shared, so the two kernels hand over at any launch boundary.  (Audio then is bit-identical
     // across different cuts of a step only while both cuts pick the same kernel; always within tolerance.)
     // PBSO_DENSE_LAUNCHES=block keeps every launch on the block kernel (bit-identical audio for any cut of a step).
-    // The kernel of under-filled engines (K1p; PBSO_SPLIT_KERNEL=time: K1s) takes the launch -- also one whose (object, buffer)
+    // The pipeline kernel of under-filled engines (K1p) takes the launch -- also one whose (object, buffer)
     // pairs mostly carry a dense force profile (sustained scraping) when the profiles come from K2's row-parallel form
     // (8 x 4096 x 86: 0.30 ms against K1b's 0.43 without qnorm rows, 0.48 against 0.74 with).  Beside K2's CHAIN form -- then
     // the step's critical chain, which a wave on every SIMD slows 2.7 x (1.28 ms against 0.48 for 8 chains of 86 rows beside

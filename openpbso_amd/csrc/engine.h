@@ -232,7 +232,14 @@ private:
     int R_ = 0, W_ = 0, m_pad_ = 0;
     bool finalized_ = false, own_stream_ = false;
     hipStream_t stream_ = nullptr;                       // oscillator bank (caller's stream if given)
-    hipStream_t prep_stream_ = nullptr;                  // plan upload + projection + FFAT + combine
+    hipStream_t prep_stream_ = nullptr;                  // plan upload + projection + FFAT + force profiles + combine + scan
+    // The hand-over preparation -> bank (desc.stream_sync).  An event costs the waiting stream 10 - 12 us after the preparation's
+    // last kernel (scripts/microbench/wait_value.hip, profiles/r04_stream_sync.txt); a value in signal memory, written by a
+    // one-wave kernel behind that kernel, and a hipStreamWaitValue64 in front of the bank: 5 - 6 us.  Opt-in: the bank then starts
+    // while the preparation's last workgroups still hold slots, and the step gains 1 % (128 x 512 x 86), not 4.
+    unsigned long long *sig_prep_ = nullptr;             // hipMallocSignalMemory: the number of the last prepared launch
+    unsigned long long prep_seq_ = 0;
+    bool sync_values_ = false;
     // Plan sets: the host plans and uploads step k while the device still runs step k - N_SETS + 1.  Two sets are enough for
     // a host that never stalls; with three, a hiccup of the host thread (the boxes of this pool stall it for a millisecond now
     // and then) is absorbed by the steps already queued instead of idling the device.  Not four: with three steps of preparation
@@ -270,9 +277,9 @@ private:
     DevBuf<SplitObj> d_split_;                           // objects stepped by more than one team
     DevBuf<float> d_audio_parts_;                        // [n_part_rows_][nb * B] their partial sample sums
     int n_teams_ = 0, n_split_ = 0, n_part_rows_ = 0;
-    // K1p / K1s (kernels_pipe.hip, kernels_split.hip): the team table of the kernels of under-filled engines -- one team per 64
-    // columns -- for engines with less than a wave of oscillators per SIMD (f32 block form, one mode per lane; PBSO_SPLIT=0: never)
-    bool split_ok_ = false, split_always_ = false;      // PBSO_SPLIT=2: also the launches that are mostly dense-profile buffers
+    // K1p (kernels_pipe.hip): the team table of the pipeline kernel -- one team per 64 columns -- for engines with less than
+    // a wave of oscillators per SIMD (f32 block form, one mode per lane; desc.bank_kernel = BLOCK: never)
+    bool split_ok_ = false, split_always_ = false;      // bank_kernel = PIPE: every launch it can run, not only the dense ones
     DevBuf<TeamDesc> d_ts_teams_;
     DevBuf<SplitObj> d_ts_split_;
     int n_ts_teams_ = 0, n_ts_split_ = 0, n_ts_part_rows_ = 0;

@@ -263,4 +263,8 @@ int launch_copy_rows(const int *src_row, const int *dst_row, int n, double *rows
 int mix_objects_groups(int n_obj);
 int launch_mix_objects(const float *audio, int n_obj, long long stride, long long n, float *parts, float *out, hipStream_t stream);
 
+// One wave that stores `value` (system scope, release) into signal memory: behind the last kernel of a stream's batch it tells a
+// hipStreamWaitValue64 of another stream that the batch is done -- half the latency of an event (scripts/microbench/wait_value.hip)
+int launch_signal_value(unsigned long long *sig, unsigned long long value, hipStream_t stream);
+
 }  // namespace pbso

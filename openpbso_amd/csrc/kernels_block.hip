@@ -95,6 +95,17 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// The samples leave the kernel for good (181 MB per launch at 1024 x 512 x 86): nontemporal stores keep them from pushing the
+// operand tables and coefficient rows out of the L2 (kernel 0.944 -> 0.939 ms; write-through `sc0 sc1` stores: 0.954;
+// scripts/debug/r04_nt.sh).  -DPBSO_AUDIO_STORE=0: plain stores, 2: write-through.
+#if defined(PBSO_AUDIO_STORE) && PBSO_AUDIO_STORE == 0
+#define AUDIO_STORE(p, v) (*(p) = (v))
+#elif defined(PBSO_AUDIO_STORE) && PBSO_AUDIO_STORE == 2
+#define AUDIO_STORE(p, v) asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory")
+#else
+#define AUDIO_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#endif
+
 template <int K0, int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (N > 0) {
@@ -1019,15 +1030,15 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
             for (int j = tid; j < GROUP * NG / 4; j += blockDim.x) {
                 f4 acc = *reinterpret_cast<const f4 *>(r0 + 4 * j);
                 for (int w = 1; w < W; ++w) acc += *reinterpret_cast<const f4 *>(r0 + w * WAVE_FLOATS + 4 * j);
-                ao[4 * j + 1] = acc.x;
-                ao[4 * j + 2] = acc.y;
-                ao[4 * j + 3] = acc.z;
-                ao[4 * j + 4] = acc.w;
+                AUDIO_STORE(&ao[4 * j + 1], acc.x);
+                AUDIO_STORE(&ao[4 * j + 2], acc.y);
+                AUDIO_STORE(&ao[4 * j + 3], acc.z);
+                AUDIO_STORE(&ao[4 * j + 4], acc.w);
             }
             if (tid == 0) {
                 float acc = r0[GROUP * NG];
                 for (int w = 1; w < W; ++w) acc += r0[w * WAVE_FLOATS + GROUP * NG];
-                ao[0] = acc;
+                AUDIO_STORE(&ao[0], acc);
             }
         }
         lap(cy_comb);

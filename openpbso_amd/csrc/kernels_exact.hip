@@ -1161,4 +1161,12 @@ int launch_mix_objects(const float *audio, int n_obj, long long stride, long lon
     return (int)hipGetLastError();
 }
 
+__global__ __launch_bounds__(64) void signal_value_kernel(unsigned long long *sig, unsigned long long value) {
+    if (threadIdx.x == 0) __hip_atomic_store(sig, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int launch_signal_value(unsigned long long *sig, unsigned long long value, hipStream_t stream) {
+    hipLaunchKernelGGL(signal_value_kernel, dim3(1), dim3(64), 0, stream, sig, value);
+    return (int)hipGetLastError();
+}
+
 }  // namespace pbso

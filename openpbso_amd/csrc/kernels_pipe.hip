@@ -1,14 +1,13 @@
 // K1p: the block state-space oscillator bank for an UNDER-FILLED chip as a PIPELINE of waves (gfx950, wave64, f32 MFMA).
 //
-// Replaces the same reference code as K1 / K1b / K1s: the hot loop of ModalSolver::step (modal_solver.h:262-272) around
+// Replaces the same reference code as K1 / K1b: the hot loop of ModalSolver::step (modal_solver.h:262-272) around
 // ModalIntegrator::Step (modal_integrator.h:103-113).  Same formulation as kernels_block.hip (read that first): a buffer
 // is sample 0 + 2 groups of 16 blocks of 16 samples; block-start states are parked in LDS and projected on the f32
 // matrix pipe with the per-mode table W = (a_j, b_j); a dense force profile adds a 16-tap FIR of the profile.
 //
-// A scene with fewer waves of oscillators than SIMDs is bound by the LATENCY of one buffer in one wave.  K1s
-// (kernels_split.hip) splits a buffer's two groups between two waves; its waves still alternate between stepping and
-// projecting, wait for each other at two barriers per buffer, and a dense profile needs a zero-state superposition and a
-// hand-over of the state.  Here the two kinds of work never share a wave: a team of 1 + NC waves owns 64 modes,
+// A scene with fewer waves of oscillators than SIMDs is bound by the LATENCY of one buffer in one wave, and a wave of K1b
+// alternates between stepping and projecting.  Here the two kinds of work never share a wave: a team of 1 + NC waves owns
+// 64 modes,
 //   wave 0          the PRODUCER: steps buffer b -- sample 0, the 32 coarse steps (a dense profile: a block at a time
 //                   with the increments F . T on the matrix pipe, or every sample when qnorm rows are asked for) -- from
 //                   the true state, parks the 32 block-start states in the staging area of parity b & 1, writes sample 0
@@ -17,7 +16,7 @@
 //                   NC = 1: both groups), add the profile's FIR, store 256 samples per group straight from the MFMA's
 //                   result registers.
 // One workgroup barrier per buffer; the buffer costs max(stepping, projection) instead of their sum, and the state never
-// changes hands.  The registers hold the state UNSCALED (the parked values carry the transfer weight), as in K1s.
+// changes hands.  The registers hold the state UNSCALED (the parked values carry the transfer weight).
 #include <type_traits>
 
 #include "kernels.h"

@@ -75,6 +75,7 @@ for r in sorted(set(rank_in_cu.tolist())):
 
 if c.shape[1] >= 10 and c[:, 6:10].any():
     tot = c[:, 6:10].astype(np.float64).sum(axis=1)
+    print(f"outside the buffer loop (launch preamble: operand table, coefficients, state; write-back): median {np.median(cyc - tot):.3e} cycles of {np.median(cyc):.3e} per workgroup; time-chunked launches {info['total_time_chunk_launches']}")
     for name, k in (("head", 6), ("pipeline", 7), ("barrier", 8), ("combine", 9)):
         v = c[:, k].astype(np.float64)
         print(f"block form, wave 0 of each team: {name:9s} median {np.median(v):.3e} cycles ({np.median(v / tot) * 100:.1f} % of the loop), per buffer {np.median(v) / nb:.0f}")

@@ -35,7 +35,7 @@ st c2_1x512 --objects 1 --modes 512 --steps 40
 st c3_64x256_listener --objects 64 --modes 256 --scenario listener --steps 40
 st c5_8x4096_scraping --objects 8 --modes 4096 --scenario scraping --steps 40
 st share_128x512 --objects 128 --steps 40
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/tl_128 -- python3 $R/bench.py --no-cpu-baseline --no-second-form --no-parity --objects 128 --steps 20 --warmup 3 > /dev/null 2>&1); python scripts/debug/r04_timeline.py $O/tl_128 24 > $O/timeline_share_128x512.txt 2>&1; rm -rf $O/tl_128
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/tl_128 -- python3 $R/bench.py --no-cpu-baseline --no-second-form --no-parity --no-strong-share --objects 128 --steps 20 --warmup 3 > /dev/null 2>&1); python scripts/debug/r04_timeline.py $O/tl_128 24 > $O/timeline_share_128x512.txt 2>&1; rm -rf $O/tl_128
 echo "== PMC passes"
 pmc() { form=$1; name=$2; shift; shift; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_${form}_$name -- python3 $R/bench.py --steps 3 --warmup 1 --settle 0 --no-cpu-baseline --no-parity --no-second-form --no-strong-share --form $form > $O/pmc_${form}_$name.log 2>&1); echo "pmc $form $name rc=$?"; }
 for form in block; do

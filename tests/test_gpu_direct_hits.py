@@ -12,11 +12,12 @@ pytestmark = pytest.mark.gpu
 NB = 24
 
 
-@pytest.fixture(autouse=True)
-def _one_wave_per_64_modes(monkeypatch):
-    """these scenes are small: the f32 block form would run them on the time-split kernel K1s (kernels_split.hip), which takes
-    every hit's gain from the combine kernel's row; DESC_DIRECT is a feature of K1 / K1b"""
-    monkeypatch.setenv("PBSO_SPLIT", "0")
+@pytest.fixture(autouse=True, params=["0", "1"], ids=["k1b", "auto"])
+def _bank_kernel(request, monkeypatch):
+    """these scenes are small: with "1" (the default) the f32 block form may hand a launch to the pipeline kernel K1p
+    (kernels_pipe.hip) or cut it into time chunks (K5); "0" pins the one-wave-per-64-modes kernel.  DESC_DIRECT descriptors
+    are read by all of them."""
+    monkeypatch.setenv("PBSO_SPLIT", request.param)
 
 
 def _scene(n_obj=6, n_modes=300, seed=5):

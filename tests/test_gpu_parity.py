@@ -479,7 +479,7 @@ def test_projection_bit_exact_through_state(monkeypatch, direct_hits):
     f32 rounding (the face hit, and any hit on an object with live forces, still is the fp64 path)."""
     monkeypatch.setenv("PBSO_DIRECT_HITS", direct_hits)
     if direct_hits == "1":
-        monkeypatch.setenv("PBSO_SPLIT", "0")        # (the table path is K1 / K1b's; the time-split kernel of small engines has none)
+        monkeypatch.setenv("PBSO_SPLIT", "0")        # (pin K1 / K1b: the bit-identity below is a property of one kernel)
     from oracle import oracle_py as orc
     n_modes = 200
     seed = 44
@@ -629,8 +629,8 @@ def test_long_steps_cut_into_launches(monkeypatch):
     #  choice is checked against the oracle at the end)
     monkeypatch.setenv("PBSO_DENSE_LAUNCHES", "block")
     want = run_oracle(objs, evs, nb)
-    # ... and so does the choice between K1b and the time-split kernel K1s (small f32 engines; it takes a launch unless most of
-    # its buffers carry a dense profile): "0" = K1b for every launch, "2" = K1s for every launch
+    # ... and so does the choice between K1b and the pipeline kernel K1p (small f32 engines): "0" = K1b for every launch,
+    # "2" = K1p for every launch
     for split in ("0", "2"):
         monkeypatch.setenv("PBSO_SPLIT", split)
         monkeypatch.setenv("PBSO_CHUNK_BUFFERS", "1000")
@@ -652,12 +652,12 @@ def test_long_steps_cut_into_launches(monkeypatch):
     auto = run_engine(objs, evs, nb, modes_per_lane=1)
     if auto["info"]["recurrence_form"] == capi.FORM_BLOCK:
         # the f32 block kernels run dense-profile buffers in block form themselves: no hand-over to the per-sample kernel; a
-        # small engine like this one runs every launch -- the all-dense ones (buffers 3..5) too -- on the time-split kernel
+        # small engine like this one runs every launch -- the all-dense ones (buffers 3..5) too -- on the pipeline kernel
         assert auto["info"]["total_sample_launches"] == 0 and auto["info"]["total_block_launches"] >= 9
         assert auto["info"]["total_split_launches"] == auto["info"]["total_block_launches"]
     _check(auto, want)
     # the hand-over between the two kernels at launch boundaries (what the split-bf16 form does by itself; small f32 engines
-    # run on the time-split kernel K1s, which never hands over: switched off here)
+    # run on the pipeline kernel K1p, which never hands over: switched off here)
     monkeypatch.setenv("PBSO_SPLIT", "0")
     monkeypatch.setenv("PBSO_DENSE_LAUNCHES", "sample")
     hand = run_engine(objs, evs, nb, modes_per_lane=1)
