@@ -130,7 +130,9 @@ typedef struct pbso_engine_desc {
     int stream_sync;          /* how the preparation stream hands a launch to the bank stream: 0 policy (= 1), 1 events, 2 a value in
                                * signal memory and hipStreamWaitValue64 (a beta interface of the runtime: half the latency of an
                                * event, 1 % per step on small scenes; creation fails where the device does not support it) */
-    int reserved[2];
+    int latency_path;         /* < 0: never prepare a launch on the bank's own stream (0: a step of at most four buffers submitted
+                               * while the device is idle does -- nothing to overlap with, one stream hand-over less) */
+    int reserved[1];
 } pbso_engine_desc;
 
 enum pbso_bank_kernel {
@@ -430,6 +432,8 @@ typedef struct pbso_engine_info {
                                        * buffer-start states, then the block kernel over (team, chunk of buffers) workgroups) */
     int64_t total_dropped_hits;       /* hits of pbso_enqueue_vertex_hits scripts that found their object's 1023-slot queue full:
                                        * rejected, as enqueueForceMessage would have been (modal_solver.h:329-333)              */
+    int64_t total_one_stream_launches;/* launches whose preparation ran on the bank's own stream (the latency path: a short step
+                                       * submitted while the device was idle -- the real-time facade's pattern)                   */
 } pbso_engine_info;
 int pbso_get_info(pbso_engine *e, pbso_engine_info *out);
 /* diagnostics (engine created with env PBSO_CENSUS=1): for every object's

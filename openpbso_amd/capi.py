@@ -52,7 +52,7 @@ class EngineDesc(C.Structure):
                 ("profile_margin_pct", C.c_int), ("profile_priority", C.c_int), ("team_waves", C.c_int),
                 ("pipe_consumers", C.c_int), ("pipe_max_teams", C.c_longlong), ("chunk_buffers", C.c_int),
                 ("plan_threads", C.c_int), ("plan_pin", C.c_int), ("timing_every", C.c_int), ("warm_copies", C.c_int),
-                ("stream_sync", C.c_int), ("reserved", C.c_int * 2)]
+                ("stream_sync", C.c_int), ("latency_path", C.c_int), ("reserved", C.c_int * 1)]
 BANK_AUTO, BANK_BLOCK, BANK_PIPE = 0, 1, 2
 
 
@@ -89,7 +89,7 @@ class EngineInfo(C.Structure):
                 ("total_host_plan_ms", C.c_double), ("total_steps", C.c_int64), ("n_teams", C.c_int),
                 ("recurrence_form", C.c_int), ("total_block_launches", C.c_int64), ("total_sample_launches", C.c_int64),
                 ("total_timed_launches", C.c_int64), ("total_split_launches", C.c_int64),
-                ("total_time_chunk_launches", C.c_int64), ("total_dropped_hits", C.c_int64)]
+                ("total_time_chunk_launches", C.c_int64), ("total_dropped_hits", C.c_int64), ("total_one_stream_launches", C.c_int64)]
 
 
 GroupDesc._fields_ = [("abi_version", C.c_int), ("devices", C.POINTER(C.c_int)), ("n_devices", C.c_int), ("world_size", C.c_int),

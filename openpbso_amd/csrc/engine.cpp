@@ -345,6 +345,7 @@ int Engine::init() {
     if (desc_.pipe_consumers < 0 || desc_.pipe_consumers > 3) return fail(PBSO_ERR_INVALID, "pipe_consumers");
     if (desc_.profile_priority < 0 || desc_.profile_priority > 4) return fail(PBSO_ERR_INVALID, "profile_priority");
     if (desc_.stream_sync < 0 || desc_.stream_sync > 2) return fail(PBSO_ERR_INVALID, "stream_sync");
+    latency_path_ = desc_.latency_path >= 0;
     if (desc_.qnorm_mode < PBSO_QNORM_OFF || desc_.qnorm_mode > PBSO_QNORM_CLOSED)
         return fail(PBSO_ERR_INVALID, "qnorm_mode");
     {
@@ -2017,7 +2018,17 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     const int n_frows = n_frows_;
     last_frows_ = n_frows;
     last_trows_ = (int64_t)ffat_.size();
-    hipStream_t sp = prep_stream_, sk = stream_;
+    // Latency path: a short single-launch step submitted while the device is idle (the real-time facade: step, wait, step) has
+    // nothing to run beside -- its preparation goes on the bank's own stream, and the 11 us an event takes to hand a launch
+    // from one stream to the other (profiles/r04_stream_sync.txt) are saved.  Ordering only: same kernels, same arguments.
+    bool one_stream = false;
+    if (latency_path_ && nb == nb_total && nb <= 4) {
+        one_stream = last_set_ < 0 || hipEventQuery(ev_k1_done_[last_set_]) == hipSuccess;      // (the previous bank, hence its preparation)
+        (void)hipGetLastError();
+    }
+    hipStream_t sk = stream_, sp = one_stream ? sk : prep_stream_;
+    // (the preparation stream takes over again behind a launch that went without it: behind that launch's bank)
+    if (!one_stream && last_one_stream_ && last_set_ >= 0) HIPTRY(hipStreamWaitEvent(sp, ev_k1_done_[last_set_], 0));
     DevBuf<float> &grows = d_grows_[cur_set_];
     // device arenas (growth drains the device first, see DevBuf::ensure)
     HIPTRY(d_slots_.ensure(std::max<size_t>(1, n_slots_.load()) * m_pad_, true, sp));
@@ -2215,7 +2226,9 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         LAUNCHTRY(launch_iir_scan(kp, N, d_scan_.p, tc_cb, n_chunks, d_xs_[cur_set_].p, d_xtrow_[cur_set_].p, direct_hits_, sp));
     }
     // ---- compute stream: the bank after its preparation (and, stream order, after the previous bank)
-    if (sync_values_) {
+    if (one_stream) {
+        tot_one_stream_launches_ += 1;
+    } else if (sync_values_) {
         LAUNCHTRY(launch_signal_value(sig_prep_, ++prep_seq_, sp));
         HIPTRY(hipStreamWaitValue64(sk, sig_prep_, prep_seq_, hipStreamWaitValueGte, ~0ull));
     } else {
@@ -2322,6 +2335,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     else ev_free_.push_back(evq);
     buffers_done_ += nb;
     last_launch_tc_ = tc_launch;
+    last_one_stream_ = one_stream;
     last_set_ = cur_set_;
     cur_set_ = (cur_set_ + 1) % N_SETS;
     hprof_[4] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - last_plan_ms_;
@@ -2701,6 +2715,7 @@ int Engine::info(pbso_engine_info *out) {
     out->total_split_launches = tot_split_launches_;
     out->total_time_chunk_launches = tot_tc_launches_;
     out->total_dropped_hits = dropped_hits_.load();
+    out->total_one_stream_launches = tot_one_stream_launches_;
     out->buffers_done = buffers_done_;
     out->last_step_host_plan_ms = last_plan_ms_;
     out->last_step_forced_rows = last_frows_;

@@ -305,6 +305,8 @@ private:
     DevBuf<int> d_xtrow_[N_SETS];                        // [n_obj][n_chunks] the transfer row in force there
     bool last_launch_tc_ = false;                        // the previous launch was time-chunked (its bank did not write the state)
     int last_set_ = -1;
+    bool latency_path_ = true, last_one_stream_ = false;  // desc.latency_path; the previous launch prepared on the bank's stream
+    int64_t tot_one_stream_launches_ = 0;
     int64_t tot_tc_launches_ = 0;
     bool choose_time_chunks(int nb, int n_dense_rows, int *set, int *cb) const;
     int n_cus_ = 256;                                     // hipDeviceProp_t::multiProcessorCount of the engine's device

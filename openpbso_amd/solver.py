@@ -130,7 +130,7 @@ def _select_from_env():
 
 SELECT_FIELDS = ("bank_kernel", "time_chunks", "direct_hits", "forced_block", "dense_launches", "device_profiles",
                  "profile_kernel", "profile_margin_pct", "profile_priority", "team_waves", "pipe_consumers",
-                 "pipe_max_teams", "chunk_buffers", "plan_threads", "plan_pin", "timing_every", "warm_copies", "stream_sync")
+                 "pipe_max_teams", "chunk_buffers", "plan_threads", "plan_pin", "timing_every", "warm_copies", "stream_sync", "latency_path")
 
 
 def fill_engine_desc(d, device, form, qnorm, modes_per_lane, stream, frames_per_buffer, select):
@@ -495,6 +495,7 @@ class ModalSolver:
         self._queue_qnorm = collections.deque()
         self._pending_maps = None
         self._final = False
+        self._host = None                             # pinned [1][513]: the bank stores the buffer's samples straight into it
 
     def readFFATMaps(self, maps_or_dir):
         if isinstance(maps_or_dir, str):
@@ -537,12 +538,17 @@ class ModalSolver:
 
     def step(self):
         self._ensure()
-        self.engine.step(1)
+        if self._host is None:
+            self._host = self.engine.host_buffer(1)
+        # the buffer's samples arrive in pinned host memory with the kernel's own stores (pbso_step_to_host): no copy call
+        # between the oscillator bank and the SoundMessage
+        self.engine.step_to_host(1, self._host)
+        self.engine.host_wait()
         if not self.engine.emitted()[0, 0]:
             return                                   # clearAllForces: no SoundMessage (modal_solver.h:186-189)
         if self.engine.qnorm_mode != capi.QNORM_OFF and len(self._queue_qnorm) < 3:
             self._queue_qnorm.append(self.engine.qnorm(0, 0))     # try_enqueue, may drop (:273)
-        self._queue_sound.append(self.engine.audio()[0].copy())   # enqueueSoundMessageNoFail (:275)
+        self._queue_sound.append(self._host[0].copy())            # enqueueSoundMessageNoFail (:275)
 
     def dequeueSoundMessage(self):
         if not self._queue_sound:

@@ -11,8 +11,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openpbso_amd import Engine, ForceMessage, synth, capi   # noqa: E402
 
-for n_modes in (128, 512, 2048):
-    eng = Engine(qnorm=capi.QNORM_ALL)
+# latency_path = -1: every launch prepared on the preparation stream (round 3's behaviour), for comparison
+for n_modes, lp in ((128, 0), (512, 0), (2048, 0), (512, -1)):
+    eng = Engine(qnorm=capi.QNORM_ALL, latency_path=lp)
     eng.add_object(synth.eigenvalues(n_modes, 5), synth.RHO, synth.ALPHA, synth.BETA)
     eng.finalize()
     eng.set_use_transfer(0, False)
@@ -30,18 +31,30 @@ for n_modes in (128, 512, 2048):
         ts.append(t1 - t0)
         ts_read.append(t2 - t0)
     ts, ts_read = np.array(ts[50:]) * 1e6, np.array(ts_read[50:]) * 1e6
+    # ... and the facade's delivery: pbso_step_to_host into a pinned buffer (the bank's own stores), pbso_host_wait
+    hb = eng.host_buffer(1)
+    ts_host = []
+    for i in range(300):
+        if i % 7 == 0:
+            eng.enqueue_force(0, ForceMessage(data=rng.standard_normal(n_modes) * 1e-3))
+        t0 = time.perf_counter()
+        eng.step_to_host(1, hb)
+        eng.host_wait()
+        ts_host.append(time.perf_counter() - t0)
+    ts_host = np.array(ts_host[50:]) * 1e6
     info = eng.info()
-    print(f"modes={n_modes:5d} R={info['modes_per_lane']} W={info['waves_per_object']}: step+sync median {np.median(ts):7.1f} us "
+    print(f"modes={n_modes:5d} latency_path={lp:2d} R={info['modes_per_lane']} W={info['waves_per_object']}: step+sync median {np.median(ts):7.1f} us "
           f"p99 {np.percentile(ts, 99):7.1f} us; with audio D2H median {np.median(ts_read):7.1f} us p99 {np.percentile(ts_read, 99):7.1f} us; "
-          f"kernel {info['last_step_kernel_ms'] * 1e3:6.1f} us  (deadline 11 630 us)")
+          f"step_to_host + host_wait (samples in pinned host memory) median {np.median(ts_host):7.1f} us p99 {np.percentile(ts_host, 99):7.1f} us; "
+          f"kernel {info['last_step_kernel_ms'] * 1e3:6.1f} us; one-stream launches {info['total_one_stream_launches']} of {info['total_steps']}  (deadline 11 630 us)")
     eng.close()
 
 
 # Sustained contact in real-time mode (the facade's use: ONE buffer per step, an AutoregressiveForce alive, a new face hit every
 # buffer: tools/real_time_modal_sound.cpp:754-776, 1127-1160): the force-profile kernels (K2) and the oscillator bank of every
 # buffer are on the critical path here -- nothing runs a step ahead.
-for n_modes in (512, 2048):
-    eng = Engine(qnorm=capi.QNORM_ALL)
+for n_modes, lp in ((512, 0), (2048, 0), (512, -1)):
+    eng = Engine(qnorm=capi.QNORM_ALL, latency_path=lp)
     shapes = synth.mode_shapes(n_modes, 6)
     eng.add_object(synth.eigenvalues(n_modes, 6), synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes)
     eng.finalize()
@@ -60,6 +73,6 @@ for n_modes in (512, 2048):
         ks.append(info["last_step_kernel_ms"] * 1e3)
         ds.append(info["last_step_device_ms"] * 1e3)
     ts = np.array(ts[50:]) * 1e6
-    print(f"sustained AR scraping, modes={n_modes:5d}: step+sync median {np.median(ts):7.1f} us p99 {np.percentile(ts, 99):7.1f} us; "
+    print(f"sustained AR scraping, modes={n_modes:5d} latency_path={lp:2d}: step+sync median {np.median(ts):7.1f} us p99 {np.percentile(ts, 99):7.1f} us; "
           f"device pipeline (K2 + projection + combine + bank) median {np.median(ds[50:]):6.1f} us, bank alone {np.median(ks[50:]):6.1f} us  (deadline 11 630 us)")
     eng.close()

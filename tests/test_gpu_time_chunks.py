@@ -192,6 +192,24 @@ def test_stream_hand_over_by_value_equals_the_event_path(time_chunks):
         run_engine(objs[:1], [], 1, stream_sync=3)
 
 
+def test_latency_path_is_ordering_only():
+    """A step of at most four buffers submitted while the device is idle (step, read, step: the real-time facade) prepares on
+    the bank's own stream (desc.latency_path, info.total_one_stream_launches): same kernels, same arguments -- bit-identical to
+    the two-stream path, every buffer kind, and the preparation stream takes over again behind it"""
+    nb = 16
+    objs, evs = _every_kind_scene(nb)
+    for cut, n_one in (([1] * nb, nb), ([4, 4, 8], 2), ([2, 8, 1, 1, 4], 4)):
+        a = run_engine(objs, evs, nb, split=cut)
+        b = run_engine(objs, evs, nb, split=cut, latency_path=-1)
+        assert a["info"]["total_one_stream_launches"] == n_one and b["info"]["total_one_stream_launches"] == 0
+        assert np.array_equal(a["audio"], b["audio"]) and np.array_equal(a["emitted"], b["emitted"])
+        for key in a["qnorm"]:
+            assert np.array_equal(a["qnorm"][key], b["qnorm"][key]), key
+        for x, y in zip(a["state"], b["state"]):
+            assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+    _check(a, run_oracle(objs, evs, nb))
+
+
 @pytest.mark.parametrize("n_obj,n_modes", [(128, 512), (64, 256)])
 def test_strong_scaling_shares_full_size(n_obj, n_modes):
     """the per-GPU share of BASELINE configs[3] on 8 GPUs (128 x 512) and configs[2]'s shape, 86 buffers, auto policy:
