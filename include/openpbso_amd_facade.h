@@ -217,6 +217,8 @@ class ModalSolver {
     std::recursive_mutex _engine_mutex;                      // the C ABI wants one caller at a time (never taken by the audio callback)
     TransMessage<T> _latest_transfer;
     std::vector<float> _audio32, _qnorm32;
+    bool _host32_failed = false;
+    float *_host32 = nullptr;                 // pinned [BUF_SIZE]: the oscillator bank stores the buffer straight into it (pbso_step_to_host)
     std::vector<double> _tmp;
 
     // engine errors are the reference's assert / uncaught-exception paths: stop in EVERY build type
@@ -256,7 +258,10 @@ public:
         _audio32.resize(BUF_SIZE);
         _qnorm32.resize(N_modes > 0 ? N_modes : 1);
     }
-    ~ModalSolver() { pbso_engine_destroy(_engine); }
+    ~ModalSolver() {
+        pbso_engine_destroy(_engine);
+        if (_host32) pbso_host_free(_host32);
+    }
     ModalSolver(const ModalSolver &) = delete;
     ModalSolver &operator=(const ModalSolver &) = delete;
 
@@ -286,17 +291,33 @@ public:
     void step() {
         EngineLock lk_(_engine_mutex);
         _finalize();
-        _require(pbso_step(_engine, 1));
+        // the samples reach the host with the kernel's own stores into pinned memory -- no copy call between the oscillator bank
+        // and the SoundMessage (pageable fallback: step, then pbso_read_audio)
+        if (!_host32 && !_host32_failed) {
+            void *p = nullptr;
+            if (pbso_host_alloc((size_t)BUF_SIZE * sizeof(float), &p) == PBSO_OK) _host32 = static_cast<float *>(p);
+            else _host32_failed = true;
+        }
+        if (_host32) {
+            _require(pbso_step_to_host(_engine, 1, _host32, (size_t)BUF_SIZE));
+            _require(pbso_host_wait(_engine));
+        } else {
+            _require(pbso_step(_engine, 1));
+        }
         unsigned char emitted = 1;
         _require(pbso_read_emitted(_engine, &emitted, 1));
         if (!emitted) return;                                     // clearAllForces: no buffer (:186-189)
-        _require(pbso_read_audio(_engine, _audio32.data(), (size_t)BUF_SIZE));
+        const float *samples = _host32;
+        if (!samples) {
+            _require(pbso_read_audio(_engine, _audio32.data(), (size_t)BUF_SIZE));
+            samples = _audio32.data();
+        }
         DataMessage<T> qn;
         qn.data.setZero(_N_modes);
         if (_N_modes > 0 && pbso_read_qnorm(_engine, _obj, 0, _qnorm32.data(), _N_modes) == PBSO_OK)
             for (int i = 0; i < _N_modes; ++i) qn.data(i) = (T)_qnorm32[i];
         SoundMessage<T, BUF_SIZE> mess;
-        for (int i = 0; i < BUF_SIZE; ++i) mess.data(i) = (T)_audio32[i];
+        for (int i = 0; i < BUF_SIZE; ++i) mess.data(i) = (T)samples[i];
         _engine_mutex.unlock();          // the spin below must not block the GUI thread's enqueue calls
         struct Relock { std::recursive_mutex &m; ~Relock() { m.lock(); } } relock_{_engine_mutex};
         (void)_queue_qnorm.try_enqueue(qn);                    // try_enqueue, may drop (:273)

@@ -287,6 +287,7 @@ Engine::~Engine() {
             if (ev) (void)hipEventDestroy(ev);
     if (prep_stream_) (void)hipStreamDestroy(prep_stream_);
     if (sig_prep_) (void)hipFree(sig_prep_);
+    if (sig_start_) (void)hipFree(sig_start_);
     for (hipStream_t cs : class_stream_)
         if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
@@ -344,7 +345,7 @@ int Engine::init() {
     if (desc_.profile_kernel < 0 || desc_.profile_kernel > 2) return fail(PBSO_ERR_INVALID, "profile_kernel");
     if (desc_.pipe_consumers < 0 || desc_.pipe_consumers > 3) return fail(PBSO_ERR_INVALID, "pipe_consumers");
     if (desc_.profile_priority < 0 || desc_.profile_priority > 4) return fail(PBSO_ERR_INVALID, "profile_priority");
-    if (desc_.stream_sync < 0 || desc_.stream_sync > 2) return fail(PBSO_ERR_INVALID, "stream_sync");
+    if (desc_.stream_sync < 0 || desc_.stream_sync > 3) return fail(PBSO_ERR_INVALID, "stream_sync");
     latency_path_ = desc_.latency_path >= 0;
     if (desc_.qnorm_mode < PBSO_QNORM_OFF || desc_.qnorm_mode > PBSO_QNORM_CLOSED)
         return fail(PBSO_ERR_INVALID, "qnorm_mode");
@@ -381,16 +382,18 @@ int Engine::init() {
         HIPTRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPTRY(hipStreamCreateWithPriority(&prep_stream_, hipStreamNonBlocking, greatest));
     }
-    if (desc_.stream_sync == 2) {
+    if (desc_.stream_sync >= 2) {
         int can = 0;
-        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, desc_.device) == hipSuccess && can &&
-            hipExtMallocWithFlags((void **)&sig_prep_, sizeof(unsigned long long), hipMallocSignalMemory) == hipSuccess) {
-            HIPTRY(hipMemset(sig_prep_, 0, sizeof(unsigned long long)));
-            HIPTRY(hipDeviceSynchronize());
-            sync_values_ = true;
+        auto signal_word = [&](unsigned long long **p) {
+            if (hipExtMallocWithFlags((void **)p, sizeof(unsigned long long), hipMallocSignalMemory) != hipSuccess) { *p = nullptr; return false; }
+            return hipMemset(*p, 0, sizeof(unsigned long long)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+        };
+        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, desc_.device) == hipSuccess && can) {
+            if (desc_.stream_sync == 3) start_gate_ = signal_word(&sig_start_);
+            if (desc_.stream_sync == 2) sync_values_ = signal_word(&sig_prep_);
         }
         (void)hipGetLastError();
-        if (!sync_values_) return fail(PBSO_ERR_HIP, "stream_sync = values: the device has no hipStreamWaitValue64");
+        if (!sync_values_ && !start_gate_) return fail(PBSO_ERR_HIP, "stream_sync = 2 / 3: the device has no hipStreamWaitValue64");
     }
     for (int i = 0; i < N_SETS; ++i) {
         // (waited for by the engine's own streams only, never by the host or another device: without the system-scope fence
@@ -2136,6 +2139,9 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     HIPTRY(ps.d_arena.ensure(off, false, sp));
     HIPTRY(hipMemcpyAsync(ps.d_arena.p, ha, off, hipMemcpyHostToDevice, sp));
     HIPTRY(hipEventRecord(ev_set_[cur_set_], sp));          // this set's pinned arena is reusable
+    // the start gate: this launch's preparation kernels behind the START of the previous launch's bank (engine.h)
+    if (start_gate_ && !one_stream && last_bank_seq_ > 0)
+        HIPTRY(hipStreamWaitValue64(sp, sig_start_, last_bank_seq_, hipStreamWaitValueGte, ~0ull));
     evq.h_copy = host_ms();
     const auto tsub1 = std::chrono::steady_clock::now();
     unsigned char *da = ps.d_arena.p;
@@ -2183,6 +2189,8 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.rotate_prio = (rotate_prio_ == 2 && total_team_waves_ < 12LL * n_cus_) ? 1 : rotate_prio_;
     kp.board = d_board_.p;
     kp.launch_seq = ++launch_seq_;
+    kp.start_flag = start_gate_ ? sig_start_ : nullptr;
+    kp.start_seq = ++bank_seq_;
     kp.pc = d_pc_.p;
     kp.wtab = d_wtab_.p;
     kp.frames = B_;
@@ -2336,6 +2344,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     buffers_done_ += nb;
     last_launch_tc_ = tc_launch;
     last_one_stream_ = one_stream;
+    last_bank_seq_ = kp.start_seq;
     last_set_ = cur_set_;
     cur_set_ = (cur_set_ + 1) % N_SETS;
     hprof_[4] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - last_plan_ms_;

@@ -240,6 +240,12 @@ private:
     unsigned long long *sig_prep_ = nullptr;             // hipMallocSignalMemory: the number of the last prepared launch
     unsigned long long prep_seq_ = 0;
     bool sync_values_ = false;
+    // The start gate (desc.stream_sync = 3): the bank kernel's first workgroup stores the launch's number into signal memory, and the preparation
+    // kernels of the NEXT launch wait for that value -- they never start together with a bank (whose workgroups would then wait
+    // for the slots they hold), only beside one that is resident, i.e. in the slots its workgroups free when they retire.
+    unsigned long long *sig_start_ = nullptr;
+    unsigned long long bank_seq_ = 0, last_bank_seq_ = 0;
+    bool start_gate_ = false;
     // Plan sets: the host plans and uploads step k while the device still runs step k - N_SETS + 1.  Two sets are enough for
     // a host that never stalls; with three, a hiccup of the host thread (the boxes of this pool stall it for a millisecond now
     // and then) is absorbed by the steps already queued instead of idling the device.  Not four: with three steps of preparation

@@ -77,6 +77,12 @@ struct IirParams {
     int rotate_prio;             // 1: rotate s_setprio per tile (fair progress of resident teams); 2: + progress feedback per CU
     unsigned *board;             // [4096] per-CU progress words for rotate_prio == 2
     unsigned launch_seq;
+    // "this launch's bank has started": workgroup 0 stores start_seq here (signal memory) before anything else, and the engine's
+    // preparation stream holds the NEXT launch's kernels back until it has (hipStreamWaitValue64) -- a preparation kernel that
+    // starts together with a bank takes slots the bank's workgroups then wait for (128 x 512 x 86: 136 -> 234 us, once per
+    // host hiccup: profiles/r04_timeline_share_128x512.txt).  nullptr: no gate.
+    unsigned long long *start_flag = nullptr;
+    unsigned long long start_seq = 0;
     // block state-space form (kernels_block.hip)
     const float *pc;             // planes P11 - 1, P12, P21, P22 of P = A^16 in the (q, q - q_prev) basis, each [n_obj][m_pad] (stride gq_plane)
     const float *wtab;           // [n_obj * m_pad / 2][64]: MFMA A operand per pair of columns (a_j, b_j of both modes, j = 1..16)

@@ -71,6 +71,8 @@ struct BlkDims {
     // state the scan left at p_xs[obj][c] (unscaled) under the transfer row p_xtrow[obj][c]; it does NOT write the state back
     // (the scan has).  cb == 0: one workgroup per team walks all nb buffers from the state arrays.
     int cb, n_chunks, census_stride;
+    unsigned long long *start_flag;     // see IirParams::start_flag
+    unsigned long long start_seq;
 };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -133,6 +135,8 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     const float *__restrict__ p_ftab, const float *__restrict__ p_xs, const int *__restrict__ p_xtrow, const BlkDims p) {
     constexpr bool QN = QNM != 0;
     constexpr int NG = 2;                              // groups per buffer (513 = 1 + 2 * 256; checked at launch)
+    if (p.start_flag && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        __hip_atomic_store(p.start_flag, p.start_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     constexpr bool chunked = CHUNKED;
     const int chunk = chunked ? (int)blockIdx.y : 0;
     const int b_begin = chunk * p.cb;
@@ -1091,7 +1095,7 @@ static int launch_one(const IirParams &p, int n_teams, int W, hipStream_t stream
     const int frames = p.frames;
     const int n_chunks = p.tc_cb > 0 ? (p.nb + p.tc_cb - 1) / p.tc_cb : 1;
     const BlkDims dims = {p.nb, p.m_pad, p.b_pad, frames, (frames - 1) / GROUP, p.audio_stride, p.gq_plane, p.qn_nb, p.qn_b0, p.rotate_prio, p.forced_block,
-                          p.tc_cb, n_chunks, p.census_stride};
+                          p.tc_cb, n_chunks, p.census_stride, p.start_flag, p.start_seq};
     hipLaunchKernelGGL(kern, dim3(n_teams, n_chunks), dim3(64 * W), lds, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows, p.g32, p.g32_off,
                        p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.pc, p.wtab, p.teams, p.audio_parts, p.census, p.xdump, p.xscale, p.dump_row, p.board, p.ftab,
                        p.tc_xs, p.tc_xtrow, dims);

@@ -131,6 +131,8 @@ struct IirDims {
     long long gq_plane;          // elements between the G11 / 2 G12 / G22 planes
     int qn_nb, qn_b0;            // qnorm is [n_obj][qn_nb][m_pad]; this launch fills buffers qn_b0 ..
     unsigned launch_seq;
+    unsigned long long *start_flag;     // see IirParams::start_flag
+    unsigned long long start_seq;
 };
 
 // QNM: 0 no qnorm; 1 per-sample accumulation (the reference's loop, modal_solver.h:270);
@@ -147,6 +149,8 @@ __global__ __launch_bounds__(MAXT) void iir_bank_kernel(
     const float *__restrict__ p_gq, const TeamDesc *__restrict__ p_teams, float *__restrict__ p_audio_parts, unsigned *__restrict__ p_board,
     unsigned long long *__restrict__ p_census, const IirDims p) {
     constexpr bool QN = QNM != 0;
+    if (p.start_flag && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        __hip_atomic_store(p.start_flag, p.start_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const TeamDesc team = p_teams[blockIdx.x];
     const int obj = team.obj;
@@ -500,7 +504,7 @@ static int launch_one(const IirParams &p, int n_obj, int W, hipStream_t stream) 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    const IirDims dims = {p.nb, p.n_tiles, p.m_pad, p.b_pad, p.audio_stride, p.rotate_prio, p.gq_plane, p.qn_nb, p.qn_b0, p.launch_seq};
+    const IirDims dims = {p.nb, p.n_tiles, p.m_pad, p.b_pad, p.audio_stride, p.rotate_prio, p.gq_plane, p.qn_nb, p.qn_b0, p.launch_seq, p.start_flag, p.start_seq};
     hipLaunchKernelGGL(kern, dim3(n_obj), dim3(64 * W), lds, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc,
                        p.grows, p.g32, p.g32_off, p.tprof, p.xfer_rows, p.xfer_init, p.audio, p.qnorm, p.gq, p.teams, p.audio_parts, p.board, p.census, dims);
     return (int)hipGetLastError();

@@ -37,6 +37,8 @@ struct PipeDims {
     int nb, m_pad, b_pad, frames;
     long long audio_stride, plane;
     int qn_nb, qn_b0;
+    unsigned long long *start_flag;     // see IirParams::start_flag
+    unsigned long long start_seq;
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -69,6 +71,8 @@ __global__ __launch_bounds__(256) void iir_pipe_kernel(
     const float *__restrict__ p_ftab, unsigned long long *__restrict__ p_census, const float *__restrict__ p_g32,
     const long long *__restrict__ p_g32_off, const PipeDims p) {
     constexpr bool QN = QNM != 0;
+    if (p.start_flag && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        __hip_atomic_store(p.start_flag, p.start_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __shared__ __attribute__((aligned(16))) float lds_stage[2][2][ST_AREA];       // [buffer parity][group]
     __shared__ __attribute__((aligned(16))) float lds_incr[64 * U_ROW];           // the producer's increments on their way back to lane = mode
     // qnorm rows of dense buffers (block path): the UNWEIGHTED state at the start of every fourth block (0, 4, 8, 12 | 16, 20, 24, 28), from
@@ -576,7 +580,7 @@ int launch_iir_pipe(const IirParams &p, int n_teams, int n_consumers, int qnorm_
     if (n_teams <= 0) return 0;
     if (p.frames != 1 + 2 * GROUP || n_consumers < 1 || n_consumers > 3) return (int)hipErrorInvalidValue;
     if (n_consumers == 3 && (qnorm_mode == 0 || p.ftab == nullptr)) n_consumers = 2;      // (the third only steps qnorm chains)
-    const PipeDims dims = {p.nb, p.m_pad, p.b_pad, p.frames, p.audio_stride, p.gq_plane, p.qn_nb, p.qn_b0};
+    const PipeDims dims = {p.nb, p.m_pad, p.b_pad, p.frames, p.audio_stride, p.gq_plane, p.qn_nb, p.qn_b0, p.start_flag, p.start_seq};
     const dim3 block(64 * (1 + n_consumers));
     if (qnorm_mode != 0)
         hipLaunchKernelGGL(iir_pipe_kernel<2>, dim3(n_teams), block, 0, stream, p.ca, p.cb, p.sq, p.sd, p.ss, p.desc, p.grows, p.tprof,
