@@ -327,18 +327,26 @@ def measure(args, ctx, global_ids, want_parity):
     if use_group:
         # (should the group not come up on some rank -- librccl missing, a communicator error -- every rank falls back to the
         #  torch.distributed collectives together: the ranks agree on it with one all-reduce, and the JSON line says so)
+        ident = [None]
+        if rank == 0 and world > 1:
+            try:
+                from openpbso_amd.group import unique_id
+                ident[0] = unique_id()
+            except Exception as ex:                      # (librccl missing: the broadcast below still has to happen on every rank)
+                group_note = repr(ex)
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0, device=ctx["coll_dev"])
         try:
-            from openpbso_amd.group import Group, unique_id
-            ident = [unique_id() if (rank == 0 and world > 1) else None]
-            if world > 1:
-                dist.broadcast_object_list(ident, src=0, device=ctx["coll_dev"])
+            from openpbso_amd.group import Group
+            if world > 1 and ident[0] is None:
+                raise RuntimeError("no RCCL unique id from rank 0")
             counts_all = ctx.get("counts") or [n_obj]
             grp = Group([ctx["dev_index"]], world_size=world, first_rank=rank, unique_id=ident[0], form=form_c, qnorm=qnorm_c,
                         modes_per_lane=args.modes_per_lane)
             grp.plan([args.modes] * int(sum(counts_all)))
             assert grp.span(rank) == (global_ids[0], global_ids[-1] + 1), (grp.span(rank), global_ids[0], global_ids[-1])
         except Exception as ex:
-            group_note = repr(ex)
+            group_note = group_note or repr(ex)
             if grp is not None:
                 grp.close()
             grp = None
