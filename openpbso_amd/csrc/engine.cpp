@@ -2285,7 +2285,11 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         kp.tc_xs = d_xs_[cur_set_].p;
         kp.tc_xtrow = d_xtrow_[cur_set_].p;
         kp.census_stride = ts.n_teams;
-        kp.rotate_prio = rotate_prio_ ? 1 : 0;
+        // The priority rotation (kernels_block.hip) assumes the teams of a CU walk their buffers in step.  A launch of several
+        // ROUNDS of workgroups does not: a team that arrives when another retires starts at its own chunk's first buffer, two
+        // teams of a CU then hold the same priority and the oldest-first arbitration is back -- 1024 x 512 forced into two
+        // chunks: 1.33 ms against 1.07 without the rotation; 700 x 512: 0.751 against 0.742 (scripts/debug/r04_tcrounds.py).
+        kp.rotate_prio = (rotate_prio_ && ts.waves * (long long)((nb + tc_cb - 1) / tc_cb) <= 8LL * n_cus_) ? 1 : 0;
         for (const SizeClass &c : ts.classes) {
             kp.teams = ts.d_teams.p + c.first;
             LAUNCHTRY(iir_block::launch_iir_block(kp, c.count, ts.R, c.W, desc_.qnorm_mode, form_ == PBSO_FORM_BLOCK_BF16 ? 1 : 0, sk));
