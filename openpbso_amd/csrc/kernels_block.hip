@@ -446,7 +446,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
         const BufDesc cur = next;
         next = dsc[b + 1 < p.nb ? b + 1 : b];
         if (p.rotate) {
-            switch ((prio_rank + b) & 3) {
+            switch ((prio_rank + b - b_begin) & 3) {       // (the team's OWN buffer count: the chunks of a CU start together at different b)
             case 0: __builtin_amdgcn_s_setprio(0); break;
             case 1: __builtin_amdgcn_s_setprio(1); break;
             case 2: __builtin_amdgcn_s_setprio(2); break;
