@@ -2289,6 +2289,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         // ROUNDS of workgroups does not: a team that arrives when another retires starts at its own chunk's first buffer, two
         // teams of a CU then hold the same priority and the oldest-first arbitration is back -- 1024 x 512 forced into two
         // chunks: 1.33 ms against 1.07 without the rotation; 700 x 512: 0.751 against 0.742 (scripts/debug/r04_tcrounds.py).
+        // (A phase taken from the wall clock instead of the team's buffer count does not help: 0.752 ms at 700 x 512.)
         kp.rotate_prio = (rotate_prio_ && ts.waves * (long long)((nb + tc_cb - 1) / tc_cb) <= 8LL * n_cus_) ? 1 : 0;
         for (const SizeClass &c : ts.classes) {
             kp.teams = ts.d_teams.p + c.first;
