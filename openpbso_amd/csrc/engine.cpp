@@ -1917,12 +1917,27 @@ bool Engine::choose_time_chunks(int nb, int n_dense_rows, int *set, int *cb) con
     if (tc_mode_ > 0) {
         best = std::min(tc_mode_, nb);
     } else {
-        if (waves >= capacity) return false;              // the chip is full without cutting time
+        // cost of a launch in buffer times: rounds of workgroups x (chunk length + 0.3 for a workgroup's start-up: operand table,
+        // coefficients, state).  A scene LARGER than the chip, whose walk is a launch of several rounds of full-length
+        // workgroups, does not pack perfectly -- a CU may be handed a ninth workgroup while another gets seven
+        // (scripts/census.py 2048: a third, nearly empty round; 1100 / 1536 / 2048 x 512 walk 1.68 / 2.04 / 2.72 ms: half a round
+        // more than their 1.07 / 1.5 / 2 rounds) -- and the shorter the workgroups, the cheaper that tail: such scenes are cut in
+        // time too (1.22 / 1.66 / 2.21 ms).  A scene that fills the chip exactly (1024 x 512: one round) is not.
+        const bool over_full = waves > capacity;
+        if (over_full) {
+            // measured, in rounds of the exactly-full chip (scripts/debug/r04_tcrounds.py): the walk of 1100 / 1536 / 2048 / 3000
+            // objects x 512 modes takes 1.57 / 1.90 / 2.54 / 3.07 -- whole rounds + a last, partly filled one that runs faster the
+            // emptier it is (0.57 + 0.54 x its fill), or half a round of stragglers when the rounds are exactly full -- and the
+            // same scenes cut in time 1.07 x their share of the chip (1.14 / 1.57 / 2.12 / 3.17): at 3000 the walk wins
+            const double frac = (double)waves / (double)capacity, whole = std::floor(frac), fill = frac - whole;
+            const double walk = whole + (fill > 1e-9 ? 0.57 + 0.54 * fill : 0.5);
+            if (frac * 1.07 >= walk) return false;
+        }
         double best_cost = 0;
         for (int c = nb; c >= 1; --c) {
             const long long chunks = (nb + c - 1) / c;
             const long long rounds = (waves * chunks + capacity - 1) / capacity;
-            const double cost = (double)rounds * (c + 0.3);
+            const double cost = ((double)rounds + (over_full ? 0.5 : 0.0)) * (c + 0.3);
             if (c == nb || cost < best_cost - 1e-9) { best = c; best_cost = cost; }
         }
     }

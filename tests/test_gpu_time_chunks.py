@@ -226,6 +226,48 @@ def test_strong_scaling_shares_full_size(n_obj, n_modes):
     assert (mx <= 1e-4).all() and (l2 <= 1e-3).all(), (mx.max(), l2.max())
 
 
+def test_scenes_larger_than_the_chip_are_cut_in_time_too():
+    """1100 x 512 is 1.07 rounds of full-length workgroups for the walk (a second, nearly empty round: 1.68 ms per 86 buffers);
+    the policy cuts it in time (1.22 ms).  A scene that fills the chip exactly (1024 x 512) keeps the walk.  Sampled objects
+    against the oracle on both paths."""
+    from openpbso_amd import Engine
+    nb, n_obj = 86, 1100
+    lam, shp = synth.eigenvalues(512, 77), synth.mode_shapes(512, 77)
+    nv = shp.shape[1] // 3
+    rng = np.random.default_rng(99)
+    objs = [ObjSpec(lam, shapes=shp) for _ in range(n_obj)]
+    evs = []
+    for i in range(n_obj):
+        vns = synth.unit_normals(nb, 300 + i % 7)
+        evs += [force_ev(int(b), i, vid=int(rng.integers(0, nv)), vn=vns[b]) for b in np.nonzero(rng.random(nb) < 0.233)[0]]
+        evs.append(dict(t=0, obj=i, kind="use_transfer", use=False))
+    pick = [0, 333, 1024, 1099]
+    want = run_oracle(objs, evs, nb, only=pick, threads=4)
+    for tc, n_tc in ((0, 1), (-1, 0)):
+        with Engine(time_chunks=tc) as eng:
+            for o in objs:
+                eng.add_object(o.lam, o.rho, o.alpha, o.beta, o.n_modes, o.shapes)
+            eng.finalize()
+            from openpbso_amd import ForceMessage
+            for ev in evs:
+                if ev["kind"] == "force":
+                    assert eng.enqueue_force(ev["obj"], ForceMessage(vid=ev["vid"], vn=ev["vn"]), ev["t"])
+                else:
+                    eng.set_use_transfer(ev["obj"], ev["use"], ev["t"])
+            eng.step(nb)
+            got = eng.audio_rows(pick)
+            assert eng.info()["total_time_chunk_launches"] == n_tc
+        mx, l2 = rel_errors(got, want["audio"])
+        assert (mx <= 1e-4).all() and (l2 <= 1e-3).all(), (tc, mx.max(), l2.max())
+    with Engine() as eng:                              # exactly one round: the walk
+        for o in objs[:1024]:
+            eng.add_object(o.lam, o.rho, o.alpha, o.beta, o.n_modes, o.shapes)
+        eng.finalize()
+        eng.step(nb)
+        eng.sync()
+        assert eng.info()["total_time_chunk_launches"] == 0
+
+
 def test_step_to_host_delivers_what_read_audio_returns():
     """pbso_step_to_host: the step's audio of all objects in pinned host memory, double-buffered on the device so that the copy
     of step k runs beside the bank of step k + 1 -- three steps into two alternating host buffers, each equal to what a second
