@@ -61,16 +61,22 @@ DTYPE_OF_FORM = {
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--settle", type=int, default=40,
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--settle", type=int, default=-1,
                     help="untimed steps run before the warm-up so that the shader clock has ramped (the first ~70 ms "
                          "after idle run 10 %% slower, profiles/r01_clock_ramp.txt) and the runtime's one-time work is behind "
                          "(one or two asynchronous uploads among an engine's first ~30 block the caller for 6 - 7 ms: "
-                         "PBSO_TIMELINE=1, scripts/debug/r03_stalls.py); reported as settle_steps")
+                         "PBSO_TIMELINE=1, scripts/debug/r03_stalls.py); reported as settle_steps.  Default: 40 s of audio "
+                         "(40 steps of 86 buffers, 4 of 860)")
     ap.add_argument("--objects", type=int, default=1024, help="objects per GPU (weak scaling); the total for the strong leg")
     ap.add_argument("--modes", type=int, default=512)
-    ap.add_argument("--buffers", type=int, default=86, help="audio buffers per step")
+    ap.add_argument("--buffers", type=int, default=860,
+                    help="audio buffers per step = per pbso_step call = per oscillator-bank launch (chunk_buffers follows).  860 = 10 s of "
+                         "audio: the duration SURVEY.md 8(d) quotes throughput on (86 = 1 s is its parity size).  A launch's fixed "
+                         "costs -- ramp, write drain, the hand-over from the preparation stream -- are per launch: rounds 1 - 3 and "
+                         "the start of round 4 measured 86-buffer steps; the line's `steps_of_one_second` leg still does")
+    ap.add_argument("--no-one-second-leg", action="store_true", help="skip the extra leg with 86-buffer steps (N = 1)")
     ap.add_argument("--form", choices=["block", "block_bf16", "velocity", "direct"], default="block",
                     help="block: block state-space form with the exact f32 MFMA projection (default: every product of the line is f32); "
                          "block_bf16: the same with the output projection as a split-bf16 MFMA product (mixed precision, reported as "
@@ -108,7 +114,10 @@ def parse(argv=None):
                          "mixed_precision_projection; headline block_bf16 -> exact_f32_projection), reported beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-objects", type=int, default=0, help="objects in the CPU baseline sample (0 = auto)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.settle < 0:
+        args.settle = max(2, round(40 * 86 / max(1, args.buffers)))
+    return args
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -213,7 +222,7 @@ def cpu_baseline(args, lam, shapes, scripts):
         lib = orc.lib(native=True)
     except Exception:
         lib = orc.lib()
-    nb, M = args.buffers, args.modes
+    nb, M = min(args.buffers, 86), args.modes         # (a bounded sample: one second of audio per object whatever the GPU's step is)
     # sample size: about 15 s of single-thread work (one object-second costs ~15-40 ms), at least two objects per thread
     n_obj = args.cpu_objects or min(len(shapes), max(2 * ncores, 512))
     om = np.ascontiguousarray(lam[:n_obj])
@@ -342,7 +351,7 @@ def measure(args, ctx, global_ids, want_parity):
                 raise RuntimeError("no RCCL unique id from rank 0")
             counts_all = ctx.get("counts") or [n_obj]
             grp = Group([ctx["dev_index"]], world_size=world, first_rank=rank, unique_id=ident[0], form=form_c, qnorm=qnorm_c,
-                        modes_per_lane=args.modes_per_lane)
+                        modes_per_lane=args.modes_per_lane, chunk_buffers=max(128, args.buffers))
             grp.plan([args.modes] * int(sum(counts_all)))
             assert grp.span(rank) == (global_ids[0], global_ids[-1] + 1), (grp.span(rank), global_ids[0], global_ids[-1])
         except Exception as ex:
@@ -363,7 +372,8 @@ def measure(args, ctx, global_ids, want_parity):
             grp.add_object(gid, lam[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
         eng = grp.engine(rank)
     else:
-        eng = Engine(device=ctx["dev_index"], form=form_c, qnorm=qnorm_c, modes_per_lane=args.modes_per_lane, stream=stream)
+        eng = Engine(device=ctx["dev_index"], form=form_c, qnorm=qnorm_c, modes_per_lane=args.modes_per_lane, stream=stream,
+                     chunk_buffers=max(128, args.buffers))
         for i, gid in enumerate(global_ids):
             eng.add_object(lam[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
     if args.scenario == "listener":
@@ -751,6 +761,17 @@ def main():
             ctx["counts"] = [a3.objects]
             shares.append((n_ranks, a3.objects, measure(a3, ctx, list(range(a3.objects)), want_parity=(not args.no_parity and rank == 0))))
         ctx["counts"] = [args.objects]
+    # one GPU: the same scene stepped ONE SECOND of audio at a time (86 buffers per pbso_step: the step size of rounds 1 - 3 and of
+    # SURVEY 8(d)'s parity runs) -- what a launch's fixed costs take when they are paid every second of audio instead of every ten
+    one_second = None
+    if world == 1 and args.buffers > 86 and not args.no_one_second_leg and args.scenario == "impulses":
+        import copy
+        a4 = copy.copy(args)
+        a4.buffers = 86
+        a4.settle = max(args.settle, 40 if args.steps >= 20 else 8)
+        a4.steps = max(args.steps, 40) if args.steps >= 20 else args.steps
+        ctx["counts"] = [args.objects]
+        one_second = (a4, measure(a4, ctx, weak_ids, want_parity=False))
     # what the collective costs: the head leg once more with the all-gather left out, with a gather to rank 0 only
     # (send / receive) and with the reduce a consumer of ONE mixed stream needs (reported beside it, never as `value`)
     bare = mixed = rooted = None
@@ -881,7 +902,8 @@ def main():
                                 "scraping": "sustained AutoregressiveForce scraping (one GetModalForceFace message per buffer, "
                                             "profiles generated on the device), unit transfer, ",
                                 "listener": "Poisson impulse stream + FFAT maps (16x16 cube faces) with a new listener position every buffer, ",
-                            }[args.scenario] + f"{nb} buffers x 513 samples per step, "
+                            }[args.scenario] + f"{nb} buffers x 513 samples = {nb * B / SAMPLE_RATE:.1f} s of audio per step "
+                            f"(one pbso_step call, {-(-nb // max(128, nb))} oscillator-bank launch), "
                             f"qnorm {qn_txt}, {args.form} recurrence form"
                             + (f", {coll_txt} all-gather of the audio buffers inside the timed region" if m["gather"] else ""),
                 "scenario": args.scenario, "objects_per_gpu": m["n_local"], "modes": M, "buffers_per_step": nb, "frames_per_buffer": B,
@@ -980,6 +1002,15 @@ def main():
                         "steps objects / N of them -- this is that rank's compute, gather not included; implied_efficiency_at_N = "
                         "(this line's ms_per_step / N) / the share's ms_per_step.  Shares that leave SIMDs idle run the block kernel cut "
                         "along the time axis (K5: time_chunked_launches)"}
+        if one_second is not None:
+            a4, r4 = one_second
+            secs = 86 * B * a4.steps / SAMPLE_RATE
+            out["steps_of_one_second"] = {
+                "value": args.objects * 86 * B * a4.steps / r4["elapsed"], "realtime_x": secs / r4["elapsed"],
+                "ms_per_step": r4["elapsed"] / a4.steps * 1e3, "buffers_per_step": 86, "steps": a4.steps, "kernel_ms": r4["kernel_ms"],
+                "note": "the same engine and scene with 86 buffers (one second of audio) per pbso_step, the step size of the lines of "
+                        "rounds 1 - 3: a launch's fixed costs (ramp, write drain, hand-over from the preparation stream: ~35 us) "
+                        "are paid per second of audio instead of per ten"}
         if mixed is not None:
             out["mix"] = dict(leg_numbers(head, mixed), scaling=head, collective="all_reduce(sum) of one mixed row per rank",
                               bytes_per_rank=nb * B * 4,

@@ -24,8 +24,9 @@ def counter(text, kernel, name):
     return None
 
 
-counts = {"note": "per wave and buffer of iir_block_kernel at the headline shape (1024 objects x 512 modes, R = 4: 2048 waves x 86 buffers per launch): "
-                  "(SQ_INSTS_VALU - SQ_INSTS_MFMA) / 176128 and SQ_INSTS_MFMA / 176128; rocprofv3 --kernel-trace --pmc, own passes",
+NB = 860      # buffers per launch of the PMC passes (bench.py's default step)
+counts = {"note": f"per wave and buffer of iir_block_kernel at the headline shape (1024 objects x 512 modes, R = 4: 2048 waves x {NB} buffers per launch): "
+                  f"(SQ_INSTS_VALU - SQ_INSTS_MFMA) / {2048 * NB} and SQ_INSTS_MFMA / {2048 * NB}; rocprofv3 --kernel-trace --pmc, own passes",
           "forms": {}}
 for form in ("block", "block_bf16"):
     p = f"{dst}/{rnd}_pmc_summary_{form}.txt"
@@ -34,9 +35,9 @@ for form in ("block", "block_bf16"):
     s = open(p).read()
     valu, mfma = counter(s, "iir_block_kernel", "SQ_INSTS_VALU"), counter(s, "iir_block_kernel", "SQ_INSTS_MFMA")
     waves = counter(s, "iir_block_kernel", "SQ_WAVES")
-    cfg = {"objects_per_gpu": 1024, "modes": 512, "buffers_per_step": 86, "qnorm": "sample", "scenario": "impulses"}
+    cfg = {"objects_per_gpu": 1024, "modes": 512, "buffers_per_step": NB, "qnorm": "sample", "scenario": "impulses"}
     if valu and mfma and waves:
-        wb = waves * 86
+        wb = waves * NB
         counts["forms"][form] = {"config": cfg, "valu_per_wave_buffer": round((valu - mfma) / wb, 1), "mfma_per_wave_buffer": round(mfma / wb, 1),
                                  "lds_per_wave_buffer": round((counter(s, "iir_block_kernel", "SQ_INSTS_LDS") or 0) / wb, 1),
                                  "coexec_cycles": counter(s, "iir_block_kernel", "SQ_VALU_MFMA_COEXEC_CYCLES"),

@@ -12,8 +12,8 @@ from openpbso_amd import Engine, synth   # noqa: E402
 
 n_obj, tc, p_hit = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
 direct = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-M, nb, steps = 512, 86, 14
-eng = Engine(time_chunks=tc, direct_hits=direct, timing_every=1)
+M, nb, steps = 512, int(os.environ.get("NB", "86")), 14
+eng = Engine(time_chunks=tc, direct_hits=direct, timing_every=1, chunk_buffers=max(128, nb))
 lam = synth.eigenvalues(M, 7)
 shp = synth.mode_shapes(M, 7)
 nv = shp.shape[1] // 3
@@ -32,9 +32,13 @@ for k in range(steps):
         vn = synth.unit_normals(o.size, 11 + k)
         assert eng.enqueue_vertex_hits(o.astype(np.int32), v, vn, (k * nb + b).astype(np.int64)) == o.size
     eng.step(nb)
-    eng.sync()
+    if os.environ.get("SYNC", "1") == "1":
+        eng.sync()
     ks.append(eng.info()["last_step_kernel_ms"])
 info = eng.info()
-print(f"objects={n_obj} time_chunks={tc} p_hit={p_hit} direct_hits={direct}: kernel ms per launch median {np.median(ks[4:]):.4f} (min {min(ks[4:]):.4f}); "
+eng.sync()
+if os.environ.get("ALL"):
+    print("kernel ms per step:", [round(x, 3) for x in ks])
+print(f"objects={n_obj} nb={nb} time_chunks={tc} p_hit={p_hit} direct_hits={direct}: kernel ms per launch median {np.median(ks[4:]):.4f} (min {min(ks[4:]):.4f}); "
       f"time-chunked launches {info['total_time_chunk_launches']} of {info['total_block_launches']}")
 eng.close()

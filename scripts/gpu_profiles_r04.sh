@@ -13,29 +13,34 @@ b form_block_bf16 --no-cpu-baseline --form block_bf16 --no-strong-share
 b qnorm_off --no-cpu-baseline --qnorm off --no-second-form --no-strong-share
 b host_delivery --host-delivery --no-cpu-baseline --no-second-form --no-strong-share
 echo "== other BASELINE configurations"
-b c2_1x512 --no-cpu-baseline --objects 1 --modes 512 --steps 40 --warmup 2
-b c3_64x256_listener --no-cpu-baseline --objects 64 --modes 256 --scenario listener --steps 40 --warmup 2
-b c5_8x4096_scraping --no-cpu-baseline --objects 8 --modes 4096 --scenario scraping --steps 40 --warmup 2
-b c5_8x4096_scraping_qnorm_off --no-cpu-baseline --objects 8 --modes 4096 --scenario scraping --qnorm off --steps 40 --warmup 2
+# (one second of audio per step, as in rounds 1 - 3, and the bench's default ten)
+b c2_1x512 --no-cpu-baseline --objects 1 --modes 512 --buffers 86 --steps 40 --warmup 2
+b c3_64x256_listener --no-cpu-baseline --objects 64 --modes 256 --scenario listener --buffers 86 --steps 40 --warmup 2
+b c5_8x4096_scraping --no-cpu-baseline --objects 8 --modes 4096 --scenario scraping --buffers 86 --steps 40 --warmup 2
+b c5_8x4096_scraping_qnorm_off --no-cpu-baseline --objects 8 --modes 4096 --scenario scraping --qnorm off --buffers 86 --steps 40 --warmup 2
+b c2_1x512_10s_steps --no-cpu-baseline --objects 1 --modes 512
+b c3_64x256_listener_10s_steps --no-cpu-baseline --objects 64 --modes 256 --scenario listener
+b c5_8x4096_scraping_10s_steps --no-cpu-baseline --objects 8 --modes 4096 --scenario scraping
 echo "== the per-rank shares of configs[3] on 2 / 4 / 8 GPUs, alone (the default line carries them as strong_share), and the same without K5"
 for o in 512 256 128; do
-b share_${o}x512 --no-cpu-baseline --no-second-form --objects $o --steps 40 --warmup 3
-PBSO_TIME_CHUNKS=-1 b share_${o}x512_buffer_by_buffer --no-cpu-baseline --no-second-form --objects $o --steps 40 --warmup 3
+b share_${o}x512 --no-cpu-baseline --no-second-form --objects $o --buffers 86 --steps 40 --warmup 3
+PBSO_TIME_CHUNKS=-1 b share_${o}x512_buffer_by_buffer --no-cpu-baseline --no-second-form --objects $o --buffers 86 --steps 40 --warmup 3
+b share_${o}x512_10s_steps --no-cpu-baseline --no-second-form --no-one-second-leg --objects $o
 done
-PBSO_TIME_CHUNKS=-1 b c2_1x512_buffer_by_buffer --no-cpu-baseline --objects 1 --modes 512 --steps 40 --warmup 2
-PBSO_TIME_CHUNKS=-1 b c3_64x256_listener_buffer_by_buffer --no-cpu-baseline --objects 64 --modes 256 --scenario listener --steps 40 --warmup 2
-PBSO_ENGINE_OPTS=time_chunks=-1,bank_kernel=1 b c2_1x512_block_kernel_only --no-cpu-baseline --objects 1 --modes 512 --steps 40 --warmup 2
+PBSO_TIME_CHUNKS=-1 b c2_1x512_buffer_by_buffer --no-cpu-baseline --objects 1 --modes 512 --buffers 86 --steps 40 --warmup 2
+PBSO_TIME_CHUNKS=-1 b c3_64x256_listener_buffer_by_buffer --no-cpu-baseline --objects 64 --modes 256 --scenario listener --buffers 86 --steps 40 --warmup 2
+PBSO_ENGINE_OPTS=time_chunks=-1,bank_kernel=1 b c2_1x512_block_kernel_only --no-cpu-baseline --objects 1 --modes 512 --buffers 86 --steps 40 --warmup 2
 echo "== N > 1 path on one GPU"
 PBSO_BENCH_BACKEND=gloo b 2ranks_one_gpu_gloo --no-cpu-baseline --gpus 2 --steps 20 --warmup 2
-(PBSO_BENCH_GATHER_SELF=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29633 bench.py --gpus 1 --no-cpu-baseline --steps 40 --warmup 3 > $O/bench_1rank_torchrun_device_group_selfgather.json 2> $O/bench_1rank.err; echo "selfgather rc=$?")
+(PBSO_BENCH_GATHER_SELF=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29633 bench.py --gpus 1 --no-cpu-baseline --steps 20 --warmup 3 > $O/bench_1rank_torchrun_device_group_selfgather.json 2> $O/bench_1rank.err; echo "selfgather rc=$?")
 echo "== rocprofv3 kernel trace + stats"
 st() { name=$1; shift; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/st_$name -- python3 $R/bench.py --no-cpu-baseline --no-second-form "$@" > $O/st_$name.log 2>&1); f=$(find $O/st_$name -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats_$name.csv; [ $name = default ] && python scripts/trace_gaps.py $O/st_$name > $O/trace_gaps.txt 2>&1; rm -rf $O/st_$name; echo "stats $name: $(sed -n 2p $O/kernel_stats_$name.csv | cut -c1-70 | tr -d '\n') ... $(sed -n 2p $O/kernel_stats_$name.csv | awk -F, '{print $(NF-5), $(NF-4)}')"; }
-st default
-st c2_1x512 --objects 1 --modes 512 --steps 40
-st c3_64x256_listener --objects 64 --modes 256 --scenario listener --steps 40
-st c5_8x4096_scraping --objects 8 --modes 4096 --scenario scraping --steps 40
-st share_128x512 --objects 128 --steps 40
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/tl_128 -- python3 $R/bench.py --no-cpu-baseline --no-second-form --no-parity --no-strong-share --objects 128 --steps 20 --warmup 3 > /dev/null 2>&1); python scripts/debug/r04_timeline.py $O/tl_128 24 > $O/timeline_share_128x512.txt 2>&1; rm -rf $O/tl_128
+st default --no-one-second-leg
+st c2_1x512 --objects 1 --modes 512 --buffers 86 --steps 40
+st c3_64x256_listener --objects 64 --modes 256 --scenario listener --buffers 86 --steps 40
+st c5_8x4096_scraping --objects 8 --modes 4096 --scenario scraping --buffers 86 --steps 40
+st share_128x512 --objects 128 --buffers 86 --steps 40
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/tl_128 -- python3 $R/bench.py --no-cpu-baseline --no-second-form --no-parity --no-strong-share --objects 128 --buffers 86 --steps 20 --warmup 3 > /dev/null 2>&1); python scripts/debug/r04_timeline.py $O/tl_128 24 > $O/timeline_share_128x512.txt 2>&1; rm -rf $O/tl_128
 echo "== PMC passes"
 pmc() { form=$1; name=$2; shift; shift; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_${form}_$name -- python3 $R/bench.py --steps 3 --warmup 1 --settle 0 --no-cpu-baseline --no-parity --no-second-form --no-strong-share --form $form > $O/pmc_${form}_$name.log 2>&1); echo "pmc $form $name rc=$?"; }
 for form in block; do

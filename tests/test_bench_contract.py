@@ -62,6 +62,10 @@ def test_committed_headline_line_has_the_contract_keys(rnd):
             assert x["time_chunked_launches"] == x["bank_launches"] > 0          # the shares run cut along the time axis (K5)
         assert cfg["time_chunked_launches"] == 0                                 # ... the full chip does not
         assert 0.5 < hd["mix_on_device"]["frac_of_value"] <= 1.0
+        # the line of the round's final form steps ten seconds of audio per call and carries the one-second-step rate beside it
+        if cfg["buffers_per_step"] > 86:
+            one = d["steps_of_one_second"]
+            assert one["buffers_per_step"] == 86 and 0.9 * d["value"] < one["value"] < d["value"]
         # delivery to the host through the product's own path is measured by `bench.py --host-delivery` (its launches are the
         # headline kernel at the PCIe link's pace: kept out of the default command so that a profiler's per-kernel average over it
         # stays the headline's)
@@ -109,5 +113,6 @@ def test_bench_defaults_are_the_single_gpu_headline(monkeypatch):
     import bench
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
-    assert (a.gpus, a.objects, a.modes, a.buffers) == (1, 1024, 512, 86)
+    assert (a.gpus, a.objects, a.modes, a.buffers) == (1, 1024, 512, 860)      # 10 s of audio per step: SURVEY 8(d)'s throughput duration
+    assert a.settle * a.buffers >= 3000                                        # (the clock-ramp steps follow the step size)
     assert a.steps > 0 and a.warmup >= 0 and a.qnorm == "sample" and a.form == "block"

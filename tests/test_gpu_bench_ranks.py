@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_two_ranks_on_one_gpu_print_one_line_with_gather_and_strong_leg():
     env = dict(os.environ, PBSO_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     env.pop("WORLD_SIZE", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--objects", "96", "--steps", "3", "--warmup", "1",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--objects", "96", "--buffers", "86", "--steps", "3", "--warmup", "1",
                         "--settle", "2", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -65,5 +65,6 @@ def test_one_rank_under_torchrun_runs_the_rccl_gather_path():
     assert d["n_gpus"] == 1 and d["config"]["gather"] is True and d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 1
     assert d["config"]["launched_by"] == "torch.distributed.run" and d["parity"]["pass"]
     assert d["config"]["collective_by"].startswith("pbso_group")          # the collective was issued by the C++ device group
-    assert d["gather_cost"]["bytes_sent_per_rank"] == 256 * 86 * 513 * 4 and d["gather_cost"]["bytes_received_per_rank"] == 0
+    assert d["config"]["buffers_per_step"] == 860                          # (the driver's command: the default step, ten seconds of audio)
+    assert d["gather_cost"]["bytes_sent_per_rank"] == 256 * 860 * 513 * 4 and d["gather_cost"]["bytes_received_per_rank"] == 0
     assert "RCCL all-gather" in d["config"]["workload"] and d["gather_to_root"]["value"] > 0 and d["mix"]["value"] > 0
