@@ -42,7 +42,7 @@ st c5_8x4096_scraping --objects 8 --modes 4096 --scenario scraping --buffers 86 
 st share_128x512 --objects 128 --buffers 86 --steps 40
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/tl_128 -- python3 $R/bench.py --no-cpu-baseline --no-second-form --no-parity --no-strong-share --objects 128 --buffers 86 --steps 20 --warmup 3 > /dev/null 2>&1); python scripts/debug/r04_timeline.py $O/tl_128 24 > $O/timeline_share_128x512.txt 2>&1; rm -rf $O/tl_128
 echo "== PMC passes"
-pmc() { form=$1; name=$2; shift; shift; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_${form}_$name -- python3 $R/bench.py --steps 3 --warmup 1 --settle 0 --no-cpu-baseline --no-parity --no-second-form --no-strong-share --form $form > $O/pmc_${form}_$name.log 2>&1); echo "pmc $form $name rc=$?"; }
+pmc() { form=$1; name=$2; shift; shift; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_${form}_$name -- python3 $R/bench.py --steps 3 --warmup 1 --settle 0 --no-cpu-baseline --no-parity --no-second-form --no-strong-share --no-one-second-leg --form $form > $O/pmc_${form}_$name.log 2>&1); echo "pmc $form $name rc=$?"; }
 for form in block; do
 pmc $form m1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA
 pmc $form m2 SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE
