@@ -127,12 +127,13 @@ typedef struct pbso_engine_desc {
     int plan_pin;             /* != 0: pin the helper threads into the caller's core complex */
     int timing_every;         /* HIP-event pairs around every n-th launch (0 -> 1; < 0: none) */
     int warm_copies;          /* < 0: pbso_finalize does not warm the runtime's copy queues */
-    int stream_sync;          /* how the engine's two streams order their launches: 0 policy (= 1), 1 events.  Two measured alternatives
-                               * on hipStreamWaitValue64 (a beta interface of the runtime; creation fails where the device lacks it):
-                               * 2 the hand-over to the bank through a value in signal memory (half the latency of an event, 1 % per
-                               * step on small scenes); 3 events + a START GATE -- the next launch's preparation kernels wait for a
-                               * value the bank kernel stores when it starts, so they never start together with a bank (which costs
-                               * that bank 100 us when it happens, after a host hiccup; the gate itself costs 0.5 - 1.5 % per step) */
+    int stream_sync;          /* how the engine's two streams order their launches.  0 policy: events, and -- where the device supports
+                               * hipStreamWaitValue64 -- a START GATE in front of the preparation kernels of launches of >= 256 buffers:
+                               * they wait for a value the previous launch's bank kernel stores when it starts, so the preparation
+                               * never runs two launches ahead (a long scan that does trails its bank and collides with the next
+                               * bank's start).  1 events only.  2 the hand-over to the bank through a value in signal memory too (half
+                               * the latency of an event, 1 % per step on small scenes).  3 the gate for every launch (costs 0.5 - 1.5 %
+                               * per step of 86 buffers).  2 and 3 fail at creation where the device lacks the interface */
     int latency_path;         /* < 0: never prepare a launch on the bank's own stream (0: a step of at most four buffers submitted
                                * while the device is idle does -- nothing to overlap with, one stream hand-over less) */
     int reserved[1];

@@ -382,18 +382,19 @@ int Engine::init() {
         HIPTRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPTRY(hipStreamCreateWithPriority(&prep_stream_, hipStreamNonBlocking, greatest));
     }
-    if (desc_.stream_sync >= 2) {
+    if (desc_.stream_sync != 1) {
         int can = 0;
         auto signal_word = [&](unsigned long long **p) {
             if (hipExtMallocWithFlags((void **)p, sizeof(unsigned long long), hipMallocSignalMemory) != hipSuccess) { *p = nullptr; return false; }
             return hipMemset(*p, 0, sizeof(unsigned long long)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
         };
         if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, desc_.device) == hipSuccess && can) {
-            if (desc_.stream_sync == 3) start_gate_ = signal_word(&sig_start_);
+            start_gate_ = signal_word(&sig_start_);
             if (desc_.stream_sync == 2) sync_values_ = signal_word(&sig_prep_);
         }
         (void)hipGetLastError();
-        if (!sync_values_ && !start_gate_) return fail(PBSO_ERR_HIP, "stream_sync = 2 / 3: the device has no hipStreamWaitValue64");
+        if (desc_.stream_sync >= 2 && !(desc_.stream_sync == 2 ? sync_values_ : start_gate_))
+            return fail(PBSO_ERR_HIP, "stream_sync = 2 / 3: the device has no hipStreamWaitValue64");
     }
     for (int i = 0; i < N_SETS; ++i) {
         // (waited for by the engine's own streams only, never by the host or another device: without the system-scope fence
@@ -2154,8 +2155,13 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     HIPTRY(ps.d_arena.ensure(off, false, sp));
     HIPTRY(hipMemcpyAsync(ps.d_arena.p, ha, off, hipMemcpyHostToDevice, sp));
     HIPTRY(hipEventRecord(ev_set_[cur_set_], sp));          // this set's pinned arena is reusable
-    // the start gate: this launch's preparation kernels behind the START of the previous launch's bank (engine.h)
-    if (start_gate_ && !one_stream && last_bank_seq_ > 0)
+    // the start gate: this launch's preparation kernels behind the START of the previous launch's bank (engine.h).  By policy
+    // for LONG launches only: there the gate's few microseconds are nothing, and what it prevents is expensive -- a scan of 860
+    // buffers that the preparation stream runs TWO launches ahead trails the bank it was squeezed beside by 0.2 ms, holds LDS
+    // while the next bank starts, and that bank's left-over workgroups wait a whole workgroup's length (512 x 512 x 860: every
+    // other launch 9 instead of 4.6 ms in one run of four).  Gated, a scan is never more than one launch ahead, and the bank
+    // that needs it waits for it.
+    if (start_gate_ && !one_stream && last_bank_seq_ > 0 && (desc_.stream_sync == 3 || nb >= 256))
         HIPTRY(hipStreamWaitValue64(sp, sig_start_, last_bank_seq_, hipStreamWaitValueGte, ~0ull));
     evq.h_copy = host_ms();
     const auto tsub1 = std::chrono::steady_clock::now();

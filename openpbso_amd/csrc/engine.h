@@ -240,7 +240,7 @@ private:
     unsigned long long *sig_prep_ = nullptr;             // hipMallocSignalMemory: the number of the last prepared launch
     unsigned long long prep_seq_ = 0;
     bool sync_values_ = false;
-    // The start gate (desc.stream_sync = 3): the bank kernel's first workgroup stores the launch's number into signal memory, and the preparation
+    // The start gate (policy: launches of >= 256 buffers; desc.stream_sync = 3: every launch): the bank kernel's first workgroup stores the launch's number into signal memory, and the preparation
     // kernels of the NEXT launch wait for that value -- they never start together with a bank (whose workgroups would then wait
     // for the slots they hold), only beside one that is resident, i.e. in the slots its workgroups free when they retire.
     unsigned long long *sig_start_ = nullptr;
