@@ -194,6 +194,23 @@ def test_stream_hand_over_by_value_equals_the_event_path(time_chunks):
         run_engine(objs[:1], [], 1, stream_sync=4)
 
 
+def test_long_launches_are_gated_by_policy_and_equal_the_ungated_run():
+    """launches of >= 256 buffers hold their preparation kernels behind the START of the previous launch's bank (the start gate:
+    hipStreamWaitValue64 on the preparation stream) by policy; ordering only -- three 300-buffer steps of a Poisson scene,
+    time-chunked and not, bit-identical to stream_sync = 1 (events, no gate) and inside the oracle's tolerance"""
+    nb, steps = 300, 3
+    objs, evs = _poisson_scene(3, 300, nb * steps, p_hit=0.3)
+    want = run_oracle(objs, evs, nb * steps)
+    for tc in (0, -1):
+        a = run_engine(objs, evs, nb * steps, split=[nb] * steps, time_chunks=tc, chunk_buffers=512)
+        b = run_engine(objs, evs, nb * steps, split=[nb] * steps, time_chunks=tc, chunk_buffers=512, stream_sync=1)
+        assert np.array_equal(a["audio"], b["audio"]) and np.array_equal(a["emitted"], b["emitted"])
+        for x, y in zip(a["state"], b["state"]):
+            assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+        assert a["info"]["total_time_chunk_launches"] == (steps if tc == 0 else 0)
+        _check(a, want, qnorm=False)
+
+
 def test_latency_path_is_ordering_only():
     """A step of at most four buffers submitted while the device is idle (step, read, step: the real-time facade) prepares on
     the bank's own stream (desc.latency_path, info.total_one_stream_launches): same kernels, same arguments -- bit-identical to
