@@ -122,7 +122,9 @@ typedef struct pbso_engine_desc {
     int team_waves;           /* > 0: waves per team (workgroup) of the oscillator bank; 0 = policy */
     int pipe_consumers;       /* pipeline kernel: 0 policy, 1..3 consumer waves per team */
     long long pipe_max_teams; /* pipeline kernel eligibility: at most this many 64-mode teams (0 -> 2 per CU) */
-    int chunk_buffers;        /* a step longer than this is cut into several launches (0 -> 128) */
+    int chunk_buffers;        /* a step longer than this is cut into several launches (0 -> 128).  A launch's fixed costs (ramp, write drain,
+                               * hand-over between the streams: ~35 us) are per launch: throughput callers that step many seconds per call
+                               * set it to their step */
     int plan_threads;         /* host planner threads (0 -> 1: the caller's thread) */
     int plan_pin;             /* != 0: pin the helper threads into the caller's core complex */
     int timing_every;         /* HIP-event pairs around every n-th launch (0 -> 1; < 0: none) */
