@@ -81,10 +81,12 @@ def parse(argv=None):
                     help="block: block state-space form with the exact f32 MFMA projection (default: every product of the line is f32); "
                          "block_bf16: the same with the output projection as a split-bf16 MFMA product (mixed precision, reported as "
                          "such); velocity / direct: per-sample kernel (K1)")
-    ap.add_argument("--plan-threads", type=int, default=1,
-                    help="host planner threads (PBSO_PLAN_THREADS; helpers are pinned into the caller's core complex).  One -- the engine's "
-                         "own default -- since round 3: a step's vertex hits go to the engine as one borrowed script "
-                         "(pbso_enqueue_vertex_hits: 0.02 ms) and are planned in 0.07 ms; a second thread's hand-shake costs more than it saves")
+    ap.add_argument("--plan-threads", type=int, default=0,
+                    help="host planner threads (PBSO_PLAN_THREADS; helpers are pinned into the caller's core complex).  Default: one for "
+                         "steps of up to 128 buffers (a one-second step's hits are planned in 0.07 ms: a second thread's hand-shake costs "
+                         "more than it saves), four for longer ones: a ten-second step of 1024 objects takes ONE thread 3 ms to plan -- "
+                         "overlapped with the device in steady state, but the timed region starts with an empty pipeline, and the first "
+                         "step's planning is 0.15 ms per step of a 20-step region")
     ap.add_argument("--qnorm", choices=["sample", "closed", "off"], default="sample",
                     help="getQBufferNorm rows: on (the block form evaluates them in closed form), closed form, or off")
     ap.add_argument("--no-qnorm", action="store_true", help="same as --qnorm off")
@@ -117,6 +119,8 @@ def parse(argv=None):
     args = ap.parse_args(argv)
     if args.settle < 0:
         args.settle = max(2, round(40 * 86 / max(1, args.buffers)))
+    if args.plan_threads <= 0:
+        args.plan_threads = 1 if args.buffers <= 128 else 4
     return args
 
 
@@ -771,7 +775,16 @@ def main():
         a4.settle = max(args.settle, 40 if args.steps >= 20 else 8)
         a4.steps = max(args.steps, 40) if args.steps >= 20 else args.steps
         ctx["counts"] = [args.objects]
-        one_second = (a4, measure(a4, ctx, weak_ids, want_parity=False))
+        keep = {k: os.environ.get(k) for k in ("PBSO_PLAN_THREADS", "PBSO_PLAN_PIN")}
+        os.environ["PBSO_PLAN_THREADS"], os.environ["PBSO_PLAN_PIN"] = "1", "0"      # (one planner thread, as in the lines it is compared with)
+        try:
+            one_second = (a4, measure(a4, ctx, weak_ids, want_parity=False))
+        finally:
+            for k, v in keep.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
     # what the collective costs: the head leg once more with the all-gather left out, with a gather to rank 0 only
     # (send / receive) and with the reduce a consumer of ONE mixed stream needs (reported beside it, never as `value`)
     bare = mixed = rooted = None
