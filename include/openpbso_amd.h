@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PBSO_ABI_VERSION 4
+#define PBSO_ABI_VERSION 5
 #define PBSO_SAMPLE_RATE 44100          /* config.h:13 */
 #define PBSO_FRAMES_PER_BUFFER 513      /* config.h:14 */
 
@@ -138,7 +138,8 @@ typedef struct pbso_engine_desc {
                                * per step of 86 buffers).  2 and 3 fail at creation where the device lacks the interface */
     int latency_path;         /* < 0: never prepare a launch on the bank's own stream (0: a step of at most four buffers submitted
                                * while the device is idle does -- nothing to overlap with, one stream hand-over less) */
-    int reserved[1];
+    /* ---- ABI 5 */
+    int time_chunk_shape;     /* modes per lane of the teams of a time-chunked launch: 0 policy, 1 / 2 / 4 (A/B runs) */
 } pbso_engine_desc;
 
 enum pbso_bank_kernel {
@@ -357,6 +358,15 @@ enum pbso_gather_mode {
                                  (pbso_mix_objects) and the ranks all-reduce n_buffers * 513 floats */
 };
 #define PBSO_GROUP_ID_BYTES 128
+enum pbso_group_transport {
+    PBSO_GROUP_RCCL = 0,        /* the product: RCCL whenever the job has more than one rank (a one-rank group has nothing to exchange) */
+    PBSO_GROUP_RCCL_ALWAYS = 1, /* tests: a one-rank group builds its communicator too (ncclCommInitRank) and issues every collective --
+                                   the in-place ncclAllGather, ncclAllReduce, and for GATHER_ROOT an ncclSend / ncclRecv pair to itself
+                                   whose received rows are the result -- so the RCCL code runs on a one-GPU box */
+    PBSO_GROUP_LOOPBACK = 2     /* tests: ALL ranks of the job in this process, several of them on one device (devices[] may repeat); the
+                                   collectives are plain device copies.  Everything the group does around them -- shards, padding of
+                                   ragged shards, slice offsets, the two gather targets and their events, ROOT / MIX -- is the product's */
+};
 typedef struct pbso_group_desc {
     int abi_version;          /* PBSO_ABI_VERSION */
     const int *devices;       /* HIP ordinals THIS process drives: one rank (engine) each */
@@ -366,6 +376,8 @@ typedef struct pbso_group_desc {
     const void *unique_id;    /* world_size > n_devices: the PBSO_GROUP_ID_BYTES bytes pbso_group_unique_id() gave ONE process,
                                  handed to all of them by the launcher (a file, an environment variable, a store) */
     pbso_engine_desc engine;  /* settings of every engine; `device` and `stream` are the group's */
+    /* ---- ABI 5 */
+    int transport;            /* enum pbso_group_transport; 0 = the product's */
 } pbso_group_desc;
 int pbso_group_unique_id(void *out_bytes);
 int pbso_group_create(const pbso_group_desc *d, pbso_group **out);
@@ -440,6 +452,12 @@ typedef struct pbso_engine_info {
                                        * rejected, as enqueueForceMessage would have been (modal_solver.h:329-333)              */
     int64_t total_one_stream_launches;/* launches whose preparation ran on the bank's own stream (the latency path: a short step
                                        * submitted while the device was idle -- the real-time facade's pattern)                   */
+    /* ---- ABI 5 */
+    int64_t total_dense_increment_launches; /* of the time-chunked launches, those with dense-profile buffers (Gaussian / AR: forces.h:92-128):
+                                       * dense_increment_kernel evaluated what each leaves in the state, all of them at once      */
+    int last_time_chunk_shape;        /* the last time-chunked launch: modes per lane of its teams (0: none yet), ...              */
+    int last_time_chunk_buffers;      /* ... buffers per chunk, ...                                                               */
+    int last_time_chunk_teams;        /* ... and teams per chunk (its census has teams x chunks rows, chunk-major)                */
 } pbso_engine_info;
 int pbso_get_info(pbso_engine *e, pbso_engine_info *out);
 /* diagnostics (engine created with env PBSO_CENSUS=1): for every object's

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBSO_LIB") or os.path.join(_HERE, "libopenpbso_amd.so")      # PBSO_LIB: A/B runs of two builds in one process tree
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_STATE, ERR_IO, ERR_MISSING_MAP, ERR_ASSERT, ERR_NOMEM = -1, -2, -3, -4, -5, -6, -7
 POINT_FORCE, GAUSSIAN_FORCE, AUTOREGRESSIVE_FORCE = 0, 1, 2
@@ -52,7 +52,7 @@ class EngineDesc(C.Structure):
                 ("profile_margin_pct", C.c_int), ("profile_priority", C.c_int), ("team_waves", C.c_int),
                 ("pipe_consumers", C.c_int), ("pipe_max_teams", C.c_longlong), ("chunk_buffers", C.c_int),
                 ("plan_threads", C.c_int), ("plan_pin", C.c_int), ("timing_every", C.c_int), ("warm_copies", C.c_int),
-                ("stream_sync", C.c_int), ("latency_path", C.c_int), ("reserved", C.c_int * 1)]
+                ("stream_sync", C.c_int), ("latency_path", C.c_int), ("time_chunk_shape", C.c_int)]
 BANK_AUTO, BANK_BLOCK, BANK_PIPE = 0, 1, 2
 
 
@@ -89,11 +89,14 @@ class EngineInfo(C.Structure):
                 ("total_host_plan_ms", C.c_double), ("total_steps", C.c_int64), ("n_teams", C.c_int),
                 ("recurrence_form", C.c_int), ("total_block_launches", C.c_int64), ("total_sample_launches", C.c_int64),
                 ("total_timed_launches", C.c_int64), ("total_split_launches", C.c_int64),
-                ("total_time_chunk_launches", C.c_int64), ("total_dropped_hits", C.c_int64), ("total_one_stream_launches", C.c_int64)]
+                ("total_time_chunk_launches", C.c_int64), ("total_dropped_hits", C.c_int64), ("total_one_stream_launches", C.c_int64),
+                ("total_dense_increment_launches", C.c_int64), ("last_time_chunk_shape", C.c_int), ("last_time_chunk_buffers", C.c_int),
+                ("last_time_chunk_teams", C.c_int)]
 
 
 GroupDesc._fields_ = [("abi_version", C.c_int), ("devices", C.POINTER(C.c_int)), ("n_devices", C.c_int), ("world_size", C.c_int),
-                      ("first_rank", C.c_int), ("unique_id", C.c_void_p), ("engine", EngineDesc)]
+                      ("first_rank", C.c_int), ("unique_id", C.c_void_p), ("engine", EngineDesc), ("transport", C.c_int)]
+GROUP_RCCL, GROUP_RCCL_ALWAYS, GROUP_LOOPBACK = 0, 1, 2
 
 _lib = None
 

@@ -90,7 +90,7 @@ private:
 };
 
 void PlanCtx::begin() {
-    row_ptr.clear(); slot_idx.clear(); row_obj.clear(); stage_slot.clear(); chain_ptr.clear();
+    row_ptr.clear(); slot_idx.clear(); row_obj.clear(); stage_slot.clear(); chain_ptr.clear(); prow_obj.clear();
     tprof.clear(); prof_entries.clear(); prof_rows.clear(); stage.clear(); proj.clear(); proj_direct.clear(); ffat.clear();
     forced.clear(); freed_this_plan.clear(); freed_ar.clear();
     n_frows = n_prows = n_xfer = 0;
@@ -279,7 +279,7 @@ Engine::~Engine() {
     }
     d_census_.release();
     d_scan_.release();
-    for (int i = 0; i < N_SETS; ++i) { d_xs_[i].release(); d_xtrow_[i].release(); }
+    for (int i = 0; i < N_SETS; ++i) { d_xs_[i].release(); d_xtrow_[i].release(); d_vinc_[i].release(); }
     for (TcSet &ts : tc_) { ts.d_teams.release(); ts.d_split.release(); }
     for (DevBuf<float> &g : d_grows_) g.release();
     for (int i = 0; i < N_SETS; ++i)
@@ -423,6 +423,7 @@ int Engine::init() {
     timing_every_ = desc_.timing_every < 0 ? 0 : std::max(1, desc_.timing_every);
     if (desc_.chunk_buffers > 0) chunk_buffers_ = desc_.chunk_buffers;
     tc_mode_ = desc_.time_chunks;
+    tc_shape_ = desc_.time_chunk_shape;
     return PBSO_OK;
 }
 
@@ -669,9 +670,16 @@ int Engine::finalize() {
             ts.n_part_rows = 0;
             ts.waves = 0;
             ts.cover = 0;
+            const int tcap_desc = desc_.team_waves > 0 ? std::min(MAX_WAVES_PER_BLOCK_TEAM, desc_.team_waves) : MAX_WAVES_PER_BLOCK_TEAM;
+            int wmax_set = 1;
             for (int i = 0; i < N; ++i) {
                 const int w = waves_of(objs_[i], ts.R);
-                const int parts = (w + MAX_WAVES_PER_BLOCK_TEAM - 1) / MAX_WAVES_PER_BLOCK_TEAM;
+                // One mode per lane: an object that needs several teams anyway gets teams of FOUR waves -- three such workgroups
+                // fit a CU's LDS (twelve waves, three per SIMD; one team of eight leaves it at two per SIMD), and these builds are
+                // bound by what a wave does between its matrix bursts, not by the matrix pipe (8 x 4096 sustained scraping).
+                const int tcap = (ts.R == 1 && w > MAX_WAVES_PER_BLOCK_TEAM && desc_.team_waves <= 0) ? 4 : tcap_desc;
+                wmax_set = std::max(wmax_set, std::min(w, tcap));
+                const int parts = (w + tcap - 1) / tcap;
                 const int base = w / parts, rem = w % parts;
                 int w0 = 0;
                 if (parts > 1) {
@@ -701,6 +709,15 @@ int Engine::finalize() {
             for (size_t j = 0; j < flat.size(); ++j) flat[j].id = (int)j;
             ts.n_teams = (int)flat.size();
             ts.n_split = (int)split.size();
+            {
+                // waves of this shape a CU holds at once: two 256-register waves per SIMD for two and four modes per lane; one mode
+                // per lane: three per SIMD by its registers, as many whole workgroups as the LDS takes (allocated in 1280-byte granules)
+                ts.waves_per_cu = 8;
+                if (ts.R == 1) {
+                    const size_t lds = (block_lds_bytes(wmax_set, 1) + 1279) / 1280 * 1280;
+                    ts.waves_per_cu = (int)std::max<size_t>(wmax_set, std::min<size_t>(12, (160 * 1024 / lds) * wmax_set));
+                }
+            }
             HIPTRY(ts.d_teams.ensure(flat.size()));
             HIPTRY(hipMemcpy(ts.d_teams.p, flat.data(), flat.size() * sizeof(TeamDesc), hipMemcpyHostToDevice));
             if (ts.n_split) {
@@ -880,7 +897,10 @@ int Engine::finalize() {
             HIPTRY(d_scan_.ensure(6 * nm));
             HIPTRY(hipMemcpy(d_scan_.p, sc.data(), 6 * nm * sizeof(float), hipMemcpyHostToDevice));
         }
-        if (form_ == PBSO_FORM_BLOCK && (R_ <= 2 || tc_ok_) && forced_block_) {      // (a time-chunked launch picks its own team shape: one or two modes per lane use the table)
+        // (a time-chunked launch picks its own team shape: one or two modes per lane use the table; K5's dense_increment_kernel
+        //  uses it whatever the projection and the bank's own path for dense buffers are)
+        ftab_forced_ = form_ == PBSO_FORM_BLOCK && (R_ <= 2 || tc_ok_) && forced_block_;
+        if (ftab_forced_ || tc_ok_) {
             // Forced block path without qnorm rows (kernels_block.hip, FT): a force sample f enters the state as f u, u = (1, 1)'
             // (d += f, q += d), so the samples 16 n + i, i = 1..16, of a dense profile move the next block-start state by
             // sum_i A^(16 - i) u f_i.  Plane 2 i' + c holds component c of A^(15 - i') u, i' = 0..15, per mode (fp64, rounded once).
@@ -1577,6 +1597,7 @@ int Engine::plan_object(PlanCtx &c, int oi, int b, int nb, int64_t t) {
                 c.prof_entries.resize(entry_begin);
             } else {
                 d.prow = c.n_prows++;
+                c.prow_obj.push_back(oi);
                 d.tile_mask = n_tiles_ >= 32 ? 0xFFFFFFFFu : ((1u << n_tiles_) - 1u);
                 ProfRow pr = {d.prow, entry_begin, (int)c.prof_entries.size()};
                 c.prof_rows.push_back(pr);
@@ -1634,6 +1655,7 @@ int Engine::plan_object(PlanCtx &c, int oi, int b, int nb, int64_t t) {
                 d.amp = (float)T[0];
             } else {
                 d.prow = c.n_prows++;
+                c.prow_obj.push_back(oi);
                 const size_t off = c.tprof.size();
                 c.tprof.resize(off + b_pad_, 0.f);
                 for (int i = 0; i <= last_nz; ++i) c.tprof[off + i] = (float)T[i];
@@ -1783,7 +1805,7 @@ int Engine::plan(int nb) {
     // merge in object order: the numbering is the one a single context would have produced
     row_ptr_.assign(1, 0);
     slot_idx_.clear(); row_obj_.clear(); tprof_.clear(); stage_.clear(); stage_slot_.clear();
-    proj_.clear(); proj_direct_.clear(); ffat_.clear(); prof_entries_.clear(); prof_rows_.clear(); chain_ptr_.clear();
+    proj_.clear(); proj_direct_.clear(); ffat_.clear(); prof_entries_.clear(); prof_rows_.clear(); chain_ptr_.clear(); prow_obj_.clear();
     n_frows_ = 0;
     n_prows_ = 0;
     for (int t = 0; t < T; ++t) {
@@ -1802,6 +1824,7 @@ int Engine::plan(int nb) {
         else for (int e : c.slot_idx) slot_idx_.push_back(e >= 0 ? e : e - base_d);     // on-the-fly projections: global event index
         proj_direct_.insert(proj_direct_.end(), c.proj_direct.begin(), c.proj_direct.end());
         row_obj_.insert(row_obj_.end(), c.row_obj.begin(), c.row_obj.end());
+        prow_obj_.insert(prow_obj_.end(), c.prow_obj.begin(), c.prow_obj.end());
         tprof_.insert(tprof_.end(), c.tprof.begin(), c.tprof.end());
         prof_entries_.insert(prof_entries_.end(), c.prof_entries.begin(), c.prof_entries.end());
         for (ProfRow r : c.prof_rows) {
@@ -1908,11 +1931,22 @@ bool Engine::choose_time_chunks(int nb, int n_dense_rows, int *set, int *cb) con
     if (!tc_ok_ || !d_scan_.p || (nb < 2 && tc_mode_ <= 0)) return false;
     if (n_dump_ > 0) return false;                       // (objects that keep their block-start states for a listener mix: the walk in buffer order, as K1p)
     const long long N = (long long)objs_.size();
-    const long long capacity = 8LL * n_cus_;             // two 256-register waves per SIMD
-    if (tc_mode_ == 0 && (long long)n_dense_rows * 8 > N * nb) return false;
+    // Dense-profile buffers (Gaussian / AR, sustained contact: forces.h:92-128, modal_solver.h:222-240) take their place in the scan
+    // through their increments (dense_increment_kernel); the bank steps them in its forced block path.
+    if (n_dense_rows > 0 && !d_ftab_.p) return false;
+    // (engines whose bank steps dense buffers per sample -- the split-bf16 projection, forced_block < 0 -- keep their launches with
+    //  many of them on the kernels that walk the buffers in order, as before round 5)
+    if (tc_mode_ == 0 && !ftab_forced_ && (long long)n_dense_rows * 8 > N * nb) return false;
+    const bool dense_majority = (long long)n_dense_rows * 2 > N * nb;
     int k = 0;
     for (int c = 2; c >= 1; --c)
-        if (tc_[c].cover * 100 <= tc_[0].cover * 115 && tc_[c].waves * nb >= capacity) { k = c; break; }
+        if (tc_[c].cover * 100 <= tc_[0].cover * 115 && tc_[c].waves * nb >= (long long)tc_[c].waves_per_cu * n_cus_) { k = c; break; }
+    // a launch of mostly dense buffers: ONE mode per lane -- the only shape whose registers hold the increment table F next to the
+    // operand table W, so that the state moves a block at a time (F . T_n on the matrix pipe) instead of a sample at a time, and
+    // whose per-sample chain for the qnorm rows has three waves per SIMD to hide behind
+    if (dense_majority && ftab_forced_) k = 0;
+    if (tc_shape_ == 1 || tc_shape_ == 2 || tc_shape_ == 4) k = tc_shape_ == 4 ? 2 : tc_shape_ - 1;
+    const long long capacity = (long long)tc_[k].waves_per_cu * n_cus_;
     const long long waves = tc_[k].waves;
     int best = nb;
     if (tc_mode_ > 0) {
@@ -1925,7 +1959,7 @@ bool Engine::choose_time_chunks(int nb, int n_dense_rows, int *set, int *cb) con
         // more than their 1.07 / 1.5 / 2 rounds) -- and the shorter the workgroups, the cheaper that tail: such scenes are cut in
         // time too (1.22 / 1.66 / 2.21 ms).  A scene that fills the chip exactly (1024 x 512: one round) is not.
         const bool over_full = waves > capacity;
-        if (over_full) {
+        if (over_full && !dense_majority) {
             // measured, in rounds of the exactly-full chip (scripts/debug/r04_tcrounds.py): the walk of 1100 / 1536 / 2048 / 3000
             // objects x 512 modes takes 1.57 / 1.90 / 2.54 / 3.07 -- whole rounds + a last, partly filled one that runs faster the
             // emptier it is (0.57 + 0.54 x its fill), or half a round of stragglers when the rounds are exactly full -- and the
@@ -2098,6 +2132,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     auto place = [&](size_t bytes) { const size_t o = off; off += arena_align(bytes); return o; };
     const size_t o_row_ptr = place(row_ptr_.size() * sizeof(int)), o_slot_idx = place(slot_idx_.size() * sizeof(int));
     const size_t o_row_obj = place(row_obj_.size() * sizeof(int));
+    const size_t o_prow_obj = place(prow_obj_.size() * sizeof(int));
     const size_t o_pent = place(device_profiles_ ? prof_entries_.size() * sizeof(ProfEntry) : 0);
     const size_t o_prow = place(device_profiles_ ? prof_rows_.size() * sizeof(ProfRow) : 0);
     const size_t o_chain = place(device_profiles_ ? chain_ptr_.size() * sizeof(int) : 0);
@@ -2122,6 +2157,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     put(o_row_ptr, row_ptr_.data(), row_ptr_.size() * sizeof(int));
     put(o_slot_idx, slot_idx_.data(), slot_idx_.size() * sizeof(int));
     put(o_row_obj, row_obj_.data(), row_obj_.size() * sizeof(int));
+    put(o_prow_obj, prow_obj_.data(), prow_obj_.size() * sizeof(int));
     if (device_profiles_) {
         put(o_pent, prof_entries_.data(), prof_entries_.size() * sizeof(ProfEntry));
         put(o_prow, prof_rows_.data(), prof_rows_.size() * sizeof(ProfRow));
@@ -2215,7 +2251,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.pc = d_pc_.p;
     kp.wtab = d_wtab_.p;
     kp.frames = B_;
-    kp.ftab = d_ftab_.p;
+    kp.ftab = ftab_forced_ ? d_ftab_.p : nullptr;
     kp.forced_block = (forced_block_ && n_prows_ > 0) ? 1 : 0;      // (the build with the forced block path only when a buffer needs it)
     // K5: a launch without (many) dense-profile buffers on a chip the scene cannot fill runs the block kernel as (team, chunk of
     // buffers) workgroups behind a scan of the buffer-start states (kernels_scan.hip)
@@ -2251,8 +2287,17 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         const int n_chunks = (nb + tc_cb - 1) / tc_cb;
         HIPTRY(d_xs_[cur_set_].ensure((size_t)N * n_chunks * m_pad_ * 2, false, sp));
         HIPTRY(d_xtrow_[cur_set_].ensure((size_t)N * n_chunks, false, sp));
+        // dense-profile buffers (Gaussian / AR, forces.h:92-128): what each leaves in the state per unit gain, all of them at once
+        const float *vinc = nullptr;
+        if (n_prows_ > 0) {
+            HIPTRY(d_vinc_[cur_set_].ensure((size_t)n_prows_ * m_pad_ * 2, false, sp));
+            LAUNCHTRY(launch_dense_increments(d_pc_.p, d_ftab_.p, (long long)N * m_pad_, d_tprof, reinterpret_cast<const int *>(da + o_prow_obj),
+                                              d_n_modes_.p, n_prows_, m_pad_, b_pad_, B_, d_vinc_[cur_set_].p, sp));
+            vinc = d_vinc_[cur_set_].p;
+            tot_tc_dense_launches_ += 1;
+        }
         if (!last_launch_tc_ && last_set_ >= 0) HIPTRY(hipStreamWaitEvent(sp, ev_k1_done_[last_set_], 0));
-        LAUNCHTRY(launch_iir_scan(kp, N, d_scan_.p, tc_cb, n_chunks, d_xs_[cur_set_].p, d_xtrow_[cur_set_].p, direct_hits_, sp));
+        LAUNCHTRY(launch_iir_scan(kp, N, d_scan_.p, tc_cb, n_chunks, d_xs_[cur_set_].p, d_xtrow_[cur_set_].p, direct_hits_, vinc, sp));
     }
     // ---- compute stream: the bank after its preparation (and, stream order, after the previous bank)
     if (one_stream) {
@@ -2285,11 +2330,16 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     // K1b's 512 waves) -- K1b's forced block path keeps those launches (state and teams hand over at any launch boundary).
     // Without the F table of the forced block path (PBSO_FORCED_BLOCK=0) and without qnorm rows they go to K1b as well.
     const bool dense_majority = (long long)n_prows_ * 2 > (long long)N * nb;
-    const bool split_dense_ok = k2_rows_launch_ && (desc_.qnorm_mode != PBSO_QNORM_OFF || d_ftab_.p != nullptr);
+    const bool split_dense_ok = k2_rows_launch_ && (desc_.qnorm_mode != PBSO_QNORM_OFF || ftab_forced_);
     const bool split_launch = !tc_launch && use_split() && (split_always_ || !dense_majority || split_dense_ok);      // (PBSO_SPLIT=2: always)
     (tc_launch || split_launch || !(dense_heavy || !is_block()) ? tot_block_launches_ : tot_sample_launches_) += 1;
     if (split_launch) tot_split_launches_ += 1;
-    if (tc_launch) tot_tc_launches_ += 1;
+    if (tc_launch) {
+        tot_tc_launches_ += 1;
+        last_tc_shape_ = tc_[tc_set].R;
+        last_tc_cb_ = tc_cb;
+        last_tc_teams_ = tc_[tc_set].n_teams;
+    }
     if (n_dump_ > 0) {
         // the mix needs block states: a launch on the per-sample kernel leaves none, a dense-profile buffer neither
         for (int i = 0; i < N; ++i) {
@@ -2325,7 +2375,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
             int nc = 2;
             // qnorm rows of a mostly-dense launch: the consumers re-step every sample for the sums and are the long stage -- a third
             // consumer wave that only steps (half of the chains) when that still leaves at most two waves per SIMD
-            if (dense_majority && desc_.qnorm_mode != PBSO_QNORM_OFF && d_ftab_.p != nullptr && 4LL * n_ts_teams_ <= 8LL * n_cus_) nc = 3;
+            if (dense_majority && desc_.qnorm_mode != PBSO_QNORM_OFF && ftab_forced_ && 4LL * n_ts_teams_ <= 8LL * n_cus_) nc = 3;
             if (desc_.pipe_consumers > 0) nc = desc_.pipe_consumers;
             LAUNCHTRY(iir_pipe::launch_iir_pipe(kp, n_ts_teams_, nc, desc_.qnorm_mode, sk));
         }
@@ -2417,9 +2467,10 @@ int Engine::read_audio_rows(const int *rows, int n_rows, float *out) {
 int Engine::read_census(unsigned long long *out, size_t n) {
     { int src = sync(); if (src != PBSO_OK) return src; }      // (results come from two streams: the bank's, and the scan's state on the preparation stream)
     if (!census_ || !d_census_.p) return fail(PBSO_ERR_STATE, "census not enabled (PBSO_CENSUS=1) or no step yet");
-    // (n_teams rows -- or, for an engine that also keeps the table of the kernel of under-filled scenes, that table's rows)
-    if (n != (size_t)n_teams_ * CENSUS_WORDS && !(use_split() && n == (size_t)n_ts_teams_ * CENSUS_WORDS))
-        return fail(PBSO_ERR_INVALID, "read_census size mismatch (12 words per team)");
+    // (n_teams rows; for the pipeline kernel its own table's rows; for a time-chunked launch (teams of its shape) x (chunks) rows,
+    //  chunk-major: any whole number of rows the launch can have written)
+    if (n == 0 || n % CENSUS_WORDS || n > d_census_.cap)
+        return fail(PBSO_ERR_INVALID, "read_census size mismatch (12 words per team, at most the rows of the last launch)");
     HIPTRY(hipMemcpyAsync(out, d_census_.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
     return sync();
 }
@@ -2749,6 +2800,10 @@ int Engine::info(pbso_engine_info *out) {
     out->total_sample_launches = tot_sample_launches_;
     out->total_split_launches = tot_split_launches_;
     out->total_time_chunk_launches = tot_tc_launches_;
+    out->total_dense_increment_launches = tot_tc_dense_launches_;
+    out->last_time_chunk_shape = last_tc_shape_;
+    out->last_time_chunk_buffers = last_tc_cb_;
+    out->last_time_chunk_teams = last_tc_teams_;
     out->total_dropped_hits = dropped_hits_.load();
     out->total_one_stream_launches = tot_one_stream_launches_;
     out->buffers_done = buffers_done_;

@@ -150,6 +150,7 @@ struct Object {
 // the pooled data slots do, and those are storage locations without meaning.
 struct PlanCtx {
     std::vector<int> row_ptr, slot_idx, row_obj, stage_slot, chain_ptr;   // row_ptr: END offset of each forced row in slot_idx
+    std::vector<int> prow_obj;                           // the object of every dense profile row (K5: dense_increment_kernel)
     std::vector<float> tprof;
     std::vector<ProfEntry> prof_entries;
     std::vector<ProfRow> prof_rows;
@@ -302,6 +303,7 @@ private:
         DevBuf<SplitObj> d_split;
         int n_teams = 0, n_split = 0, n_part_rows = 0;
         long long waves = 0, cover = 0;                  // waves of all teams; columns they cover (padding included)
+        int waves_per_cu = 8;                            // of this shape's build, resident at once (registers, LDS)
     } tc_[3];                                            // R = 1, 2, 4
     bool tc_ok_ = false;
     int tc_mode_ = 0;                                    // pbso_engine_desc::time_chunks: 0 auto, < 0 never, n > 0 chunks of n buffers always
@@ -309,6 +311,10 @@ private:
     // per plan set (the scan of launch k + 1 runs beside the bank of launch k):
     DevBuf<float> d_xs_[N_SETS];                         // [n_obj][n_chunks][m_pad] pairs: the state at the first buffer of every chunk
     DevBuf<int> d_xtrow_[N_SETS];                        // [n_obj][n_chunks] the transfer row in force there
+    DevBuf<float> d_vinc_[N_SETS];                       // [n_prows][m_pad] pairs: the increments of the launch's dense-profile buffers (dense_increment_kernel)
+    int tc_shape_ = 0;                                   // pbso_engine_desc::time_chunk_shape: 0 policy, 1 / 2 / 4 modes per lane in time-chunked launches
+    int64_t tot_tc_dense_launches_ = 0;
+    int last_tc_shape_ = 0, last_tc_cb_ = 0, last_tc_teams_ = 0;
     bool last_launch_tc_ = false;                        // the previous launch was time-chunked (its bank did not write the state)
     int last_set_ = -1;
     bool latency_path_ = true, last_one_stream_ = false;  // desc.latency_path; the previous launch prepared on the bank's stream
@@ -326,7 +332,8 @@ private:
     bool dump_rows_dirty_ = false;
     DevBuf<int> d_dump_row_;
     DevBuf<float> d_xdump_, d_xscale_, d_wtab32_;
-    DevBuf<float> d_ftab_;                               // forced block path: A^(15-i) u per mode (engines with <= 2 modes per lane)
+    DevBuf<float> d_ftab_;                               // A^(15-i) u per mode: the forced block path (engines with <= 2 modes per lane) and K5's dense increments
+    bool ftab_forced_ = false;                           // ... the bank's forced block path may use it
     DevBuf<float> d_pc_, d_wtab_;                        // block form: P = A^16 planes and the MFMA W table (kernels_block.hip)
     bool is_block() const { return form_ == PBSO_FORM_BLOCK || form_ == PBSO_FORM_BLOCK_BF16; }
     int form_ = PBSO_FORM_BLOCK;                         // the form that runs (block falls back to velocity for odd buffer lengths)
@@ -373,7 +380,7 @@ private:
     } set_[N_SETS];
     DevBuf<float> d_grows_[N_SETS];                      // g rows, one arena per plan set
     // plan scratch (host)
-    std::vector<int> row_ptr_, slot_idx_, row_obj_, stage_slot_, busy_;
+    std::vector<int> row_ptr_, slot_idx_, row_obj_, stage_slot_, busy_, prow_obj_;
     std::vector<float> tprof_;
     int n_frows_ = 0, n_prows_ = 0;
     // K2: device-side time profiles

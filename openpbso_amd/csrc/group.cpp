@@ -1,10 +1,11 @@
 // Device group: one engine per GPU, objects sharded over the ranks, RCCL only to gather the finished audio
 // (include/openpbso_amd.h "device group").  Objects never interact (modal_solver.h:100-126), so
 // stepping needs no exchange; this file is host-side plumbing over the C ABI of the single engine plus three collectives.
-// librccl is loaded at run time (dlopen) when a group of more than one rank is created: an engine alone does not need it.
+// librccl is loaded at run time (dlopen) when a group of more than one rank is created -- or when a test asks for the
+// communicator of a one-rank group (PBSO_GROUP_RCCL_ALWAYS) --: an engine alone does not need it, and this file does not
+// need RCCL's headers to build (the dozen declarations it uses are below).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cstring>
@@ -16,8 +17,16 @@
 
 namespace {
 
+// ---- the part of RCCL's C API this file calls (rccl/rccl.h; the values are NCCL's ABI)
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[PBSO_GROUP_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+
 struct Rccl {
     void *lib = nullptr;
+    bool ok = false;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
@@ -31,21 +40,22 @@ struct Rccl {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
     bool load() {
-        if (lib) return true;
+        if (lib) return ok;                              // (a library that lacks a symbol stays unusable: no second try through null pointers)
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (lib) break;
         }
         if (!lib) { err = std::string("librccl not found: ") + dlerror(); return false; }
-        bool ok = true;
+        bool all = true;
         auto sym = [&](auto &fp, const char *n) {
             fp = reinterpret_cast<std::remove_reference_t<decltype(fp)>>(dlsym(lib, n));
-            if (!fp) { ok = false; err = std::string("librccl lacks ") + n; }
+            if (!fp) { all = false; err = std::string("librccl lacks ") + n; }
         };
         sym(GetUniqueId, "ncclGetUniqueId"); sym(CommInitRank, "ncclCommInitRank"); sym(CommInitAll, "ncclCommInitAll");
         sym(CommDestroy, "ncclCommDestroy"); sym(AllGather, "ncclAllGather"); sym(AllReduce, "ncclAllReduce");
         sym(Send, "ncclSend"); sym(Recv, "ncclRecv"); sym(GroupStart, "ncclGroupStart"); sym(GroupEnd, "ncclGroupEnd");
         sym(GetErrorString, "ncclGetErrorString");
+        ok = all;
         return ok;
     }
 };
@@ -58,7 +68,8 @@ struct Rank {
     ncclComm_t comm = nullptr;
     float *target[2] = {nullptr, nullptr};               // gather targets [rows_total][row] (ALL / ROOT on rank 0) or the rank's own rows
     float *mix[2] = {nullptr, nullptr};                  // [row]
-    size_t target_floats = 0, mix_floats = 0;
+    float *scratch = nullptr;                            // RCCL_ALWAYS, one rank: where the send to itself lands; LOOPBACK: [world][row] mix rows + the sum's partial rows
+    size_t target_floats = 0, mix_floats = 0, scratch_floats = 0;
     hipEvent_t ev_step[2] = {nullptr, nullptr}, ev_coll[2] = {nullptr, nullptr};
     int n_local = 0, next_local = 0;
 };
@@ -74,6 +85,9 @@ struct pbso_group {
     bool planned = false, finalized = false;
     int slot = 0, last_nb = 0, last_mode = 0, last_slot = -1;
     bool stepped = false;
+    int transport = PBSO_GROUP_RCCL;
+    bool use_rccl = false;                               // a communicator exists: the collectives go through librccl
+    bool loopback() const { return transport == PBSO_GROUP_LOOPBACK; }
     std::string err;
     int frames = PBSO_FRAMES_PER_BUFFER;
 };
@@ -94,11 +108,34 @@ int gfail(pbso_group *g, int code, const std::string &m) {
         ncclResult_t _r = (expr);                                                                 \
         if (_r != ncclSuccess) return gfail(g, PBSO_ERR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(_r)); \
     } while (0)
+// ... between ncclGroupStart and ncclGroupEnd: the group is closed before the error is returned (an open group would swallow
+// every later call of this thread)
+#define GNCCL_OPEN(g, expr)                                                                       \
+    do {                                                                                          \
+        ncclResult_t _r = (expr);                                                                 \
+        if (_r != ncclSuccess) {                                                                  \
+            (void)g_rccl.GroupEnd();                                                              \
+            return gfail(g, PBSO_ERR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(_r)); \
+        }                                                                                         \
+    } while (0)
+#define GHIP_OPEN(g, expr)                                                                        \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            (void)g_rccl.GroupEnd();                                                              \
+            return gfail(g, PBSO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));     \
+        }                                                                                         \
+    } while (0)
 #define GENG(g, rk, expr)                                                                         \
     do {                                                                                          \
         int _c = (expr);                                                                          \
         if (_c < 0) return gfail(g, _c, std::string("rank ") + std::to_string((rk).rank) + ": " + pbso_last_error((rk).eng)); \
     } while (0)
+
+// loopback all-reduce: [world mix rows | partial rows of the sum | the result row]
+float *loop_mix_out(const pbso_group *g, const Rank &rk, size_t row) {
+    return rk.scratch + (size_t)(g->world + pbso::mix_objects_groups(g->world)) * row;
+}
 
 Rank *local_rank(pbso_group *g, int rank) {
     const int i = rank - g->first;
@@ -127,6 +164,15 @@ int ensure_buffers(pbso_group *g, Rank &rk, int nb, int mode) {
             GHIP(g, hipMalloc(&rk.mix[s], row * sizeof(float)));
         }
         rk.mix_floats = row;
+    }
+    size_t want_scratch = 0;
+    if (g->loopback()) want_scratch = row * (size_t)(g->world + pbso::mix_objects_groups(g->world) + 1);
+    else if (g->use_rccl && g->world == 1) want_scratch = row * (size_t)std::max(1, g->cmax);
+    if (want_scratch > rk.scratch_floats) {
+        GHIP(g, hipStreamSynchronize(rk.coll));
+        if (rk.scratch) GHIP(g, hipFree(rk.scratch));
+        GHIP(g, hipMalloc(&rk.scratch, want_scratch * sizeof(float)));
+        rk.scratch_floats = want_scratch;
     }
     return PBSO_OK;
 }
@@ -159,10 +205,19 @@ int pbso_group_create(const pbso_group_desc *d, pbso_group **out) {
         g->world = d->world_size > 0 ? d->world_size : d->n_devices;
         g->first = d->first_rank;
         if (g->first < 0 || g->first + d->n_devices > g->world) return gfail(g, PBSO_ERR_INVALID, "first_rank + n_devices exceeds world_size");
-        if (g->world > d->n_devices && !d->unique_id) return gfail(g, PBSO_ERR_INVALID, "a job of several processes needs the shared unique_id");
-        for (int i = 0; i < d->n_devices; ++i)
-            for (int j = 0; j < i; ++j)
-                if (d->devices[i] == d->devices[j]) return gfail(g, PBSO_ERR_INVALID, "a device appears twice (one rank per GPU)");
+        g->transport = d->transport;
+        if (g->transport != PBSO_GROUP_RCCL && g->transport != PBSO_GROUP_RCCL_ALWAYS && g->transport != PBSO_GROUP_LOOPBACK)
+            return gfail(g, PBSO_ERR_INVALID, "transport");
+        if (g->loopback()) {
+            // every rank of the job in this process, any of them on any device (the same one, typically): the collectives are
+            // device copies -- what the group does AROUND them (shards, padding, slices, the two targets, the events) is the product's
+            if (g->world != d->n_devices || g->first != 0) return gfail(g, PBSO_ERR_INVALID, "the loopback transport holds every rank of the job in one process");
+        } else {
+            if (g->world > d->n_devices && !d->unique_id) return gfail(g, PBSO_ERR_INVALID, "a job of several processes needs the shared unique_id");
+            for (int i = 0; i < d->n_devices; ++i)
+                for (int j = 0; j < i; ++j)
+                    if (d->devices[i] == d->devices[j]) return gfail(g, PBSO_ERR_INVALID, "a device appears twice (one rank per GPU)");
+        }
         g->edesc = d->engine;
         g->edesc.abi_version = PBSO_ABI_VERSION;
         g->frames = d->engine.frames_per_buffer > 0 ? d->engine.frames_per_buffer : PBSO_FRAMES_PER_BUFFER;
@@ -188,9 +243,17 @@ int pbso_group_create(const pbso_group_desc *d, pbso_group **out) {
             int rc = pbso_engine_create(&ed, &rk.eng);
             if (rc != PBSO_OK) return gfail(g, rc, std::string("engine on device ") + std::to_string(rk.device) + ": " + (rk.eng ? pbso_last_error(rk.eng) : "create failed"));
         }
-        if (g->world > 1) {
+        g->use_rccl = !g->loopback() && (g->world > 1 || g->transport == PBSO_GROUP_RCCL_ALWAYS);
+        if (g->use_rccl) {
             if (!g_rccl.load()) return gfail(g, PBSO_ERR_HIP, g_rccl.err);
-            if (g->world == d->n_devices) {
+            if (g->world == 1) {
+                // (tests: a communicator of one rank, created the way a rank of a larger job creates its own)
+                ncclUniqueId id;
+                if (d->unique_id) std::memcpy(&id, d->unique_id, sizeof(id));
+                else GNCCL(g, g_rccl.GetUniqueId(&id));
+                GHIP(g, hipSetDevice(g->ranks[0].device));
+                GNCCL(g, g_rccl.CommInitRank(&g->ranks[0].comm, 1, id, 0));
+            } else if (g->world == d->n_devices) {
                 std::vector<ncclComm_t> comms(d->n_devices);
                 GNCCL(g, g_rccl.CommInitAll(comms.data(), d->n_devices, d->devices));
                 for (int i = 0; i < d->n_devices; ++i) g->ranks[i].comm = comms[i];
@@ -199,8 +262,8 @@ int pbso_group_create(const pbso_group_desc *d, pbso_group **out) {
                 std::memcpy(&id, d->unique_id, sizeof(id));
                 GNCCL(g, g_rccl.GroupStart());
                 for (Rank &rk : g->ranks) {
-                    GHIP(g, hipSetDevice(rk.device));
-                    GNCCL(g, g_rccl.CommInitRank(&rk.comm, g->world, id, rk.rank));
+                    GHIP_OPEN(g, hipSetDevice(rk.device));
+                    GNCCL_OPEN(g, g_rccl.CommInitRank(&rk.comm, g->world, id, rk.rank));
                 }
                 GNCCL(g, g_rccl.GroupEnd());
             }
@@ -222,6 +285,7 @@ void pbso_group_destroy(pbso_group *g) {
         for (int s = 0; s < 2; ++s) {
             if (rk.target[s]) (void)hipFree(rk.target[s]);
             if (rk.mix[s]) (void)hipFree(rk.mix[s]);
+            if (s == 0 && rk.scratch) (void)hipFree(rk.scratch);
             if (rk.ev_step[s]) (void)hipEventDestroy(rk.ev_step[s]);
             if (rk.ev_coll[s]) (void)hipEventDestroy(rk.ev_coll[s]);
         }
@@ -338,11 +402,18 @@ int pbso_group_step(pbso_group *g, int nb) {
         // (the target doubles as the all-gather's receive buffer: sized for that from the start, so the engine's slice never moves)
         int rc = ensure_buffers(g, rk, nb, PBSO_GATHER_ALL);
         if (rc != PBSO_OK) return rc;
-        if (rk.n_local == 0) continue;
         GHIP(g, hipSetDevice(rk.device));
-        GHIP(g, hipStreamWaitEvent(rk.stream, rk.ev_coll[slot], 0));      // the collective that last read this target is done
-        GENG(g, rk, pbso_step_into(rk.eng, nb, rk.target[slot] + (size_t)rk.rank * g->cmax * row));
-        GHIP(g, hipEventRecord(rk.ev_step[slot], rk.stream));
+        // the collective that last read this target is done (loopback: the OTHER ranks' copies read this rank's slice)
+        if (g->loopback()) for (Rank &other : g->ranks) GHIP(g, hipStreamWaitEvent(rk.stream, other.ev_coll[slot], 0));
+        else GHIP(g, hipStreamWaitEvent(rk.stream, rk.ev_coll[slot], 0));
+        float *mine = rk.target[slot] + (size_t)rk.rank * g->cmax * row;
+        // Ragged shards: the rows behind this rank's objects are shipped to every rank with the all-gather and must be SILENT.
+        // The row layout depends on n_buffers, so a step shorter than an earlier one would find old samples there: zeroed
+        // every step (a few rows), on the stream the step runs on.
+        if (rk.n_local < g->cmax)
+            GHIP(g, hipMemsetAsync(mine + (size_t)rk.n_local * row, 0, (size_t)(g->cmax - rk.n_local) * row * sizeof(float), rk.stream));
+        if (rk.n_local > 0) GENG(g, rk, pbso_step_into(rk.eng, nb, mine));
+        GHIP(g, hipEventRecord(rk.ev_step[slot], rk.stream));       // (an empty rank too: its silent rows are ordered before the collective)
     }
     g->last_slot = slot;
     g->last_nb = nb;
@@ -360,6 +431,9 @@ int pbso_group_gather(pbso_group *g, int mode) {
     if (mode == PBSO_GATHER_MIX) {
         for (Rank &rk : g->ranks) {
             GHIP(g, hipSetDevice(rk.device));
+            // (a second collective on the same step: the first one's reads of the mix row are done)
+            if (g->loopback()) for (Rank &other : g->ranks) GHIP(g, hipStreamWaitEvent(rk.stream, other.ev_coll[slot], 0));
+            else GHIP(g, hipStreamWaitEvent(rk.stream, rk.ev_coll[slot], 0));
             if (rk.n_local > 0) GENG(g, rk, pbso_mix_objects(rk.eng, rk.mix[slot]));
             else GHIP(g, hipMemsetAsync(rk.mix[slot], 0, row * sizeof(float), rk.stream));
             GHIP(g, hipEventRecord(rk.ev_step[slot], rk.stream));
@@ -367,23 +441,49 @@ int pbso_group_gather(pbso_group *g, int mode) {
     }
     for (Rank &rk : g->ranks) {
         GHIP(g, hipSetDevice(rk.device));
-        GHIP(g, hipStreamWaitEvent(rk.coll, rk.ev_step[slot], 0));
+        // (loopback: a rank's copies read the other ranks' slices)
+        if (g->loopback()) for (Rank &other : g->ranks) GHIP(g, hipStreamWaitEvent(rk.coll, other.ev_step[slot], 0));
+        else GHIP(g, hipStreamWaitEvent(rk.coll, rk.ev_step[slot], 0));
     }
-    if (g->world > 1) {
+    if (g->use_rccl) {
         GNCCL(g, g_rccl.GroupStart());
         for (Rank &rk : g->ranks) {
             float *base = rk.target[slot], *mine = base + (size_t)rk.rank * blk;
             if (mode == PBSO_GATHER_ALL) {
-                GNCCL(g, g_rccl.AllGather(mine, base, blk, ncclFloat, rk.comm, rk.coll));          // in place: sendbuff == recvbuff + rank * count
+                GNCCL_OPEN(g, g_rccl.AllGather(mine, base, blk, ncclFloat, rk.comm, rk.coll));          // in place: sendbuff == recvbuff + rank * count
             } else if (mode == PBSO_GATHER_MIX) {
-                GNCCL(g, g_rccl.AllReduce(rk.mix[slot], rk.mix[slot], row, ncclFloat, ncclSum, rk.comm, rk.coll));
+                GNCCL_OPEN(g, g_rccl.AllReduce(rk.mix[slot], rk.mix[slot], row, ncclFloat, ncclSum, rk.comm, rk.coll));
+            } else if (g->world == 1) {
+                // (PBSO_GROUP_RCCL_ALWAYS: the root's receive and a rank's send, both on the one rank there is -- the rows land in
+                //  the scratch rows, which is what pbso_group_result_device_ptr then hands out)
+                GNCCL_OPEN(g, g_rccl.Send(mine, blk, ncclFloat, 0, rk.comm, rk.coll));
+                GNCCL_OPEN(g, g_rccl.Recv(rk.scratch, blk, ncclFloat, 0, rk.comm, rk.coll));
             } else if (rk.rank == 0) {
-                for (int r = 1; r < g->world; ++r) GNCCL(g, g_rccl.Recv(base + (size_t)r * blk, blk, ncclFloat, r, rk.comm, rk.coll));
+                for (int r = 1; r < g->world; ++r) GNCCL_OPEN(g, g_rccl.Recv(base + (size_t)r * blk, blk, ncclFloat, r, rk.comm, rk.coll));
             } else {
-                GNCCL(g, g_rccl.Send(mine, blk, ncclFloat, 0, rk.comm, rk.coll));
+                GNCCL_OPEN(g, g_rccl.Send(mine, blk, ncclFloat, 0, rk.comm, rk.coll));
             }
         }
         GNCCL(g, g_rccl.GroupEnd());
+    } else if (g->loopback()) {
+        for (Rank &rk : g->ranks) {
+            GHIP(g, hipSetDevice(rk.device));
+            if (mode == PBSO_GATHER_ALL || (mode == PBSO_GATHER_ROOT && rk.rank == 0)) {
+                for (Rank &src : g->ranks) {
+                    if (src.rank == rk.rank) continue;
+                    GHIP(g, hipMemcpyAsync(rk.target[slot] + (size_t)src.rank * blk, src.target[slot] + (size_t)src.rank * blk, blk * sizeof(float),
+                                           hipMemcpyDeviceToDevice, rk.coll));
+                }
+            } else if (mode == PBSO_GATHER_MIX) {
+                // all-reduce: every rank collects the ranks' mixed rows and adds them in rank order (the object sum's kernels)
+                float *rows = rk.scratch, *parts = rk.scratch + (size_t)g->world * row;
+                for (Rank &src : g->ranks)
+                    GHIP(g, hipMemcpyAsync(rows + (size_t)src.rank * row, src.mix[slot], row * sizeof(float), hipMemcpyDeviceToDevice, rk.coll));
+                // (into a row of its own: the other ranks' copies still read this rank's mix row)
+                int lrc = pbso::launch_mix_objects(rows, g->world, (long long)row, (long long)row, parts, loop_mix_out(g, rk, row), rk.coll);
+                if (lrc != 0) return gfail(g, PBSO_ERR_HIP, "loopback all-reduce: launch_mix_objects");
+            }
+        }
     }
     for (Rank &rk : g->ranks) {
         GHIP(g, hipSetDevice(rk.device));
@@ -411,10 +511,12 @@ void *pbso_group_result_device_ptr(pbso_group *g, int rank, size_t *rows, size_t
     if (row_floats) *row_floats = row;
     if (g->last_mode == PBSO_GATHER_MIX) {
         if (rows) *rows = 1;
-        return rk->mix[g->last_slot];
+        return g->loopback() ? loop_mix_out(g, *rk, row) : rk->mix[g->last_slot];
     }
     const bool full = g->last_mode == PBSO_GATHER_ALL || (g->last_mode == PBSO_GATHER_ROOT && rk->rank == 0);
     if (rows) *rows = full ? (size_t)g->world * g->cmax : (size_t)g->cmax;
+    // (a one-rank communicator made for tests: the rows this rank sent to itself through ncclSend / ncclRecv)
+    if (g->last_mode == PBSO_GATHER_ROOT && g->use_rccl && g->world == 1) return rk->scratch;
     return full ? rk->target[g->last_slot] : rk->target[g->last_slot] + (size_t)rk->rank * g->cmax * row;
 }
 

@@ -122,13 +122,18 @@ constexpr int BLOCK_N = 16;                // blocks per group = its columns; a 
 constexpr int BLOCK_STAGE_FLOATS = 2304;   // (split-bf16 projection: two planes of [16 blocks][72 dwords])
 constexpr int BLOCK_STAGE_FLOATS_F32 = 2080;   // per wave: block-start states of one slice, [16 blocks][64 lanes][Q, D] + 2 per row
 constexpr int BLOCK_RING_FLOATS = 516;     // per wave and buffer parity: the wave's partial sums of one buffer
+// one mode per lane: a ring per GROUP of 256 samples (+ sample 0), combined at the end of every group -- half the LDS per wave
+// (12 KB instead of 14: twelve waves of such teams fit a CU, three per SIMD, where eight did)
+constexpr int BLOCK_HALF_RING_FLOATS = 260;
 constexpr int MAX_WAVES_PER_BLOCK_TEAM = 8;
 // split-bf16 projection: the kernel splits every block-start state into two TRUNCATED 8-bit parts, which loses
 // 7.2e-6 of its value on average (measured on normal, log-normal and uniform data: 7.0 .. 7.3e-6); the operand table
 // carries the inverse
 constexpr double TRUNC_SPLIT_GAIN = 1.0 + 7.2e-6;
 // per wave: the staging area, two rings, and the landing area of a direct hit's three g32 rows ([3][R][64] floats)
-inline size_t block_lds_bytes(int W, int R) { return sizeof(float) * (size_t)W * (BLOCK_STAGE_FLOATS + 2 * BLOCK_RING_FLOATS + 3 * R * 64); }
+inline size_t block_lds_bytes(int W, int R) {
+    return sizeof(float) * (size_t)W * (BLOCK_STAGE_FLOATS + 2 * (R == 1 ? BLOCK_HALF_RING_FLOATS : BLOCK_RING_FLOATS) + 3 * R * 64);
+}
 namespace iir_pipe {
 // K1p (kernels_pipe.hip): teams of one producer wave (steps, parks block-start states) and n_consumers (1 or 2) consumer waves
 // (project the previous buffer); one team per 64 modes
@@ -150,8 +155,13 @@ int launch_listener_mix(const float *xdump, const float *xscale, const float *wt
 // ---- K5: the scan of buffer-start states that makes a launch's buffers independent (kernels_scan.hip).  sc: 6 planes
 // [n_obj][m_pad] (stride gq_plane): A^513 as (P11 - 1, P12, P21, P22), then A^512 u.  Writes the state at the first buffer of
 // every chunk of cb buffers to xs, the transfer row in force there to xtrow, and the launch's end state to sq / sd / ss.
+// vinc: the increments of the launch's dense-profile buffers (launch_dense_increments), or nullptr when it has none
 int launch_iir_scan(const IirParams &p, int n_obj, const float *sc, int cb, int n_chunks, float *xs, int *xtrow, bool direct,
-                    hipStream_t stream);
+                    const float *vinc, hipStream_t stream);
+// vinc[row][m_pad] pairs (q, d): what a unit force gain with the dense time profile tprof[row] leaves in every mode's state over one
+// buffer, from rest (row_obj[row] = the object the row belongs to; pc / ftab: planes of P = A^16 and of A^(15-i) u, stride `plane`)
+int launch_dense_increments(const float *pc, const float *ftab, long long plane, const float *tprof, const int *row_obj,
+                            const int *n_modes, int n_rows, int m_pad, int b_pad, int frames, float *vinc, hipStream_t stream);
 
 // ---- exact fp64 helper kernels (kernels_exact.hip, built with -ffp-contract=off)
 struct ProjectEvent {

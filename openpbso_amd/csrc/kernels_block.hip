@@ -163,9 +163,15 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     const float *__restrict__ b_cb = p_cb + ubase;
     const float *__restrict__ b_gq = p_gq + ubase;
     float *__restrict__ b_qn = p_qnorm + ((size_t)obj * p.qn_nb + p.qn_b0) * p.m_pad + team.col0;
-    constexpr int WAVE_FLOATS = ST_FLOATS + 2 * RING;
+    // HALF (one mode per lane): the ring holds ONE group of 256 samples per parity and the team combines at the end of every
+    // group -- two barriers per buffer instead of one, 2 KB of LDS per wave less: a CU then holds twelve waves of such teams
+    // (three per SIMD) instead of eight, and these builds are bound by what a wave does BETWEEN its matrix bursts (head, taps,
+    // combine: 8 x 4096 sustained scraping, time-chunked: per-wave pace unchanged at 10 waves per CU, profiles/r05_*census*)
+    constexpr bool HALF = R == 1;
+    constexpr int RINGF = HALF ? BLOCK_HALF_RING_FLOATS : RING;
+    constexpr int WAVE_FLOATS = ST_FLOATS + 2 * RINGF;
     float *stage = lds + wave * WAVE_FLOATS;
-    float *ring = stage + ST_FLOATS;                   // [2][RING]
+    float *ring = stage + ST_FLOATS;                   // [2][RINGF]
 
     // per-mode registers for the whole launch: scaled state, coarse step P - I / P, transfer weight
     // state x = (Q, D) and the coarse-step matrix as register PAIRS: c1 = (P11 - 1, P21), c2 = (P12, P22)
@@ -213,8 +219,8 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     constexpr bool FT = FORCED && PROJ == 0 && !QN && R <= 2;
     // FTM (one mode per lane): the 16 increments of a group's blocks are a [16 blocks x 16 taps] . [16 taps x 16 modes] product
     // per tile of 16 modes and state component -- 32 MFMAs per group whose A operand is the profile exactly as the FIR's B
-    // operand holds it; the tiles come back to "lane = mode" through an LDS area of [64 modes][U_ROW] floats behind the landing
-    // areas (per block the vector ALU is left with the coarse step and two FMAs: 8.5 K -> 4 K cycles per buffer).
+    // operand holds it; the tiles come back to "lane = mode" through [64 modes][U_ROW] floats of LDS (the staging area itself,
+    // between two slices; per block the vector ALU is left with the coarse step and two FMAs: 8.5 K -> 4 K cycles per buffer).
     constexpr bool FTM = FT && R == 1;
     constexpr int U_ROW = FTM_U_ROW;
     float fB[FTM ? 4 : 1][2][4];
@@ -459,7 +465,37 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
         const float amp = cur.amp;
         const int trow = cur.trow;
         const uint32_t flags = cur.flags;
-        float *rg = ring + (b & 1) * RING;
+        float *rg = ring + (b & 1) * RING;             // (HALF: unused)
+        // where a group's 256 partial sums and the buffer's sample 0 go
+        auto ring_grp = [&](int grp) { return HALF ? ring + grp * RINGF : rg + GROUP * grp; };
+        auto ring_s0 = [&]() { return HALF ? ring + GROUP : rg + GROUP * NG; };
+        // HALF: the team's waves add their rings of group `grp` and store its samples (sample 0 with group 0); the ring of a group
+        // is written again a whole buffer later, behind the OTHER group's barrier, so one barrier per group is enough.  The wave
+        // that adds rotates (the others go on).
+        auto combine_half = [&](int grp) {
+            if constexpr (HALF) {
+                lap(cy_pipe);
+                __syncthreads();
+                lap(cy_bar);
+                if (wave == (2 * (b - b_begin) + grp) % W) {
+                    const float *r0 = lds + ST_FLOATS + grp * RINGF;
+                    float *__restrict__ ao = aout + (size_t)b * B + GROUP * grp;
+                    const unsigned j = lane_off() & 63u;
+                    f4 acc = *reinterpret_cast<const f4 *>(r0 + 4 * j);
+                    for (int w = 1; w < W; ++w) acc += *reinterpret_cast<const f4 *>(r0 + w * WAVE_FLOATS + 4 * j);
+                    AUDIO_STORE(&ao[4 * j + 1], acc.x);
+                    AUDIO_STORE(&ao[4 * j + 2], acc.y);
+                    AUDIO_STORE(&ao[4 * j + 3], acc.z);
+                    AUDIO_STORE(&ao[4 * j + 4], acc.w);
+                    if (grp == 0 && j == 0) {
+                        float a0 = r0[GROUP];
+                        for (int w = 1; w < W; ++w) a0 += r0[w * WAVE_FLOATS + GROUP];
+                        AUDIO_STORE(&ao[0], a0);
+                    }
+                }
+                lap(cy_comb);
+            }
+        };
         dump_b = p.qn_b0 + b;
 
         if (flags & DESC_SKIP) {
@@ -534,7 +570,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 }
             }
             p0 = wave_sum(p0);
-            if (lane == 0) rg[GROUP * NG] = p0;
+            if (lane == 0) *ring_s0() = p0;
 
             if constexpr (PROJ == 0) {
             // ---- software pipeline over the U = NG * R slices of the buffer, in BURSTS.  Slice u's 32 MFMAs take their B
@@ -591,7 +627,8 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 if constexpr (r == R - 1) {
                     const f4 acc = acc0 + acc1;
                     const unsigned l = lane_off() & 63u;       // (recomputed: not worth two registers across the pipeline)
-                    *reinterpret_cast<f4 *>(rg + GROUP * grp + 16 * (l & 15u) + 4 * (l >> 4)) = acc;
+                    *reinterpret_cast<f4 *>(ring_grp(grp) + 16 * (l & 15u) + 4 * (l >> 4)) = acc;
+                    combine_half(grp);
                 }
             });
             } else {
@@ -683,7 +720,8 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                     if constexpr (r == R - 1) {
                         const f4 acc = acc0 + acc1;
                         const unsigned l = lane_off() & 63u;
-                        *reinterpret_cast<f4 *>(rg + GROUP * grp + 16 * (l & 15u) + 4 * (l >> 4)) = acc;
+                        *reinterpret_cast<f4 *>(ring_grp(grp) + 16 * (l & 15u) + 4 * (l >> 4)) = acc;
+                        combine_half(grp);
                     }
                 });
             }
@@ -733,7 +771,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 }
                 p0 = wave_sum(p0);
                 if (!TAPS_VALU) gs = wave_sum(gs);
-                if (lane == 0) rg[GROUP * NG] = p0;
+                if (lane == 0) *ring_s0() = p0;
                 wave_sync();                                    // the previous buffer's staging reads are issued
                 if (!TAPS_VALU && lane == 0) taps[0] = gs;
             }
@@ -852,7 +890,11 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                     lap(cy_pipe);
                     const float gr = g_[r];
                     if constexpr (FTM) {
-                        float *ua = lds + (blockDim.x >> 6) * (WAVE_FLOATS + 3 * R * 64) + wave * (64 * U_ROW);
+                        // (the tiles land in the wave's own staging area -- [64 modes][U_ROW] floats are exactly its size: the previous
+                        //  group's operand reads are issued, the taps behind the staging rows are in registers, and the lane reads its row
+                        //  back before it parks the first state; an area of its own cost 9 KB per wave: teams of eight did not fit the CU)
+                        static_assert(64 * U_ROW <= ST_FLOATS, "FTM tiles alias the staging area");
+                        float *ua = stage;
                         static_for<0, 4>([&](auto tc) {
                             constexpr int tl = decltype(tc)::value;
                             f4 dq = f4{0.f, 0.f, 0.f, 0.f}, dd = f4{0.f, 0.f, 0.f, 0.f};
@@ -953,7 +995,8 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 }
                 const f4 acc = acc0 + acc1;
                 const unsigned l = lane_off() & 63u;
-                *reinterpret_cast<f4 *>(rg + GROUP * grp + 16 * (l & 15u) + 4 * (l >> 4)) = acc;
+                *reinterpret_cast<f4 *>(ring_grp(grp) + 16 * (l & 15u) + 4 * (l >> 4)) = acc;
+                combine_half(grp);
             });
             if (QN) {
                 const unsigned utid = lane_off();
@@ -987,7 +1030,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 const float tk0 = dense ? tprow[0] : ((frow >= 0 && ((flags & DESC_DIRECT) || (cur.tile_mask & 1u))) ? amp : 0.f);
                 float p0 = step1(tk0, frow >= 0);
                 p0 = wave_sum(p0);
-                if (lane == 0) rg[GROUP * NG] = p0;
+                if (lane == 0) *ring_s0() = p0;
             }
             for (int c = 0; c < NG * BN; ++c) {
                 wave_sync();                           // the previous chunk's row reads are issued
@@ -1009,7 +1052,8 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 }
                 rs += __shfl_xor(rs, 16, 64);
                 rs += __shfl_xor(rs, 32, 64);
-                if (lane < BJ) rg[c * BJ + lane] = rs;
+                if (lane < BJ) ring_grp(c / BN)[(c % BN) * BJ + lane] = rs;
+                if (HALF && (c % BN) == BN - 1) combine_half(c / BN);
             }
             if (QN) {
                 const unsigned utid = lane_off();
@@ -1024,6 +1068,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
 
         // ---- the team's waves add their rings and store the buffer; one barrier per buffer (the ring
         //      alternates by buffer parity, so a wave can be one buffer ahead of the slowest reader)
+        if constexpr (!HALF) {
         lap(cy_pipe);
         __syncthreads();
         lap(cy_bar);
@@ -1046,6 +1091,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
             }
         }
         lap(cy_comb);
+        }
     }
 
     if (p_census && tid == 0) {
@@ -1081,8 +1127,7 @@ static int launch_one(const IirParams &p, int n_teams, int W, hipStream_t stream
         if (p.tc_cb > 0) return launch_one<R, QNM, PROJ, DUMP, FORCED, true>(p, n_teams, W, stream);
     }
     if (!CHUNKED && p.tc_cb > 0) return (int)hipErrorInvalidValue;       // (no chunked build of this shape: the engine never asks)
-    // (the forced block path of a one-mode-per-lane engine without qnorm rows transposes its increments through LDS: FTM)
-    const size_t lds = block_lds_bytes(W, R) + (FORCED && PROJ == 0 && QNM == 0 && R == 1 ? sizeof(float) * (size_t)W * 64 * FTM_U_ROW : 0);
+    const size_t lds = block_lds_bytes(W, R);
     // R = 8 is the one-wave-per-SIMD build (512 registers: the 256 W-table operands go to AGPRs): teams of <= 4 waves
     constexpr int MAXT = R == 8 ? 256 : 64 * MAX_WAVES_PER_BLOCK_TEAM;
     if (64 * W > MAXT) return (int)hipErrorInvalidValue;

@@ -14,9 +14,15 @@
 // after which the buffers no longer depend on each other: K1b runs the launch as (team, chunk of buffers) workgroups,
 // each starting from the state this kernel left for its first buffer -- the chip fills even when a scene has fewer
 // waves of oscillators than SIMDs (BASELINE configs[1], [2], [4] and the 128 x 512 share of configs[3] on 8 GPUs).
-// A buffer with a DENSE force profile (Gaussian / AR, forces.h:92-128) has no closed form: the scan steps its 513 samples
-// literally (velocity form, the per-sample kernels' arithmetic); the engine sends launches that are mostly such buffers
-// to the kernels that walk the buffers in order (K1p / K1b unchunked) instead.
+// A buffer with a DENSE force profile T (Gaussian / AR, forces.h:92-128; the sustained branch modal_solver.h:222-240) is
+// linear in its start state too (modal_integrator.h:103-113):
+//     x_{b+1} = A^513 x_b + g V_b,      V_b = sum_k A^(512-k) u T_k          (g = c3 * S, modal_solver.h:266)
+// and V_b -- the state a UNIT force gain leaves behind from rest -- depends on the mode and the profile only, not on the state:
+// dense_increment_kernel (below) evaluates it for every dense (object, buffer) of a launch AT ONCE, a block of 16 samples at
+// a time on the matrix pipe (the increments F . T_n of kernels_block.hip's forced block path, then a 32-step Horner in
+// P = A^16), and the scan's DENSE build takes g V_b where an impulse buffer takes (g amp) A^512 u.  Round 5: before that the
+// scan stepped such buffers sample by sample (86 x 513 dependent steps for a second of sustained scraping), and launches that
+// were mostly dense kept the kernels that walk the buffers in order.
 //
 // A^513 and A^512 u are per-mode constants, fp64 on the host, rounded once (Engine::finalize); A^513's first entry is
 // stored minus one, as K1b's coarse step P = A^16.  One wave = 64 consecutive columns of one object, one mode per lane.
@@ -67,19 +73,23 @@ struct ScanDims {
 #define PBSO_SCAN_STOP 9         // (ablation builds for timing only: scripts/debug/r04_scan_abl.sh)
 #endif
 
-template <bool DIRECT>
+// DENSE: the launch has buffers with a dense force profile; p_vinc holds their increments V [profile row][m_pad] pairs (q, d)
+// and the batch's gains are kept as pairs g V (dense) / (g amp) A^512 u (impulse): 32 KB of LDS per wave instead of 16.
+template <bool DIRECT, bool DENSE>
 __global__ __launch_bounds__(64) void iir_scan_kernel(
-    const float *__restrict__ p_ca, const float *__restrict__ p_cb, float *__restrict__ p_sq, float *__restrict__ p_sd,
+    float *__restrict__ p_sq, float *__restrict__ p_sd,
     float *__restrict__ p_ss, const float *__restrict__ p_sc, const BufDesc *__restrict__ p_desc,
     const float *__restrict__ p_grows, const float *__restrict__ p_g32, const long long *__restrict__ p_g32_off,
-    const float *__restrict__ p_tprof, const int *__restrict__ p_xfer_init, float *__restrict__ p_xs,
+    const float *__restrict__ p_vinc, const int *__restrict__ p_xfer_init, float *__restrict__ p_xs,
     int *__restrict__ p_xtrow, const ScanDims p) {
-    __shared__ __attribute__((aligned(16))) float lds_g[64][64];          // [buffer of the batch][mode]: the hit's gain g amp (0: no hit)
-    const int obj = blockIdx.y;
-    const int col0 = 64 * blockIdx.x;
+    // [buffer of the batch][mode]: the hit's gain g amp (0: no hit); DENSE: the pair it adds to the state
+    __shared__ __attribute__((aligned(16))) float lds_g[DENSE ? 128 : 64][64];
+    // (a flat grid: grid.y is capped at 65535 objects)
+    const int tiles = p.m_pad / 64;
+    const int obj = blockIdx.x / tiles;
+    const int col0 = 64 * (blockIdx.x % tiles);
     const unsigned lane = threadIdx.x;
     const size_t ubase = (size_t)obj * p.m_pad + col0;
-    const float nca = (p_ca + ubase)[lane], ncb = (p_cb + ubase)[lane];               // eps^2, -e (velocity form)
     const float s11 = (p_sc + ubase)[lane], s12 = (p_sc + p.plane + ubase)[lane];     // A^513: P11 - 1, P12, P21, P22
     const float s21 = (p_sc + 2 * p.plane + ubase)[lane], s22 = (p_sc + 3 * p.plane + ubase)[lane];
     const float hq = (p_sc + 4 * p.plane + ubase)[lane], hd = (p_sc + 5 * p.plane + ubase)[lane];      // A^512 u
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(64) void iir_scan_kernel(
         {
             f4 *z = reinterpret_cast<f4 *>(&lds_g[0][0]) + lane;
             const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
-            for (int i = 0; i < (nd + 3) / 4; ++i) z[64 * i] = zero;
+            for (int i = 0; i < (DENSE ? 2 : 1) * ((nd + 3) / 4); ++i) z[64 * i] = zero;
         }
         wave_sync();
         for (unsigned long long m = hit_mask; m;) {
@@ -187,12 +197,19 @@ __global__ __launch_bounds__(64) void iir_scan_kernel(
                 else if (h == HB - 1) m = 0;
             }
             float r[HB][NR];
+            f2 vv[DENSE ? HB : 1];
 #pragma unroll
-            for (int h = 0; h < HB; ++h)
+            for (int h = 0; h < HB; ++h) {
                 static_for<0, NR>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
                     r[h][k] = rlp(ptr[k], jj[h])[lane];
                 });
+                if constexpr (DENSE) {
+                    // what a unit gain adds to the state over this buffer: its increment row (dense), A^512 u (impulse)
+                    vv[h] = f2{hq, hd};
+                    if ((dense_mask >> jj[h]) & 1) vv[h] = (reinterpret_cast<const f2 *>(p_vinc) + (size_t)rl(prow, jj[h]) * p.m_pad + col0)[lane];
+                }
+            }
 #pragma unroll
             for (int h = 0; h < HB; ++h) {
                 const int j = jj[h];
@@ -201,7 +218,12 @@ __global__ __launch_bounds__(64) void iir_scan_kernel(
                     gv = fmaf(rlf(w[NR > 1 ? 1 : 0], j), r[h][NR > 1 ? 1 : 0], gv);
                     gv = fmaf(rlf(w[NR > 2 ? 2 : 0], j), r[h][NR > 2 ? 2 : 0], gv);
                 }
-                lds_g[j][lane] = gv;
+                if constexpr (DENSE) {
+                    lds_g[2 * j][lane] = gv * vv[h].x;
+                    lds_g[2 * j + 1][lane] = gv * vv[h].y;
+                } else {
+                    lds_g[j][lane] = gv;
+                }
             }
         }
         wave_sync();
@@ -210,63 +232,53 @@ __global__ __launch_bounds__(64) void iir_scan_kernel(
         // ---- (3) the scan, lane = mode
         // x <- A^513 x + gv A^512 u, two dependent operations deep (a lone wave issues a dependent instruction every ~8 cycles):
         // q' = (q + (P11 - 1) q) + (P12 d + gv hq), d' = P21 q + (P22 d + gv hd); the impulse's share is off the chain
-        auto coarse = [&](float gv) {
-            const float gq = gv * hq, gd = gv * hd;
+        // (DENSE: the pair (gq, gd) comes ready from LDS -- g V of a dense buffer, (g amp) A^512 u of an impulse)
+        auto coarse2 = [&](float gq, float gd) {
             const float qa = fmaf(s11, x.x, x.x), qb = fmaf(s12, x.y, gq);
             const float da = s21 * x.x, db = fmaf(s22, x.y, gd);
             x.x = qa + qb;
             x.y = da + db;
         };
+        auto coarse = [&](float gv) { coarse2(gv * hq, gv * hd); };
         auto mark = [&]() {                          // the first buffer of a chunk: its start state
             xs_next[lane] = x;
             xs_next += p.m_pad;
         };
-        const unsigned long long slow_mask = skip_mask | dense_mask;
+        const unsigned long long slow_mask = skip_mask;
         for (int j0 = 0; j0 < nd; j0 += G) {
             const int n = nd - j0 < G ? nd - j0 : G;
             if (n == G && ((slow_mask >> j0) & ((1ull << G) - 1)) == 0) {
-                float gv[G];
+                float gv[G], gw[DENSE ? G : 1];
 #pragma unroll
-                for (int i = 0; i < G; ++i) gv[i] = lds_g[j0 + i][lane];
+                for (int i = 0; i < G; ++i) {
+                    if constexpr (DENSE) {
+                        gv[i] = lds_g[2 * (j0 + i)][lane];
+                        gw[i] = lds_g[2 * (j0 + i) + 1][lane];
+                    } else {
+                        gv[i] = lds_g[j0 + i][lane];
+                    }
+                }
+                auto step = [&](int i) {
+                    if constexpr (DENSE) coarse2(gv[i], gw[i]);
+                    else coarse(gv[i]);
+                };
                 const unsigned mm = (unsigned)(mark_mask >> j0) & ((1u << G) - 1u);
                 if (mm == 0) {
 #pragma unroll
-                    for (int i = 0; i < G; ++i) coarse(gv[i]);
+                    for (int i = 0; i < G; ++i) step(i);
                 } else {
 #pragma unroll
                     for (int i = 0; i < G; ++i) {
                         if (mm & (1u << i)) mark();
-                        coarse(gv[i]);
+                        step(i);
                     }
                 }
             } else {
                 for (int j = j0; j < j0 + n; ++j) {
                     if ((mark_mask >> j) & 1) mark();
                     if ((skip_mask >> j) & 1) continue;      // step() returned before stepping: state untouched
-                    const float gv = lds_g[j][lane];
-                    if ((dense_mask >> j) & 1) {
-                        // dense force profile: every sample, literally (d = eps^2 d - e q + g T_k ; q += d); the row 64 samples at a
-                        // time, one per lane and a batch ahead; sample k reaches the FMA as a scalar operand
-                        const int pr = rl(prow, j);
-                        const float *__restrict__ tprow = p_tprof + (size_t)(pr >= 0 ? pr : 0) * p.b_pad;
-                        auto ldt = [&](int kb) { const int k = kb + (int)lane; return tprow[k < p.frames ? k : p.frames - 1]; };
-                        float tv = ldt(0);
-                        for (int kb = 0; kb < p.frames; kb += 64) {
-                            const float tn = ldt(kb + 64 < p.frames ? kb + 64 : kb);
-                            const int nk = p.frames - kb < 64 ? p.frames - kb : 64;
-                            for (int k = 0; k < nk; ++k) {
-                                const float tk = rlf(tv, k);
-                                float a = nca * x.y;
-                                a = fmaf(ncb, x.x, a);
-                                a = fmaf(gv, tk, a);
-                                x.y = a;
-                                x.x = x.x + a;
-                            }
-                            tv = tn;
-                        }
-                    } else {
-                        coarse(gv);
-                    }
+                    if constexpr (DENSE) coarse2(lds_g[2 * j][lane], lds_g[2 * j + 1][lane]);
+                    else coarse(lds_g[j][lane]);
                 }
             }
         }
@@ -276,20 +288,145 @@ __global__ __launch_bounds__(64) void iir_scan_kernel(
     (p_ss + ubase)[lane] = 1.f;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// dense_increment_kernel: V[row][mode] = sum_{k=0..512} A^(512-k) u T_row[k], the state a unit force gain with the dense time
+// profile of row `row` (one (object, buffer) of the launch: ProfRow, kernels.h) leaves behind from rest -- for ALL dense rows of
+// a launch at once: grid (tiles of NW x 64 columns, groups of RB rows), one wave per (64 columns, group of rows).
+//   per group of 16 blocks of 16 samples:  U[16 blocks][16 modes] = T[16 blocks x 16 taps] . F[16 taps x 16 modes]  per tile of
+//   16 modes and state component on v_mfma_f32_16x16x4_f32 (F = A^(15-i) u, the table of the forced block path; the A operand
+//   is the profile as the FIR of kernels_block.hip holds it), back to "lane = mode" through LDS, then
+//   v <- P v + U_n, P = A^16, sixteen times; the buffer's first sample enters as v = T_0 u.
+// 64 MFMAs + 32 coarse steps per (64 modes, buffer): the matrix pipe's half of what the oscillator bank spends on the same
+// buffer, and none of it sequential across buffers.
+constexpr int U_ROW = 36;        // LDS: [64 modes][16 Q increments | 16 D increments] + 4 floats of padding (kernels_block.hip: FTM)
+constexpr int INC_NW = 4;        // waves per workgroup
+constexpr int INC_RB = 4;        // rows per wave (the mode constants -- 32 operand registers -- are loaded once per object)
+
+struct IncDims {
+    int n_rows, m_pad, b_pad, frames;
+    long long plane;             // elements between the planes of p_pc / p_ftab
+};
+
+__global__ __launch_bounds__(64 * INC_NW) void dense_increment_kernel(
+    const float *__restrict__ p_pc, const float *__restrict__ p_ftab, const float *__restrict__ p_tprof,
+    const int *__restrict__ p_row_obj, const int *__restrict__ p_n_modes, float *__restrict__ p_vinc, const IncDims p) {
+    __shared__ __attribute__((aligned(16))) float lds_u[INC_NW][64 * U_ROW];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col0 = 64 * (blockIdx.x * INC_NW + wave);
+    if (col0 >= p.m_pad) return;                     // (no workgroup barrier in this kernel: a wave may leave)
+    float *ua = lds_u[wave];
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    int cur_obj = -1;
+    bool tile_dead = false;
+    float fB[4][2][4];                               // B operand: F[tap 4 ks + (l >> 4)][mode 16 tl + (l & 15)], both components
+    f2 c1 = f2{0.f, 0.f}, c2 = f2{0.f, 0.f};         // P = A^16 as (P11 - 1, P21), (P12, P22)
+    const int r_end = (int)(blockIdx.y + 1) * INC_RB < p.n_rows ? (int)(blockIdx.y + 1) * INC_RB : p.n_rows;
+    for (int row = blockIdx.y * INC_RB; row < r_end; ++row) {
+        const int obj = p_row_obj[row];
+        f2 *__restrict__ vdst = reinterpret_cast<f2 *>(p_vinc) + (size_t)row * p.m_pad + col0;
+        if (obj != cur_obj) {
+            cur_obj = obj;
+            tile_dead = col0 >= p_n_modes[obj];      // columns behind the object's modes: zero coefficients, zero gains
+            const size_t ubase = (size_t)obj * p.m_pad + col0;
+            if (!tile_dead) {
+#pragma unroll
+                for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks)
+                            fB[tl][c][ks] = (p_ftab + (size_t)(2 * (4 * ks + (lane >> 4)) + c) * p.plane + ubase)[16 * tl + (lane & 15)];
+                c1.x = (p_pc + ubase)[lane];
+                c2.x = (p_pc + p.plane + ubase)[lane];
+                c1.y = (p_pc + 2 * p.plane + ubase)[lane];
+                c2.y = (p_pc + 3 * p.plane + ubase)[lane];
+            }
+        }
+        if (tile_dead) {
+            vdst[lane] = f2{0.f, 0.f};
+            continue;
+        }
+        const float *__restrict__ tprow = p_tprof + (size_t)row * p.b_pad;
+        // the profile as the A operand, A[block l & 15][tap 4 ks + (l >> 4)] = T[1 + 256 grp + 16 block + tap], both groups
+        float fa[2][4];
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fa[grp][ks] = tprow[1 + 256 * grp + 16 * (lane & 15) + 4 * ks + (lane >> 4)];
+        const float t0 = tprow[0];
+        f2 v = f2{t0, t0};                           // sample 0: d += T_0, q += d from rest
+        static_for<0, 2>([&](auto gc) {
+            constexpr int grp = decltype(gc)::value;
+            static_for<0, 4>([&](auto tc) {
+                constexpr int tl = decltype(tc)::value;
+                f4 dq = f4{0.f, 0.f, 0.f, 0.f}, dd = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    dq = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[grp][ks], fB[tl][0][ks], dq, 0, 0, 0);
+                    dd = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[grp][ks], fB[tl][1][ks], dd, 0, 0, 0);
+                }
+                // D[block 4 (l >> 4) + v][mode 16 tl + (l & 15)]
+                float *dst = ua + (16 * tl + (lane & 15)) * U_ROW + 4 * (lane >> 4);
+                *reinterpret_cast<f4 *>(dst) = dq;
+                *reinterpret_cast<f4 *>(dst + 16) = dd;
+            });
+            wave_sync();
+            f4 uq[4], ud[4];
+            {
+                const f4 *src = reinterpret_cast<const f4 *>(ua + lane * U_ROW);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { uq[i] = src[i]; ud[i] = src[4 + i]; }
+            }
+            wave_sync();                             // (read before the next group's tiles land)
+            static_for<0, 16>([&](auto nc) {
+                constexpr int n = decltype(nc)::value;
+                const float qa = fmaf(c1.x, v.x, v.x);
+                const float da = c1.y * v.x;
+                const float qn = fmaf(c2.x, v.y, qa);
+                const float dn = fmaf(c2.y, v.y, da);
+                v.x = qn + uq[n / 4][n % 4];
+                v.y = dn + ud[n / 4][n % 4];
+            });
+        });
+        vdst[lane] = v;
+    }
+}
+
 }  // namespace iir_scan
 
+int launch_dense_increments(const float *pc, const float *ftab, long long plane, const float *tprof, const int *row_obj,
+                            const int *n_modes, int n_rows, int m_pad, int b_pad, int frames, float *vinc, hipStream_t stream) {
+    if (n_rows <= 0) return 0;
+    if (frames != 513 || m_pad % 64 || !ftab || !pc || !vinc) return (int)hipErrorInvalidValue;
+    const iir_scan::IncDims dims = {n_rows, m_pad, b_pad, frames, plane};
+    const dim3 grid((m_pad / 64 + iir_scan::INC_NW - 1) / iir_scan::INC_NW, (n_rows + iir_scan::INC_RB - 1) / iir_scan::INC_RB);
+    hipLaunchKernelGGL(iir_scan::dense_increment_kernel, grid, dim3(64 * iir_scan::INC_NW), 0, stream, pc, ftab, tprof, row_obj, n_modes,
+                       vinc, dims);
+    return (int)hipGetLastError();
+}
+
 int launch_iir_scan(const IirParams &p, int n_obj, const float *sc, int cb, int n_chunks, float *xs, int *xtrow, bool direct,
-                    hipStream_t stream) {
+                    const float *vinc, hipStream_t stream) {
     if (n_obj <= 0 || p.nb <= 0) return 0;
     if (cb <= 0 || n_chunks != (p.nb + cb - 1) / cb || p.m_pad % 64) return (int)hipErrorInvalidValue;
     const iir_scan::ScanDims dims = {p.nb, cb, n_chunks, p.m_pad, p.b_pad, p.frames, p.gq_plane};
-    const dim3 grid(p.m_pad / 64, n_obj), block(64);
-    if (direct)
-        hipLaunchKernelGGL(iir_scan::iir_scan_kernel<true>, grid, block, 0, stream, p.ca, p.cb, p.sq, p.sd, p.ss, sc, p.desc, p.grows,
-                           p.g32, p.g32_off, p.tprof, p.xfer_init, xs, xtrow, dims);
-    else
-        hipLaunchKernelGGL(iir_scan::iir_scan_kernel<false>, grid, block, 0, stream, p.ca, p.cb, p.sq, p.sd, p.ss, sc, p.desc, p.grows,
-                           p.g32, p.g32_off, p.tprof, p.xfer_init, xs, xtrow, dims);
+    const dim3 grid((unsigned)((size_t)(p.m_pad / 64) * n_obj)), block(64);
+#define PBSO_SCAN_LAUNCH(DIRECT, DENSE)                                                                                          \
+    hipLaunchKernelGGL((iir_scan::iir_scan_kernel<DIRECT, DENSE>), grid, block, 0, stream, p.sq, p.sd, p.ss, sc, p.desc, p.grows, p.g32, \
+                       p.g32_off, vinc, p.xfer_init, xs, xtrow, dims)
+    if (vinc) {
+        if (direct) PBSO_SCAN_LAUNCH(true, true);
+        else PBSO_SCAN_LAUNCH(false, true);
+    } else {
+        if (direct) PBSO_SCAN_LAUNCH(true, false);
+        else PBSO_SCAN_LAUNCH(false, false);
+    }
+#undef PBSO_SCAN_LAUNCH
     return (int)hipGetLastError();
 }
 

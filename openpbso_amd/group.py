@@ -20,7 +20,7 @@ def unique_id():
 
 class Group:
     def __init__(self, devices, world_size=0, first_rank=0, unique_id=None, form=None, qnorm=capi.QNORM_ALL, modes_per_lane=0,
-                 frames_per_buffer=0, **select):
+                 frames_per_buffer=0, transport=capi.GROUP_RCCL, **select):
         self._l = capi.lib()
         self.devices = list(devices)
         self.world = world_size or len(self.devices)
@@ -34,6 +34,7 @@ class Group:
         d.n_devices = len(self.devices)
         d.world_size = world_size
         d.first_rank = first_rank
+        d.transport = transport
         self._id = C.create_string_buffer(unique_id, capi.GROUP_ID_BYTES) if unique_id is not None else None
         d.unique_id = C.cast(self._id, C.c_void_p) if self._id is not None else None
         fill_engine_desc(d.engine, 0, default_form() if form is None else form, qnorm, modes_per_lane, None, frames_per_buffer, select)

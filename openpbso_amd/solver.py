@@ -97,6 +97,8 @@ def _select_from_env():
         sel.update(bank_kernel=capi.BANK_PIPE)
     if "PBSO_TIME_CHUNKS" in env:
         sel["time_chunks"] = int(env["PBSO_TIME_CHUNKS"])
+    if "PBSO_TC_SHAPE" in env:
+        sel["time_chunk_shape"] = int(env["PBSO_TC_SHAPE"])
     if env.get("PBSO_DIRECT_HITS") == "0":
         sel["direct_hits"] = -1
     if env.get("PBSO_FORCED_BLOCK") == "0":
@@ -130,7 +132,8 @@ def _select_from_env():
 
 SELECT_FIELDS = ("bank_kernel", "time_chunks", "direct_hits", "forced_block", "dense_launches", "device_profiles",
                  "profile_kernel", "profile_margin_pct", "profile_priority", "team_waves", "pipe_consumers",
-                 "pipe_max_teams", "chunk_buffers", "plan_threads", "plan_pin", "timing_every", "warm_copies", "stream_sync", "latency_path")
+                 "pipe_max_teams", "chunk_buffers", "plan_threads", "plan_pin", "timing_every", "warm_copies", "stream_sync", "latency_path",
+                 "time_chunk_shape")
 
 
 def fill_engine_desc(d, device, form, qnorm, modes_per_lane, stream, frames_per_buffer, select):

@@ -116,7 +116,8 @@ def _poisson_scene(n_obj, n_modes, nb, p_hit=0.233, seed=31):
 def test_policy_small_scenes_take_it_full_chips_and_single_buffers_do_not():
     """auto (time_chunks = 0): BASELINE configs[1] (1 x 512, 86 buffers) runs time-chunked; the same engine stepping ONE buffer
     (the real-time facade's call) does not; an engine pinned to the buffer-by-buffer walk (time_chunks < 0) never does; a launch
-    that is mostly dense-profile buffers (sustained scraping) keeps the kernels that walk the buffers in order"""
+    that is mostly dense-profile buffers (sustained scraping) is cut in time too since round 5: the increments of its dense buffers
+    (dense_increment_kernel) take their place in the scan"""
     nb = 86
     objs, evs = _poisson_scene(1, 512, nb)
     want = run_oracle(objs, evs, nb)
@@ -135,8 +136,12 @@ def test_policy_small_scenes_take_it_full_chips_and_single_buffers_do_not():
     sevs = [force_ev(0, 0, data=rng.standard_normal(512) * 1e-3, force_type=2, start=True), dict(t=0, obj=0, kind="use_transfer", use=False)]
     sevs += [force_ev(b, 0, data=rng.standard_normal(512) * 1e-3, force_type=2) for b in range(1, 12)]
     scr = run_engine(objs, sevs, 12)
-    assert scr["info"]["total_time_chunk_launches"] == 0
+    assert scr["info"]["total_time_chunk_launches"] == 1 and scr["info"]["total_dense_increment_launches"] == 1
+    assert scr["info"]["last_time_chunk_shape"] == 1         # one mode per lane: the shape that holds the increment table
     _check(scr, run_oracle(objs, sevs, 12))
+    walk = run_engine(objs, sevs, 12, time_chunks=-1)
+    assert walk["info"]["total_time_chunk_launches"] == 0
+    _check(walk, run_oracle(objs, sevs, 12))
 
 
 def test_two_engines_of_one_process_with_different_settings():

@@ -121,3 +121,121 @@ def test_group_error_paths():
             g.gather(7)
         g.gather(capi.GATHER_ALL)
         assert g.result(0).shape == (2, 2 * 513)
+
+
+def _scene(modes, nb_total, seed):
+    rng = np.random.default_rng(seed)
+    lams = [synth.eigenvalues(m, 900 + i) for i, m in enumerate(modes)]
+    shapes = [synth.mode_shapes(m, 900 + i) for i, m in enumerate(modes)]
+    nv = shapes[0].shape[1] // 3
+    hits = sorted(((int(rng.integers(0, len(modes))), int(rng.integers(0, nv)), int(rng.integers(0, nb_total))) for _ in range(6 * len(modes))),
+                  key=lambda h: h[2])
+    return lams, shapes, hits, synth.unit_normals(len(hits), seed)
+
+
+def _feed(eng, grp, modes, lams, shapes, hits, vns):
+    from openpbso_amd import ForceMessage
+    grp.plan(modes)
+    for i in range(len(modes)):
+        eng.add_object(lams[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
+        grp.add_object(i, lams[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
+    eng.finalize()
+    grp.finalize()
+    for i in range(len(modes)):
+        eng.set_use_transfer(i, False)
+    for r in grp.local_ranks():
+        lo, hi = grp.span(r)
+        for l in range(hi - lo):
+            grp.engine(r).set_use_transfer(l, False)
+    for (o, v, t), vn in zip(hits, vns):
+        m = ForceMessage(vid=v, vn=vn)
+        assert eng.enqueue_force(o, m, t) and grp.enqueue_force(o, m, t)
+
+
+def _check_gathered(grp, got, want, world, rank_label):
+    spans = [grp.span(r) for r in range(world)]
+    cmax = max(hi - lo for lo, hi in spans)
+    assert got.shape == (world * cmax, want.shape[1]), rank_label
+    for r, (lo, hi) in enumerate(spans):
+        assert np.array_equal(got[r * cmax:r * cmax + (hi - lo)], want[lo:hi]), (rank_label, r)
+        assert not got[r * cmax + (hi - lo):(r + 1) * cmax].any(), ("padding rows of a ragged shard must be silent", rank_label, r)
+
+
+@pytest.mark.gpu
+def test_one_rank_group_runs_every_rccl_call_on_one_gpu():
+    """PBSO_GROUP_RCCL_ALWAYS: librccl is dlopen'ed, the eleven symbols resolved, ncclGetUniqueId + ncclCommInitRank(1 rank) build a
+    communicator, and the gathers ISSUE their collectives -- the in-place ncclAllGather, an ncclSend / ncclRecv pair to itself
+    (the received rows are the result), ncclAllReduce -- behind the same stream / event ordering a larger job uses; results equal
+    the single engine (modal_solver.h:100-126: objects are independent)"""
+    from openpbso_amd import Engine
+    from openpbso_amd.group import Group, unique_id
+    uid = unique_id()
+    assert len(uid) == capi.GROUP_ID_BYTES and any(uid)
+    modes = [200] * 6 + [64, 333]
+    nb = 5
+    lams, shapes, hits, vns = _scene(modes, 3 * nb, 21)
+    for given_id in (uid, None):                             # the id a launcher handed over / one the group asks for itself
+        with Engine() as eng, Group([0], transport=capi.GROUP_RCCL_ALWAYS, unique_id=given_id) as grp:
+            _feed(eng, grp, modes, lams, shapes, hits, vns)
+            for k in range(3):                               # three steps: both gather targets, and the first one again
+                eng.step(nb)
+                want = eng.audio()
+                grp.step(nb)
+                grp.gather(capi.GATHER_ALL)
+                assert np.array_equal(grp.result(0), want), k
+                grp.gather(capi.GATHER_ROOT)
+                assert np.array_equal(grp.result(0), want), k     # (the rows that came back through ncclRecv)
+                grp.gather(capi.GATHER_MIX)
+                mix = grp.result(0)
+                ref = want.astype(np.float64).sum(axis=0)
+                assert mix.shape == (1, nb * 513) and np.abs(mix[0] - ref).max() <= 4e-6 * np.abs(ref).max()
+                assert np.abs(want).max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,modes", [(2, [4096, 64, 64, 64]), (3, [300] * 7), (8, [512] * 19 + [64] * 5), (3, [128, 128]), (4, [64] * 4)])
+def test_loopback_ranks_on_one_device_equal_the_single_engine(world, modes):
+    """PBSO_GROUP_LOOPBACK: the job's ranks as engines of ONE process on ONE device, the collectives as device copies -- everything
+    the group does around them is the product's code: shards by the sum of modes (ragged: [4096, 64, 64, 64] on two ranks is 1 + 3
+    objects; two objects on three ranks leave a rank empty), padding rows of the smaller shards SILENT (also when a later step is
+    shorter than an earlier one and the rows move), slice offsets, both gather targets and their events, gather-to-root, the mixed
+    stream.  Every rank's result against pbso_step on one engine fed the same messages, bit for bit (mix: f32 sums in another order)"""
+    from openpbso_amd import Engine
+    from openpbso_amd.group import Group
+    steps = [4, 4, 2, 5]
+    lams, shapes, hits, vns = _scene(modes, sum(steps), world)
+    with Engine() as eng, Group([0] * world, transport=capi.GROUP_LOOPBACK) as grp:
+        _feed(eng, grp, modes, lams, shapes, hits, vns)
+        assert [grp.span(r) for r in range(world)] == [tuple(shard_by_modes(modes, world, r)) for r in range(world)]
+        for k, nb in enumerate(steps):
+            eng.step(nb)
+            want = eng.audio()
+            grp.step(nb)
+            grp.gather(capi.GATHER_ALL)
+            for r in range(world):
+                _check_gathered(grp, grp.result(r), want, world, f"all, step {k}, rank {r}")
+            grp.gather(capi.GATHER_ROOT)
+            _check_gathered(grp, grp.result(0), want, world, f"root, step {k}")
+            for r in range(1, world):
+                lo, hi = grp.span(r)
+                assert np.array_equal(grp.result(r)[:hi - lo], want[lo:hi]), (k, r)
+            grp.gather(capi.GATHER_MIX)
+            ref = want.astype(np.float64).sum(axis=0)
+            for r in range(world):
+                mix = grp.result(r)
+                assert mix.shape == (1, nb * 513) and np.abs(mix[0] - ref).max() <= 1e-5 * np.abs(ref).max(), (k, r)
+        assert np.abs(want).max() > 0
+
+
+def test_loopback_and_transport_arguments_are_checked():
+    """descriptor validation needs no GPU work beyond device discovery; without a GPU the group fails cleanly first"""
+    import torch
+    from openpbso_amd.group import Group
+    from openpbso_amd.solver import PbsoError
+    with pytest.raises(PbsoError):
+        Group([0], transport=7)
+    with pytest.raises(PbsoError):
+        Group([0, 0], world_size=3, transport=capi.GROUP_LOOPBACK)     # every rank of the job lives in the one process
+    if torch.cuda.is_available():
+        with pytest.raises(PbsoError):
+            Group([0, 0])                                    # the product's transport: one rank per GPU
