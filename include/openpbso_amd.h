@@ -120,7 +120,7 @@ typedef struct pbso_engine_desc {
     int profile_margin_pct;   /* K2 row-parallel: candidate range in percent of the expected need (0 -> 100; tests: < 100 forces the shortfall path) */
     int profile_priority;     /* K2 chain kernel's wave priority: 0 auto, 1..4 -> s_setprio 0..3 */
     int team_waves;           /* > 0: waves per team (workgroup) of the oscillator bank; 0 = policy */
-    int pipe_consumers;       /* pipeline kernel: 0 policy, 1..3 consumer waves per team */
+    int pipe_consumers;       /* pipeline kernel: 0 policy, 1..3 consumer waves per team, 4 = the five-role team of mostly-dense launches */
     long long pipe_max_teams; /* pipeline kernel eligibility: at most this many 64-mode teams (0 -> 2 per CU) */
     int chunk_buffers;        /* a step longer than this is cut into several launches (0 -> 128).  A launch's fixed costs (ramp, write drain,
                                * hand-over between the streams: ~35 us) are per launch: throughput callers that step many seconds per call

@@ -343,7 +343,7 @@ int Engine::init() {
     if (desc_.dense_launches) dense_to_k1_ = desc_.dense_launches == 2;
     if (desc_.bank_kernel < PBSO_BANK_AUTO || desc_.bank_kernel > PBSO_BANK_PIPE) return fail(PBSO_ERR_INVALID, "bank_kernel");
     if (desc_.profile_kernel < 0 || desc_.profile_kernel > 2) return fail(PBSO_ERR_INVALID, "profile_kernel");
-    if (desc_.pipe_consumers < 0 || desc_.pipe_consumers > 3) return fail(PBSO_ERR_INVALID, "pipe_consumers");
+    if (desc_.pipe_consumers < 0 || desc_.pipe_consumers > 4) return fail(PBSO_ERR_INVALID, "pipe_consumers");
     if (desc_.profile_priority < 0 || desc_.profile_priority > 4) return fail(PBSO_ERR_INVALID, "profile_priority");
     if (desc_.stream_sync < 0 || desc_.stream_sync > 3) return fail(PBSO_ERR_INVALID, "stream_sync");
     latency_path_ = desc_.latency_path >= 0;
@@ -1938,6 +1938,11 @@ bool Engine::choose_time_chunks(int nb, int n_dense_rows, int *set, int *cb) con
     //  many of them on the kernels that walk the buffers in order, as before round 5)
     if (tc_mode_ == 0 && !ftab_forced_ && (long long)n_dense_rows * 8 > N * nb) return false;
     const bool dense_majority = (long long)n_dense_rows * 2 > N * nb;
+    // (a scene small enough for the pipeline kernel keeps its mostly-dense launches WITHOUT qnorm rows there: teams of five waves per
+    //  64 modes walk the buffers in order and evaluate every increment once -- cut in time they are evaluated twice, for the scan and
+    //  in the bank: 8 x 4096 x 86 scraping 0.25 ms per step against 0.27.  With qnorm rows the re-stepped samples are the long stage
+    //  and want the whole chip's vector ALUs at three waves per SIMD: cut in time 0.33 ms, five-wave teams 0.49, three-wave teams 0.45)
+    if (dense_majority && tc_mode_ == 0 && use_split() && ftab_forced_ && k2_rows_launch_ && desc_.qnorm_mode == PBSO_QNORM_OFF) return false;
     int k = 0;
     for (int c = 2; c >= 1; --c)
         if (tc_[c].cover * 100 <= tc_[0].cover * 115 && tc_[c].waves * nb >= (long long)tc_[c].waves_per_cu * n_cus_) { k = c; break; }
@@ -2376,6 +2381,9 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
             // qnorm rows of a mostly-dense launch: the consumers re-step every sample for the sums and are the long stage -- a third
             // consumer wave that only steps (half of the chains) when that still leaves at most two waves per SIMD
             if (dense_majority && desc_.qnorm_mode != PBSO_QNORM_OFF && ftab_forced_ && 4LL * n_ts_teams_ <= 8LL * n_cus_) nc = 3;
+            // round 5: a mostly-dense launch as teams of FIVE -- the block increments F . T_n come from two waves of their own, a buffer
+            // ahead of the producer, which is left with the 32 coarse steps (kernels_pipe.hip, iir_pipe5_kernel)
+            if (dense_majority && ftab_forced_ && desc_.qnorm_mode == PBSO_QNORM_OFF) nc = 4;
             if (desc_.pipe_consumers > 0) nc = desc_.pipe_consumers;
             LAUNCHTRY(iir_pipe::launch_iir_pipe(kp, n_ts_teams_, nc, desc_.qnorm_mode, sk));
         }

@@ -107,6 +107,8 @@ def _run_seed(seed, size_choices, engine_kw, projected_hits=False):
     # qnorm: 5e-4 of the buffer's largest entry, plus 2e-6 of the object's peak over the run -- the ringing
     # left behind by a smooth (Gaussian) pulse is a 1e-4 residue of the response during the pulse, and
     # fp32 resolves it only relative to that response (seed 519)
+    if engine_kw.get("qnorm") == capi.QNORM_OFF:
+        return
     peak = {}
     for (oi, _), w in want["qnorm"].items():
         peak[oi] = max(peak.get(oi, 0.0), float(np.abs(w).max()))
@@ -147,3 +149,14 @@ def test_random_scripts_random_engine_shapes(seed, monkeypatch):
     kw = dict(form=form, modes_per_lane=int(rng.choice(mpl)), qnorm=int(rng.choice([capi.QNORM_ALL, capi.QNORM_CLOSED])),
               time_chunks=int(rng.choice([0, -1, 1, 3])))
     _run_seed(seed + 100000, [5, 64, 200, 1100, 2100], kw, projected_hits=True)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PBSO_FUZZ_PIPE5_SEEDS", "48"))))
+def test_random_scripts_five_role_pipeline_teams(seed):
+    """round 5: the pipeline kernel's five-role teams (kernels_pipe.hip, iir_pipe5_kernel: one wave steps the state from increments
+    that two others evaluated a buffer ahead, two project) pinned for EVERY launch of arbitrary scripts -- dense profiles,
+    impulses, clears, listener moves with zero weights (the unscaled fallback), objects of one to five teams, an odd number of teams
+    (a workgroup holds two), with and without qnorm rows, launches cut anywhere"""
+    kw = dict(form=capi.FORM_BLOCK, modes_per_lane=1, bank_kernel=capi.BANK_PIPE, pipe_consumers=4,
+              qnorm=capi.QNORM_ALL if seed % 2 else capi.QNORM_OFF)
+    _run_seed(seed + 200000, [3, 64, 65, 130, 300], kw, projected_hits=bool(seed % 3 == 0))

@@ -329,3 +329,42 @@ def test_step_to_host_delivers_what_read_audio_returns():
         a.step_to_host(nb, plain)
         a.host_wait()
         assert np.array_equal(plain, b.audio())
+
+
+@pytest.mark.parametrize("qnorm", [capi.QNORM_ALL, capi.QNORM_OFF])
+@pytest.mark.parametrize("shape", [1, 2, 4])
+def test_dense_launches_cut_in_time_every_team_shape(shape, qnorm):
+    """round 5: launches that are MOSTLY dense-profile buffers (sustained AutoregressiveForce contact, forces.h:107-128,
+    modal_solver.h:222-240, with a parameter update, an end and free ringing; a Gaussian on the side) cut along the time axis:
+    dense_increment_kernel evaluates what every dense buffer leaves in the state per unit gain, the scan takes g V where an impulse
+    has (g amp) A^512 u, the bank steps the chunks in its forced block path -- for every team shape (time_chunk_shape), by policy
+    and forced chunk lengths, objects of one team and of several, and with ONE buffer per chunk bit-identical for any cut"""
+    nb = 24
+    rng = np.random.default_rng(99 + shape)
+    objs, evs = [], []
+    for i, m in enumerate((64, 600, 1100)):
+        objs.append(ObjSpec(synth.eigenvalues(m, 2300 + i), shapes=synth.mode_shapes(m, 2300 + i)))
+        vns = synth.unit_normals(nb, 2300 + i)
+        evs.append(dict(t=0, obj=i, kind="use_transfer", use=False))
+        evs.append(force_ev(0, i, data=rng.standard_normal(m) * 1e-3, force_type=2, start=True))
+        for b in range(1, 19):
+            bary = rng.random(3)
+            evs.append(force_ev(b, i, vids=rng.integers(0, synth.N_VERTS, 3), coords=bary / bary.sum(), vn=vns[b], force_type=2))
+        evs.append(dict(t=7, obj=i, kind="arprm", a=[0.5, 0.3], sigma=0.004, mu=0.2))
+        evs.append(force_ev(19, i, force_type=2, end=True))
+        evs.append(force_ev(21, i, data=rng.standard_normal(m) * 1e-3, force_type=1, width=900.0))
+    want = run_oracle(objs, evs, nb)
+    kw = dict(qnorm=qnorm, form=capi.FORM_BLOCK, time_chunk_shape=shape, bank_kernel=capi.BANK_BLOCK)
+    got = run_engine(objs, evs, nb, **kw)                                   # by policy (the pipeline kernel excluded)
+    info = got["info"]
+    assert info["total_time_chunk_launches"] == 1 and info["total_dense_increment_launches"] == 1 and info["last_time_chunk_shape"] == shape
+    _check(got, want, qnorm=qnorm != capi.QNORM_OFF)
+    for cb in (1, 5):
+        a = run_engine(objs, evs, nb, time_chunks=cb, **kw)
+        _check(a, want, qnorm=qnorm != capi.QNORM_OFF)
+        if cb == 1:
+            b = run_engine(objs, evs, nb, split=[3, 9, 12], time_chunks=cb, **kw)
+            assert b["info"]["total_dense_increment_launches"] == 3
+            assert np.array_equal(a["audio"], b["audio"])
+            for sa, sb in zip(a["state"], b["state"]):
+                assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])
