@@ -49,6 +49,10 @@ FLOP_PROJ_F32, FLOP_PROJ_BF16, FLOP_COARSE = 4.0, 12.0, 0.5
 # forced block path (dense force profiles): the state is stepped per sample (2 FMA + 1 add = 5 flop, + 2 with qnorm rows)
 # and projected on the matrix pipe (4 flop)
 FLOP_FORCED_STATE, FLOP_QNORM = 5.0, 2.0
+# ... or, without qnorm rows (nothing needs the state of every sample), a block at a time: the increments F . T_n of a block's 16
+# profile samples on the matrix pipe (2 products per mode-sample = 4 flop) + the coarse step with its two extra FMAs (6 FMA per
+# mode and 16 samples = 0.75 flop); round 5: kernels_pipe.hip iir_pipe5_kernel, kernels_block.hip FTM
+FLOP_FORCED_BLOCK = 4.0 + 0.75
 XGMI_LINK_GBPS = 153.0         # one xGMI link (point to point; 7 per GPU): the figure the task statement and the guide quote
 TOL_MAX, TOL_L2 = 5e-4, 1e-3   # stated fp32 tolerance vs the fp64 oracle
 DTYPE_OF_FORM = {
@@ -104,6 +108,7 @@ def parse(argv=None):
                          "(3.5 ms instead of 0.94), which would skew a profiler's per-kernel average over the default command")
     ap.add_argument("--no-strong-share", action="store_true",
                     help="one GPU: skip the strong-scaling proxy (the per-rank shares objects / 2, 4, 8 measured on this GPU)")
+    ap.add_argument("--share-repeats", type=int, default=3, help="one GPU: runs of every strong-share leg (min / median / max reported)")
     ap.add_argument("--strong", action="store_true",
                     help="make the strong-scaling leg the headline: --objects is the TOTAL, split over the ranks")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the nested strong-scaling measurement")
@@ -354,8 +359,12 @@ def measure(args, ctx, global_ids, want_parity):
             if world > 1 and ident[0] is None:
                 raise RuntimeError("no RCCL unique id from rank 0")
             counts_all = ctx.get("counts") or [n_obj]
+            # (a one-rank group gathers nothing by itself; PBSO_BENCH_GATHER_SELF=1 asks for the communicator and the collectives
+            #  all the same -- ncclCommInitRank, the in-place ncclAllGather, ncclSend / ncclRecv to itself, ncclAllReduce:
+            #  PBSO_GROUP_RCCL_ALWAYS -- so that the RCCL calls of group.cpp EXECUTE on a one-GPU box)
             grp = Group([ctx["dev_index"]], world_size=world, first_rank=rank, unique_id=ident[0], form=form_c, qnorm=qnorm_c,
-                        modes_per_lane=args.modes_per_lane, chunk_buffers=max(128, args.buffers))
+                        modes_per_lane=args.modes_per_lane, chunk_buffers=max(128, args.buffers),
+                        transport=capi.GROUP_RCCL_ALWAYS if world == 1 else capi.GROUP_RCCL)
             grp.plan([args.modes] * int(sum(counts_all)))
             assert grp.span(rank) == (global_ids[0], global_ids[-1] + 1), (grp.span(rank), global_ids[0], global_ids[-1])
         except Exception as ex:
@@ -541,25 +550,27 @@ def measure(args, ctx, global_ids, want_parity):
     import gc
     gc.collect()
     gc.disable()
-    for k in range(args.settle + args.warmup):
-        one_step(k, capture=(k == 0 and want_parity))     # (loads the copy kernel's code object outside the timed region)
-    drain()
-    torch.cuda.synchronize()
-    info0 = eng.info()
-    if ctx["use_dist"]:
-        dist.barrier()
-    torch.cuda.synchronize()
-    enqueue_s[0] = 0.0
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step(args.settle + args.warmup + k, capture=(k == 0 and want_parity))
-    drain()
-    torch.cuda.synchronize()
-    if ctx["use_dist"]:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
+    try:
+        for k in range(args.settle + args.warmup):
+            one_step(k, capture=(k == 0 and want_parity))     # (loads the copy kernel's code object outside the timed region)
+        drain()
+        torch.cuda.synchronize()
+        info0 = eng.info()
+        if ctx["use_dist"]:
+            dist.barrier()
+        torch.cuda.synchronize()
+        enqueue_s[0] = 0.0
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            one_step(args.settle + args.warmup + k, capture=(k == 0 and want_parity))
+        drain()
+        torch.cuda.synchronize()
+        if ctx["use_dist"]:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    finally:
+        gc.enable()                                       # (also when a step raises: the caller may run further legs)
     if ctx["use_dist"]:
         t = torch.tensor([elapsed], dtype=torch.float64, device=ctx["coll_dev"])
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -652,7 +663,8 @@ def measure(args, ctx, global_ids, want_parity):
             "pass": bool((mx <= TOL_MAX).all() and (l2 <= TOL_L2).all()),
         }
     res["_cpu_inputs"] = (lam, shapes, scripts)
-    res["collective_by"] = "pbso_group (C ABI: RCCL called from C++)" if use_group else (
+    res["collective_by"] = ("pbso_group (C ABI: RCCL called from C++" + ("; ONE rank: the collectives are issued on a one-rank communicator, "
+                            "nothing crosses a link)" if world == 1 else ")")) if use_group else (
         ("torch.distributed" + (" (pbso_group not used: %s)" % group_note if group_note else "")) if do_gather else None)
     (grp or eng).close()
     return res
@@ -763,7 +775,10 @@ def main():
             a3 = copy.copy(args)
             a3.objects = args.objects // n_ranks
             ctx["counts"] = [a3.objects]
-            shares.append((n_ranks, a3.objects, measure(a3, ctx, list(range(a3.objects)), want_parity=(not args.no_parity and rank == 0))))
+            # (three runs of every share, each a fresh engine: one hiccup -- a co-start collision, a host stall -- shows as such)
+            runs = [measure(a3, ctx, list(range(a3.objects)), want_parity=(not args.no_parity and rank == 0 and rep == 0))
+                    for rep in range(max(1, args.share_repeats))]
+            shares.append((n_ranks, a3.objects, runs))
         ctx["counts"] = [args.objects]
     # one GPU: the same scene stepped ONE SECOND of audio at a time (86 buffers per pbso_step: the step size of rounds 1 - 3 and of
     # SURVEY 8(d)'s parity runs) -- what a launch's fixed costs take when they are paid every second of audio instead of every ten
@@ -826,8 +841,8 @@ def main():
             # a small scene whose launches are mostly dense-profile buffers runs on the pipeline kernel K1p (kernels_pipe.hip); other
             # small scenes run the block kernel cut along the time axis behind a scan of buffer-start states (K5, kernels_scan.hip)
             small = block and 2 * info.get("total_split_launches", 0) > info["total_block_launches"]
-            small_kernel = "iir_pipe_kernel"
             dense = args.scenario == "scraping"
+            small_kernel = "iir_pipe5_kernel" if (dense and not qn_on) else "iir_pipe_kernel"
             per_s = 1.0 / (k_ms * 1e-3)
             if block and not bf16 and not dense:
                 work = {"f32_matrix_pipe": FLOP_PROJ_F32, "f32_vector_alu": FLOP_COARSE}
@@ -843,13 +858,27 @@ def main():
                         "bf16 halves) + 0.5 f32 flop of coarse recurrence on the vector ALU; the bf16 MFMA co-executes with the VALU, so min "
                         "time = max(12 x mode-samples / 2500 TFLOP/s, 0.5 x mode-samples / 157.3 TFLOP/s) = the matrix term; what the kernel "
                         "actually spends its time on is vector-ALU ISSUE (hi / lo split and packing of every block-start state: issue_utilisation)")
+            elif block and dense and not qn_on:
+                flop = FLOP_FORCED_BLOCK + FLOP_PROJ_F32
+                work = {"f32_matrix_pipe": 4.0 + FLOP_PROJ_F32, "f32_vector_alu": flop - 4.0 - FLOP_PROJ_F32}
+                peak, bound = F32_PEAK_TFLOPS, "mfma"
+                note = ("dense force profile every buffer, no qnorm rows: the state moves a block of 16 samples at a time -- the increments "
+                        "F . T_n on the f32 matrix pipe (4 flop per mode-sample), the coarse step x <- P x + g U_n on the vector ALU (0.75) -- "
+                        "and is projected on the matrix pipe (4 flop): 8.75 flop per mode-sample on the one f32 datapath.  "
+                        + ("Pipeline kernel, teams of five waves per 64 modes (kernels_pipe.hip, iir_pipe5_kernel): every increment is evaluated "
+                           "once, the buffers are walked in order" if small else
+                           "Cut in time (K5): the increments are evaluated TWICE, by dense_increment_kernel for the scan (not in kernel_ms) and "
+                           "by the bank"))
             elif block and dense:
-                flop = FLOP_FORCED_STATE + FLOP_PROJ_F32 + (FLOP_QNORM if qn_on else 0.0)
+                flop = FLOP_FORCED_STATE + FLOP_PROJ_F32 + FLOP_QNORM
                 work = {"f32_matrix_pipe": FLOP_PROJ_F32, "f32_vector_alu": flop - FLOP_PROJ_F32}
                 peak, bound = F32_PEAK_TFLOPS, "valu"
-                note = ("forced block path (dense force profile every buffer): per mode-sample the state is stepped literally on the vector ALU "
-                        "(2 FMA + 1 add, + 1 FMA with qnorm rows) and projected on the f32 matrix pipe (4 flop); 512 waves on 1024 SIMDs: the "
-                        "launch is bound by ONE wave's issue rate (one VALU instruction per 4 cycles), not by the chip's peak")
+                note = ("dense force profile every buffer, qnorm rows on: per mode-sample the state is stepped literally on the vector ALU "
+                        "(2 FMA + 1 add + 1 FMA for the sum of q^2 = 7 flop) and projected on the f32 matrix pipe (4 flop).  "
+                        + ("Cut in time (K5, round 5): dense_increment_kernel + the scan make the launch's chunks of buffers independent "
+                           "(their time is in device_pipeline_ms, not in kernel_ms), the bank runs one mode per lane, three waves per SIMD"
+                           if info.get("total_time_chunk_launches", 0) * 2 > info["total_block_launches"] else
+                           "512 waves on 1024 SIMDs: the launch is bound by ONE wave's issue rate, not by the chip's peak"))
             else:
                 flop, peak, bound = float(FLOP_REF), F32_PEAK_TFLOPS, "valu"
                 work = {"f32_vector_alu": flop}
@@ -906,6 +935,7 @@ def main():
             "value": hn["value"], "unit": "audio samples/s", "realtime_x": hn["realtime_x"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle,
             "ms_per_step": hn["ms_per_step"],
+            "value_step_seconds": nb * B / SAMPLE_RATE,      # seconds of audio per step of `value` (rounds 1 - 3: 1.0; since round 4: 10.0 -- `steps_of_one_second` carries the comparable figure)
             "higher_is_better": True, "scaling": head, "vs_baseline": None,
             "dtype": DTYPE_OF_FORM[args.form], "data": "synthetic",
             "hbm_frac": roof["hbm"]["frac"],
@@ -999,11 +1029,17 @@ def main():
                 rc = 3
         if shares:
             rows_s = []
-            for n_ranks, n_o, r in shares:
-                ln = leg_numbers("strong", r)
-                rows_s.append({"n_gpus": n_ranks, "objects": n_o, "ms_per_step": ln["ms_per_step"], "kernel_ms": r["kernel_ms"],
+            for n_ranks, n_o, runs in shares:
+                lns = sorted((leg_numbers("strong", r_) for r_ in runs), key=lambda d: d["ms_per_step"])
+                r = runs[0]                                   # (the run that carries the oracle check)
+                ln = lns[len(lns) // 2]                       # the median run
+                rows_s.append({"n_gpus": n_ranks, "objects": n_o, "ms_per_step": ln["ms_per_step"], "kernel_ms": float(np.median([r_["kernel_ms"] for r_ in runs])),
                                "realtime_x": ln["realtime_x"],
                                "implied_efficiency_at_N": hn["ms_per_step"] / n_ranks / ln["ms_per_step"],
+                               "runs": len(runs), "ms_per_step_min_median_max": [lns[0]["ms_per_step"], ln["ms_per_step"], lns[-1]["ms_per_step"]],
+                               "implied_efficiency_min_median_max": [hn["ms_per_step"] / n_ranks / lns[-1]["ms_per_step"],
+                                                                     hn["ms_per_step"] / n_ranks / ln["ms_per_step"],
+                                                                     hn["ms_per_step"] / n_ranks / lns[0]["ms_per_step"]],
                                "time_chunked_launches": r["info"].get("total_time_chunk_launches", 0),
                                "bank_launches": r["info"]["total_block_launches"] + r["info"]["total_sample_launches"],
                                "max_err": r.get("parity", {}).get("max_err"), "parity_pass": r.get("parity", {}).get("pass")})

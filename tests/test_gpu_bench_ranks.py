@@ -48,10 +48,12 @@ def test_two_ranks_on_one_gpu_print_one_line_with_gather_and_strong_leg():
 
 
 @pytest.mark.gpu
-def test_one_rank_under_torchrun_runs_the_rccl_gather_path():
+def test_one_rank_under_torchrun_issues_the_groups_collectives_on_a_one_rank_communicator():
     """the launcher the driver uses for N > 1 (python -m torch.distributed.run ... bench.py --gpus N), with N = 1 and
-    PBSO_BENCH_GATHER_SELF=1: backend nccl (= RCCL), init with device_id, the asynchronous double-buffered
-    all_gather_into_tensor beside the next step's oscillator bank, the equality check of the gathered rows"""
+    PBSO_BENCH_GATHER_SELF=1: backend nccl (= RCCL), and the device group in its PBSO_GROUP_RCCL_ALWAYS transport -- librccl
+    loaded, ncclCommInitRank for ONE rank, and every leg's collective ISSUED on it (in-place ncclAllGather; ncclSend / ncclRecv to
+    itself; ncclAllReduce) beside the next step's oscillator bank.  What it cannot show is traffic: with one rank nothing crosses a
+    link (bytes_received_per_rank == 0); the ranks' LOGIC at world 2, 3, 8 is tests/test_group.py's loopback transport"""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PBSO_BENCH_GATHER_SELF="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PBSO_BENCH_BACKEND"):
         env.pop(k, None)
