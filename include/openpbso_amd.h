@@ -140,6 +140,9 @@ typedef struct pbso_engine_desc {
                                * while the device is idle does -- nothing to overlap with, one stream hand-over less) */
     /* ---- ABI 5 */
     int time_chunk_shape;     /* modes per lane of the teams of a time-chunked launch: 0 policy, 1 / 2 / 4 (A/B runs) */
+    int scan_kernel;          /* K5's scan of chunk-start states: 0 policy (cut along the time axis itself -- one wave per chunk, the chunks' affine
+                               * maps composed in LDS -- for launches of 2 .. 8 chunks of more than one buffer), 1 always the serial scan,
+                               * 2 the segmented one wherever the launch has 2 .. 8 chunks */
 } pbso_engine_desc;
 
 enum pbso_bank_kernel {
@@ -455,6 +458,7 @@ typedef struct pbso_engine_info {
     /* ---- ABI 5 */
     int64_t total_dense_increment_launches; /* of the time-chunked launches, those with dense-profile buffers (Gaussian / AR: forces.h:92-128):
                                        * dense_increment_kernel evaluated what each leaves in the state, all of them at once      */
+    int64_t total_segmented_scans;    /* ... whose scan of chunk-start states ran cut along the time axis (one wave per chunk)             */
     int last_time_chunk_shape;        /* the last time-chunked launch: modes per lane of its teams (0: none yet), ...              */
     int last_time_chunk_buffers;      /* ... buffers per chunk, ...                                                               */
     int last_time_chunk_teams;        /* ... and teams per chunk (its census has teams x chunks rows, chunk-major)                */

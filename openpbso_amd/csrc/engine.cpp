@@ -424,6 +424,7 @@ int Engine::init() {
     if (desc_.chunk_buffers > 0) chunk_buffers_ = desc_.chunk_buffers;
     tc_mode_ = desc_.time_chunks;
     tc_shape_ = desc_.time_chunk_shape;
+    if (desc_.scan_kernel < 0 || desc_.scan_kernel > 2) return fail(PBSO_ERR_INVALID, "scan_kernel");
     return PBSO_OK;
 }
 
@@ -2275,7 +2276,8 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     LAUNCHTRY(launch_scatter_rows(d_stage, d_stage_slot, (int)stage_slot_.size(), d_slots_.p, m_pad_, sp));
     LAUNCHTRY(launch_modal_project(d_proj, (int)proj_.size(), d_shapes_.p, d_shape_off_.p, d_n_modes_.p, d_slots_.p, m_pad_, sp));
     // (a few events: one thread per (event, mode); listener paths -- many events per object -- by runs)
-    if (ffat_.size() >= 4 * ffat_runs_.size() && !ffat_runs_.empty())
+    // (the run form puts the runs on grid.y: at most 65535 of them -- a larger launch takes the per-event form)
+    if (ffat_.size() >= 4 * ffat_runs_.size() && !ffat_runs_.empty() && ffat_runs_.size() <= 65535)
         LAUNCHTRY(launch_ffat_lookup_runs(d_ffat, reinterpret_cast<const FfatRun *>(da + o_ffat_runs), (int)ffat_runs_.size(), d_geom_.p,
                                           d_geom_off_.p, d_n_modes_.p, d_psi_.p, d_xfer_.p, m_pad_, sp));
     else
@@ -2302,7 +2304,11 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
             tot_tc_dense_launches_ += 1;
         }
         if (!last_launch_tc_ && last_set_ >= 0) HIPTRY(hipStreamWaitEvent(sp, ev_k1_done_[last_set_], 0));
-        LAUNCHTRY(launch_iir_scan(kp, N, d_scan_.p, tc_cb, n_chunks, d_xs_[cur_set_].p, d_xtrow_[cur_set_].p, direct_hits_, vinc, sp));
+        // (cut along the time axis itself when the launch has a few long chunks; one buffer per chunk keeps the serial scan, whose
+        //  arithmetic does not depend on where a step is cut)
+        const bool seg = n_chunks >= 2 && n_chunks <= SCAN_SEG_MAX && desc_.scan_kernel != 1 && (tc_cb > 1 || desc_.scan_kernel == 2);
+        if (seg) tot_seg_scans_ += 1;
+        LAUNCHTRY(launch_iir_scan(kp, N, d_scan_.p, tc_cb, n_chunks, d_xs_[cur_set_].p, d_xtrow_[cur_set_].p, direct_hits_, vinc, seg, sp));
     }
     // ---- compute stream: the bank after its preparation (and, stream order, after the previous bank)
     if (one_stream) {
@@ -2809,6 +2815,7 @@ int Engine::info(pbso_engine_info *out) {
     out->total_split_launches = tot_split_launches_;
     out->total_time_chunk_launches = tot_tc_launches_;
     out->total_dense_increment_launches = tot_tc_dense_launches_;
+    out->total_segmented_scans = tot_seg_scans_;
     out->last_time_chunk_shape = last_tc_shape_;
     out->last_time_chunk_buffers = last_tc_cb_;
     out->last_time_chunk_teams = last_tc_teams_;

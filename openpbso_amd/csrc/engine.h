@@ -313,7 +313,7 @@ private:
     DevBuf<int> d_xtrow_[N_SETS];                        // [n_obj][n_chunks] the transfer row in force there
     DevBuf<float> d_vinc_[N_SETS];                       // [n_prows][m_pad] pairs: the increments of the launch's dense-profile buffers (dense_increment_kernel)
     int tc_shape_ = 0;                                   // pbso_engine_desc::time_chunk_shape: 0 policy, 1 / 2 / 4 modes per lane in time-chunked launches
-    int64_t tot_tc_dense_launches_ = 0;
+    int64_t tot_tc_dense_launches_ = 0, tot_seg_scans_ = 0;
     int last_tc_shape_ = 0, last_tc_cb_ = 0, last_tc_teams_ = 0;
     bool last_launch_tc_ = false;                        // the previous launch was time-chunked (its bank did not write the state)
     int last_set_ = -1;

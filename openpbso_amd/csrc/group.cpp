@@ -423,6 +423,10 @@ int pbso_group_step(pbso_group *g, int nb) {
     return PBSO_OK;
 }
 
+// point-to-point transfers in pieces of at most 256 MB: a 1.8 GB ncclSend / ncclRecv pair of a rank to itself (1024 objects x ten seconds
+// of audio) came back WRONG on RCCL 2.26.6 while 0.45 GB was right (profiles/r05 bench_1rank.err); sender and receiver cut alike
+static constexpr size_t P2P_MAX = (size_t)64 << 20;      // floats
+
 int pbso_group_gather(pbso_group *g, int mode) {
     if (!g || !g->stepped) return gfail(g, PBSO_ERR_STATE, "gather before step");
     if (mode != PBSO_GATHER_ALL && mode != PBSO_GATHER_ROOT && mode != PBSO_GATHER_MIX) return gfail(g, PBSO_ERR_INVALID, "gather mode");
@@ -456,12 +460,18 @@ int pbso_group_gather(pbso_group *g, int mode) {
             } else if (g->world == 1) {
                 // (PBSO_GROUP_RCCL_ALWAYS: the root's receive and a rank's send, both on the one rank there is -- the rows land in
                 //  the scratch rows, which is what pbso_group_result_device_ptr then hands out)
-                GNCCL_OPEN(g, g_rccl.Send(mine, blk, ncclFloat, 0, rk.comm, rk.coll));
-                GNCCL_OPEN(g, g_rccl.Recv(rk.scratch, blk, ncclFloat, 0, rk.comm, rk.coll));
+                for (size_t o = 0; o < blk; o += P2P_MAX) {
+                    const size_t n = std::min(P2P_MAX, blk - o);
+                    GNCCL_OPEN(g, g_rccl.Send(mine + o, n, ncclFloat, 0, rk.comm, rk.coll));
+                    GNCCL_OPEN(g, g_rccl.Recv(rk.scratch + o, n, ncclFloat, 0, rk.comm, rk.coll));
+                }
             } else if (rk.rank == 0) {
-                for (int r = 1; r < g->world; ++r) GNCCL_OPEN(g, g_rccl.Recv(base + (size_t)r * blk, blk, ncclFloat, r, rk.comm, rk.coll));
+                for (int r = 1; r < g->world; ++r)
+                    for (size_t o = 0; o < blk; o += P2P_MAX)
+                        GNCCL_OPEN(g, g_rccl.Recv(base + (size_t)r * blk + o, std::min(P2P_MAX, blk - o), ncclFloat, r, rk.comm, rk.coll));
             } else {
-                GNCCL_OPEN(g, g_rccl.Send(mine, blk, ncclFloat, 0, rk.comm, rk.coll));
+                for (size_t o = 0; o < blk; o += P2P_MAX)
+                    GNCCL_OPEN(g, g_rccl.Send(mine + o, std::min(P2P_MAX, blk - o), ncclFloat, 0, rk.comm, rk.coll));
             }
         }
         GNCCL(g, g_rccl.GroupEnd());

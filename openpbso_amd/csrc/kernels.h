@@ -156,8 +156,11 @@ int launch_listener_mix(const float *xdump, const float *xscale, const float *wt
 // [n_obj][m_pad] (stride gq_plane): A^513 as (P11 - 1, P12, P21, P22), then A^512 u.  Writes the state at the first buffer of
 // every chunk of cb buffers to xs, the transfer row in force there to xtrow, and the launch's end state to sq / sd / ss.
 // vinc: the increments of the launch's dense-profile buffers (launch_dense_increments), or nullptr when it has none
+// segmented (2 <= n_chunks <= SCAN_SEG_MAX): one wave per chunk scans its own buffers as an affine map of the state, the maps are
+// composed in LDS -- the depth of the longest chunk instead of the launch's
+constexpr int SCAN_SEG_MAX = 8;
 int launch_iir_scan(const IirParams &p, int n_obj, const float *sc, int cb, int n_chunks, float *xs, int *xtrow, bool direct,
-                    const float *vinc, hipStream_t stream);
+                    const float *vinc, bool segmented, hipStream_t stream);
 // vinc[row][m_pad] pairs (q, d): what a unit force gain with the dense time profile tprof[row] leaves in every mode's state over one
 // buffer, from rest (row_obj[row] = the object the row belongs to; pc / ftab: planes of P = A^16 and of A^(15-i) u, stride `plane`)
 int launch_dense_increments(const float *pc, const float *ftab, long long plane, const float *tprof, const int *row_obj,

@@ -975,6 +975,7 @@ int launch_ffat_lookup_runs(const FfatEvent *events, const FfatRun *runs, int n_
                             const long long *geom_off, const int *n_modes, const double *psi,
                             double *rows, int m_pad, hipStream_t stream) {
     if (n_runs <= 0) return 0;
+    if (n_runs > 65535) return (int)hipErrorInvalidValue;     // (runs sit on grid.y; the engine sends larger launches through launch_ffat_lookup)
     hipLaunchKernelGGL(ffat_lookup_runs_kernel, dim3(m_pad, n_runs), dim3(128), 0, stream, events, runs, geom, geom_off,
                        n_modes, psi, rows, m_pad);
     return (int)hipGetLastError();

@@ -289,6 +289,180 @@ __global__ __launch_bounds__(64) void iir_scan_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The scan cut along the time axis itself (round 5).  The serial scan above takes ~0.1 us per buffer and, beside a bank that
+// holds every register of the chip, cannot start before that bank retires: a launch of 860 buffers leaves ~90 us between two
+// banks (128 x 512 x 860: 1.32 ms per step against a 1.22 ms bank).  A chunk of buffers is an AFFINE map of the state,
+//     x_end = M x_start + v,      M = (A^513)^(buffers stepped),  v = what the chunk's forces leave behind from rest,
+// so one wave per CHUNK scans three vectors side by side -- the zero-state response (with the gains) and the images of the two
+// basis vectors (without) -- over its own buffers only, the waves of a workgroup (one per chunk, same 64 columns) leave (M, v) in
+// LDS, and every wave composes the maps of the chunks before its own: n_chunks - 1 steps of six FMAs.  860 buffers in 8
+// chunks: the depth of a 108-buffer scan.  The three chains are independent (same latency as one); M comes from the same f32
+// steps the serial scan takes, applied to (1, 0) and (0, 1).  Used when a launch has 2 .. 8 chunks (the policy's long chunks); one
+// buffer per chunk keeps the serial scan, whose arithmetic does not depend on where a step is cut.
+constexpr int SEG_B = 16;        // buffers per batch of a wave (lane = buffer for the decode: 16 lanes)
+constexpr int SEG_MAX = 8;       // chunks (= waves per workgroup)
+
+template <bool DIRECT, bool DENSE>
+__global__ __launch_bounds__(64 * SEG_MAX) void iir_scan_seg_kernel(
+    float *__restrict__ p_sq, float *__restrict__ p_sd, float *__restrict__ p_ss, const float *__restrict__ p_sc,
+    const BufDesc *__restrict__ p_desc, const float *__restrict__ p_grows, const float *__restrict__ p_g32,
+    const long long *__restrict__ p_g32_off, const float *__restrict__ p_vinc, const int *__restrict__ p_xfer_init,
+    float *__restrict__ p_xs, int *__restrict__ p_xtrow, const ScanDims p) {
+    __shared__ __attribute__((aligned(16))) float lds_g[SEG_MAX][2 * SEG_B][64];     // per wave: [buffer of the batch][q | d][mode]: what the hit adds to the state
+    __shared__ float lds_map[SEG_MAX][6][64];        // per chunk: M e1, M e2, v
+    __shared__ int lds_row[SEG_MAX][2];              // per chunk: did a buffer set the transfer row, and the last one set
+    const int tiles = p.m_pad / 64;
+    const int obj = blockIdx.x / tiles;
+    const int col0 = 64 * (blockIdx.x % tiles);
+    const unsigned lane = threadIdx.x & 63u;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // the chunk
+    const size_t ubase = (size_t)obj * p.m_pad + col0;
+    const float s11 = (p_sc + ubase)[lane], s12 = (p_sc + p.plane + ubase)[lane];     // A^513: P11 - 1, P12, P21, P22
+    const float s21 = (p_sc + 2 * p.plane + ubase)[lane], s22 = (p_sc + 3 * p.plane + ubase)[lane];
+    const float hq = (p_sc + 4 * p.plane + ubase)[lane], hd = (p_sc + 5 * p.plane + ubase)[lane];      // A^512 u
+    const BufDesc *__restrict__ dsc = p_desc + (size_t)obj * p.nb;
+    const float *__restrict__ g32_obj = DIRECT ? p_g32 + (size_t)p_g32_off[obj] * p.m_pad + col0 : nullptr;
+    constexpr int NR = DIRECT ? 3 : 1;
+    auto rl = [](int v, int j) { return __builtin_amdgcn_readlane(v, j); };
+    auto rlf = [](float v, int j) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j)); };
+    auto rlp = [&](unsigned long long v, int j) {
+        const unsigned lo = (unsigned)rl((int)(unsigned)v, j), hi = (unsigned)rl((int)(unsigned)(v >> 32), j);
+        return (gptr)(((unsigned long long)hi << 32) | lo);
+    };
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    const int b_lo = wv * p.cb, b_hi = b_lo + p.cb < p.nb ? b_lo + p.cb : p.nb;
+    f2 xz = f2{0.f, 0.f}, xa = f2{1.f, 0.f}, xb = f2{0.f, 1.f};
+    int has_set = 0, last_row = XFER_KEEP;
+    float (*lg)[64] = lds_g[wv];
+    for (int base = b_lo; base < b_hi; base += SEG_B) {
+        const int nd = b_hi - base < SEG_B ? b_hi - base : SEG_B;
+        // ---- lane = buffer base + lane (lanes 0 .. nd - 1): as the serial scan's stage (1)
+        unsigned long long ptr[NR];
+        float w[NR];
+        int trow, prow;
+        unsigned hit_mask, skip_mask, dense_mask;
+        {
+            const bool in = (int)lane < nd;
+            const i4 *src = reinterpret_cast<const i4 *>(dsc + (in ? base + (int)lane : base));
+            const i4 dlo = src[0], dhi = src[1];
+            const int frow = dlo.x, w_prow = dlo.y, w_mask = dlo.z, w_amp = dlo.w, w_pad0 = dhi.z;
+            const unsigned flags = (unsigned)dhi.y;
+            const bool skip = in && (flags & DESC_SKIP) != 0;
+            const bool live = in && frow >= 0 && !(flags & DESC_SKIP);
+            const bool impulse = (flags & DESC_IMPULSE) != 0;
+            const bool direct = DIRECT && (flags & DESC_DIRECT) != 0;
+            const bool hit0 = direct || (w_mask & 1);
+            const float a = impulse ? (hit0 ? __builtin_bit_cast(float, w_amp) : 0.f) : 1.f;
+            const bool dl = live && direct;
+            const float *r0 = dl ? g32_obj + (size_t)frow * p.m_pad : p_grows + (size_t)(live ? frow : 0) * p.m_pad + col0;
+            ptr[0] = (unsigned long long)r0;
+            w[0] = dl ? a * __builtin_bit_cast(float, w_prow) : a;
+            if constexpr (DIRECT) {
+                ptr[1] = (unsigned long long)(dl ? r0 + p.m_pad : r0);
+                ptr[2] = (unsigned long long)(dl ? r0 + 2 * (size_t)p.m_pad : r0);
+                w[1] = dl ? a * __builtin_bit_cast(float, w_mask) : 0.f;
+                w[2] = dl ? a * __builtin_bit_cast(float, w_pad0) : 0.f;
+            }
+            trow = dhi.x;
+            prow = direct ? -1 : w_prow;
+            hit_mask = (unsigned)__ballot(live && (a != 0.f || !impulse));
+            skip_mask = (unsigned)__ballot(skip);
+            dense_mask = (unsigned)__ballot(live && !impulse);
+            const unsigned set_mask = (unsigned)__ballot(in && !skip && trow != XFER_KEEP);
+            if (set_mask) {
+                has_set = 1;
+                last_row = rl(trow, 31 - __builtin_clz(set_mask));
+            }
+        }
+        // ---- what every hit adds to the state, [buffer][q | d][mode]
+        wave_sync();
+        for (int i = 0; i < 2 * nd; ++i) lg[i][lane] = 0.f;
+        wave_sync();
+        {
+            // the batch's rows, all loads issued before the first is used (a hit per ~4 buffers: a handful per batch)
+            float r[SEG_B][NR];
+            f2 vv[DENSE ? SEG_B : 1];
+#pragma unroll
+            for (int j = 0; j < SEG_B; ++j) {
+                if ((hit_mask >> j) & 1) {
+                    static_for<0, NR>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        r[j][k] = rlp(ptr[k], j)[lane];
+                    });
+                    if constexpr (DENSE) {
+                        if ((dense_mask >> j) & 1) vv[j] = (reinterpret_cast<const f2 *>(p_vinc) + (size_t)rl(prow, j) * p.m_pad + col0)[lane];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < SEG_B; ++j) {
+                if ((hit_mask >> j) & 1) {
+                    float gv = rlf(w[0], j) * r[j][0];
+                    if constexpr (DIRECT) {
+                        gv = fmaf(rlf(w[NR > 1 ? 1 : 0], j), r[j][NR > 1 ? 1 : 0], gv);
+                        gv = fmaf(rlf(w[NR > 2 ? 2 : 0], j), r[j][NR > 2 ? 2 : 0], gv);
+                    }
+                    float aq = hq, ad = hd;          // what a unit gain adds: A^512 u (impulse), the increment row (dense)
+                    if constexpr (DENSE) {
+                        if ((dense_mask >> j) & 1) { aq = vv[j].x; ad = vv[j].y; }
+                    }
+                    lg[2 * j][lane] = gv * aq;
+                    lg[2 * j + 1][lane] = gv * ad;
+                }
+            }
+        }
+        wave_sync();
+        // ---- the three chains
+        auto step = [&](f2 v, float gq, float gd) {
+            const float qa = fmaf(s11, v.x, v.x), qb = fmaf(s12, v.y, gq);
+            const float da = s21 * v.x, db = fmaf(s22, v.y, gd);
+            return f2{qa + qb, da + db};
+        };
+        for (int j = 0; j < nd; ++j) {
+            if ((skip_mask >> j) & 1) continue;      // step() returned before stepping: state untouched
+            xz = step(xz, lg[2 * j][lane], lg[2 * j + 1][lane]);
+            xa = step(xa, 0.f, 0.f);
+            xb = step(xb, 0.f, 0.f);
+        }
+    }
+    lds_map[wv][0][lane] = xa.x; lds_map[wv][1][lane] = xa.y;
+    lds_map[wv][2][lane] = xb.x; lds_map[wv][3][lane] = xb.y;
+    lds_map[wv][4][lane] = xz.x; lds_map[wv][5][lane] = xz.y;
+    if (lane == 0) { lds_row[wv][0] = has_set; lds_row[wv][1] = last_row; }
+    __syncthreads();
+    // ---- compose the maps of the chunks in front of this one
+    f2 x;
+    {
+        const float s0 = (p_ss + ubase)[lane];       // the arrays hold scale x state (kernels_iir.hip, "scaled state")
+        x.x = (p_sq + ubase)[lane] / s0;
+        x.y = (p_sd + ubase)[lane] / s0;
+    }
+    auto apply = [&](int c, f2 v) {
+        const float q = fmaf(lds_map[c][0][lane], v.x, fmaf(lds_map[c][2][lane], v.y, lds_map[c][4][lane]));
+        const float d = fmaf(lds_map[c][1][lane], v.x, fmaf(lds_map[c][3][lane], v.y, lds_map[c][5][lane]));
+        return f2{q, d};
+    };
+    int row = p_xfer_init[obj];
+    for (int c = 0; c < wv; ++c) {
+        x = apply(c, x);
+        if (lds_row[c][0]) row = lds_row[c][1];
+    }
+    (reinterpret_cast<f2 *>(p_xs) + ((size_t)obj * p.n_chunks + wv) * p.m_pad + col0)[lane] = x;
+    if (col0 == 0 && lane == 0) p_xtrow[(size_t)obj * p.n_chunks + wv] = row;
+    __syncthreads();                                 // (every wave has read the launch's start state)
+    if (wv == p.n_chunks - 1) {
+        x = apply(wv, x);
+        (p_sq + ubase)[lane] = x.x;
+        (p_sd + ubase)[lane] = x.y;
+        (p_ss + ubase)[lane] = 1.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // dense_increment_kernel: V[row][mode] = sum_{k=0..512} A^(512-k) u T_row[k], the state a unit force gain with the dense time
 // profile of row `row` (one (object, buffer) of the launch: ProfRow, kernels.h) leaves behind from rest -- for ALL dense rows of
 // a launch at once: grid (tiles of NW x 64 columns, groups of RB rows), one wave per (64 columns, group of rows).
@@ -411,11 +585,27 @@ int launch_dense_increments(const float *pc, const float *ftab, long long plane,
 }
 
 int launch_iir_scan(const IirParams &p, int n_obj, const float *sc, int cb, int n_chunks, float *xs, int *xtrow, bool direct,
-                    const float *vinc, hipStream_t stream) {
+                    const float *vinc, bool segmented, hipStream_t stream) {
     if (n_obj <= 0 || p.nb <= 0) return 0;
     if (cb <= 0 || n_chunks != (p.nb + cb - 1) / cb || p.m_pad % 64) return (int)hipErrorInvalidValue;
     const iir_scan::ScanDims dims = {p.nb, cb, n_chunks, p.m_pad, p.b_pad, p.frames, p.gq_plane};
     const dim3 grid((unsigned)((size_t)(p.m_pad / 64) * n_obj)), block(64);
+    if (segmented) {
+        if (n_chunks < 2 || n_chunks > iir_scan::SEG_MAX) return (int)hipErrorInvalidValue;
+        const dim3 bseg(64 * n_chunks);
+#define PBSO_SCAN_SEG(DIRECT, DENSE)                                                                                             \
+    hipLaunchKernelGGL((iir_scan::iir_scan_seg_kernel<DIRECT, DENSE>), grid, bseg, 0, stream, p.sq, p.sd, p.ss, sc, p.desc, p.grows, p.g32, \
+                       p.g32_off, vinc, p.xfer_init, xs, xtrow, dims)
+        if (vinc) {
+            if (direct) PBSO_SCAN_SEG(true, true);
+            else PBSO_SCAN_SEG(false, true);
+        } else {
+            if (direct) PBSO_SCAN_SEG(true, false);
+            else PBSO_SCAN_SEG(false, false);
+        }
+#undef PBSO_SCAN_SEG
+        return (int)hipGetLastError();
+    }
 #define PBSO_SCAN_LAUNCH(DIRECT, DENSE)                                                                                          \
     hipLaunchKernelGGL((iir_scan::iir_scan_kernel<DIRECT, DENSE>), grid, block, 0, stream, p.sq, p.sd, p.ss, sc, p.desc, p.grows, p.g32, \
                        p.g32_off, vinc, p.xfer_init, xs, xtrow, dims)

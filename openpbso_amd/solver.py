@@ -133,7 +133,7 @@ def _select_from_env():
 SELECT_FIELDS = ("bank_kernel", "time_chunks", "direct_hits", "forced_block", "dense_launches", "device_profiles",
                  "profile_kernel", "profile_margin_pct", "profile_priority", "team_waves", "pipe_consumers",
                  "pipe_max_teams", "chunk_buffers", "plan_threads", "plan_pin", "timing_every", "warm_copies", "stream_sync", "latency_path",
-                 "time_chunk_shape")
+                 "time_chunk_shape", "scan_kernel")
 
 
 def fill_engine_desc(d, device, form, qnorm, modes_per_lane, stream, frames_per_buffer, select):

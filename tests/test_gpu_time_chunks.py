@@ -368,3 +368,33 @@ def test_dense_launches_cut_in_time_every_team_shape(shape, qnorm):
             assert np.array_equal(a["audio"], b["audio"])
             for sa, sb in zip(a["state"], b["state"]):
                 assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])
+
+
+@pytest.mark.parametrize("qnorm", [capi.QNORM_ALL, capi.QNORM_OFF])
+@pytest.mark.parametrize("cb", [2, 3, 7, 16])
+def test_scan_cut_along_the_time_axis_equals_the_serial_scan(cb, qnorm):
+    """round 5: the scan of chunk-start states itself cut in time (kernels_scan.hip, iir_scan_seg_kernel: one wave per chunk scans its
+    buffers as an affine map of the state -- the zero-state response and the images of the two basis vectors --, the maps are
+    composed in LDS).  Every buffer kind (impulses, direct hits, a Gaussian, sustained AR contact with its dense increments, a
+    clear, listener moves with a zero weight), chunk lengths that give 1 .. 8 chunks, launch cuts: against the oracle, and against
+    the serial scan of the same engine settings within rounding"""
+    nb = 16
+    objs, evs = _every_kind_scene(nb)
+    want = run_oracle(objs, evs, nb)
+    n_chunks = (nb + cb - 1) // cb
+    for split in (None, [9, 7]):
+        seg = run_engine(objs, evs, nb, split=split, qnorm=qnorm, time_chunks=cb, scan_kernel=2)
+        ser = run_engine(objs, evs, nb, split=split, qnorm=qnorm, time_chunks=cb, scan_kernel=1)
+        launches = 1 if split is None else 2
+        assert seg["info"]["total_time_chunk_launches"] == launches and ser["info"]["total_segmented_scans"] == 0
+        if split is None:
+            assert seg["info"]["total_segmented_scans"] == (1 if 2 <= n_chunks <= 8 else 0)
+        _check(seg, want, qnorm=qnorm != capi.QNORM_OFF)
+        _check(ser, want, qnorm=qnorm != capi.QNORM_OFF)
+        mx, _ = rel_errors(seg["audio"], ser["audio"])
+        assert mx.max() <= 2e-5, mx.max()
+    # by policy: chunks of several buffers take it, one buffer per chunk keeps the serial scan (bit-identical for any cut)
+    pol = run_engine(objs, evs, nb, qnorm=qnorm, time_chunks=cb)
+    assert pol["info"]["total_segmented_scans"] == (1 if 2 <= n_chunks <= 8 else 0)
+    one = run_engine(objs, evs, nb, qnorm=qnorm, time_chunks=1, split=[8, 8])
+    assert one["info"]["total_segmented_scans"] == 0
