@@ -141,8 +141,9 @@ typedef struct pbso_engine_desc {
     /* ---- ABI 5 */
     int time_chunk_shape;     /* modes per lane of the teams of a time-chunked launch: 0 policy, 1 / 2 / 4 (A/B runs) */
     int scan_kernel;          /* K5's scan of chunk-start states: 0 policy (cut along the time axis itself -- one wave per chunk, the chunks' affine
-                               * maps composed in LDS -- for launches of 2 .. 8 chunks of more than one buffer), 1 always the serial scan,
-                               * 2 the segmented one wherever the launch has 2 .. 8 chunks */
+                               * maps composed in LDS -- for launches of 2 .. 8 chunks of more than one buffer whose whole scan is a few hundred
+                               * waves: it shortens a lone scan, not a throughput-bound one), 1 always the serial scan, 2 the segmented one
+                               * wherever the launch has 2 .. 8 chunks */
 } pbso_engine_desc;
 
 enum pbso_bank_kernel {

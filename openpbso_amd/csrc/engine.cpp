@@ -2304,9 +2304,15 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
             tot_tc_dense_launches_ += 1;
         }
         if (!last_launch_tc_ && last_set_ >= 0) HIPTRY(hipStreamWaitEvent(sp, ev_k1_done_[last_set_], 0));
-        // (cut along the time axis itself when the launch has a few long chunks; one buffer per chunk keeps the serial scan, whose
-        //  arithmetic does not depend on where a step is cut)
-        const bool seg = n_chunks >= 2 && n_chunks <= SCAN_SEG_MAX && desc_.scan_kernel != 1 && (tc_cb > 1 || desc_.scan_kernel == 2);
+        // Cut along the time axis itself -- one wave per chunk -- when the launch has a few long chunks AND the whole scan is a
+        // handful of waves: it halves the latency of a scan that has the device to itself (1 x 512 x 86: 11.3 -> 5.7 us), but it
+        // carries n_chunks times the waves of the serial scan, and where the scan is throughput-bound -- beside or behind a bank of a
+        // larger scene -- that made the strong-scaling shares SLOWER (256 x 512 x 86: 0.273 -> 0.290 ms per step, 512 x 512 x 860:
+        // 4.98 -> 5.27; scripts/debug/r05_shares.sh).  One buffer per chunk keeps the serial scan, whose arithmetic does not depend
+        // on where a step is cut.
+        const bool seg_fits = n_chunks >= 2 && n_chunks <= SCAN_SEG_MAX;
+        const bool seg = seg_fits && desc_.scan_kernel != 1 &&
+                         (desc_.scan_kernel == 2 || (tc_cb > 1 && (long long)N * (m_pad_ / 64) * n_chunks <= 2LL * n_cus_));
         if (seg) tot_seg_scans_ += 1;
         LAUNCHTRY(launch_iir_scan(kp, N, d_scan_.p, tc_cb, n_chunks, d_xs_[cur_set_].p, d_xtrow_[cur_set_].p, direct_hits_, vinc, seg, sp));
     }

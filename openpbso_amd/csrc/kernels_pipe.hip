@@ -620,8 +620,17 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __shared__ __attribute__((aligned(16))) float lds_t_[2][QN ? 4 : 1][2 * GROUP];   // [slice][buffer & 3]: T_1 .. T_512 for the qnorm chains
     __shared__ int lds_flag_[2];                     // buffers whose increments P has taken into registers
     const int wave_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifndef PBSO_PIPE5_ORDER
+#define PBSO_PIPE5_ORDER 2
+#endif
+#if PBSO_PIPE5_ORDER == 1        // P0 A0 B0 C0 | P1 A1 B1 C1 | D0 D1
     const int slice = wave_wg < 8 ? wave_wg >> 2 : wave_wg - 8;
     const int wave = wave_wg < 8 ? (wave_wg & 3) : 4;                             // the role: 0 P, 1 A, 2 B, 3 C, 4 D
+#else                            // P0 P1 B0 B1 | A1 A0 C0 C1 | D1 D0: every SIMD two matrix waves (A + D = B + C = 68 MFMAs), the P on top
+    //                                  w:  0  1  2  3  4  5  6  7  8  9
+    const int slice = (0x19Au >> wave_wg) & 1;                                    // 0  1  0  1  1  0  0  1  1  0
+    const int wave = (int)((0x4433112200ull >> (4 * wave_wg)) & 15);             // 0  0  2  2  1  1  3  3  4  4
+#endif
     float (*lds_stage)[2][ST5_AREA] = lds_stage_[slice];
     float (*lds_u)[64 * U_ROW] = lds_u_[slice];
     f2 (*lds_raw)[8][64] = lds_raw_[slice];
