@@ -2305,11 +2305,11 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         }
         if (!last_launch_tc_ && last_set_ >= 0) HIPTRY(hipStreamWaitEvent(sp, ev_k1_done_[last_set_], 0));
         // Cut along the time axis itself -- one wave per chunk -- when the launch has a few long chunks AND the whole scan is a
-        // handful of waves: it halves the latency of a scan that has the device to itself (1 x 512 x 86: 11.3 -> 5.7 us), but it
-        // carries n_chunks times the waves of the serial scan, and where the scan is throughput-bound -- beside or behind a bank of a
-        // larger scene -- that made the strong-scaling shares SLOWER (256 x 512 x 86: 0.273 -> 0.290 ms per step, 512 x 512 x 860:
-        // 4.98 -> 5.27; scripts/debug/r05_shares.sh).  One buffer per chunk keeps the serial scan, whose arithmetic does not depend
-        // on where a step is cut.
+        // handful of waves: it halves the latency of a scan that has the device to itself (1 x 512 x 86: 11.3 -> 5.7 us).  It does
+        // NOT shorten the scans of larger scenes: those are bound by gathering the hits' gain rows (three table rows per hit and 64
+        // columns: 155 MB for 128 x 512 x 860), not by the chain -- 128 x 512 x 860: 100 - 125 us serial, 138 - 157 us segmented, both
+        // run only once the bank's first workgroups retire (scripts/debug/r05_timeline_share.sh); the 512-object share got slower
+        // (4.98 -> 5.12 ms per step).  One buffer per chunk keeps the serial scan, whose arithmetic does not depend on where a step is cut.
         const bool seg_fits = n_chunks >= 2 && n_chunks <= SCAN_SEG_MAX;
         const bool seg = seg_fits && desc_.scan_kernel != 1 &&
                          (desc_.scan_kernel == 2 || (tc_cb > 1 && (long long)N * (m_pad_ / 64) * n_chunks <= 2LL * n_cus_));

@@ -293,11 +293,10 @@ __global__ __launch_bounds__(64) void iir_scan_kernel(
 // holds every register of the chip, cannot start before that bank retires: a launch of 860 buffers leaves ~90 us between two
 // banks (128 x 512 x 860: 1.32 ms per step against a 1.22 ms bank).  A chunk of buffers is an AFFINE map of the state,
 //     x_end = M x_start + v,      M = (A^513)^(buffers stepped),  v = what the chunk's forces leave behind from rest,
-// so one wave per CHUNK scans three vectors side by side -- the zero-state response (with the gains) and the images of the two
-// basis vectors (without) -- over its own buffers only, the waves of a workgroup (one per chunk, same 64 columns) leave (M, v) in
-// LDS, and every wave composes the maps of the chunks before its own: n_chunks - 1 steps of six FMAs.  860 buffers in 8
-// chunks: the depth of a 108-buffer scan.  The three chains are independent (same latency as one); M comes from the same f32
-// steps the serial scan takes, applied to (1, 0) and (0, 1).  Used when a launch has 2 .. 8 chunks (the policy's long chunks); one
+// so one wave per CHUNK scans the zero-state response v of its own buffers only (the serial scan's chain from x = 0) and raises
+// A^513 to the number of buffers it stepped (square-and-multiply in fp64, rounded once), the waves of a workgroup (one per chunk,
+// same 64 columns) leave (M, v) in LDS, and every wave composes the maps of the chunks before its own: n_chunks - 1 steps of six
+// FMAs.  860 buffers in 8 chunks: the depth of a 108-buffer scan for the work of the serial one.  Used when a launch has 2 .. 8 chunks (the policy's long chunks); one
 // buffer per chunk keeps the serial scan, whose arithmetic does not depend on where a step is cut.
 constexpr int SEG_B = 16;        // buffers per batch of a wave (lane = buffer for the decode: 16 lanes)
 constexpr int SEG_MAX = 8;       // chunks (= waves per workgroup)
@@ -308,9 +307,13 @@ __global__ __launch_bounds__(64 * SEG_MAX) void iir_scan_seg_kernel(
     const BufDesc *__restrict__ p_desc, const float *__restrict__ p_grows, const float *__restrict__ p_g32,
     const long long *__restrict__ p_g32_off, const float *__restrict__ p_vinc, const int *__restrict__ p_xfer_init,
     float *__restrict__ p_xs, int *__restrict__ p_xtrow, const ScanDims p) {
-    __shared__ __attribute__((aligned(16))) float lds_g[SEG_MAX][2 * SEG_B][64];     // per wave: [buffer of the batch][q | d][mode]: what the hit adds to the state
-    __shared__ float lds_map[SEG_MAX][6][64];        // per chunk: M e1, M e2, v
-    __shared__ int lds_row[SEG_MAX][2];              // per chunk: did a buffer set the transfer row, and the last one set
+    // (dynamic: sized by the launch's chunk count -- a workgroup of two waves takes 20 KB, not the 78 KB of eight)
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    const int n_waves = (int)(blockDim.x >> 6);
+    typedef float row64[64];
+    row64 *lds_g_all = reinterpret_cast<row64 *>(lds_dyn);                           // per wave: [buffer of the batch][q | d][mode]: what the hit adds to the state
+    row64 *lds_map_all = lds_g_all + (size_t)n_waves * 2 * SEG_B;                    // per chunk: M e1, M e2, v
+    int *lds_row_all = reinterpret_cast<int *>(lds_map_all + (size_t)n_waves * 6);   // per chunk: did a buffer set the transfer row, and the last one set
     const int tiles = p.m_pad / 64;
     const int obj = blockIdx.x / tiles;
     const int col0 = 64 * (blockIdx.x % tiles);
@@ -335,9 +338,10 @@ __global__ __launch_bounds__(64 * SEG_MAX) void iir_scan_seg_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     const int b_lo = wv * p.cb, b_hi = b_lo + p.cb < p.nb ? b_lo + p.cb : p.nb;
-    f2 xz = f2{0.f, 0.f}, xa = f2{1.f, 0.f}, xb = f2{0.f, 1.f};
-    int has_set = 0, last_row = XFER_KEEP;
-    float (*lg)[64] = lds_g[wv];
+    f2 xz = f2{0.f, 0.f};
+    int has_set = 0, last_row = XFER_KEEP, n_stepped = 0;
+    row64 *lg = lds_g_all + (size_t)wv * 2 * SEG_B;
+    row64 *lds_map = lds_map_all + (size_t)wv * 6;
     for (int base = b_lo; base < b_hi; base += SEG_B) {
         const int nd = b_hi - base < SEG_B ? b_hi - base : SEG_B;
         // ---- lane = buffer base + lane (lanes 0 .. nd - 1): as the serial scan's stage (1)
@@ -422,17 +426,32 @@ __global__ __launch_bounds__(64 * SEG_MAX) void iir_scan_seg_kernel(
             const float da = s21 * v.x, db = fmaf(s22, v.y, gd);
             return f2{qa + qb, da + db};
         };
+        n_stepped += nd - __builtin_popcount(skip_mask);
         for (int j = 0; j < nd; ++j) {
             if ((skip_mask >> j) & 1) continue;      // step() returned before stepping: state untouched
             xz = step(xz, lg[2 * j][lane], lg[2 * j + 1][lane]);
-            xa = step(xa, 0.f, 0.f);
-            xb = step(xb, 0.f, 0.f);
         }
     }
-    lds_map[wv][0][lane] = xa.x; lds_map[wv][1][lane] = xa.y;
-    lds_map[wv][2][lane] = xb.x; lds_map[wv][3][lane] = xb.y;
-    lds_map[wv][4][lane] = xz.x; lds_map[wv][5][lane] = xz.y;
-    if (lane == 0) { lds_row[wv][0] = has_set; lds_row[wv][1] = last_row; }
+    {
+        // M = (A^513)^(buffers stepped): square-and-multiply in fp64 from the f32 constants the chain uses (a chunk of 430 buffers: nine
+        // squarings; two more chains beside the first tripled the kernel's work and made a throughput-bound scan slower)
+        double b00 = 1.0 + (double)s11, b01 = (double)s12, b10 = (double)s21, b11 = (double)s22;      // the running power of A^513
+        double m00 = 1.0, m01 = 0.0, m10 = 0.0, m11 = 1.0;
+        for (int e = n_stepped; e > 0; e >>= 1) {
+            if (e & 1) {
+                const double t00 = b00 * m00 + b01 * m10, t01 = b00 * m01 + b01 * m11;
+                const double t10 = b10 * m00 + b11 * m10, t11 = b10 * m01 + b11 * m11;
+                m00 = t00; m01 = t01; m10 = t10; m11 = t11;
+            }
+            const double q00 = b00 * b00 + b01 * b10, q01 = b00 * b01 + b01 * b11;
+            const double q10 = b10 * b00 + b11 * b10, q11 = b10 * b01 + b11 * b11;
+            b00 = q00; b01 = q01; b10 = q10; b11 = q11;
+        }
+        lds_map[0][lane] = (float)m00; lds_map[1][lane] = (float)m10;        // M e1
+        lds_map[2][lane] = (float)m01; lds_map[3][lane] = (float)m11;        // M e2
+        lds_map[4][lane] = xz.x; lds_map[5][lane] = xz.y;
+    }
+    if (lane == 0) { lds_row_all[2 * wv] = has_set; lds_row_all[2 * wv + 1] = last_row; }
     __syncthreads();
     // ---- compose the maps of the chunks in front of this one
     f2 x;
@@ -442,14 +461,15 @@ __global__ __launch_bounds__(64 * SEG_MAX) void iir_scan_seg_kernel(
         x.y = (p_sd + ubase)[lane] / s0;
     }
     auto apply = [&](int c, f2 v) {
-        const float q = fmaf(lds_map[c][0][lane], v.x, fmaf(lds_map[c][2][lane], v.y, lds_map[c][4][lane]));
-        const float d = fmaf(lds_map[c][1][lane], v.x, fmaf(lds_map[c][3][lane], v.y, lds_map[c][5][lane]));
+        const row64 *mp = lds_map_all + (size_t)c * 6;
+        const float q = fmaf(mp[0][lane], v.x, fmaf(mp[2][lane], v.y, mp[4][lane]));
+        const float d = fmaf(mp[1][lane], v.x, fmaf(mp[3][lane], v.y, mp[5][lane]));
         return f2{q, d};
     };
     int row = p_xfer_init[obj];
     for (int c = 0; c < wv; ++c) {
         x = apply(c, x);
-        if (lds_row[c][0]) row = lds_row[c][1];
+        if (lds_row_all[2 * c]) row = lds_row_all[2 * c + 1];
     }
     (reinterpret_cast<f2 *>(p_xs) + ((size_t)obj * p.n_chunks + wv) * p.m_pad + col0)[lane] = x;
     if (col0 == 0 && lane == 0) p_xtrow[(size_t)obj * p.n_chunks + wv] = row;
@@ -593,15 +613,21 @@ int launch_iir_scan(const IirParams &p, int n_obj, const float *sc, int cb, int 
     if (segmented) {
         if (n_chunks < 2 || n_chunks > iir_scan::SEG_MAX) return (int)hipErrorInvalidValue;
         const dim3 bseg(64 * n_chunks);
+        const size_t lds_seg = (size_t)n_chunks * ((2 * iir_scan::SEG_B + 6) * 64 * sizeof(float) + 2 * sizeof(int));
 #define PBSO_SCAN_SEG(DIRECT, DENSE)                                                                                             \
-    hipLaunchKernelGGL((iir_scan::iir_scan_seg_kernel<DIRECT, DENSE>), grid, bseg, 0, stream, p.sq, p.sd, p.ss, sc, p.desc, p.grows, p.g32, \
+    if (lds_seg > 64 * 1024) {                                                                                                  \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(iir_scan::iir_scan_seg_kernel<DIRECT, DENSE>),       \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_seg);                          \
+        if (e_ != hipSuccess) return (int)e_;                                                                                   \
+    }                                                                                                                           \
+    hipLaunchKernelGGL((iir_scan::iir_scan_seg_kernel<DIRECT, DENSE>), grid, bseg, lds_seg, stream, p.sq, p.sd, p.ss, sc, p.desc, p.grows, p.g32, \
                        p.g32_off, vinc, p.xfer_init, xs, xtrow, dims)
         if (vinc) {
-            if (direct) PBSO_SCAN_SEG(true, true);
-            else PBSO_SCAN_SEG(false, true);
+            if (direct) { PBSO_SCAN_SEG(true, true); }
+            else { PBSO_SCAN_SEG(false, true); }
         } else {
-            if (direct) PBSO_SCAN_SEG(true, false);
-            else PBSO_SCAN_SEG(false, false);
+            if (direct) { PBSO_SCAN_SEG(true, false); }
+            else { PBSO_SCAN_SEG(false, false); }
         }
 #undef PBSO_SCAN_SEG
         return (int)hipGetLastError();
