@@ -147,3 +147,40 @@ def test_pipe_kernel_generated_code(tmp_path):
         n_mfma = len(re.findall(r"\n\s+v_mfma_f32_16x16x4_f32", body))
         assert n_mfma == 32 + 4 + 2 * 32, (qnm, n_mfma)
         assert "s_load_dwordx16" not in body and "ds_read_b128" in body
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
+def test_round5_kernels_generated_code(tmp_path):
+    """the kernels of round 5: the five-role pipeline teams (kernels_pipe.hip, iir_pipe5_kernel: no scratch, at most 168 VGPRs -- a
+    workgroup of ten waves needs three per SIMD --, two teams' LDS within a CU, the roles' matrix work: projection 32 + the FIR's 4,
+    increments 32), dense_increment_kernel (64 MFMAs per profile row and 64 columns, no scratch, four waves per SIMD) and the scan cut
+    along the time axis (no scratch; its chunk matrix in fp64)"""
+    out = tmp_path / "kp.s"
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"),
+                    "-S", "--cuda-device-only", os.path.join(CSRC, "kernels_pipe.hip"), "-o", str(out)], check=True, capture_output=True)
+    asm = open(out).read()
+    meta = asm[asm.find(".amdgpu_metadata"):]
+    bodies = {int(re.search(r"iir_pipe5_kernelILi(\d)E", k).group(1)): k.split("s_endpgm")[0]
+              for k in re.split(r"\n(?=_ZN4pbso8iir_pipe16iir_pipe5_kernel\S*:)", asm)[1:]}
+    assert set(bodies) == {0, 2}
+    for qnm, body in bodies.items():
+        blk = [b for b in meta.split("- .agpr_count") if "iir_pipe5_kernelILi%dE" % qnm in b][0]
+        lds, scratch, vgpr, spill = (int(re.search(r"\.%s:\s+(\d+)" % f, blk).group(1)) for f in
+                                     ("group_segment_fixed_size", "private_segment_fixed_size", "vgpr_count", "vgpr_spill_count"))
+        assert scratch == 0 and spill == 0 and vgpr <= 168 and lds <= 160 * 1024, (qnm, lds, scratch, vgpr, spill)
+        assert len(re.findall(r"\n\s+v_mfma_f32_16x16x4_f32", body)) == 32 + 4 + 32, qnm
+        assert "s_barrier" in body and "s_setprio 3" in body
+    out = tmp_path / "ks.s"
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"),
+                    "-S", "--cuda-device-only", os.path.join(CSRC, "kernels_scan.hip"), "-o", str(out)], check=True, capture_output=True)
+    asm = open(out).read()
+    meta = asm[asm.find(".amdgpu_metadata"):]
+    inc = [k for k in re.split(r"\n(?=_ZN4pbso8iir_scan22dense_increment_kernel\S*:)", asm)[1:]][0].split("s_endpgm")[0]
+    assert len(re.findall(r"\n\s+v_mfma_f32_16x16x4_f32", inc)) == 64 and "scratch_" not in inc
+    blk = [b for b in meta.split("- .agpr_count") if "dense_increment_kernel" in b][0]
+    assert int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)) <= 128
+    segs = re.split(r"\n(?=_ZN4pbso8iir_scan19iir_scan_seg_kernel\S*:)", asm)[1:]
+    assert len(segs) == 4
+    for k in segs:
+        body = k.split("s_endpgm")[0]
+        assert "scratch_" not in body and "v_fma_f64" in body and "s_barrier" in body
