@@ -135,7 +135,10 @@ typedef struct pbso_engine_desc {
                                * never runs two launches ahead (a long scan that does trails its bank and collides with the next
                                * bank's start).  1 events only.  2 the hand-over to the bank through a value in signal memory too (half
                                * the latency of an event, 1 % per step on small scenes).  3 the gate for every launch (costs 0.5 - 1.5 %
-                               * per step of 86 buffers).  2 and 3 fail at creation where the device lacks the interface */
+                               * per step of 86 buffers).  2 and 3 fail at creation where the device lacks the interface.  4 (round 5): the gate
+                               * for every launch as a wait of the SUBMITTING thread on a word of pinned host memory the previous bank's first
+                               * workgroup writes (hipStreamWaitValue64 runs as a waiting kernel on this stack); costs the host one launch of
+                               * run-ahead */
     int latency_path;         /* < 0: never prepare a launch on the bank's own stream (0: a step of at most four buffers submitted
                                * while the device is idle does -- nothing to overlap with, one stream hand-over less) */
     /* ---- ABI 5 */

@@ -46,46 +46,64 @@ public:
         for (std::thread &t : th_) t.join();
     }
     int workers() const { return (int)th_.size(); }
+    // Shares are CLAIMED, not assigned: helper i goes for share i (the same objects every step: their queues stay in its cache),
+    // the caller for share 0 and then for every share nobody has claimed yet -- so a helper that is slow to wake (the boxes of this
+    // pool take 3 - 8 ms now and then to schedule a thread that slept on a condition variable: the outlier runs of the 128 x 512 x
+    // 860 share, 2.0 - 2.6 ms per step instead of 1.3, scripts/debug/r05_stall_hunt.sh) costs its share's time on the caller, not
+    // its wake-up.  Which thread runs a share does not matter: share t always works in context t.
     void run(int n, const std::function<void(int)> &job) {
+        unsigned gen;
         {
             std::lock_guard<std::mutex> lk(m_);
+            if ((int)claim_.size() < n) claim_ = std::vector<std::atomic<unsigned>>(n);
             job_ = &job;
-            active_ = n;
-            pending_ = std::min(n - 1, (int)th_.size());
-            ++gen_;
+            n_shares_ = n;
+            gen = (unsigned)++gen_;
+            completed_.store(0, std::memory_order_release);
         }
         cv_.notify_all();
-        job(0);
-        std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [this] { return pending_ == 0; });
+        if (take(0, gen)) { job(0); completed_.fetch_add(1, std::memory_order_release); }
+        for (int t = 1; t < n; ++t)
+            if (take(t, gen)) { job(t); completed_.fetch_add(1, std::memory_order_release); }
+        // (shares a helper has claimed and not finished yet: short -- a share is a fraction of a millisecond)
+        while (completed_.load(std::memory_order_acquire) < n) std::this_thread::yield();
     }
 
 private:
+    // the round's number goes into the share's word: first come, first served, and a helper of an earlier round claims nothing
+    bool take(int t, unsigned gen) {
+        unsigned seen = claim_[t].load(std::memory_order_acquire);
+        return seen != gen && claim_[t].compare_exchange_strong(seen, gen, std::memory_order_acq_rel);
+    }
     void loop(int idx) {
         int seen = 0;
         for (;;) {
             const std::function<void(int)> *job;
+            int n;
+            unsigned gen;
             {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_.wait(lk, [&] { return gen_ != seen; });
                 seen = gen_;
                 if (stop_) return;
-                if (idx >= active_) continue;
                 job = job_;
+                n = n_shares_;
+                gen = (unsigned)gen_;
             }
-            (*job)(idx);
-            {
-                std::lock_guard<std::mutex> lk(m_);
-                --pending_;
+            // (the caller is inside run() for as long as a share of ITS round can still be taken: claim_, job and the contexts are alive)
+            if (idx < n && take(idx, gen)) {
+                (*job)(idx);
+                completed_.fetch_add(1, std::memory_order_release);
             }
-            done_.notify_one();
         }
     }
     std::vector<std::thread> th_;
     std::mutex m_;
-    std::condition_variable cv_, done_;
+    std::condition_variable cv_;
     const std::function<void(int)> *job_ = nullptr;
-    int gen_ = 0, active_ = 0, pending_ = 0;
+    std::vector<std::atomic<unsigned>> claim_;
+    std::atomic<int> completed_{0};
+    int gen_ = 0, n_shares_ = 0;
     bool stop_ = false;
 };
 
@@ -288,6 +306,7 @@ Engine::~Engine() {
     if (prep_stream_) (void)hipStreamDestroy(prep_stream_);
     if (sig_prep_) (void)hipFree(sig_prep_);
     if (sig_start_) (void)hipFree(sig_start_);
+    if (host_start_) (void)hipHostFree(host_start_);
     for (hipStream_t cs : class_stream_)
         if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
@@ -345,7 +364,7 @@ int Engine::init() {
     if (desc_.profile_kernel < 0 || desc_.profile_kernel > 2) return fail(PBSO_ERR_INVALID, "profile_kernel");
     if (desc_.pipe_consumers < 0 || desc_.pipe_consumers > 4) return fail(PBSO_ERR_INVALID, "pipe_consumers");
     if (desc_.profile_priority < 0 || desc_.profile_priority > 4) return fail(PBSO_ERR_INVALID, "profile_priority");
-    if (desc_.stream_sync < 0 || desc_.stream_sync > 3) return fail(PBSO_ERR_INVALID, "stream_sync");
+    if (desc_.stream_sync < 0 || desc_.stream_sync > 4) return fail(PBSO_ERR_INVALID, "stream_sync");
     latency_path_ = desc_.latency_path >= 0;
     if (desc_.qnorm_mode < PBSO_QNORM_OFF || desc_.qnorm_mode > PBSO_QNORM_CLOSED)
         return fail(PBSO_ERR_INVALID, "qnorm_mode");
@@ -383,6 +402,18 @@ int Engine::init() {
         HIPTRY(hipStreamCreateWithPriority(&prep_stream_, hipStreamNonBlocking, greatest));
     }
     if (desc_.stream_sync != 1) {
+        // the HOST form of the start gate (policy since round 5, see step_chunk): a word of pinned host memory the bank's first
+        // workgroup writes and the submitting thread reads -- no waiting kernel on the device
+        void *dptr = nullptr;
+        if (hipHostMalloc((void **)&host_start_, sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer(&dptr, host_start_, 0) == hipSuccess) {
+            *host_start_ = 0;
+            host_start_dev_ = static_cast<unsigned long long *>(dptr);
+        } else {
+            if (host_start_) (void)hipHostFree(host_start_);
+            host_start_ = nullptr;
+            (void)hipGetLastError();
+        }
         int can = 0;
         auto signal_word = [&](unsigned long long **p) {
             if (hipExtMallocWithFlags((void **)p, sizeof(unsigned long long), hipMallocSignalMemory) != hipSuccess) { *p = nullptr; return false; }
@@ -2203,8 +2234,25 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     // while the next bank starts, and that bank's left-over workgroups wait a whole workgroup's length (512 x 512 x 860: every
     // other launch 9 instead of 4.6 ms in one run of four).  Gated, a scan is never more than one launch ahead, and the bank
     // that needs it waits for it.
-    if (start_gate_ && !one_stream && last_bank_seq_ > 0 && (desc_.stream_sync == 3 || nb >= 256))
+    // (stream_sync = 4, round 5: the gate as a wait of the SUBMITTING thread on a word of pinned host memory the previous bank's
+    //  first workgroup writes.  Built because hipStreamWaitValue64 runs on this stack as a kernel that waits -- `__amd_rocclr_streamOpsWait`
+    //  sits 1.1 of a 1.28 ms bank until workgroups retire, scripts/debug/r05_timeline_share.sh -- and was suspected behind the share's
+    //  outlier runs; those came from the planner's helper threads (PlanPool::run), both forms show them alike, and the host form
+    //  costs the host its second launch of run-ahead: an option, not the policy.)
+    const bool gate_now = !one_stream && last_bank_seq_ > 0 && (desc_.stream_sync == 3 || desc_.stream_sync == 4 || nb >= 256);
+    host_gate_used_ = false;
+    if (gate_now && host_start_ && desc_.stream_sync == 4) {
+        const auto tg0 = std::chrono::steady_clock::now();
+        volatile unsigned long long *w = host_start_;
+        while (*w < last_bank_seq_) {
+            std::this_thread::yield();
+            // (fail-safe: a bank that never starts -- a device fault -- must not hang the caller; the launch then goes ungated)
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count() > 2.0) break;
+        }
+        host_gate_used_ = true;
+    } else if (gate_now && start_gate_) {
         HIPTRY(hipStreamWaitValue64(sp, sig_start_, last_bank_seq_, hipStreamWaitValueGte, ~0ull));
+    }
     evq.h_copy = host_ms();
     const auto tsub1 = std::chrono::steady_clock::now();
     unsigned char *da = ps.d_arena.p;
@@ -2252,7 +2300,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.rotate_prio = (rotate_prio_ == 2 && total_team_waves_ < 12LL * n_cus_) ? 1 : rotate_prio_;
     kp.board = d_board_.p;
     kp.launch_seq = ++launch_seq_;
-    kp.start_flag = start_gate_ ? sig_start_ : nullptr;
+    kp.start_flag = (host_start_ && desc_.stream_sync == 4) ? host_start_dev_ : (start_gate_ ? sig_start_ : nullptr);
     kp.start_seq = ++bank_seq_;
     kp.pc = d_pc_.p;
     kp.wtab = d_wtab_.p;

@@ -245,6 +245,9 @@ private:
     // kernels of the NEXT launch wait for that value -- they never start together with a bank (whose workgroups would then wait
     // for the slots they hold), only beside one that is resident, i.e. in the slots its workgroups free when they retire.
     unsigned long long *sig_start_ = nullptr;
+    unsigned long long *host_start_ = nullptr;          // the same word in pinned host memory: the host form of the gate (policy)
+    unsigned long long *host_start_dev_ = nullptr;      // ... as the device sees it
+    bool host_gate_used_ = false;
     unsigned long long bank_seq_ = 0, last_bank_seq_ = 0;
     bool start_gate_ = false;
     // Plan sets: the host plans and uploads step k while the device still runs step k - N_SETS + 1.  Two sets are enough for

@@ -181,13 +181,14 @@ def test_two_engines_of_one_process_with_different_settings():
 def test_stream_hand_over_by_value_equals_the_event_path(time_chunks):
     """desc.stream_sync = 2: the preparation stream tells the bank stream that a launch is ready through a value in signal
     memory (hipStreamWaitValue64) instead of an event; 3: the next launch's preparation kernels wait for a value the bank
-    kernel stores when it starts.  Ordering only: audio, qnorm rows and state are bit-identical to the
+    kernel stores when it starts; 4 (round 5): the same gate on the host -- the submitting thread waits for that value in pinned
+    host memory.  Ordering only: audio, qnorm rows and state are bit-identical to the
     event path over many launches, with the scan (K5) and without, with the combine kernel (a Gaussian force) in the batch."""
     nb = 24
     objs, evs = _every_kind_scene(nb)
     cut = [1, 2, 5, 4, 1, 1, 3, 7]
     a = run_engine(objs, evs, nb, split=cut, time_chunks=time_chunks, stream_sync=1)
-    for mode in (2, 3):                              # (3: events + the start gate -- the next preparation behind the bank's START)
+    for mode in (2, 3, 4):                           # (3: events + the start gate -- the next preparation behind the bank's START; 4: that gate as a wait of the submitting thread)
         b = run_engine(objs, evs, nb, split=cut, time_chunks=time_chunks, stream_sync=mode, latency_path=-1)
         assert np.array_equal(a["audio"], b["audio"]) and np.array_equal(a["emitted"], b["emitted"])
         for key in a["qnorm"]:
@@ -196,7 +197,7 @@ def test_stream_hand_over_by_value_equals_the_event_path(time_chunks):
             assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
     _check(b, run_oracle(objs, evs, nb))
     with pytest.raises(Exception):
-        run_engine(objs[:1], [], 1, stream_sync=4)
+        run_engine(objs[:1], [], 1, stream_sync=5)
 
 
 def test_long_launches_are_gated_by_policy_and_equal_the_ungated_run():
