@@ -126,59 +126,143 @@ __global__ __launch_bounds__(64) void iir_scan_kernel(
     load_descs(0, nlo, nhi);
     f2 *__restrict__ xs_next = xs;                   // where the next chunk's start state goes (chunks start in order)
 
+    // Software pipeline over the batches (round 5): batch k + 1 is DECODED and the rows of its first HB hits are REQUESTED before
+    // the chain of batch k runs, so the rows' way from HBM (half of a lone scan's time: scripts/debug/r05_scan_abl.sh, stop 3
+    // against stop 2) passes beside the chain instead of in front of it.  Same operations on the same values as the staged form.
+    struct Batch {
+        unsigned long long ptr[NR];                  // lane = buffer: address of its row(s), this wave's columns
+        float w[NR];
+        int prow;
+        unsigned long long hit_mask, skip_mask, dense_mask, mark_mask;
+    };
+    // ---- (1) lane = buffer base + lane
+    auto decode = [&](int base, Batch &d) {
+        const int nd = p.nb - base < 64 ? p.nb - base : 64;
+        const int bi = base + (int)lane;
+        const bool in = bi < p.nb;
+        const i4 dlo = nlo, dhi = nhi;
+        if (base + 64 < p.nb) load_descs(base + 64, nlo, nhi);
+        // (scalars first: __builtin_bit_cast of a vector ELEMENT expression reads element 0 with this compiler)
+        const int frow = dlo.x, w_prow = dlo.y, w_mask = dlo.z, w_amp = dlo.w, w_pad0 = dhi.z;
+        const unsigned flags = (unsigned)dhi.y;
+        const bool skip = in && (flags & DESC_SKIP) != 0;
+        const bool live = in && frow >= 0 && !(flags & DESC_SKIP);
+        const bool impulse = (flags & DESC_IMPULSE) != 0;
+        const bool direct = DIRECT && (flags & DESC_DIRECT) != 0;
+        const bool hit0 = direct || (w_mask & 1);
+        const float a = impulse ? (hit0 ? __builtin_bit_cast(float, w_amp) : 0.f) : 1.f;      // (a dense buffer wants g itself)
+        const bool dl = live && direct;
+        // a DESC_DIRECT hit: g = n . (three rows of the object's (float)(c3 * shape) table), the normal in the descriptor's
+        // spare words (kernels.h); any other hit has ONE row, g = c3 * S from the combine kernel (its other two reads repeat
+        // it with weight 0)
+        const float *r0 = dl ? g32_obj + (size_t)frow * p.m_pad : p_grows + (size_t)(live ? frow : 0) * p.m_pad + col0;
+        d.ptr[0] = (unsigned long long)r0;
+        d.w[0] = dl ? a * __builtin_bit_cast(float, w_prow) : a;
+        if constexpr (DIRECT) {
+            d.ptr[1] = (unsigned long long)(dl ? r0 + p.m_pad : r0);
+            d.ptr[2] = (unsigned long long)(dl ? r0 + 2 * (size_t)p.m_pad : r0);
+            d.w[1] = dl ? a * __builtin_bit_cast(float, w_mask) : 0.f;
+            d.w[2] = dl ? a * __builtin_bit_cast(float, w_pad0) : 0.f;
+        }
+        const int trow = dhi.x;
+        d.prow = direct ? -1 : w_prow;
+        d.hit_mask = __ballot(live && (a != 0.f || !impulse));
+        d.skip_mask = __ballot(skip);
+        d.dense_mask = __ballot(live && !impulse);
+        // chunk starts in this batch (a handful: scalar), and the transfer row in force when one starts: the last row a
+        // non-skipped buffer before it switched to
+        d.mark_mask = 0;
+        const int c0 = (base + p.cb - 1) / p.cb;                  // the first chunk that starts at or behind `base`
+        for (int b = c0 * p.cb; b < base + nd; b += p.cb) d.mark_mask |= 1ull << (b - base);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const unsigned long long set_mask = __ballot(in && !skip && trow != XFER_KEEP);
+        const unsigned long long before = set_mask & below;
+        const int src_lane = before ? 63 - __builtin_clzll(before) : 0;
+        const int got = __shfl(trow, src_lane, 64);
+        if (((d.mark_mask >> lane) & 1) && col0 == 0)
+            p_xtrow[(size_t)obj * p.n_chunks + c0 + __builtin_popcountll(d.mark_mask & below)] = before ? got : cur_row;
+        if (set_mask) cur_row = rl(trow, 63 - __builtin_clzll(set_mask));
+    };
+    // the next HB hits of a mask (the last one repeated when fewer are left); returns what is left of the mask
+    auto take_hits = [](unsigned long long m, int (&jj)[HB]) {
+#pragma unroll
+        for (int h = 0; h < HB; ++h) {
+            jj[h] = __builtin_ctzll(m);
+            const unsigned long long rest = m & (m - 1);
+            if (rest) m = rest;
+            else if (h == HB - 1) m = 0;
+        }
+        return m;
+    };
+    // ---- (2a) lane = mode: the rows of HB hits, requested back to back
+    auto request = [&](const Batch &d, const int (&jj)[HB], float (&r)[HB][NR], f2 (&vv)[DENSE ? HB : 1]) {
+#pragma unroll
+        for (int h = 0; h < HB; ++h) {
+            static_for<0, NR>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                r[h][k] = rlp(d.ptr[k], jj[h])[lane];
+            });
+            if constexpr (DENSE) {
+                // what a unit gain adds to the state over this buffer: its increment row (dense), A^512 u (impulse)
+                vv[h] = f2{hq, hd};
+                if ((d.dense_mask >> jj[h]) & 1) vv[h] = (reinterpret_cast<const f2 *>(p_vinc) + (size_t)rl(d.prow, jj[h]) * p.m_pad + col0)[lane];
+            }
+        }
+    };
+    // ---- (2b) their gains g amp to LDS [buffer][mode]
+    auto deposit = [&](const Batch &d, const int (&jj)[HB], const float (&r)[HB][NR], const f2 (&vv)[DENSE ? HB : 1]) {
+#pragma unroll
+        for (int h = 0; h < HB; ++h) {
+            const int j = jj[h];
+            float gv = rlf(d.w[0], j) * r[h][0];
+            if constexpr (DIRECT) {
+                gv = fmaf(rlf(d.w[NR > 1 ? 1 : 0], j), r[h][NR > 1 ? 1 : 0], gv);
+                gv = fmaf(rlf(d.w[NR > 2 ? 2 : 0], j), r[h][NR > 2 ? 2 : 0], gv);
+            }
+            if constexpr (DENSE) {
+                lds_g[2 * j][lane] = gv * vv[h].x;
+                lds_g[2 * j + 1][lane] = gv * vv[h].y;
+            } else {
+                lds_g[j][lane] = gv;
+            }
+        }
+    };
+    // x <- A^513 x + gv A^512 u, two dependent operations deep (a lone wave issues a dependent instruction every ~8 cycles):
+    // q' = (q + (P11 - 1) q) + (P12 d + gv hq), d' = P21 q + (P22 d + gv hd); the impulse's share is off the chain
+    // (DENSE: the pair (gq, gd) comes ready from LDS -- g V of a dense buffer, (g amp) A^512 u of an impulse)
+    auto coarse2 = [&](float gq, float gd) {
+        const float qa = fmaf(s11, x.x, x.x), qb = fmaf(s12, x.y, gq);
+        const float da = s21 * x.x, db = fmaf(s22, x.y, gd);
+        x.x = qa + qb;
+        x.y = da + db;
+    };
+    auto coarse = [&](float gv) { coarse2(gv * hq, gv * hd); };
+    auto mark = [&]() {                              // the first buffer of a chunk: its start state
+        xs_next[lane] = x;
+        xs_next += p.m_pad;
+    };
+
+    Batch cur, nxt;
+    float r[HB][NR];
+    f2 vv[DENSE ? HB : 1];
+    bool requested = false;                          // r / vv hold the rows of the first HB hits of `cur`
+    if (p.nb > 0 && PBSO_SCAN_STOP > 1) {
+        decode(0, cur);
+        if (cur.hit_mask && PBSO_SCAN_STOP > 2) {
+            int jj[HB];
+            take_hits(cur.hit_mask, jj);
+            request(cur, jj, r, vv);
+            requested = true;
+        }
+    }
     for (int base = 0; base < p.nb && PBSO_SCAN_STOP > 1; base += 64) {
         const int nd = p.nb - base < 64 ? p.nb - base : 64;
-        // ---- (1) lane = buffer base + lane
-        unsigned long long ptr[NR];                  // address of its row(s), this wave's columns
-        float w[NR];
-        int trow, prow;
-        unsigned long long hit_mask, skip_mask, dense_mask, mark_mask = 0;
-        {
-            const int bi = base + (int)lane;
-            const bool in = bi < p.nb;
-            const i4 dlo = nlo, dhi = nhi;
-            if (base + 64 < p.nb) load_descs(base + 64, nlo, nhi);
-            // (scalars first: __builtin_bit_cast of a vector ELEMENT expression reads element 0 with this compiler)
-            const int frow = dlo.x, w_prow = dlo.y, w_mask = dlo.z, w_amp = dlo.w, w_pad0 = dhi.z;
-            const unsigned flags = (unsigned)dhi.y;
-            const bool skip = in && (flags & DESC_SKIP) != 0;
-            const bool live = in && frow >= 0 && !(flags & DESC_SKIP);
-            const bool impulse = (flags & DESC_IMPULSE) != 0;
-            const bool direct = DIRECT && (flags & DESC_DIRECT) != 0;
-            const bool hit0 = direct || (w_mask & 1);
-            const float a = impulse ? (hit0 ? __builtin_bit_cast(float, w_amp) : 0.f) : 1.f;      // (a dense buffer wants g itself)
-            const bool dl = live && direct;
-            // a DESC_DIRECT hit: g = n . (three rows of the object's (float)(c3 * shape) table), the normal in the descriptor's
-            // spare words (kernels.h); any other hit has ONE row, g = c3 * S from the combine kernel (its other two reads repeat
-            // it with weight 0)
-            const float *r0 = dl ? g32_obj + (size_t)frow * p.m_pad : p_grows + (size_t)(live ? frow : 0) * p.m_pad + col0;
-            ptr[0] = (unsigned long long)r0;
-            w[0] = dl ? a * __builtin_bit_cast(float, w_prow) : a;
-            if constexpr (DIRECT) {
-                ptr[1] = (unsigned long long)(dl ? r0 + p.m_pad : r0);
-                ptr[2] = (unsigned long long)(dl ? r0 + 2 * (size_t)p.m_pad : r0);
-                w[1] = dl ? a * __builtin_bit_cast(float, w_mask) : 0.f;
-                w[2] = dl ? a * __builtin_bit_cast(float, w_pad0) : 0.f;
-            }
-            trow = dhi.x;
-            prow = direct ? -1 : w_prow;
-            hit_mask = __ballot(live && (a != 0.f || !impulse));
-            skip_mask = __ballot(skip);
-            dense_mask = __ballot(live && !impulse);
-            // chunk starts in this batch (a handful: scalar), and the transfer row in force when one starts: the last row a
-            // non-skipped buffer before it switched to
-            const int c0 = (base + p.cb - 1) / p.cb;                  // the first chunk that starts at or behind `base`
-            for (int b = c0 * p.cb; b < base + nd; b += p.cb) mark_mask |= 1ull << (b - base);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            const unsigned long long set_mask = __ballot(in && !skip && trow != XFER_KEEP);
-            const unsigned long long before = set_mask & below;
-            const int src_lane = before ? 63 - __builtin_clzll(before) : 0;
-            const int got = __shfl(trow, src_lane, 64);
-            if (((mark_mask >> lane) & 1) && col0 == 0)
-                p_xtrow[(size_t)obj * p.n_chunks + c0 + __builtin_popcountll(mark_mask & below)] = before ? got : cur_row;
-            if (set_mask) cur_row = rl(trow, 63 - __builtin_clzll(set_mask));
+        const bool more = base + 64 < p.nb;
+        if (PBSO_SCAN_STOP <= 2) {
+            x.x += (float)(cur.hit_mask ^ cur.skip_mask ^ cur.dense_mask ^ cur.mark_mask) + cur.w[0] + (float)cur.prow + (float)cur.ptr[0];
+            if (more) decode(base + 64, cur);
+            continue;
         }
-        if (PBSO_SCAN_STOP <= 2) { x.x += (float)(hit_mask ^ skip_mask ^ dense_mask ^ mark_mask) + w[0] + (float)trow + (float)prow + (float)ptr[0]; continue; }
         // ---- (2) the gains of the batch's hits, [buffer][mode] in LDS
         wave_sync();                                 // (the previous batch's reads are done)
         {
@@ -187,77 +271,55 @@ __global__ __launch_bounds__(64) void iir_scan_kernel(
             for (int i = 0; i < (DENSE ? 2 : 1) * ((nd + 3) / 4); ++i) z[64 * i] = zero;
         }
         wave_sync();
-        for (unsigned long long m = hit_mask; m;) {
+        for (unsigned long long m = cur.hit_mask; m;) {
             int jj[HB];
-#pragma unroll
-            for (int h = 0; h < HB; ++h) {           // the next HB hits (the last one repeated when fewer are left)
-                jj[h] = __builtin_ctzll(m);
-                const unsigned long long rest = m & (m - 1);
-                if (rest) m = rest;
-                else if (h == HB - 1) m = 0;
-            }
-            float r[HB][NR];
-            f2 vv[DENSE ? HB : 1];
-#pragma unroll
-            for (int h = 0; h < HB; ++h) {
-                static_for<0, NR>([&](auto kc) {
-                    constexpr int k = decltype(kc)::value;
-                    r[h][k] = rlp(ptr[k], jj[h])[lane];
-                });
-                if constexpr (DENSE) {
-                    // what a unit gain adds to the state over this buffer: its increment row (dense), A^512 u (impulse)
-                    vv[h] = f2{hq, hd};
-                    if ((dense_mask >> jj[h]) & 1) vv[h] = (reinterpret_cast<const f2 *>(p_vinc) + (size_t)rl(prow, jj[h]) * p.m_pad + col0)[lane];
-                }
-            }
-#pragma unroll
-            for (int h = 0; h < HB; ++h) {
-                const int j = jj[h];
-                float gv = rlf(w[0], j) * r[h][0];
-                if constexpr (DIRECT) {
-                    gv = fmaf(rlf(w[NR > 1 ? 1 : 0], j), r[h][NR > 1 ? 1 : 0], gv);
-                    gv = fmaf(rlf(w[NR > 2 ? 2 : 0], j), r[h][NR > 2 ? 2 : 0], gv);
-                }
-                if constexpr (DENSE) {
-                    lds_g[2 * j][lane] = gv * vv[h].x;
-                    lds_g[2 * j + 1][lane] = gv * vv[h].y;
-                } else {
-                    lds_g[j][lane] = gv;
-                }
-            }
+            m = take_hits(m, jj);
+            if (!requested) request(cur, jj, r, vv);         // (a batch's hits behind its first HB: requested here)
+            requested = false;
+            deposit(cur, jj, r, vv);
         }
         wave_sync();
-        if (PBSO_SCAN_STOP <= 3) { x.x += lds_g[lane][lane]; continue; }
+        // ---- the next batch: decoded, its first rows on their way while this batch's chain runs
+        if (more) {
+            decode(base + 64, nxt);
+            if (nxt.hit_mask) {
+                int jj[HB];
+                take_hits(nxt.hit_mask, jj);
+                request(nxt, jj, r, vv);
+                requested = true;
+            }
+        }
+        if (PBSO_SCAN_STOP <= 3) {
+            x.x += lds_g[lane][lane];
+            if (more) cur = nxt;
+            continue;
+        }
 
-        // ---- (3) the scan, lane = mode
-        // x <- A^513 x + gv A^512 u, two dependent operations deep (a lone wave issues a dependent instruction every ~8 cycles):
-        // q' = (q + (P11 - 1) q) + (P12 d + gv hq), d' = P21 q + (P22 d + gv hd); the impulse's share is off the chain
-        // (DENSE: the pair (gq, gd) comes ready from LDS -- g V of a dense buffer, (g amp) A^512 u of an impulse)
-        auto coarse2 = [&](float gq, float gd) {
-            const float qa = fmaf(s11, x.x, x.x), qb = fmaf(s12, x.y, gq);
-            const float da = s21 * x.x, db = fmaf(s22, x.y, gd);
-            x.x = qa + qb;
-            x.y = da + db;
-        };
-        auto coarse = [&](float gv) { coarse2(gv * hq, gv * hd); };
-        auto mark = [&]() {                          // the first buffer of a chunk: its start state
-            xs_next[lane] = x;
-            xs_next += p.m_pad;
-        };
-        const unsigned long long slow_mask = skip_mask;
-        for (int j0 = 0; j0 < nd; j0 += G) {
-            const int n = nd - j0 < G ? nd - j0 : G;
-            if (n == G && ((slow_mask >> j0) & ((1ull << G) - 1)) == 0) {
-                float gv[G], gw[DENSE ? G : 1];
+        // ---- (3) the scan, lane = mode: the gains of a group of G buffers are read from LDS TWO groups ahead (two register sets)
+        const unsigned long long slow_mask = cur.skip_mask, mark_mask = cur.mark_mask;
+        auto fetch = [&](int j0, float (&gv)[G], float (&gw)[DENSE ? G : 1]) {
 #pragma unroll
-                for (int i = 0; i < G; ++i) {
-                    if constexpr (DENSE) {
-                        gv[i] = lds_g[2 * (j0 + i)][lane];
-                        gw[i] = lds_g[2 * (j0 + i) + 1][lane];
-                    } else {
-                        gv[i] = lds_g[j0 + i][lane];
-                    }
+            for (int i = 0; i < G; ++i) {
+                if constexpr (DENSE) {
+                    gv[i] = lds_g[2 * (j0 + i)][lane];
+                    gw[i] = lds_g[2 * (j0 + i) + 1][lane];
+                } else {
+                    gv[i] = lds_g[j0 + i][lane];
                 }
+            }
+        };
+        auto generic = [&](int j0, int n) {          // chunk starts, skipped buffers, the batch's tail
+#pragma unroll 1
+            for (int j = j0; j < j0 + n; ++j) {
+                if ((mark_mask >> j) & 1) mark();
+                if ((slow_mask >> j) & 1) continue;          // step() returned before stepping: state untouched
+                if constexpr (DENSE) coarse2(lds_g[2 * j][lane], lds_g[2 * j + 1][lane]);
+                else coarse(lds_g[j][lane]);
+            }
+        };
+        // a full group from registers; then the registers take the group two ahead
+        auto group = [&](int j0, float (&gv)[G], float (&gw)[DENSE ? G : 1]) {
+            if (((slow_mask >> j0) & ((1ull << G) - 1)) == 0) {
                 auto step = [&](int i) {
                     if constexpr (DENSE) coarse2(gv[i], gw[i]);
                     else coarse(gv[i]);
@@ -274,14 +336,25 @@ __global__ __launch_bounds__(64) void iir_scan_kernel(
                     }
                 }
             } else {
-                for (int j = j0; j < j0 + n; ++j) {
-                    if ((mark_mask >> j) & 1) mark();
-                    if ((skip_mask >> j) & 1) continue;      // step() returned before stepping: state untouched
-                    if constexpr (DENSE) coarse2(lds_g[2 * j][lane], lds_g[2 * j + 1][lane]);
-                    else coarse(lds_g[j][lane]);
-                }
+                generic(j0, G);
             }
+            if (j0 + 3 * G <= nd) fetch(j0 + 2 * G, gv, gw);
+        };
+        float ga[G], gb[G], wa[DENSE ? G : 1], wb[DENSE ? G : 1];
+        if (nd >= G) fetch(0, ga, wa);
+        if (nd >= 2 * G) fetch(G, gb, wb);
+        int j0 = 0;
+#pragma unroll 1
+        for (; j0 + 2 * G <= nd; j0 += 2 * G) {
+            group(j0, ga, wa);
+            group(j0 + G, gb, wb);
         }
+        if (j0 + G <= nd) {
+            group(j0, ga, wa);
+            j0 += G;
+        }
+        if (j0 < nd) generic(j0, nd - j0);
+        if (more) cur = nxt;
     }
     (p_sq + ubase)[lane] = x.x;
     (p_sd + ubase)[lane] = x.y;
