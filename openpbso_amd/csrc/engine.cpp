@@ -2352,15 +2352,22 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
             tot_tc_dense_launches_ += 1;
         }
         if (!last_launch_tc_ && last_set_ >= 0) HIPTRY(hipStreamWaitEvent(sp, ev_k1_done_[last_set_], 0));
-        // Cut along the time axis itself -- one wave per chunk -- when the launch has a few long chunks AND the whole scan is a
-        // handful of waves: it halves the latency of a scan that has the device to itself (1 x 512 x 86: 11.3 -> 5.7 us).  It does
-        // NOT shorten the scans of larger scenes: those are bound by gathering the hits' gain rows (three table rows per hit and 64
-        // columns: 155 MB for 128 x 512 x 860), not by the chain -- 128 x 512 x 860: 100 - 125 us serial, 138 - 157 us segmented, both
-        // run only once the bank's first workgroups retire (scripts/debug/r05_timeline_share.sh); the 512-object share got slower
-        // (4.98 -> 5.12 ms per step).  One buffer per chunk keeps the serial scan, whose arithmetic does not depend on where a step is cut.
+        // Cut along the time axis itself -- one wave per chunk (kernels_scan.hip, SEG) -- in two cases.  (a) The whole scan is a
+        // handful of waves: it halves the latency of a scan that has the device to itself (1 x 512 x 86: 11.3 -> 5.7 us).  (b) LONG
+        // chunks of a scene whose serial scan is at most two waves per SIMD: that scan can only start as the previous bank's
+        // workgroups retire (the bank holds every register), so the waves placed last start when the bank ends and what the next
+        // bank waits for is ONE WAVE'S walk over all buffers of the launch -- 82 us for 860 buffers; cut into the bank's own
+        // chunks a wave walks 108 and the whole scan is 45 us of a throughput-bound kernel, most of it beside the bank's tail:
+        // 128 x 512 x 860 1.31 -> 1.27 ms per step, 256 x 512 x 860 2.45 -> 2.42 (scripts/debug/r05_scan_seg2.sh).  NOT for
+        // four serial waves per SIMD (512 x 512: the serial scan is throughput-bound already and does less work: 4.79 against
+        // 4.87 ms) and not for short chunks (86-buffer steps, 11 buffers per chunk: 0.156 against 0.160 ms -- eight times the
+        // waves for one batch each).  One buffer per chunk keeps the serial scan, whose arithmetic does not depend on where a
+        // step is cut.
         const bool seg_fits = n_chunks >= 2 && n_chunks <= SCAN_SEG_MAX;
+        const long long scan_waves = (long long)N * (m_pad_ / 64);
         const bool seg = seg_fits && desc_.scan_kernel != 1 &&
-                         (desc_.scan_kernel == 2 || (tc_cb > 1 && (long long)N * (m_pad_ / 64) * n_chunks <= 2LL * n_cus_));
+                         (desc_.scan_kernel == 2 || (tc_cb > 1 && scan_waves * n_chunks <= 2LL * n_cus_) ||
+                          (tc_cb >= 32 && scan_waves <= 8LL * n_cus_));
         if (seg) tot_seg_scans_ += 1;
         LAUNCHTRY(launch_iir_scan(kp, N, d_scan_.p, tc_cb, n_chunks, d_xs_[cur_set_].p, d_xtrow_[cur_set_].p, direct_hits_, vinc, seg, sp));
     }

@@ -447,6 +447,13 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
         __syncthreads();
         // (starting the teams of a CU half a slice period apart -- one wave's vector burst under its SIMD partner's matrix
         //  burst -- changed nothing: 0.948 ms with any stagger of 1, 2 or 4 K cycles on either rank bit, 0.948 without)
+#ifdef PBSO_STAGGER_BIT
+        // (round 5, scripts/debug/r05_stagger.sh: half a BUFFER apart -- one team's head and combine under its SIMD partner's
+        //  pipeline -- 8 or 16 K cycles on rank bit 1 or 2: 9.147 / 9.148 / 9.257 / 9.276 ms per 860 buffers against 9.18 - 9.27
+        //  of the product on the same box: nothing either; kept as a build option for the next idea)
+        if (prio_rank & PBSO_STAGGER_BIT)
+            for (int i = 0; i < PBSO_STAGGER_N; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     }
     for (int b = b_begin; b < b_end; ++b) {
         const BufDesc cur = next;

@@ -73,35 +73,61 @@ struct ScanDims {
 #define PBSO_SCAN_STOP 9         // (ablation builds for timing only: scripts/debug/r04_scan_abl.sh)
 #endif
 
+// One body, two kernels.  SERIAL (iir_scan_kernel): one wave per 64 columns of an object walks ALL buffers of the launch, batches
+// of 64, and stores the state at every chunk start.  SEG (iir_scan_seg_kernel, round 5): the scan cut along the time axis itself.
+// A chunk of buffers is an AFFINE map of the state,
+//     x_end = M x_start + v,      M = (A^513)^(buffers stepped),  v = what the chunk's forces leave behind from rest,
+// so one wave per CHUNK (a workgroup = the chunks of one 64-column tile, at most SEG_MAX) scans the zero-state response v of its own
+// buffers only -- the same chain from x = 0, batches of 32 buffers (16 with the pairs of a DENSE launch: 8 KB of LDS per wave) --
+// and raises A^513 to the number of buffers it stepped (square-and-multiply in fp64, rounded once), the waves leave (M, v) in LDS,
+// and every wave composes the maps of the chunks before its own: n_chunks - 1 steps of six FMAs.  860 buffers in 8 chunks: the
+// depth of a 108-buffer scan for the work of the serial one.  One buffer per chunk keeps the serial scan, whose arithmetic does
+// not depend on where a step is cut.
+//
 // DENSE: the launch has buffers with a dense force profile; p_vinc holds their increments V [profile row][m_pad] pairs (q, d)
-// and the batch's gains are kept as pairs g V (dense) / (g amp) A^512 u (impulse): 32 KB of LDS per wave instead of 16.
-template <bool DIRECT, bool DENSE>
-__global__ __launch_bounds__(64) void iir_scan_kernel(
+// and the batch's gains are kept as pairs g V (dense) / (g amp) A^512 u (impulse): twice the LDS per buffer.
+constexpr int SEG_MAX = 8;       // chunks (= waves per workgroup) of the segmented form
+constexpr int SEG_ROWS = 32;     // rows of 64 floats of LDS per wave of the segmented form: 32 gains, or the pairs of 16 buffers
+
+template <bool DIRECT, bool DENSE, bool SEG>
+__device__ __forceinline__ void scan_body(
     float *__restrict__ p_sq, float *__restrict__ p_sd,
     float *__restrict__ p_ss, const float *__restrict__ p_sc, const BufDesc *__restrict__ p_desc,
     const float *__restrict__ p_grows, const float *__restrict__ p_g32, const long long *__restrict__ p_g32_off,
     const float *__restrict__ p_vinc, const int *__restrict__ p_xfer_init, float *__restrict__ p_xs,
-    int *__restrict__ p_xtrow, const ScanDims p) {
-    // [buffer of the batch][mode]: the hit's gain g amp (0: no hit); DENSE: the pair it adds to the state
-    __shared__ __attribute__((aligned(16))) float lds_g[DENSE ? 128 : 64][64];
+    int *__restrict__ p_xtrow, const ScanDims &p) {
+    constexpr int BATCH = SEG ? (DENSE ? SEG_ROWS / 2 : SEG_ROWS) : 64;       // buffers per batch (lane = buffer for the decode)
+    typedef float row64[64];
+    // [buffer of the batch][mode]: the hit's gain g amp (0: no hit); DENSE: the pair it adds to the state.  (Dynamic: the
+    // segmented form sizes it by the launch's chunk count -- a workgroup of two waves takes 20 KB, not the 78 KB of eight)
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    const int n_waves = SEG ? (int)(blockDim.x >> 6) : 1;
+    const int wv = SEG ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;        // SEG: the chunk
+    row64 *lds_g = reinterpret_cast<row64 *>(lds_dyn) + (size_t)wv * (SEG ? SEG_ROWS : 0);
+    row64 *lds_map_all = reinterpret_cast<row64 *>(lds_dyn) + (size_t)n_waves * SEG_ROWS;      // SEG, per chunk: M e1, M e2, v
+    int *lds_row_all = reinterpret_cast<int *>(lds_map_all + (size_t)n_waves * 6);            // SEG, per chunk: did a buffer set the transfer row, and the last one set
     // (a flat grid: grid.y is capped at 65535 objects)
     const int tiles = p.m_pad / 64;
     const int obj = blockIdx.x / tiles;
     const int col0 = 64 * (blockIdx.x % tiles);
-    const unsigned lane = threadIdx.x;
+    const unsigned lane = threadIdx.x & 63u;
     const size_t ubase = (size_t)obj * p.m_pad + col0;
     const float s11 = (p_sc + ubase)[lane], s12 = (p_sc + p.plane + ubase)[lane];     // A^513: P11 - 1, P12, P21, P22
     const float s21 = (p_sc + 2 * p.plane + ubase)[lane], s22 = (p_sc + 3 * p.plane + ubase)[lane];
     const float hq = (p_sc + 4 * p.plane + ubase)[lane], hd = (p_sc + 5 * p.plane + ubase)[lane];      // A^512 u
-    f2 x;
-    {
+    // the wave's buffers: all of the launch, or its chunk
+    const int b_lo = SEG ? wv * p.cb : 0;
+    const int b_hi = SEG ? (b_lo + p.cb < p.nb ? b_lo + p.cb : p.nb) : p.nb;
+    f2 x = f2{0.f, 0.f};                             // SEG: the zero-state response
+    if constexpr (!SEG) {
         const float s0 = (p_ss + ubase)[lane];       // the arrays hold scale x state (kernels_iir.hip, "scaled state")
         x.x = (p_sq + ubase)[lane] / s0;
         x.y = (p_sd + ubase)[lane] / s0;
     }
     const BufDesc *__restrict__ dsc = p_desc + (size_t)obj * p.nb;
     const float *__restrict__ g32_obj = DIRECT ? p_g32 + (size_t)p_g32_off[obj] * p.m_pad + col0 : nullptr;
-    int cur_row = p_xfer_init[obj];
+    int cur_row = SEG ? XFER_KEEP : p_xfer_init[obj];        // SEG: the last row a buffer of the chunk set (XFER_KEEP: none did)
+    int n_stepped = 0;                               // SEG: the buffers that stepped the state
     f2 *__restrict__ xs = reinterpret_cast<f2 *>(p_xs) + (size_t)obj * p.n_chunks * p.m_pad + col0;
     constexpr int NR = DIRECT ? 3 : 1;
     auto rl = [](int v, int j) { return __builtin_amdgcn_readlane(v, j); };
@@ -118,30 +144,29 @@ __global__ __launch_bounds__(64) void iir_scan_kernel(
     // the descriptors of a batch, one per lane, fetched a batch ahead
     auto load_descs = [&](int base, i4 &lo, i4 &hi) {
         const int bi = base + (int)lane;
-        const i4 *src = reinterpret_cast<const i4 *>(dsc + (bi < p.nb ? bi : p.nb - 1));
+        const i4 *src = reinterpret_cast<const i4 *>(dsc + (bi < b_hi ? bi : b_hi - 1));
         lo = src[0];                                 // frow, prow, tile_mask, amp
         hi = src[1];                                 // trow, flags, pad[0], pad[1]
     };
-    i4 nlo, nhi;
-    load_descs(0, nlo, nhi);
+    i4 nlo = i4{0, 0, 0, 0}, nhi = i4{0, 0, 0, 0};
+    if (b_lo < b_hi) load_descs(b_lo, nlo, nhi);
     f2 *__restrict__ xs_next = xs;                   // where the next chunk's start state goes (chunks start in order)
 
     // Software pipeline over the batches (round 5): batch k + 1 is DECODED and the rows of its first HB hits are REQUESTED before
     // the chain of batch k runs, so the rows' way from HBM (half of a lone scan's time: scripts/debug/r05_scan_abl.sh, stop 3
     // against stop 2) passes beside the chain instead of in front of it.  Same operations on the same values as the staged form.
     struct Batch {
-        unsigned long long ptr[NR];                  // lane = buffer: address of its row(s), this wave's columns
+        unsigned long long ptr;                      // lane = buffer: address of its (first) row, this wave's columns
         float w[NR];
         int prow;
-        unsigned long long hit_mask, skip_mask, dense_mask, mark_mask;
+        unsigned long long hit_mask, skip_mask, dense_mask, mark_mask, direct_mask;
     };
     // ---- (1) lane = buffer base + lane
     auto decode = [&](int base, Batch &d) {
-        const int nd = p.nb - base < 64 ? p.nb - base : 64;
-        const int bi = base + (int)lane;
-        const bool in = bi < p.nb;
+        const int nd = b_hi - base < BATCH ? b_hi - base : BATCH;
+        const bool in = (int)lane < nd;
         const i4 dlo = nlo, dhi = nhi;
-        if (base + 64 < p.nb) load_descs(base + 64, nlo, nhi);
+        if (base + BATCH < b_hi) load_descs(base + BATCH, nlo, nhi);
         // (scalars first: __builtin_bit_cast of a vector ELEMENT expression reads element 0 with this compiler)
         const int frow = dlo.x, w_prow = dlo.y, w_mask = dlo.z, w_amp = dlo.w, w_pad0 = dhi.z;
         const unsigned flags = (unsigned)dhi.y;
@@ -156,11 +181,11 @@ __global__ __launch_bounds__(64) void iir_scan_kernel(
         // spare words (kernels.h); any other hit has ONE row, g = c3 * S from the combine kernel (its other two reads repeat
         // it with weight 0)
         const float *r0 = dl ? g32_obj + (size_t)frow * p.m_pad : p_grows + (size_t)(live ? frow : 0) * p.m_pad + col0;
-        d.ptr[0] = (unsigned long long)r0;
+        d.ptr = (unsigned long long)r0;
         d.w[0] = dl ? a * __builtin_bit_cast(float, w_prow) : a;
+        d.direct_mask = 0;
         if constexpr (DIRECT) {
-            d.ptr[1] = (unsigned long long)(dl ? r0 + p.m_pad : r0);
-            d.ptr[2] = (unsigned long long)(dl ? r0 + 2 * (size_t)p.m_pad : r0);
+            d.direct_mask = __ballot(dl);            // (its rows 1 and 2 follow row 0 at m_pad floats: a scalar stride, no lane reads)
             d.w[1] = dl ? a * __builtin_bit_cast(float, w_mask) : 0.f;
             d.w[2] = dl ? a * __builtin_bit_cast(float, w_pad0) : 0.f;
         }
@@ -169,63 +194,71 @@ __global__ __launch_bounds__(64) void iir_scan_kernel(
         d.hit_mask = __ballot(live && (a != 0.f || !impulse));
         d.skip_mask = __ballot(skip);
         d.dense_mask = __ballot(live && !impulse);
-        // chunk starts in this batch (a handful: scalar), and the transfer row in force when one starts: the last row a
-        // non-skipped buffer before it switched to
         d.mark_mask = 0;
-        const int c0 = (base + p.cb - 1) / p.cb;                  // the first chunk that starts at or behind `base`
-        for (int b = c0 * p.cb; b < base + nd; b += p.cb) d.mark_mask |= 1ull << (b - base);
-        const unsigned long long below = (1ull << lane) - 1ull;
         const unsigned long long set_mask = __ballot(in && !skip && trow != XFER_KEEP);
-        const unsigned long long before = set_mask & below;
-        const int src_lane = before ? 63 - __builtin_clzll(before) : 0;
-        const int got = __shfl(trow, src_lane, 64);
-        if (((d.mark_mask >> lane) & 1) && col0 == 0)
-            p_xtrow[(size_t)obj * p.n_chunks + c0 + __builtin_popcountll(d.mark_mask & below)] = before ? got : cur_row;
+        if constexpr (!SEG) {
+            // chunk starts in this batch (a handful: scalar), and the transfer row in force when one starts: the last row a
+            // non-skipped buffer before it switched to
+            const int c0 = (base + p.cb - 1) / p.cb;              // the first chunk that starts at or behind `base`
+            for (int b = c0 * p.cb; b < base + nd; b += p.cb) d.mark_mask |= 1ull << (b - base);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const unsigned long long before = set_mask & below;
+            const int src_lane = before ? 63 - __builtin_clzll(before) : 0;
+            const int got = __shfl(trow, src_lane, 64);
+            if (((d.mark_mask >> lane) & 1) && col0 == 0)
+                p_xtrow[(size_t)obj * p.n_chunks + c0 + __builtin_popcountll(d.mark_mask & below)] = before ? got : cur_row;
+        }
         if (set_mask) cur_row = rl(trow, 63 - __builtin_clzll(set_mask));
     };
-    // the next HB hits of a mask (the last one repeated when fewer are left); returns what is left of the mask
-    auto take_hits = [](unsigned long long m, int (&jj)[HB]) {
+    // the next (at most HB) hits of a mask: their buffers in jj[0 .. n), n returned; `m` loses them
+    auto take_hits = [](unsigned long long &m, int (&jj)[HB]) {
+        const int total = __builtin_popcountll(m);
 #pragma unroll
         for (int h = 0; h < HB; ++h) {
-            jj[h] = __builtin_ctzll(m);
-            const unsigned long long rest = m & (m - 1);
-            if (rest) m = rest;
-            else if (h == HB - 1) m = 0;
+            jj[h] = m ? __builtin_ctzll(m) : 0;
+            m &= m - 1;                              // (0 stays 0)
         }
-        return m;
+        return total < HB ? total : HB;
     };
-    // ---- (2a) lane = mode: the rows of HB hits, requested back to back
-    auto request = [&](const Batch &d, const int (&jj)[HB], float (&r)[HB][NR], f2 (&vv)[DENSE ? HB : 1]) {
-#pragma unroll
-        for (int h = 0; h < HB; ++h) {
-            static_for<0, NR>([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                r[h][k] = rlp(d.ptr[k], jj[h])[lane];
-            });
-            if constexpr (DENSE) {
-                // what a unit gain adds to the state over this buffer: its increment row (dense), A^512 u (impulse)
-                vv[h] = f2{hq, hd};
-                if ((d.dense_mask >> jj[h]) & 1) vv[h] = (reinterpret_cast<const f2 *>(p_vinc) + (size_t)rl(d.prow, jj[h]) * p.m_pad + col0)[lane];
+    // ---- (2a) lane = mode: the rows of the hits, requested back to back (a uniform branch per hit: a batch of the segmented
+    //      form has eight on average, and the sixteen slots' worth of lane reads and loads was a third of its instructions)
+    auto request = [&](const Batch &d, const int (&jj)[HB], int nh, float (&r)[HB][NR], f2 (&vv)[DENSE ? HB : 1]) {
+        static_for<0, HB>([&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            if (h < nh) {
+                const gptr row0 = rlp(d.ptr, jj[h]);
+                const size_t stride = DIRECT && ((d.direct_mask >> jj[h]) & 1) ? (size_t)p.m_pad : 0;
+                static_for<0, NR>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    r[h][k] = (row0 + k * stride)[lane];
+                });
+                if constexpr (DENSE) {
+                    // what a unit gain adds to the state over this buffer: its increment row (dense), A^512 u (impulse)
+                    vv[h] = f2{hq, hd};
+                    if ((d.dense_mask >> jj[h]) & 1) vv[h] = (reinterpret_cast<const f2 *>(p_vinc) + (size_t)rl(d.prow, jj[h]) * p.m_pad + col0)[lane];
+                }
             }
-        }
+        });
     };
     // ---- (2b) their gains g amp to LDS [buffer][mode]
-    auto deposit = [&](const Batch &d, const int (&jj)[HB], const float (&r)[HB][NR], const f2 (&vv)[DENSE ? HB : 1]) {
-#pragma unroll
-        for (int h = 0; h < HB; ++h) {
-            const int j = jj[h];
-            float gv = rlf(d.w[0], j) * r[h][0];
-            if constexpr (DIRECT) {
-                gv = fmaf(rlf(d.w[NR > 1 ? 1 : 0], j), r[h][NR > 1 ? 1 : 0], gv);
-                gv = fmaf(rlf(d.w[NR > 2 ? 2 : 0], j), r[h][NR > 2 ? 2 : 0], gv);
+    auto deposit = [&](const Batch &d, const int (&jj)[HB], int nh, const float (&r)[HB][NR], const f2 (&vv)[DENSE ? HB : 1]) {
+        static_for<0, HB>([&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            if (h < nh) {
+                const int j = jj[h];
+                float gv = rlf(d.w[0], j) * r[h][0];
+                if constexpr (DIRECT) {
+                    gv = fmaf(rlf(d.w[NR > 1 ? 1 : 0], j), r[h][NR > 1 ? 1 : 0], gv);
+                    gv = fmaf(rlf(d.w[NR > 2 ? 2 : 0], j), r[h][NR > 2 ? 2 : 0], gv);
+                }
+                if constexpr (DENSE) {
+                    lds_g[2 * j][lane] = gv * vv[h].x;
+                    lds_g[2 * j + 1][lane] = gv * vv[h].y;
+                } else {
+                    lds_g[j][lane] = gv;
+                }
             }
-            if constexpr (DENSE) {
-                lds_g[2 * j][lane] = gv * vv[h].x;
-                lds_g[2 * j + 1][lane] = gv * vv[h].y;
-            } else {
-                lds_g[j][lane] = gv;
-            }
-        }
+        });
     };
     // x <- A^513 x + gv A^512 u, two dependent operations deep (a lone wave issues a dependent instruction every ~8 cycles):
     // q' = (q + (P11 - 1) q) + (P12 d + gv hq), d' = P21 q + (P22 d + gv hd); the impulse's share is off the chain
@@ -246,21 +279,22 @@ __global__ __launch_bounds__(64) void iir_scan_kernel(
     float r[HB][NR];
     f2 vv[DENSE ? HB : 1];
     bool requested = false;                          // r / vv hold the rows of the first HB hits of `cur`
-    if (p.nb > 0 && PBSO_SCAN_STOP > 1) {
-        decode(0, cur);
+    if (b_lo < b_hi && PBSO_SCAN_STOP > 1) {
+        decode(b_lo, cur);
         if (cur.hit_mask && PBSO_SCAN_STOP > 2) {
             int jj[HB];
-            take_hits(cur.hit_mask, jj);
-            request(cur, jj, r, vv);
+            unsigned long long m = cur.hit_mask;
+            const int nh = take_hits(m, jj);
+            request(cur, jj, nh, r, vv);
             requested = true;
         }
     }
-    for (int base = 0; base < p.nb && PBSO_SCAN_STOP > 1; base += 64) {
-        const int nd = p.nb - base < 64 ? p.nb - base : 64;
-        const bool more = base + 64 < p.nb;
+    for (int base = b_lo; base < b_hi && PBSO_SCAN_STOP > 1; base += BATCH) {
+        const int nd = b_hi - base < BATCH ? b_hi - base : BATCH;
+        const bool more = base + BATCH < b_hi;
         if (PBSO_SCAN_STOP <= 2) {
-            x.x += (float)(cur.hit_mask ^ cur.skip_mask ^ cur.dense_mask ^ cur.mark_mask) + cur.w[0] + (float)cur.prow + (float)cur.ptr[0];
-            if (more) decode(base + 64, cur);
+            x.x += (float)(cur.hit_mask ^ cur.skip_mask ^ cur.dense_mask ^ cur.mark_mask) + cur.w[0] + (float)cur.prow + (float)cur.ptr;
+            if (more) decode(base + BATCH, cur);
             continue;
         }
         // ---- (2) the gains of the batch's hits, [buffer][mode] in LDS
@@ -273,30 +307,32 @@ __global__ __launch_bounds__(64) void iir_scan_kernel(
         wave_sync();
         for (unsigned long long m = cur.hit_mask; m;) {
             int jj[HB];
-            m = take_hits(m, jj);
-            if (!requested) request(cur, jj, r, vv);         // (a batch's hits behind its first HB: requested here)
+            const int nh = take_hits(m, jj);
+            if (!requested) request(cur, jj, nh, r, vv);     // (a batch's hits behind its first HB: requested here)
             requested = false;
-            deposit(cur, jj, r, vv);
+            deposit(cur, jj, nh, r, vv);
         }
         wave_sync();
         // ---- the next batch: decoded, its first rows on their way while this batch's chain runs
         if (more) {
-            decode(base + 64, nxt);
+            decode(base + BATCH, nxt);
             if (nxt.hit_mask) {
                 int jj[HB];
-                take_hits(nxt.hit_mask, jj);
-                request(nxt, jj, r, vv);
+                unsigned long long m = nxt.hit_mask;
+                const int nh = take_hits(m, jj);
+                request(nxt, jj, nh, r, vv);
                 requested = true;
             }
         }
         if (PBSO_SCAN_STOP <= 3) {
-            x.x += lds_g[lane][lane];
+            x.x += lds_g[lane & (BATCH - 1)][lane];
             if (more) cur = nxt;
             continue;
         }
 
         // ---- (3) the scan, lane = mode: the gains of a group of G buffers are read from LDS TWO groups ahead (two register sets)
         const unsigned long long slow_mask = cur.skip_mask, mark_mask = cur.mark_mask;
+        if constexpr (SEG) n_stepped += nd - __builtin_popcountll(slow_mask);
         auto fetch = [&](int j0, float (&gv)[G], float (&gw)[DENSE ? G : 1]) {
 #pragma unroll
             for (int i = 0; i < G; ++i) {
@@ -356,204 +392,78 @@ __global__ __launch_bounds__(64) void iir_scan_kernel(
         if (j0 < nd) generic(j0, nd - j0);
         if (more) cur = nxt;
     }
-    (p_sq + ubase)[lane] = x.x;
-    (p_sd + ubase)[lane] = x.y;
-    (p_ss + ubase)[lane] = 1.f;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// The scan cut along the time axis itself (round 5).  The serial scan above takes ~0.1 us per buffer and, beside a bank that
-// holds every register of the chip, cannot start before that bank retires: a launch of 860 buffers leaves ~90 us between two
-// banks (128 x 512 x 860: 1.32 ms per step against a 1.22 ms bank).  A chunk of buffers is an AFFINE map of the state,
-//     x_end = M x_start + v,      M = (A^513)^(buffers stepped),  v = what the chunk's forces leave behind from rest,
-// so one wave per CHUNK scans the zero-state response v of its own buffers only (the serial scan's chain from x = 0) and raises
-// A^513 to the number of buffers it stepped (square-and-multiply in fp64, rounded once), the waves of a workgroup (one per chunk,
-// same 64 columns) leave (M, v) in LDS, and every wave composes the maps of the chunks before its own: n_chunks - 1 steps of six
-// FMAs.  860 buffers in 8 chunks: the depth of a 108-buffer scan for the work of the serial one.  Used when a launch has 2 .. 8 chunks (the policy's long chunks); one
-// buffer per chunk keeps the serial scan, whose arithmetic does not depend on where a step is cut.
-constexpr int SEG_B = 16;        // buffers per batch of a wave (lane = buffer for the decode: 16 lanes)
-constexpr int SEG_MAX = 8;       // chunks (= waves per workgroup)
-
-template <bool DIRECT, bool DENSE>
-__global__ __launch_bounds__(64 * SEG_MAX) void iir_scan_seg_kernel(
-    float *__restrict__ p_sq, float *__restrict__ p_sd, float *__restrict__ p_ss, const float *__restrict__ p_sc,
-    const BufDesc *__restrict__ p_desc, const float *__restrict__ p_grows, const float *__restrict__ p_g32,
-    const long long *__restrict__ p_g32_off, const float *__restrict__ p_vinc, const int *__restrict__ p_xfer_init,
-    float *__restrict__ p_xs, int *__restrict__ p_xtrow, const ScanDims p) {
-    // (dynamic: sized by the launch's chunk count -- a workgroup of two waves takes 20 KB, not the 78 KB of eight)
-    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
-    const int n_waves = (int)(blockDim.x >> 6);
-    typedef float row64[64];
-    row64 *lds_g_all = reinterpret_cast<row64 *>(lds_dyn);                           // per wave: [buffer of the batch][q | d][mode]: what the hit adds to the state
-    row64 *lds_map_all = lds_g_all + (size_t)n_waves * 2 * SEG_B;                    // per chunk: M e1, M e2, v
-    int *lds_row_all = reinterpret_cast<int *>(lds_map_all + (size_t)n_waves * 6);   // per chunk: did a buffer set the transfer row, and the last one set
-    const int tiles = p.m_pad / 64;
-    const int obj = blockIdx.x / tiles;
-    const int col0 = 64 * (blockIdx.x % tiles);
-    const unsigned lane = threadIdx.x & 63u;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // the chunk
-    const size_t ubase = (size_t)obj * p.m_pad + col0;
-    const float s11 = (p_sc + ubase)[lane], s12 = (p_sc + p.plane + ubase)[lane];     // A^513: P11 - 1, P12, P21, P22
-    const float s21 = (p_sc + 2 * p.plane + ubase)[lane], s22 = (p_sc + 3 * p.plane + ubase)[lane];
-    const float hq = (p_sc + 4 * p.plane + ubase)[lane], hd = (p_sc + 5 * p.plane + ubase)[lane];      // A^512 u
-    const BufDesc *__restrict__ dsc = p_desc + (size_t)obj * p.nb;
-    const float *__restrict__ g32_obj = DIRECT ? p_g32 + (size_t)p_g32_off[obj] * p.m_pad + col0 : nullptr;
-    constexpr int NR = DIRECT ? 3 : 1;
-    auto rl = [](int v, int j) { return __builtin_amdgcn_readlane(v, j); };
-    auto rlf = [](float v, int j) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j)); };
-    auto rlp = [&](unsigned long long v, int j) {
-        const unsigned lo = (unsigned)rl((int)(unsigned)v, j), hi = (unsigned)rl((int)(unsigned)(v >> 32), j);
-        return (gptr)(((unsigned long long)hi << 32) | lo);
-    };
-    auto wave_sync = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-    const int b_lo = wv * p.cb, b_hi = b_lo + p.cb < p.nb ? b_lo + p.cb : p.nb;
-    f2 xz = f2{0.f, 0.f};
-    int has_set = 0, last_row = XFER_KEEP, n_stepped = 0;
-    row64 *lg = lds_g_all + (size_t)wv * 2 * SEG_B;
-    row64 *lds_map = lds_map_all + (size_t)wv * 6;
-    for (int base = b_lo; base < b_hi; base += SEG_B) {
-        const int nd = b_hi - base < SEG_B ? b_hi - base : SEG_B;
-        // ---- lane = buffer base + lane (lanes 0 .. nd - 1): as the serial scan's stage (1)
-        unsigned long long ptr[NR];
-        float w[NR];
-        int trow, prow;
-        unsigned hit_mask, skip_mask, dense_mask;
-        {
-            const bool in = (int)lane < nd;
-            const i4 *src = reinterpret_cast<const i4 *>(dsc + (in ? base + (int)lane : base));
-            const i4 dlo = src[0], dhi = src[1];
-            const int frow = dlo.x, w_prow = dlo.y, w_mask = dlo.z, w_amp = dlo.w, w_pad0 = dhi.z;
-            const unsigned flags = (unsigned)dhi.y;
-            const bool skip = in && (flags & DESC_SKIP) != 0;
-            const bool live = in && frow >= 0 && !(flags & DESC_SKIP);
-            const bool impulse = (flags & DESC_IMPULSE) != 0;
-            const bool direct = DIRECT && (flags & DESC_DIRECT) != 0;
-            const bool hit0 = direct || (w_mask & 1);
-            const float a = impulse ? (hit0 ? __builtin_bit_cast(float, w_amp) : 0.f) : 1.f;
-            const bool dl = live && direct;
-            const float *r0 = dl ? g32_obj + (size_t)frow * p.m_pad : p_grows + (size_t)(live ? frow : 0) * p.m_pad + col0;
-            ptr[0] = (unsigned long long)r0;
-            w[0] = dl ? a * __builtin_bit_cast(float, w_prow) : a;
-            if constexpr (DIRECT) {
-                ptr[1] = (unsigned long long)(dl ? r0 + p.m_pad : r0);
-                ptr[2] = (unsigned long long)(dl ? r0 + 2 * (size_t)p.m_pad : r0);
-                w[1] = dl ? a * __builtin_bit_cast(float, w_mask) : 0.f;
-                w[2] = dl ? a * __builtin_bit_cast(float, w_pad0) : 0.f;
-            }
-            trow = dhi.x;
-            prow = direct ? -1 : w_prow;
-            hit_mask = (unsigned)__ballot(live && (a != 0.f || !impulse));
-            skip_mask = (unsigned)__ballot(skip);
-            dense_mask = (unsigned)__ballot(live && !impulse);
-            const unsigned set_mask = (unsigned)__ballot(in && !skip && trow != XFER_KEEP);
-            if (set_mask) {
-                has_set = 1;
-                last_row = rl(trow, 31 - __builtin_clz(set_mask));
-            }
-        }
-        // ---- what every hit adds to the state, [buffer][q | d][mode]
-        wave_sync();
-        for (int i = 0; i < 2 * nd; ++i) lg[i][lane] = 0.f;
-        wave_sync();
-        {
-            // the batch's rows, all loads issued before the first is used (a hit per ~4 buffers: a handful per batch)
-            float r[SEG_B][NR];
-            f2 vv[DENSE ? SEG_B : 1];
-#pragma unroll
-            for (int j = 0; j < SEG_B; ++j) {
-                if ((hit_mask >> j) & 1) {
-                    static_for<0, NR>([&](auto kc) {
-                        constexpr int k = decltype(kc)::value;
-                        r[j][k] = rlp(ptr[k], j)[lane];
-                    });
-                    if constexpr (DENSE) {
-                        if ((dense_mask >> j) & 1) vv[j] = (reinterpret_cast<const f2 *>(p_vinc) + (size_t)rl(prow, j) * p.m_pad + col0)[lane];
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < SEG_B; ++j) {
-                if ((hit_mask >> j) & 1) {
-                    float gv = rlf(w[0], j) * r[j][0];
-                    if constexpr (DIRECT) {
-                        gv = fmaf(rlf(w[NR > 1 ? 1 : 0], j), r[j][NR > 1 ? 1 : 0], gv);
-                        gv = fmaf(rlf(w[NR > 2 ? 2 : 0], j), r[j][NR > 2 ? 2 : 0], gv);
-                    }
-                    float aq = hq, ad = hd;          // what a unit gain adds: A^512 u (impulse), the increment row (dense)
-                    if constexpr (DENSE) {
-                        if ((dense_mask >> j) & 1) { aq = vv[j].x; ad = vv[j].y; }
-                    }
-                    lg[2 * j][lane] = gv * aq;
-                    lg[2 * j + 1][lane] = gv * ad;
-                }
-            }
-        }
-        wave_sync();
-        // ---- the three chains
-        auto step = [&](f2 v, float gq, float gd) {
-            const float qa = fmaf(s11, v.x, v.x), qb = fmaf(s12, v.y, gq);
-            const float da = s21 * v.x, db = fmaf(s22, v.y, gd);
-            return f2{qa + qb, da + db};
-        };
-        n_stepped += nd - __builtin_popcount(skip_mask);
-        for (int j = 0; j < nd; ++j) {
-            if ((skip_mask >> j) & 1) continue;      // step() returned before stepping: state untouched
-            xz = step(xz, lg[2 * j][lane], lg[2 * j + 1][lane]);
-        }
-    }
-    {
-        // M = (A^513)^(buffers stepped): square-and-multiply in fp64 from the f32 constants the chain uses (a chunk of 430 buffers: nine
-        // squarings; two more chains beside the first tripled the kernel's work and made a throughput-bound scan slower)
-        double b00 = 1.0 + (double)s11, b01 = (double)s12, b10 = (double)s21, b11 = (double)s22;      // the running power of A^513
-        double m00 = 1.0, m01 = 0.0, m10 = 0.0, m11 = 1.0;
-        for (int e = n_stepped; e > 0; e >>= 1) {
-            if (e & 1) {
-                const double t00 = b00 * m00 + b01 * m10, t01 = b00 * m01 + b01 * m11;
-                const double t10 = b10 * m00 + b11 * m10, t11 = b10 * m01 + b11 * m11;
-                m00 = t00; m01 = t01; m10 = t10; m11 = t11;
-            }
-            const double q00 = b00 * b00 + b01 * b10, q01 = b00 * b01 + b01 * b11;
-            const double q10 = b10 * b00 + b11 * b10, q11 = b10 * b01 + b11 * b11;
-            b00 = q00; b01 = q01; b10 = q10; b11 = q11;
-        }
-        lds_map[0][lane] = (float)m00; lds_map[1][lane] = (float)m10;        // M e1
-        lds_map[2][lane] = (float)m01; lds_map[3][lane] = (float)m11;        // M e2
-        lds_map[4][lane] = xz.x; lds_map[5][lane] = xz.y;
-    }
-    if (lane == 0) { lds_row_all[2 * wv] = has_set; lds_row_all[2 * wv + 1] = last_row; }
-    __syncthreads();
-    // ---- compose the maps of the chunks in front of this one
-    f2 x;
-    {
-        const float s0 = (p_ss + ubase)[lane];       // the arrays hold scale x state (kernels_iir.hip, "scaled state")
-        x.x = (p_sq + ubase)[lane] / s0;
-        x.y = (p_sd + ubase)[lane] / s0;
-    }
-    auto apply = [&](int c, f2 v) {
-        const row64 *mp = lds_map_all + (size_t)c * 6;
-        const float q = fmaf(mp[0][lane], v.x, fmaf(mp[2][lane], v.y, mp[4][lane]));
-        const float d = fmaf(mp[1][lane], v.x, fmaf(mp[3][lane], v.y, mp[5][lane]));
-        return f2{q, d};
-    };
-    int row = p_xfer_init[obj];
-    for (int c = 0; c < wv; ++c) {
-        x = apply(c, x);
-        if (lds_row_all[2 * c]) row = lds_row_all[2 * c + 1];
-    }
-    (reinterpret_cast<f2 *>(p_xs) + ((size_t)obj * p.n_chunks + wv) * p.m_pad + col0)[lane] = x;
-    if (col0 == 0 && lane == 0) p_xtrow[(size_t)obj * p.n_chunks + wv] = row;
-    __syncthreads();                                 // (every wave has read the launch's start state)
-    if (wv == p.n_chunks - 1) {
-        x = apply(wv, x);
+    if constexpr (!SEG) {
         (p_sq + ubase)[lane] = x.x;
         (p_sd + ubase)[lane] = x.y;
         (p_ss + ubase)[lane] = 1.f;
+    } else {
+        row64 *lds_map = lds_map_all + (size_t)wv * 6;
+        {
+            // M = (A^513)^(buffers stepped): square-and-multiply in fp64 from the f32 constants the chain uses (a chunk of 430 buffers: nine
+            // squarings; two more chains beside the first tripled the kernel's work and made a throughput-bound scan slower)
+            double b00 = 1.0 + (double)s11, b01 = (double)s12, b10 = (double)s21, b11 = (double)s22;      // the running power of A^513
+            double m00 = 1.0, m01 = 0.0, m10 = 0.0, m11 = 1.0;
+            for (int e = n_stepped; e > 0; e >>= 1) {
+                if (e & 1) {
+                    const double t00 = b00 * m00 + b01 * m10, t01 = b00 * m01 + b01 * m11;
+                    const double t10 = b10 * m00 + b11 * m10, t11 = b10 * m01 + b11 * m11;
+                    m00 = t00; m01 = t01; m10 = t10; m11 = t11;
+                }
+                const double q00 = b00 * b00 + b01 * b10, q01 = b00 * b01 + b01 * b11;
+                const double q10 = b10 * b00 + b11 * b10, q11 = b10 * b01 + b11 * b11;
+                b00 = q00; b01 = q01; b10 = q10; b11 = q11;
+            }
+            lds_map[0][lane] = (float)m00; lds_map[1][lane] = (float)m10;        // M e1
+            lds_map[2][lane] = (float)m01; lds_map[3][lane] = (float)m11;        // M e2
+            lds_map[4][lane] = x.x; lds_map[5][lane] = x.y;
+        }
+        if (lane == 0) { lds_row_all[2 * wv] = cur_row != XFER_KEEP; lds_row_all[2 * wv + 1] = cur_row; }
+        __syncthreads();
+        // ---- compose the maps of the chunks in front of this one
+        {
+            const float s0 = (p_ss + ubase)[lane];       // the arrays hold scale x state (kernels_iir.hip, "scaled state")
+            x.x = (p_sq + ubase)[lane] / s0;
+            x.y = (p_sd + ubase)[lane] / s0;
+        }
+        auto apply = [&](int c, f2 v) {
+            const row64 *mp = lds_map_all + (size_t)c * 6;
+            const float q = fmaf(mp[0][lane], v.x, fmaf(mp[2][lane], v.y, mp[4][lane]));
+            const float d = fmaf(mp[1][lane], v.x, fmaf(mp[3][lane], v.y, mp[5][lane]));
+            return f2{q, d};
+        };
+        int row = p_xfer_init[obj];
+        for (int c = 0; c < wv; ++c) {
+            x = apply(c, x);
+            if (lds_row_all[2 * c]) row = lds_row_all[2 * c + 1];
+        }
+        (reinterpret_cast<f2 *>(p_xs) + ((size_t)obj * p.n_chunks + wv) * p.m_pad + col0)[lane] = x;
+        if (col0 == 0 && lane == 0) p_xtrow[(size_t)obj * p.n_chunks + wv] = row;
+        __syncthreads();                                 // (every wave has read the launch's start state)
+        if (wv == p.n_chunks - 1) {
+            x = apply(wv, x);
+            (p_sq + ubase)[lane] = x.x;
+            (p_sd + ubase)[lane] = x.y;
+            (p_ss + ubase)[lane] = 1.f;
+        }
     }
 }
+
+#define PBSO_SCAN_ARGS                                                                                                          \
+    float *__restrict__ p_sq, float *__restrict__ p_sd, float *__restrict__ p_ss, const float *__restrict__ p_sc,               \
+        const BufDesc *__restrict__ p_desc, const float *__restrict__ p_grows, const float *__restrict__ p_g32,                 \
+        const long long *__restrict__ p_g32_off, const float *__restrict__ p_vinc, const int *__restrict__ p_xfer_init,         \
+        float *__restrict__ p_xs, int *__restrict__ p_xtrow, const ScanDims p
+
+template <bool DIRECT, bool DENSE>
+__global__ __launch_bounds__(64) void iir_scan_kernel(PBSO_SCAN_ARGS) {
+    scan_body<DIRECT, DENSE, false>(p_sq, p_sd, p_ss, p_sc, p_desc, p_grows, p_g32, p_g32_off, p_vinc, p_xfer_init, p_xs, p_xtrow, p);
+}
+
+template <bool DIRECT, bool DENSE>
+__global__ __launch_bounds__(64 * SEG_MAX) void iir_scan_seg_kernel(PBSO_SCAN_ARGS) {
+    scan_body<DIRECT, DENSE, true>(p_sq, p_sd, p_ss, p_sc, p_desc, p_grows, p_g32, p_g32_off, p_vinc, p_xfer_init, p_xs, p_xtrow, p);
+}
+#undef PBSO_SCAN_ARGS
 
 // ---------------------------------------------------------------------------------------------------------
 // dense_increment_kernel: V[row][mode] = sum_{k=0..512} A^(512-k) u T_row[k], the state a unit force gain with the dense time
@@ -686,7 +596,7 @@ int launch_iir_scan(const IirParams &p, int n_obj, const float *sc, int cb, int 
     if (segmented) {
         if (n_chunks < 2 || n_chunks > iir_scan::SEG_MAX) return (int)hipErrorInvalidValue;
         const dim3 bseg(64 * n_chunks);
-        const size_t lds_seg = (size_t)n_chunks * ((2 * iir_scan::SEG_B + 6) * 64 * sizeof(float) + 2 * sizeof(int));
+        const size_t lds_seg = (size_t)n_chunks * ((iir_scan::SEG_ROWS + 6) * 64 * sizeof(float) + 2 * sizeof(int));
 #define PBSO_SCAN_SEG(DIRECT, DENSE)                                                                                             \
     if (lds_seg > 64 * 1024) {                                                                                                  \
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(iir_scan::iir_scan_seg_kernel<DIRECT, DENSE>),       \
@@ -706,7 +616,7 @@ int launch_iir_scan(const IirParams &p, int n_obj, const float *sc, int cb, int 
         return (int)hipGetLastError();
     }
 #define PBSO_SCAN_LAUNCH(DIRECT, DENSE)                                                                                          \
-    hipLaunchKernelGGL((iir_scan::iir_scan_kernel<DIRECT, DENSE>), grid, block, 0, stream, p.sq, p.sd, p.ss, sc, p.desc, p.grows, p.g32, \
+    hipLaunchKernelGGL((iir_scan::iir_scan_kernel<DIRECT, DENSE>), grid, block, (DENSE ? 128 : 64) * 64 * sizeof(float), stream, p.sq, p.sd, p.ss, sc, p.desc, p.grows, p.g32, \
                        p.g32_off, vinc, p.xfer_init, xs, xtrow, dims)
     if (vinc) {
         if (direct) PBSO_SCAN_LAUNCH(true, true);
