@@ -73,6 +73,9 @@ def parse(argv=None):
                          "(one or two asynchronous uploads among an engine's first ~30 block the caller for 6 - 7 ms: "
                          "PBSO_TIMELINE=1, scripts/debug/r03_stalls.py); reported as settle_steps.  Default: 40 s of audio "
                          "(40 steps of 86 buffers, 4 of 860)")
+    ap.add_argument("--clock-ramp-ms", type=float, default=150.0,
+                    help="milliseconds a scratch engine (256 x 512, no messages) is stepped right before every leg's settle steps, so that "
+                         "short legs are not timed inside the shader clock's ramp from idle (scripts/debug/r05_ramp.sh); 0 = off")
     ap.add_argument("--objects", type=int, default=1024, help="objects per GPU (weak scaling); the total for the strong leg")
     ap.add_argument("--modes", type=int, default=512)
     ap.add_argument("--buffers", type=int, default=860,
@@ -316,6 +319,39 @@ def oracle_rows(args, lam, shapes, scripts, rows, n_steps):
 
 
 # ----------------------------------------------------------------------------------------------------
+def ramp_clock(ctx, ms=150.0):
+    """The shader clock takes ~70 ms of work to ramp from idle (profiles/r01_clock_ramp.txt), and a leg's engine is built on the
+    host for seconds while the device idles: a leg whose settle + warm-up steps are 10 ms of device time (the 128-object share at
+    860 buffers: 4 + 2 steps of 1.3 ms) was TIMED inside the ramp -- 1.25 - 1.27 ms per step against 1.22 with 80 settle steps,
+    the 512-object share bimodal (scripts/debug/r05_ramp.sh).  Settle steps of the leg's own script cost scripts and oracle time
+    (the parity check steps the oracle from buffer 0), so the ramp is the product's kernel on a SCRATCH engine instead: 256 objects
+    x 512 modes, no messages, stepped for `ms` of wall time right before every leg's settle steps.  Untimed, like them."""
+    import torch
+    from openpbso_amd import capi, synth
+    from openpbso_amd.solver import Engine
+    sc = ctx.get("_ramp")
+    if sc is None:
+        lam = synth.eigenvalues(512, synth.seed_for(4, 0))
+        shapes = synth.mode_shapes(512, synth.seed_for(4, 0))
+        eng = Engine(device=ctx["dev_index"], form=capi.FORM_BLOCK, qnorm=capi.QNORM_OFF, stream=ctx["stream"].cuda_stream, chunk_buffers=128)
+        for i in range(256):
+            eng.add_object(lam, synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes)
+            eng.set_use_transfer(i, False)
+        eng.finalize()
+        sc = ctx["_ramp"] = (eng, torch.empty(256, 86 * 513, dtype=torch.float32, device=ctx["dev"]))
+    eng, audio = sc
+    t0 = time.perf_counter()
+    n = 0
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(16):
+            eng.step(86, into=audio.data_ptr())
+        eng.sync()
+        n += 16
+    took = (time.perf_counter() - t0) * 1e3
+    ctx["_ramp_ms_per_step"] = took / max(1, n)          # (0.24 ms when the bank really runs: 256 x 512 x 86)
+    return took
+
+
 def measure(args, ctx, global_ids, want_parity):
     """One engine, settle + warm-up + K timed steps.  Returns the rank-local numbers (elapsed is the max over ranks)."""
     import torch
@@ -551,6 +587,8 @@ def measure(args, ctx, global_ids, want_parity):
     gc.collect()
     gc.disable()
     try:
+        if args.clock_ramp_ms > 0:
+            ramp_clock(ctx, args.clock_ramp_ms)
         for k in range(args.settle + args.warmup):
             one_step(k, capture=(k == 0 and want_parity))     # (loads the copy kernel's code object outside the timed region)
         drain()
@@ -933,7 +971,7 @@ def main():
         out = {
             "metric": "audio samples/s & real-time x at N_obj x N_modes",
             "value": hn["value"], "unit": "audio samples/s", "realtime_x": hn["realtime_x"],
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle, "clock_ramp_ms": args.clock_ramp_ms,
             "ms_per_step": hn["ms_per_step"],
             "value_step_seconds": nb * B / SAMPLE_RATE,      # seconds of audio per step of `value` (rounds 1 - 3: 1.0; since round 4: 10.0 -- `steps_of_one_second` carries the comparable figure)
             "higher_is_better": True, "scaling": head, "vs_baseline": None,
