@@ -125,6 +125,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-objects", type=int, default=0, help="objects in the CPU baseline sample (0 = auto)")
     args = ap.parse_args(argv)
+    args.settle_auto = args.settle < 0
     if args.settle < 0:
         args.settle = max(2, round(40 * 86 / max(1, args.buffers)))
     if args.plan_threads <= 0:
@@ -324,31 +325,44 @@ def ramp_clock(ctx, ms=150.0):
     host for seconds while the device idles: a leg whose settle + warm-up steps are 10 ms of device time (the 128-object share at
     860 buffers: 4 + 2 steps of 1.3 ms) was TIMED inside the ramp -- 1.25 - 1.27 ms per step against 1.22 with 80 settle steps,
     the 512-object share bimodal (scripts/debug/r05_ramp.sh).  Settle steps of the leg's own script cost scripts and oracle time
-    (the parity check steps the oracle from buffer 0), so the ramp is the product's kernel on a SCRATCH engine instead: 256 objects
-    x 512 modes, no messages, stepped for `ms` of wall time right before every leg's settle steps.  Untimed, like them."""
+    (the parity check steps the oracle from buffer 0), so short legs get the product's kernel on a SCRATCH engine first: 256 objects
+    x 512 modes under the headline's hit rate (one second of hits, replayed), stepped for `ms` of wall time right before the leg's
+    settle steps.  Untimed, like them."""
     import torch
     from openpbso_amd import capi, synth
     from openpbso_amd.solver import Engine
     sc = ctx.get("_ramp")
     if sc is None:
+        n, nb = 256, 86
         lam = synth.eigenvalues(512, synth.seed_for(4, 0))
         shapes = synth.mode_shapes(512, synth.seed_for(4, 0))
-        eng = Engine(device=ctx["dev_index"], form=capi.FORM_BLOCK, qnorm=capi.QNORM_OFF, stream=ctx["stream"].cuda_stream, chunk_buffers=128)
-        for i in range(256):
+        eng = Engine(device=ctx["dev_index"], form=capi.FORM_BLOCK, qnorm=capi.QNORM_ALL, stream=ctx["stream"].cuda_stream, chunk_buffers=128)
+        for i in range(n):
             eng.add_object(lam, synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes)
-            eng.set_use_transfer(i, False)
         eng.finalize()
-        sc = ctx["_ramp"] = (eng, torch.empty(256, 86 * 513, dtype=torch.float32, device=ctx["dev"]))
-    eng, audio = sc
+        fo, fv, fn, ft = [], [], [], []
+        for i in range(n):
+            eng.set_use_transfer(i, False)
+            hits = synth.poisson_hits(nb, synth.seed_for(4, i))
+            hb = np.nonzero(hits >= 0)[0]
+            fo.append(np.full(hb.size, i, dtype=np.int32))
+            fv.append(hits[hb].astype(np.int32))
+            fn.append(synth.unit_normals(nb, synth.seed_for(4, i))[hb])
+            ft.append(hb.astype(np.int64))
+        sc = ctx["_ramp"] = [eng, torch.empty(n, nb * 513, dtype=torch.float32, device=ctx["dev"]),
+                             tuple(np.ascontiguousarray(np.concatenate(x)) for x in (fo, fv, fn, ft)), 0]
+    eng, audio, (fo, fv, fn, ft0), done = sc
     t0 = time.perf_counter()
     n = 0
     while (time.perf_counter() - t0) * 1e3 < ms:
         for _ in range(16):
+            assert eng.enqueue_vertex_hits(fo, fv, fn, ft0 + 86 * (done + n)) == fo.size
             eng.step(86, into=audio.data_ptr())
+            n += 1
         eng.sync()
-        n += 16
+    sc[3] = done + n
     took = (time.perf_counter() - t0) * 1e3
-    ctx["_ramp_ms_per_step"] = took / max(1, n)          # (0.24 ms when the bank really runs: 256 x 512 x 86)
+    ctx["_ramp_ms_per_step"] = took / max(1, n)          # (0.27 ms when the bank runs: 256 x 512 x 86)
     return took
 
 
@@ -812,11 +826,15 @@ def main():
                 continue
             a3 = copy.copy(args)
             a3.objects = args.objects // n_ranks
+            # (as much device time before the clock starts as the headline's own settle + warm-up steps take, and at least 0.1 s:
+            #  a share's steps are 1 / N as long)
+            if args.settle_auto:
+                a3.settle = int(min(200, np.ceil(max(args.settle * n_ranks, 100.0 / (9.3 * args.buffers / 860 * args.objects / 1024 * args.modes / 512 / n_ranks)))))
             ctx["counts"] = [a3.objects]
             # (three runs of every share, each a fresh engine: one hiccup -- a co-start collision, a host stall -- shows as such)
             runs = [measure(a3, ctx, list(range(a3.objects)), want_parity=(not args.no_parity and rank == 0 and rep == 0))
                     for rep in range(max(1, args.share_repeats))]
-            shares.append((n_ranks, a3.objects, runs))
+            shares.append((n_ranks, a3.objects, runs, a3.settle))
         ctx["counts"] = [args.objects]
     # one GPU: the same scene stepped ONE SECOND of audio at a time (86 buffers per pbso_step: the step size of rounds 1 - 3 and of
     # SURVEY 8(d)'s parity runs) -- what a launch's fixed costs take when they are paid every second of audio instead of every ten
@@ -1067,14 +1085,14 @@ def main():
                 rc = 3
         if shares:
             rows_s = []
-            for n_ranks, n_o, runs in shares:
+            for n_ranks, n_o, runs, settle_s in shares:
                 lns = sorted((leg_numbers("strong", r_) for r_ in runs), key=lambda d: d["ms_per_step"])
                 r = runs[0]                                   # (the run that carries the oracle check)
                 ln = lns[len(lns) // 2]                       # the median run
                 rows_s.append({"n_gpus": n_ranks, "objects": n_o, "ms_per_step": ln["ms_per_step"], "kernel_ms": float(np.median([r_["kernel_ms"] for r_ in runs])),
                                "realtime_x": ln["realtime_x"],
                                "implied_efficiency_at_N": hn["ms_per_step"] / n_ranks / ln["ms_per_step"],
-                               "runs": len(runs), "ms_per_step_min_median_max": [lns[0]["ms_per_step"], ln["ms_per_step"], lns[-1]["ms_per_step"]],
+                               "runs": len(runs), "settle_steps": settle_s, "ms_per_step_min_median_max": [lns[0]["ms_per_step"], ln["ms_per_step"], lns[-1]["ms_per_step"]],
                                "implied_efficiency_min_median_max": [hn["ms_per_step"] / n_ranks / lns[-1]["ms_per_step"],
                                                                      hn["ms_per_step"] / n_ranks / ln["ms_per_step"],
                                                                      hn["ms_per_step"] / n_ranks / lns[0]["ms_per_step"]],
@@ -1088,7 +1106,9 @@ def main():
                 "note": "strong-scaling proxy measured on THIS GPU: objects are independent, so a rank of the N-GPU run of this configuration "
                         "steps objects / N of them -- this is that rank's compute, gather not included; implied_efficiency_at_N = "
                         "(this line's ms_per_step / N) / the share's ms_per_step.  Shares that leave SIMDs idle run the block kernel cut "
-                        "along the time axis (K5: time_chunked_launches)"}
+                        "along the time axis (K5: time_chunked_launches).  A share's steps are 1 / N as long as the headline's, so it takes "
+                        "N times the settle steps (at least 0.1 s of device time: settle_steps) -- with the headline's four, the 128-object "
+                        "share was timed inside the shader clock's ramp from idle (1.26 against 1.22 ms, profiles/r05_shares_inside_the_clock_ramp.txt)"}
         if one_second is not None:
             a4, r4 = one_second
             secs = 86 * B * a4.steps / SAMPLE_RATE

@@ -9,8 +9,8 @@ done
 echo "128 x 512 x 86: $(for i in 1 2 3; do run --objects 128 --buffers 86 --steps 40 --warmup 3; done)"
 echo "c5 qnorm: $(for i in 1 2; do run --objects 8 --modes 4096 --scenario scraping --buffers 86 --steps 40 --warmup 2; done)"
 echo "c5 qnorm off: $(for i in 1 2; do run --objects 8 --modes 4096 --scenario scraping --qnorm off --buffers 86 --steps 40 --warmup 2; done)"
-echo "c3: $(for i in 1 2; do run --objects 64 --modes 256 --scenario listener --buffers 86 --steps 40 --warmup 2; done)"
-echo "c2: $(for i in 1 2; do run --objects 1 --modes 512 --buffers 86 --steps 40 --warmup 2; done)"
+
+
 python bench.py > gpurun_out/r05_bench_default_ramp.json 2> gpurun_out/r05_bench_default_ramp.err; echo "default rc=$?"
 python -c "
 import json; d=json.load(open('gpurun_out/r05_bench_default_ramp.json'))
