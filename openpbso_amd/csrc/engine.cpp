@@ -275,6 +275,7 @@ Engine::~Engine() {
                      hprof_[4] / tot_steps_, hprof_[6] / tot_steps_, hprof_[7] / tot_steps_, hprof_[8] / tot_steps_, hprof_[5] / tot_steps_);
     delete pool_;
     if (stream_) (void)hipStreamSynchronize(stream_);
+    if (aux_stream_) (void)hipStreamSynchronize(aux_stream_);
     if (timeline_have_base_) {                         // (the reference launch's quad was kept out of the free list)
         for (hipEvent_t ev : {timeline_quad_.k0, timeline_quad_.k1, timeline_quad_.p0, timeline_quad_.p1, timeline_quad_.f0, timeline_quad_.f1})
             if (ev) (void)hipEventDestroy(ev);
@@ -301,9 +302,10 @@ Engine::~Engine() {
     for (TcSet &ts : tc_) { ts.d_teams.release(); ts.d_split.release(); }
     for (DevBuf<float> &g : d_grows_) g.release();
     for (int i = 0; i < N_SETS; ++i)
-        for (hipEvent_t ev : {ev_prep_done_[i], ev_k1_done_[i], ev_set_[i]})
+        for (hipEvent_t ev : {ev_prep_done_[i], ev_k1_done_[i], ev_set_[i], ev_aux_fork_[i], ev_aux_join_[i]})
             if (ev) (void)hipEventDestroy(ev);
     if (prep_stream_) (void)hipStreamDestroy(prep_stream_);
+    if (aux_stream_) (void)hipStreamDestroy(aux_stream_);
     if (sig_prep_) (void)hipFree(sig_prep_);
     if (sig_start_) (void)hipFree(sig_start_);
     if (host_start_) (void)hipHostFree(host_start_);
@@ -400,6 +402,7 @@ int Engine::init() {
         int least = 0, greatest = 0;
         HIPTRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPTRY(hipStreamCreateWithPriority(&prep_stream_, hipStreamNonBlocking, greatest));
+        HIPTRY(hipStreamCreateWithPriority(&aux_stream_, hipStreamNonBlocking, greatest));
     }
     if (desc_.stream_sync != 1) {
         // the HOST form of the start gate (policy since round 5, see step_chunk): a word of pinned host memory the bank's first
@@ -435,6 +438,8 @@ int Engine::init() {
 #endif
         HIPTRY(hipEventCreateWithFlags(&ev_prep_done_[i], PBSO_DEVICE_EVENT_FLAGS));
         HIPTRY(hipEventCreateWithFlags(&ev_k1_done_[i], PBSO_DEVICE_EVENT_FLAGS));
+        HIPTRY(hipEventCreateWithFlags(&ev_aux_fork_[i], PBSO_DEVICE_EVENT_FLAGS));
+        HIPTRY(hipEventCreateWithFlags(&ev_aux_join_[i], PBSO_DEVICE_EVENT_FLAGS));
     }
     plan_threads_ = std::min(16, std::max(1, desc_.plan_threads));
     ctx_.resize(plan_threads_);
@@ -443,6 +448,7 @@ int Engine::init() {
     if (const char *v = std::getenv("PBSO_CENSUS")) census_ = std::atoi(v) != 0;
     if (const char *v = std::getenv("PBSO_ROTATE_PRIO")) rotate_prio_ = std::min(2, std::max(0, std::atoi(v)));
     if (const char *v = std::getenv("PBSO_TIMELINE")) timeline_ = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PBSO_PREP_SPLIT")) prep_split_ = std::min(2, std::max(0, std::atoi(v)));
     host_profile_ = std::getenv("PBSO_HOST_PROFILE") != nullptr;
     // which kernels run and how: per engine, from the descriptor (ABI 4); the environment only switches diagnostics on
     device_profiles_ = desc_.device_profiles >= 0;
@@ -2312,6 +2318,21 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     int tc_set = -1, tc_cb = 0;
     const bool tc_launch = is_block() && !split_always_ && choose_time_chunks(nb, n_prows_, &tc_set, &tc_cb);
     // K2 -> time-profile rows ; K3 / scatter -> data slots ; K4 -> transfer rows ; combine -> g rows
+    // Round 5: a launch with many dense-profile rows FORKS its preparation.  The force profiles (variates -> zero-state chains ->
+    // rows) and the dense increments that need them are one dependent chain, projection -> combine another, and nothing connects
+    // the two before the scan; in one stream they ran one after the other BESIDE the previous bank -- 8 x 4096 x 86 sustained
+    // scraping with qnorm rows: 31 + 54 + 73 (profiles) + 29 + 15 (project, combine) + 78 (increments) = 280 us beside a bank of
+    // 283, then the scan: the preparation, not the bank, set the step (scripts/debug/r05_timeline_c5.sh).  Forked, projection +
+    // FFAT + combine run on aux_stream_ behind the upload and join the preparation stream in front of the scan (or of the
+    // hand-over to the bank): every later reader is ordered behind prep_stream_ as before.
+    const bool split_prep = !one_stream && aux_stream_ && prep_split_ > 0 && device_profiles_ && n_prows_ > 0 &&
+                            (prep_split_ == 2 || n_prows_ >= 64) && (n_frows > 0 || !proj_.empty() || !ffat_.empty() || !stage_slot_.empty());
+    hipStream_t sa = split_prep ? aux_stream_ : sp;
+    if (split_prep) {
+        tot_prep_splits_ += 1;
+        HIPTRY(hipEventRecord(ev_aux_fork_[cur_set_], sp));         // (behind the upload and, for gated launches, the start gate)
+        HIPTRY(hipStreamWaitEvent(sa, ev_aux_fork_[cur_set_], 0));
+    }
     if (device_profiles_ && timed && n_chains > 0) { HIPTRY(hipEventRecord(evq.f0, sp)); evq.has_k2 = true; }
     if (device_profiles_ && k2_rows_launch_)
         LAUNCHTRY(launch_force_rows(d_prow, (int)prof_rows_.size(), d_pent, reinterpret_cast<const ArUse *>(da + o_aruse), (int)ar_uses_.size(),
@@ -2321,20 +2342,22 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     else if (device_profiles_)
         LAUNCHTRY(launch_force_profiles(d_chain, n_chains, d_prow, d_pent, d_arstate_.p, ps.d_tprof.p, B_, b_pad_, ar_serial_ ? 1 : 0, k2_prio_, sp));
     if (evq.has_k2) HIPTRY(hipEventRecord(evq.f1, sp));
-    LAUNCHTRY(launch_scatter_rows(d_stage, d_stage_slot, (int)stage_slot_.size(), d_slots_.p, m_pad_, sp));
-    LAUNCHTRY(launch_modal_project(d_proj, (int)proj_.size(), d_shapes_.p, d_shape_off_.p, d_n_modes_.p, d_slots_.p, m_pad_, sp));
+    LAUNCHTRY(launch_scatter_rows(d_stage, d_stage_slot, (int)stage_slot_.size(), d_slots_.p, m_pad_, sa));
+    LAUNCHTRY(launch_modal_project(d_proj, (int)proj_.size(), d_shapes_.p, d_shape_off_.p, d_n_modes_.p, d_slots_.p, m_pad_, sa));
     // (a few events: one thread per (event, mode); listener paths -- many events per object -- by runs)
     // (the run form puts the runs on grid.y: at most 65535 of them -- a larger launch takes the per-event form)
     if (ffat_.size() >= 4 * ffat_runs_.size() && !ffat_runs_.empty() && ffat_runs_.size() <= 65535)
         LAUNCHTRY(launch_ffat_lookup_runs(d_ffat, reinterpret_cast<const FfatRun *>(da + o_ffat_runs), (int)ffat_runs_.size(), d_geom_.p,
-                                          d_geom_off_.p, d_n_modes_.p, d_psi_.p, d_xfer_.p, m_pad_, sp));
+                                          d_geom_off_.p, d_n_modes_.p, d_psi_.p, d_xfer_.p, m_pad_, sa));
     else
-        LAUNCHTRY(launch_ffat_lookup(d_ffat, (int)ffat_.size(), d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p, d_xfer_.p, m_pad_, sp));
+        LAUNCHTRY(launch_ffat_lookup(d_ffat, (int)ffat_.size(), d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p, d_xfer_.p, m_pad_, sa));
     // (the combine stays on the preparation stream even when the bank fills the register file: its workgroups
     //  move in as the bank's retire, so most of it is done when the last one leaves -- queued behind the bank in
     //  the bank's own stream it would start only then: 0.785 instead of 0.735 ms per step at 1024 x 512)
     LAUNCHTRY(launch_force_combine(d_row_ptr, d_slot_idx, d_row_obj, n_frows, d_slots_.p, d_c3_.p, grows.p, d_projd, d_shapes_.p,
-                                   d_shape_off_.p, d_n_modes_.p, m_pad_, sp));
+                                   d_shape_off_.p, d_n_modes_.p, m_pad_, sa));
+    if (split_prep) HIPTRY(hipEventRecord(ev_aux_join_[cur_set_], sa));
+    if (split_prep && !tc_launch) HIPTRY(hipStreamWaitEvent(sp, ev_aux_join_[cur_set_], 0));
     if (tc_launch) {
         // The scan hands the state from launch to launch by itself (the chunked bank launches never write it), so it runs HERE, on
         // the preparation stream, beside the previous launch's oscillator bank -- behind a launch of another kind it waits for
@@ -2352,6 +2375,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
             tot_tc_dense_launches_ += 1;
         }
         if (!last_launch_tc_ && last_set_ >= 0) HIPTRY(hipStreamWaitEvent(sp, ev_k1_done_[last_set_], 0));
+        if (split_prep) HIPTRY(hipStreamWaitEvent(sp, ev_aux_join_[cur_set_], 0));      // (the increments above did not need the gains; the scan does)
         // Cut along the time axis itself -- one wave per chunk (kernels_scan.hip, SEG) -- in two cases.  (a) The whole scan is a
         // handful of waves: it halves the latency of a scan that has the device to itself (1 x 512 x 86: 11.3 -> 5.7 us).  (b) LONG
         // chunks of a scene whose serial scan is at most two waves per SIMD: that scan can only start as the previous bank's
@@ -2361,13 +2385,15 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         // 128 x 512 x 860 1.31 -> 1.27 ms per step, 256 x 512 x 860 2.45 -> 2.42 (scripts/debug/r05_scan_seg2.sh).  NOT for
         // four serial waves per SIMD (512 x 512: the serial scan is throughput-bound already and does less work: 4.79 against
         // 4.87 ms) and not for short chunks (86-buffer steps, 11 buffers per chunk: 0.156 against 0.160 ms -- eight times the
-        // waves for one batch each).  One buffer per chunk keeps the serial scan, whose arithmetic does not depend on where a
-        // step is cut.
+        // waves for one batch each).  (c) A DENSE scan (every buffer a hit with a row of increments: 64 hits per serial batch,
+        // sixteen in flight) of at most two waves per CU: 8 x 4096 x 86 sustained scraping with qnorm rows 0.320 -> 0.312 ms per
+        // step (scripts/debug/r05_seg_short.sh).  One buffer per chunk keeps the serial scan, whose arithmetic does not depend
+        // on where a step is cut.
         const bool seg_fits = n_chunks >= 2 && n_chunks <= SCAN_SEG_MAX;
         const long long scan_waves = (long long)N * (m_pad_ / 64);
         const bool seg = seg_fits && desc_.scan_kernel != 1 &&
                          (desc_.scan_kernel == 2 || (tc_cb > 1 && scan_waves * n_chunks <= 2LL * n_cus_) ||
-                          (tc_cb >= 32 && scan_waves <= 8LL * n_cus_));
+                          (tc_cb >= 32 && scan_waves <= 8LL * n_cus_) || (tc_cb > 1 && vinc && scan_waves <= 2LL * n_cus_));
         if (seg) tot_seg_scans_ += 1;
         LAUNCHTRY(launch_iir_scan(kp, N, d_scan_.p, tc_cb, n_chunks, d_xs_[cur_set_].p, d_xtrow_[cur_set_].p, direct_hits_, vinc, seg, sp));
     }
@@ -2508,6 +2534,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
 
 int Engine::sync() {
     HIPTRY(hipSetDevice(desc_.device));      // the caller's thread may have another device current
+    if (aux_stream_) HIPTRY(hipStreamSynchronize(aux_stream_));
     if (prep_stream_) HIPTRY(hipStreamSynchronize(prep_stream_));
     if (stream_) HIPTRY(hipStreamSynchronize(stream_));
     if (copy_stream_) HIPTRY(hipStreamSynchronize(copy_stream_));

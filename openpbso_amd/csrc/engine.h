@@ -234,6 +234,11 @@ private:
     bool finalized_ = false, own_stream_ = false;
     hipStream_t stream_ = nullptr;                       // oscillator bank (caller's stream if given)
     hipStream_t prep_stream_ = nullptr;                  // plan upload + projection + FFAT + force profiles + combine + scan
+    // round 5: launches with many dense-profile rows fork the preparation in two -- force profiles (K2) and the dense increments
+    // stay on prep_stream_, projection + FFAT + combine go to aux_stream_ and join before the scan / the bank (step_chunk)
+    hipStream_t aux_stream_ = nullptr;
+    int prep_split_ = 1;                                 // PBSO_PREP_SPLIT (diagnostic): 0 never, 1 policy, 2 whenever there is anything to fork
+    long long tot_prep_splits_ = 0;
     // The hand-over preparation -> bank (desc.stream_sync).  An event costs the waiting stream 10 - 12 us after the preparation's
     // last kernel (scripts/microbench/wait_value.hip, profiles/r04_stream_sync.txt); a value in signal memory, written by a
     // one-wave kernel behind that kernel, and a hipStreamWaitValue64 in front of the bank: 5 - 6 us.  Opt-in: the bank then starts
@@ -260,6 +265,7 @@ private:
 #endif
     static constexpr int N_SETS = PBSO_N_SETS;
     hipEvent_t ev_prep_done_[N_SETS] = {}, ev_k1_done_[N_SETS] = {};
+    hipEvent_t ev_aux_fork_[N_SETS] = {}, ev_aux_join_[N_SETS] = {};      // the preparation's fork to aux_stream_ and its way back
     // engines with several team sizes: the size classes are launched side by side on these streams
     // (one class alone rarely fills the chip), forked from and joined into stream_ with events
     static constexpr int N_CLASS_STREAMS = 3;

@@ -5,6 +5,18 @@
 
 namespace pbso {
 
+// Wave priority of the preparation's kernels (profiles, projection, combine, increments, scan): they are small, they run BESIDE the
+// oscillator bank, and the next bank waits for them (build option for A/B runs: scripts/debug/r05_prep_prio.sh)
+#ifndef PBSO_PREP_PRIO
+#define PBSO_PREP_PRIO 0
+#endif
+#if defined(__HIPCC__)
+__device__ __forceinline__ void prep_prio() {
+    if (PBSO_PREP_PRIO > 0) __builtin_amdgcn_s_setprio(PBSO_PREP_PRIO);
+}
+#endif
+
+
 // one audio buffer is processed as tiles of TILE samples; 513 = 19 * 27.
 // 27 rows x 68 floats = 7.3 KB of LDS per wave: 16+ waves per CU fit, which the
 // VALU issue rate needs (one wave alone issues a v_fma_f32 every ~5.5 cycles,

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void modal_project_kernel(
     const ProjectEvent *__restrict__ events, const double *__restrict__ shapes,
     const long long *__restrict__ shape_off, const int *__restrict__ n_modes,
     double *__restrict__ slots, int m_pad) {
+    prep_prio();
     const ProjectEvent ev = events[blockIdx.y];
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= m_pad) return;
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(256) void force_combine_kernel(
     const double *__restrict__ c3, float *__restrict__ grows, const ProjectEvent *__restrict__ direct,
     const double *__restrict__ shapes, const long long *__restrict__ shape_off, const int *__restrict__ n_modes,
     int m_pad) {
+    prep_prio();
     const int row = blockIdx.y;
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= m_pad) return;
@@ -552,6 +554,7 @@ __device__ __forceinline__ void ar_defaults(ArState &s) {          // forces.h:7
 __global__ __launch_bounds__(K2_THREADS) void ar_variates_kernel(
     const int *__restrict__ seg_stream, const ArStream *__restrict__ streams, const ArState *__restrict__ states,
     ArState *__restrict__ snaps, double *__restrict__ vnorm, uint32_t *__restrict__ vstate, int *__restrict__ seg_count) {
+    prep_prio();
     __shared__ uint32_t cnt[2][K2_THREADS / 64];
     const int seg = blockIdx.x, lane = threadIdx.x;
     const int si = seg_stream[seg];
@@ -649,6 +652,7 @@ __global__ __launch_bounds__(K2_THREADS) void ar_zero_state_kernel(
     const ArState *__restrict__ snaps, const double *__restrict__ vnorm, const uint32_t *__restrict__ vstate,
     const int *__restrict__ seg_count, double *__restrict__ cbuf, ArRec *__restrict__ recs, ArFin *__restrict__ fins,
     int frames, int c_pitch) {
+    prep_prio();
     extern __shared__ __attribute__((aligned(16))) double k2_lds[];
     __shared__ uint32_t cnt[2][K2_THREADS / 64];
     __shared__ int carry;
@@ -776,6 +780,7 @@ __global__ __launch_bounds__(K2_THREADS) void force_rows_kernel(
     const ArStream *__restrict__ streams, const ArState *__restrict__ snaps, const ArRec *__restrict__ recs,
     const ArFin *__restrict__ fins, const double *__restrict__ cbuf, ArState *__restrict__ states, float *__restrict__ tprof,
     int frames, int b_pad, int c_pitch) {
+    prep_prio();
     extern __shared__ __attribute__((aligned(16))) double k2_lds[];
     double *nrm = k2_lds;
     double *acc = k2_lds + frames;

@@ -456,11 +456,13 @@ __device__ __forceinline__ void scan_body(
 
 template <bool DIRECT, bool DENSE>
 __global__ __launch_bounds__(64) void iir_scan_kernel(PBSO_SCAN_ARGS) {
+    prep_prio();
     scan_body<DIRECT, DENSE, false>(p_sq, p_sd, p_ss, p_sc, p_desc, p_grows, p_g32, p_g32_off, p_vinc, p_xfer_init, p_xs, p_xtrow, p);
 }
 
 template <bool DIRECT, bool DENSE>
 __global__ __launch_bounds__(64 * SEG_MAX) void iir_scan_seg_kernel(PBSO_SCAN_ARGS) {
+    prep_prio();
     scan_body<DIRECT, DENSE, true>(p_sq, p_sd, p_ss, p_sc, p_desc, p_grows, p_g32, p_g32_off, p_vinc, p_xfer_init, p_xs, p_xtrow, p);
 }
 #undef PBSO_SCAN_ARGS
@@ -487,6 +489,7 @@ struct IncDims {
 __global__ __launch_bounds__(64 * INC_NW) void dense_increment_kernel(
     const float *__restrict__ p_pc, const float *__restrict__ p_ftab, const float *__restrict__ p_tprof,
     const int *__restrict__ p_row_obj, const int *__restrict__ p_n_modes, float *__restrict__ p_vinc, const IncDims p) {
+    prep_prio();
     __shared__ __attribute__((aligned(16))) float lds_u[INC_NW][64 * U_ROW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
