@@ -62,6 +62,18 @@ DTYPE_OF_FORM = {
 }
 
 
+def auto_settle(objects, modes, buffers):
+    """Untimed steps in front of the warm-up: 40 s of audio (rounds 1 - 4), and -- round 5 -- at least 0.1 s of DEVICE time by the
+    headline's rate (9.3 ms for 1024 x 512 x 860): a scene whose steps are a tenth of a millisecond was timed 10 ms after the device
+    had idled for seconds, inside the shader clock's ramp (128 x 512 x 86: 0.156 ms per step with 40 settle steps, 0.145 with 400;
+    scripts/debug/r05_ramp.sh).  Capped so that the parity check -- the oracle steps its eight sampled objects from buffer 0 -- stays
+    within seconds."""
+    base = max(2, round(40 * 86 / max(1, buffers)))
+    est_ms = max(0.03, 9.3 * objects / 1024 * modes / 512 * buffers / 860)
+    cap = max(base, int(6000 / (8 * max(1.0, modes / 512) * buffers / 86)))
+    return int(min(cap, max(base, -(-100.0 // est_ms))))
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,8 +83,8 @@ def parse(argv=None):
                     help="untimed steps run before the warm-up so that the shader clock has ramped (the first ~70 ms "
                          "after idle run 10 %% slower, profiles/r01_clock_ramp.txt) and the runtime's one-time work is behind "
                          "(one or two asynchronous uploads among an engine's first ~30 block the caller for 6 - 7 ms: "
-                         "PBSO_TIMELINE=1, scripts/debug/r03_stalls.py); reported as settle_steps.  Default: 40 s of audio "
-                         "(40 steps of 86 buffers, 4 of 860)")
+                         "PBSO_TIMELINE=1, scripts/debug/r03_stalls.py); reported as settle_steps.  Default: 40 s of audio and at least "
+                         "0.1 s of device time (auto_settle: 11 steps of 1024 x 512 x 860, 750 of 128 x 512 x 86)")
     ap.add_argument("--clock-ramp-ms", type=float, default=150.0,
                     help="milliseconds a scratch engine (256 x 512, no messages) is stepped right before every leg's settle steps, so that "
                          "short legs are not timed inside the shader clock's ramp from idle (scripts/debug/r05_ramp.sh); 0 = off")
@@ -127,7 +139,7 @@ def parse(argv=None):
     args = ap.parse_args(argv)
     args.settle_auto = args.settle < 0
     if args.settle < 0:
-        args.settle = max(2, round(40 * 86 / max(1, args.buffers)))
+        args.settle = auto_settle(args.objects, args.modes, args.buffers)
     if args.plan_threads <= 0:
         args.plan_threads = 1 if args.buffers <= 128 else 4
     return args
@@ -829,7 +841,7 @@ def main():
             # (as much device time before the clock starts as the headline's own settle + warm-up steps take, and at least 0.1 s:
             #  a share's steps are 1 / N as long)
             if args.settle_auto:
-                a3.settle = int(min(200, np.ceil(max(args.settle * n_ranks, 100.0 / (9.3 * args.buffers / 860 * args.objects / 1024 * args.modes / 512 / n_ranks)))))
+                a3.settle = max(auto_settle(a3.objects, a3.modes, a3.buffers), min(200, args.settle * n_ranks))
             ctx["counts"] = [a3.objects]
             # (three runs of every share, each a fresh engine: one hiccup -- a co-start collision, a host stall -- shows as such)
             runs = [measure(a3, ctx, list(range(a3.objects)), want_parity=(not args.no_parity and rank == 0 and rep == 0))
@@ -843,7 +855,7 @@ def main():
         import copy
         a4 = copy.copy(args)
         a4.buffers = 86
-        a4.settle = max(args.settle, 40 if args.steps >= 20 else 8)
+        a4.settle = max(args.settle, (auto_settle(a4.objects, a4.modes, 86) if args.settle_auto else 40) if args.steps >= 20 else 8)
         a4.steps = max(args.steps, 40) if args.steps >= 20 else args.steps
         ctx["counts"] = [args.objects]
         keep = {k: os.environ.get(k) for k in ("PBSO_PLAN_THREADS", "PBSO_PLAN_PIN")}

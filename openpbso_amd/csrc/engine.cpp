@@ -402,7 +402,7 @@ int Engine::init() {
         int least = 0, greatest = 0;
         HIPTRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPTRY(hipStreamCreateWithPriority(&prep_stream_, hipStreamNonBlocking, greatest));
-        HIPTRY(hipStreamCreateWithPriority(&aux_stream_, hipStreamNonBlocking, greatest));
+        prep_priority_ = greatest;
     }
     if (desc_.stream_sync != 1) {
         // the HOST form of the start gate (policy since round 5, see step_chunk): a word of pinned host memory the bank's first
@@ -587,6 +587,20 @@ int Engine::finalize() {
     if (finalized_) return fail(PBSO_ERR_STATE, "finalize called twice");
     if (objs_.empty()) return fail(PBSO_ERR_STATE, "no objects");
     const int N = (int)objs_.size();
+    {
+        // The second preparation stream (round 5, step_chunk's fork), for engines large enough for the fork to matter.  Created
+        // HERE, not with the engine and not at the first fork: every stream a process owns shifts which hardware queue the next
+        // one lands on -- created with every engine it doubled the cross-stream hand-over of one-buffer steps of small engines
+        // (58 -> 112 us, scripts/latency.py, latency_path = -1: any third stream does, whatever its priority class), created at
+        // the first fork it came to share a queue with the bank (8 x 4096 x 86 scraping: 0.30 -> 0.40 ms per step;
+        // scripts/debug/r05_aux_queue.sh).  Large OBJECTS: that is where projection and combine are long enough to be worth a
+        // stream (64 x 256 with a moving listener, host-bound, 0.13 - 0.15 ms per step without the third stream and 0.15 - 0.19
+        // with it).  PBSO_PREP_SPLIT=2 creates it for any engine (tests), 0 never.
+        long long modes = 0;
+        for (const Object &o : objs_) modes += o.n_modes;
+        if (prep_split_ == 2 || (prep_split_ == 1 && modes >= 32768 && modes >= 1024LL * N))
+            HIPTRY(hipStreamCreateWithPriority(&aux_stream_, hipStreamNonBlocking, prep_priority_));
+    }
     // Team shape: R oscillators per lane; an object of n modes needs ceil(n / 64R) waves, cut into
     // teams (workgroups) of at most MAX_WAVES_PER_TEAM waves.  The VALU issue rate needs ~4 waves per
     // SIMD (4096 on the chip, profiles/r01_microbench.txt).

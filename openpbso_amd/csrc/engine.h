@@ -237,6 +237,7 @@ private:
     // round 5: launches with many dense-profile rows fork the preparation in two -- force profiles (K2) and the dense increments
     // stay on prep_stream_, projection + FFAT + combine go to aux_stream_ and join before the scan / the bank (step_chunk)
     hipStream_t aux_stream_ = nullptr;
+    int prep_priority_ = 0;
     int prep_split_ = 1;                                 // PBSO_PREP_SPLIT (diagnostic): 0 never, 1 policy, 2 whenever there is anything to fork
     long long tot_prep_splits_ = 0;
     // The hand-over preparation -> bank (desc.stream_sync).  An event costs the waiting stream 10 - 12 us after the preparation's

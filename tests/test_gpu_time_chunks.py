@@ -200,6 +200,27 @@ def test_stream_hand_over_by_value_equals_the_event_path(time_chunks):
         run_engine(objs[:1], [], 1, stream_sync=5)
 
 
+@pytest.mark.parametrize("time_chunks", [0, -1, 3])
+def test_forked_preparation_is_ordering_only(time_chunks, monkeypatch):
+    """round 5: a launch with dense-profile rows may fork its preparation -- force profiles and dense increments on the preparation
+    stream, projection + FFAT + combine on a second one, joined in front of the scan / the hand-over to the bank (Engine::step_chunk;
+    by policy from 64 dense rows up, PBSO_PREP_SPLIT=2 forks whenever there is anything to fork, 0 never).  Ordering only: audio,
+    qnorm rows and state bit-identical over many launches of every buffer kind, cut in time or not"""
+    nb = 24
+    objs, evs = _every_kind_scene(nb)
+    cut = [1, 2, 5, 4, 1, 1, 3, 7]
+    monkeypatch.setenv("PBSO_PREP_SPLIT", "0")
+    a = run_engine(objs, evs, nb, split=cut, time_chunks=time_chunks, latency_path=-1)
+    monkeypatch.setenv("PBSO_PREP_SPLIT", "2")
+    b = run_engine(objs, evs, nb, split=cut, time_chunks=time_chunks, latency_path=-1)
+    assert np.array_equal(a["audio"], b["audio"]) and np.array_equal(a["emitted"], b["emitted"])
+    for key in a["qnorm"]:
+        assert np.array_equal(a["qnorm"][key], b["qnorm"][key]), key
+    for x, y in zip(a["state"], b["state"]):
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+    _check(b, run_oracle(objs, evs, nb))
+
+
 def test_long_launches_are_gated_by_policy_and_equal_the_ungated_run():
     """launches of >= 256 buffers hold their preparation kernels behind the START of the previous launch's bank (the start gate:
     hipStreamWaitValue64 on the preparation stream) by policy; ordering only -- three 300-buffer steps of a Poisson scene,
