@@ -116,3 +116,11 @@ def test_bench_defaults_are_the_single_gpu_headline(monkeypatch):
     assert (a.gpus, a.objects, a.modes, a.buffers) == (1, 1024, 512, 860)      # 10 s of audio per step: SURVEY 8(d)'s throughput duration
     assert a.settle * a.buffers >= 3000                                        # (the clock-ramp steps follow the step size)
     assert a.steps > 0 and a.warmup >= 0 and a.qnorm == "sample" and a.form == "block"
+    # settle steps follow the DEVICE time of a step (round 5: short legs were timed inside the shader clock's ramp): at least 40 s of
+    # audio, at least ~0.1 s of device time by the headline's rate, capped by what the oracle check of the first timed step costs
+    assert a.settle_auto and a.settle == bench.auto_settle(1024, 512, 860) == 11 and a.clock_ramp_ms > 0
+    assert bench.auto_settle(128, 512, 860) == 75 and bench.auto_settle(128, 512, 86) == 750
+    assert bench.auto_settle(8, 4096, 86) == 93 and bench.auto_settle(1024, 512, 86) >= 100
+    for o, m, nb in ((1, 512, 86), (64, 256, 86), (8, 4096, 860), (4096, 64, 1)):
+        assert bench.auto_settle(o, m, nb) * nb >= 3000                        # never fewer than the 40 s of audio of rounds 1 - 4
+    assert bench.parse(["--settle", "3"]).settle == 3 and not bench.parse(["--settle", "3"]).settle_auto
