@@ -387,6 +387,12 @@ def measure(args, ctx, global_ids, want_parity):
 
     dev, world, rank, backend = ctx["dev"], ctx["world"], ctx["rank"], ctx["backend"]
     n_obj = len(global_ids)
+    if world > 1 and getattr(args, "settle_auto", False):
+        # (several ranks: a leg settles by the device time of ITS shard -- the strong leg's steps are 1 / N as long as the weak leg's --;
+        #  the largest shard decides, so that every rank runs the same number of steps and collectives)
+        import copy
+        args = copy.copy(args)
+        args.settle = auto_settle(max(ctx.get("counts") or [n_obj]), args.modes, args.buffers)
     # (one more step's worth of script than is stepped: the producer side runs a step AHEAD of the solver, as the reference's
     #  GUI thread does -- the messages of step k + 1 are enqueued right after step k has been submitted, while the device is
     #  busy with it; every timed step still pays for exactly one feed inside the timed region)
@@ -657,7 +663,7 @@ def measure(args, ctx, global_ids, want_parity):
         assert torch.equal(gathered[last][rank * cmax:rank * cmax + n_obj], audios[last][:n_obj])
 
     res = {
-        "elapsed": elapsed, "n_local": n_obj, "n_hits": n_hits, "gather": bool(do_gather),
+        "elapsed": elapsed, "n_local": n_obj, "n_hits": n_hits, "gather": bool(do_gather), "settle_steps": args.settle,
         # HIP events bracket every PBSO_TIMING_EVERY-th launch of the timed region (one launch per step here)
         "kernel_samples": info1["total_timed_launches"] - info0["total_timed_launches"],
         "kernel_ms": (info1["total_kernel_ms"] - info0["total_kernel_ms"]) / max(1, info1["total_timed_launches"] - info0["total_timed_launches"]),
@@ -1001,7 +1007,7 @@ def main():
         out = {
             "metric": "audio samples/s & real-time x at N_obj x N_modes",
             "value": hn["value"], "unit": "audio samples/s", "realtime_x": hn["realtime_x"],
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle, "clock_ramp_ms": args.clock_ramp_ms,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": m.get("settle_steps", args.settle), "clock_ramp_ms": args.clock_ramp_ms,
             "ms_per_step": hn["ms_per_step"],
             "value_step_seconds": nb * B / SAMPLE_RATE,      # seconds of audio per step of `value` (rounds 1 - 3: 1.0; since round 4: 10.0 -- `steps_of_one_second` carries the comparable figure)
             "higher_is_better": True, "scaling": head, "vs_baseline": None,
