@@ -52,13 +52,13 @@ public:
     // 860 share, 2.0 - 2.6 ms per step instead of 1.3, scripts/debug/r05_stall_hunt.sh) costs its share's time on the caller, not
     // its wake-up.  Which thread runs a share does not matter: share t always works in context t.
     void run(int n, const std::function<void(int)> &job) {
-        unsigned gen;
+        if (n > MAX_SHARES) n = MAX_SHARES;              // (callers pass at most their thread count: 16)
+        unsigned long long gen;
         {
             std::lock_guard<std::mutex> lk(m_);
-            if ((int)claim_.size() < n) claim_ = std::vector<std::atomic<unsigned>>(n);
             job_ = &job;
             n_shares_ = n;
-            gen = (unsigned)++gen_;
+            gen = ++gen_;
             completed_.store(0, std::memory_order_release);
         }
         cv_.notify_all();
@@ -70,17 +70,23 @@ public:
     }
 
 private:
-    // the round's number goes into the share's word: first come, first served, and a helper of an earlier round claims nothing
-    bool take(int t, unsigned gen) {
-        unsigned seen = claim_[t].load(std::memory_order_acquire);
-        return seen != gen && claim_[t].compare_exchange_strong(seen, gen, std::memory_order_acq_rel);
+    static constexpr int MAX_SHARES = 64;
+    // The round's number goes into the share's word, and only a LARGER number takes it: first come, first served within a round,
+    // and a helper that read an earlier round's (job, n, number) under the lock and was scheduled out before claiming finds every
+    // word of that round at its number or beyond -- run() returns only when all n shares of its round are done -- and claims
+    // nothing (with "!=" it could have run the earlier round's job, whose std::function is gone, beside the new round's).
+    bool take(int t, unsigned long long gen) {
+        unsigned long long seen = claim_[t].load(std::memory_order_acquire);
+        while (seen < gen)
+            if (claim_[t].compare_exchange_weak(seen, gen, std::memory_order_acq_rel)) return true;
+        return false;
     }
     void loop(int idx) {
-        int seen = 0;
+        unsigned long long seen = 0;
         for (;;) {
             const std::function<void(int)> *job;
             int n;
-            unsigned gen;
+            unsigned long long gen;
             {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_.wait(lk, [&] { return gen_ != seen; });
@@ -88,9 +94,9 @@ private:
                 if (stop_) return;
                 job = job_;
                 n = n_shares_;
-                gen = (unsigned)gen_;
+                gen = gen_;
             }
-            // (the caller is inside run() for as long as a share of ITS round can still be taken: claim_, job and the contexts are alive)
+            // (the caller is inside run() for as long as a share of ITS round can still be taken: job and the contexts are alive)
             if (idx < n && take(idx, gen)) {
                 (*job)(idx);
                 completed_.fetch_add(1, std::memory_order_release);
@@ -101,9 +107,10 @@ private:
     std::mutex m_;
     std::condition_variable cv_;
     const std::function<void(int)> *job_ = nullptr;
-    std::vector<std::atomic<unsigned>> claim_;
+    std::atomic<unsigned long long> claim_[MAX_SHARES] = {};
     std::atomic<int> completed_{0};
-    int gen_ = 0, n_shares_ = 0;
+    unsigned long long gen_ = 0;
+    int n_shares_ = 0;
     bool stop_ = false;
 };
 
