@@ -619,8 +619,12 @@ def measure(args, ctx, global_ids, want_parity):
     gc.collect()
     gc.disable()
     try:
-        if args.clock_ramp_ms > 0:
-            ramp_clock(ctx, args.clock_ramp_ms)
+        if args.clock_ramp_ms > 0 and not ctx.get("_ramp_failed"):
+            try:
+                ramp_clock(ctx, args.clock_ramp_ms)
+            except Exception as ex:                   # (a warm-up aid must never take the measurement down with it)
+                ctx["_ramp_failed"] = repr(ex)
+                print("bench.py: clock ramp skipped: " + repr(ex), file=sys.stderr)
         for k in range(args.settle + args.warmup):
             one_step(k, capture=(k == 0 and want_parity))     # (loads the copy kernel's code object outside the timed region)
         drain()
@@ -1007,7 +1011,8 @@ def main():
         out = {
             "metric": "audio samples/s & real-time x at N_obj x N_modes",
             "value": hn["value"], "unit": "audio samples/s", "realtime_x": hn["realtime_x"],
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": m.get("settle_steps", args.settle), "clock_ramp_ms": args.clock_ramp_ms,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": m.get("settle_steps", args.settle),
+            "clock_ramp_ms": 0.0 if ctx.get("_ramp_failed") else args.clock_ramp_ms,
             "ms_per_step": hn["ms_per_step"],
             "value_step_seconds": nb * B / SAMPLE_RATE,      # seconds of audio per step of `value` (rounds 1 - 3: 1.0; since round 4: 10.0 -- `steps_of_one_second` carries the comparable figure)
             "higher_is_better": True, "scaling": head, "vs_baseline": None,
