@@ -27,7 +27,12 @@ constexpr int TILE = 27;
 // group on 16 distinct 4-bank slots (68 mod 64 = 4).
 constexpr int LDS_ROW = 68;
 constexpr int MAX_TILES = 32;          // tile mask is 32 bits
+#ifdef PBSO_WAVE_TRACE
+constexpr int TRACE_B0 = 40, TRACE_NB = 12, TRACE_K = 8;          // K1b diagnostics build: per-wave stamps of buffers 40 .. 51 behind the row
+constexpr int CENSUS_WORDS = 12 + 2 * (2 + TRACE_NB * TRACE_K);
+#else
 constexpr int CENSUS_WORDS = 12;       // diagnostics row per workgroup (PBSO_CENSUS=1)
+#endif
 
 // transfer-row codes in BufDesc::trow
 constexpr int XFER_KEEP = -1;          // keep _latest_transfer

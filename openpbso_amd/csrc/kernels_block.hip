@@ -49,6 +49,16 @@ constexpr int GROUP = BJ * BN;                     // 256 samples
 // staging: [16 blocks][64 lanes][Q, D] (one ds_write_b64 per coarse step); the row stride of 130 floats
 // (= 2 mod 32) puts the 32 lanes of every ds_read_b32 lane group (2 components x 16 blocks) on 32 distinct banks
 constexpr int ST_ROW = 130;
+// Round 6: the f32 projection's staging image is laid out for ds_read_b128.  The MFMA's k index is the QUARTER of the wave's 64
+// modes (k = mode >> 4), so the lane (k, block n) of a B operand needs, for its 32 MFMAs, the 16 (Q, D) pairs of quarter k at
+// block n: 32 contiguous floats = 8 reads of 16 bytes, where the old image (k = 2 (mode & 1) + component) took 32 ds_read_b32
+// (scripts/microbench/gen_burst_shapes.py, profiles/r06_burst_shapes.txt: beside a partner wave a slice costs 1344 cycles with
+// one ds_read_b32 behind every MFMA, 1284 with one ds_read_b128 behind every fourth, 1281 with no reads at all).  Blocks n and
+// n + 8 share a row of ST_PAIR floats -- [quarter k: 64 floats][half n >> 3: 32 floats] -- and ST_PAIR = 4 mod 64 puts the 16
+// lanes of every ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...) on 16 distinct 4-bank slots; the parking lanes of a quarter
+// write 32 contiguous dwords (conflict-free as before).  Same size as the old image: 8 x 260 = 16 x 130 floats.
+constexpr int ST_PAIR = 260;
+__host__ __device__ constexpr int park_off(int n) { return (n & 7) * ST_PAIR + (n >> 3) * 32; }      // floats, block n's row
 constexpr int LIT_ROW = 68;                        // literal path: [16 samples][64 lanes] tile, 16-B aligned rows
 constexpr int ST_FLOATS = BLOCK_STAGE_FLOATS;
 constexpr int RING = BLOCK_RING_FLOATS;            // per wave and parity: samples 1..512 at [0..511], sample 0 at [512]
@@ -58,7 +68,7 @@ constexpr int RING = BLOCK_RING_FLOATS;            // per wave and parity: sampl
 constexpr int FTM_U_ROW = 36;                      // FTM: [64 modes][16 Q increments | 16 D increments] + 4 floats of padding
 constexpr int H_ROW = 72;
 constexpr int H_PLANE = BN * H_ROW;
-static_assert(BN * ST_ROW <= ST_FLOATS && BJ * LIT_ROW <= ST_FLOATS && 2 * H_PLANE <= ST_FLOATS, "staging area");
+static_assert(BN * ST_ROW <= ST_FLOATS && 8 * ST_PAIR <= BN * ST_ROW && BJ * LIT_ROW <= ST_FLOATS && 2 * H_PLANE <= ST_FLOATS, "staging area");
 
 struct BlkDims {
     int nb, m_pad, b_pad, frames, n_groups;
@@ -198,14 +208,19 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     // (team.col0 + r * rowlen + 64 * wave) / 2 + s, s = 0..31
     // (PROJ == 1: the same 32 dwords are eight MFMA operands of four registers each -- hi and lo parts of four groups
     //  of 16 modes -- and are kept as quads from the start, so that the allocator never has to re-pack them)
-    float wreg[PROJ == 0 ? R : 1][32];
+    f4 wreg4[PROJ == 0 ? R : 1][8];                   // (quads, as the B operands: the allocator packs the two big arrays alike)
     u4 wq[PROJ == 1 ? R : 1][8];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const float *__restrict__ wsrc = p_wtab + ((ubase + r * rowlen + 64 * wave) / 2) * 64;
         if constexpr (PROJ == 0) {
+            // the table is [pair of columns][lane 16 (2 (mode & 1) + component) + j - 1]; MFMA 4 i + jj of a slice contracts
+            // component jj & 1 of the modes 16 k + 2 i + (jj >> 1), k = 0 .. 3 (the staging image above): its A operand at lane
+            // (k, j - 1) is the entry of pair 8 k + i at lane 16 jj + j - 1.  Read once per launch.
 #pragma unroll
-            for (int s = 0; s < 32; ++s) wreg[r][s] = wsrc[s * 64 + lane];
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) wreg4[r][i][jj] = wsrc[(8 * (lane >> 4) + i) * 64 + 16 * jj + (lane & 15)];
         } else {
             const unsigned *__restrict__ wu = reinterpret_cast<const unsigned *>(wsrc);
 #pragma unroll
@@ -310,9 +325,11 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                                                   : p_audio + (size_t)obj * p.audio_stride;
     const int B = p.frames;
 
-    // B-operand read base: component k = lane >> 4 (k & 1: Q / D plane, k >> 1: which mode of the pair), block n = lane & 15
-    const float *bsrc = stage + (lane & 15) * ST_ROW + 2 * (lane >> 5) + ((lane >> 4) & 1);
-    f2 *wdst = reinterpret_cast<f2 *>(stage + 2 * lane);
+    // B-operand read base (f32 projection): lane (k = lane >> 4, block n = lane & 15) reads quarter k of block n's row, 16 bytes
+    // at a time; the lane that owns mode m = lane parks (Q, D) at pair m & 15 of quarter m >> 4
+    const f4 *bsrc = reinterpret_cast<const f4 *>(stage + park_off(lane & 15) + (lane >> 4) * 64);
+    f2 *wdst = reinterpret_cast<f2 *>(stage + (lane >> 4) * 64 + 2 * (lane & 15));
+    auto park = [&](int n, f2 v) { wdst[park_off(n) / 2] = v; };
     // literal path: row sums of the [16][64] tile: lane -> row (lane & 15), quarter (lane >> 4)
     const f4 *lsrc = reinterpret_cast<const f4 *>(stage + (lane & 15) * LIT_ROW + (lane >> 4) * 16);
 
@@ -359,19 +376,30 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
             for (int r = 0; r < R; ++r) dst[r * rowlen + utid] = code > 0 ? t[r] : (float)code;
         }
     };
-    auto prefetch = [&](const BufDesc &nd) {
+    // (the qnorm matrices are a fetch of their own: in the f32 pipeline they are requested BEHIND the last matrix burst, when its
+    //  operand registers are free -- with them in flight under the burst the headline build spilled -- and land under the
+    //  barrier and the combine)
+    auto prefetch_gq = [&]() {
+        if (QN) {
+            const unsigned utid = lane_off();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const unsigned k = r * rowlen + utid;
+                ng11[r] = b_gq[k];
+                ng12[r] = (b_gq + p.plane)[k];
+                ng22[r] = (b_gq + 2 * p.plane)[k];
+            }
+        }
+    };
+    auto prefetch = [&](const BufDesc &nd, bool with_gq = true) {
         const unsigned utid = lane_off();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const unsigned k = r * rowlen + utid;
             nca[r] = b_ca[k];
             ncb[r] = b_cb[k];
-            if (QN) {
-                ng11[r] = b_gq[k];
-                ng12[r] = (b_gq + p.plane)[k];
-                ng22[r] = (b_gq + 2 * p.plane)[k];
-            }
         }
+        if (with_gq) prefetch_gq();
         if (nd.frow >= 0 && !(nd.flags & DESC_DIRECT)) {
             const float *__restrict__ gsrc = p_grows + (size_t)nd.frow * p.m_pad + team.col0;
 #pragma unroll
@@ -405,28 +433,89 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
         }
     };
 
-    // one coarse step of slice r: park the block-start state of block n, then x <- P x
-    auto coarse = [&](int r, int n, int blk) {
-        dump_state(r, blk);
-        wdst[n * (ST_ROW / 2)] = f2{x2[r].x, x2[r].y};
-        // four instructions: the three-operand v_fma_f32 (through the builtin the compiler emits v_mov + v_fmac for
-        // q + (P11 - 1) q, a fifth vector instruction per step: 128 of the kernel's 855 per wave and buffer)
+    // Two coarse steps of slice r: x <- P x twice, the block-start states of blocks n and n + 1 parked by ONE ds_write2_b64 between
+    // them.  All of it volatile asm, in this order: left to the compiler the parks are paired (n, n + 8) -- neighbours in the
+    // image -- which keeps eight states in registers and issues the eight stores back to back at the end of the burst, where
+    // nothing overlaps their way to the LDS (round 6: 140 cycles per slice).  A step is four instructions: the three-operand
+    // v_fma_f32 (through the builtin the compiler emits v_mov + v_fmac for q + (P11 - 1) q, a fifth vector instruction per step).
+    const unsigned park_base = (unsigned)(size_t)wdst;
+    unsigned park_row[4];                              // byte address of row pairs 0-1, 2-3, 4-5, 6-7 (ds_write2_b64 offsets reach 2040 B)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) park_row[j] = park_base + j * 2 * ST_PAIR * 4;
+    auto step_p = [&](int r) {
         float qa, da, qn, dn;
-        asm("v_fma_f32 %0, %1, %2, %2" : "=v"(qa) : "v"(c1[r].x), "v"(x2[r].x));
-        asm("v_mul_f32 %0, %1, %2" : "=v"(da) : "v"(c1[r].y), "v"(x2[r].x));
-        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(qn) : "v"(c2[r].x), "v"(x2[r].y), "v"(qa));
-        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(dn) : "v"(c2[r].y), "v"(x2[r].y), "v"(da));
+        asm volatile("v_fma_f32 %0, %1, %2, %2" : "=v"(qa) : "v"(c1[r].x), "v"(x2[r].x));
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(da) : "v"(c1[r].y), "v"(x2[r].x));
+        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(qn) : "v"(c2[r].x), "v"(x2[r].y), "v"(qa));
+        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(dn) : "v"(c2[r].y), "v"(x2[r].y), "v"(da));
         x2[r].x = qn;
         x2[r].y = dn;
+    };
+    // The vector burst as ONE asm statement (round 6; builds without DUMP): the step on the (Q, D) register PAIR as two v_pk_fma_f32,
+    //     t = (P11 - 1, P21) * (Q, Q) + (Q, D);    x' = (P12, P22 - 1) * (D, D) + t
+    // (the same map: D' = P21 Q + D + (P22 - 1) D; P22 - 1 is exact in f32 for P22 in [0.5, 2]).  Every operand is a 64-bit pair, so
+    // the sixteen steps and their eight ds_write2_b64 fit one statement: no s_nop between statements (the compiler puts one behind
+    // every inline-asm definition that the next statement reads: 32 per burst), half the instructions to issue, the stores between the
+    // steps.  scripts/microbench/gen_burst_shapes.py, beside a partner wave and the b128 matrix burst: 1264 cycles per slice against
+    // 1336 for the four-instruction step with its s_nops (profiles/r06_burst_shapes.txt).
+#define PBSO_PK_PAIR(J, O0, O1)                                                                   \
+    "v_pk_fma_f32 %[t], %[c1], %[x], %[x] op_sel_hi:[1,0,1]\n\t"                                   \
+    "v_pk_fma_f32 %[y], %[c2], %[x], %[t] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                    \
+    "ds_write2_b64 %[a" #J "], %[x], %[y] offset0:" #O0 " offset1:" #O1 "\n\t"                      \
+    "v_pk_fma_f32 %[t], %[c1], %[y], %[y] op_sel_hi:[1,0,1]\n\t"                                   \
+    "v_pk_fma_f32 %[x], %[c2], %[y], %[t] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+    static_assert(ST_PAIR / 2 == 130, "offsets of the ds_write2_b64 pairs below (8-byte units): blocks n, n + 1 are rows 130 apart, n + 8 is 16 further");
+    auto vburst_pk = [&](int r) {
+        f2 t, y;
+        const f2 c2m = f2{c2[r].x, c2[r].y - 1.f};
+        asm volatile(PBSO_PK_PAIR(0, 0, 130) PBSO_PK_PAIR(1, 0, 130) PBSO_PK_PAIR(2, 0, 130) PBSO_PK_PAIR(3, 0, 130)
+                     PBSO_PK_PAIR(0, 16, 146) PBSO_PK_PAIR(1, 16, 146) PBSO_PK_PAIR(2, 16, 146) PBSO_PK_PAIR(3, 16, 146)
+                     : [x] "+v"(x2[r]), [t] "=&v"(t), [y] "=&v"(y)
+                     : [c1] "v"(c1[r]), [c2] "v"(c2m), [a0] "v"(park_row[0]), [a1] "v"(park_row[1]), [a2] "v"(park_row[2]), [a3] "v"(park_row[3])
+                     : "memory");
+    };
+#undef PBSO_PK_PAIR
+#ifndef PBSO_VB_FORM
+#define PBSO_VB_FORM 1           // 1: vburst_pk; 0: the four-instruction steps (A/B builds)
+#endif
+#ifndef PBSO_REFILL
+#define PBSO_REFILL 0            // 0: one ds_read_b128 behind every fourth MFMA; 1: all eight behind the burst's last MFMA (A/B builds)
+#endif
+    auto coarse2 = [&](int r, auto nc, int blk) {
+        constexpr int n = decltype(nc)::value;         // even
+        static_assert((n & 1) == 0 && park_off(n + 1) - park_off(n) == ST_PAIR, "a pair of blocks = two rows of the image");
+        dump_state(r, blk);
+        const f2 xa = x2[r];
+        step_p(r);
+        dump_state(r, blk + 1);
+        asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4"
+                     :: "v"(park_row[(n & 7) / 2]), "v"(xa), "v"(x2[r]), "n"((n >> 3) * 16), "n"((n >> 3) * 16 + ST_PAIR / 2) : "memory");
+        step_p(r);
     };
 
     // diagnostics (PBSO_CENSUS=1): where wave 0's shader cycles go
     unsigned long long cy_head = 0, cy_pipe = 0, cy_bar = 0, cy_comb = 0, cy_mark = 0, cy_taps = 0, cy_step = 0;
-    auto lap = [&](unsigned long long &acc) {
+#ifdef PBSO_WAVE_TRACE
+    // diagnostics build (scripts/debug/r06_wave_trace.py): EVERY wave of a team of <= 2 keeps the shader-clock times at which it
+    // left the head, the pipeline, the barrier and the combine of TRACE_NB buffers in the middle of the launch, and its HW_ID:
+    // do the two waves of a SIMD (they belong to different teams) take their heads together or one under the other's pipeline?
+    int trace_b = -1;
+    unsigned long long *trace_row = (p_census && wave < 2)
+        ? p_census + ((size_t)team.id + (size_t)chunk * p.census_stride) * CENSUS_WORDS + 12 + wave * (2 + TRACE_NB * TRACE_K) : nullptr;
+    if (trace_row && lane == 0) {
+        trace_row[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        trace_row[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
+    auto lap = [&](unsigned long long &acc, int k = -1) {
         if (p_census) {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
             acc += now - cy_mark;
             cy_mark = now;
+#ifdef PBSO_WAVE_TRACE
+            if (trace_row && k >= 0 && trace_b >= TRACE_B0 && trace_b < TRACE_B0 + TRACE_NB && lane == 0)
+                trace_row[2 + (trace_b - TRACE_B0) * TRACE_K + k] = now;
+#endif
         }
     };
     BufDesc next = dsc[b_begin];
@@ -458,14 +547,21 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
     for (int b = b_begin; b < b_end; ++b) {
         const BufDesc cur = next;
         next = dsc[b + 1 < p.nb ? b + 1 : b];
-        if (p.rotate) {
-            switch ((prio_rank + b - b_begin) & 3) {       // (the team's OWN buffer count: the chunks of a CU start together at different b)
-            case 0: __builtin_amdgcn_s_setprio(0); break;
-            case 1: __builtin_amdgcn_s_setprio(1); break;
-            case 2: __builtin_amdgcn_s_setprio(2); break;
-            default: __builtin_amdgcn_s_setprio(3); break;
+#ifndef PBSO_HPRIO
+#define PBSO_HPRIO 0             // A/B builds: 1 = a wave outside its pipeline (head, barrier, combine) runs at priority 3, its pipeline at 0 .. 2 in rotation
+#endif
+        auto set_pipe_prio = [&]() {
+            if (p.rotate) {
+                switch ((prio_rank + b - b_begin) & 3) {       // (the team's OWN buffer count: the chunks of a CU start together at different b)
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(PBSO_HPRIO ? 1 : 3); break;
+                }
             }
-        }
+        };
+        if (PBSO_HPRIO) { if (p.rotate) __builtin_amdgcn_s_setprio(3); }
+        else set_pipe_prio();
 
         const int frow = cur.frow;
         const int prow = (cur.flags & DESC_DIRECT) ? -1 : cur.prow;     // (a direct hit keeps its normal there)
@@ -504,6 +600,9 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
             }
         };
         dump_b = p.qn_b0 + b;
+#ifdef PBSO_WAVE_TRACE
+        trace_b = b - b_begin;
+#endif
 
         if (flags & DESC_SKIP) {
             dump_scale(-1);
@@ -544,6 +643,9 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
             g_[r] = frow >= 0 ? (scaled ? gv * t[r] : gv) : 0.f;
         }
         prefetch_direct(next);                             // (the landing area is free again: the dot above has read it)
+#ifdef PBSO_WAVE_TRACE
+        lap(cy_head, 4);
+#endif
         const bool impulse = (flags & DESC_IMPULSE) != 0;
         const bool dense = frow >= 0 && !impulse;
 
@@ -563,6 +665,9 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 x2[v].x = x2[v].x + a;
                 p0 = (v == 0) ? x2[v].x : p0 + x2[v].x;
             }
+#ifdef PBSO_WAVE_TRACE
+            lap(cy_head, 5);
+#endif
             if (QN) {
                 // sum_{k=0}^{B-1} q_k^2 = x0' G x0, x0 = state after sample 0 (the rest of the buffer is force-free)
                 const unsigned utid = lane_off();
@@ -576,6 +681,9 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                     (b_qn + (size_t)b * p.m_pad)[v * rowlen + utid] = nrm * __builtin_amdgcn_rcpf(t[v]);
                 }
             }
+#ifdef PBSO_WAVE_TRACE
+            lap(cy_head, 6);
+#endif
             p0 = wave_sum(p0);
             if (lane == 0) *ring_s0() = p0;
 
@@ -590,14 +698,25 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
             // only at 38 cycles each while its SIMD partner issues a v_fma_f32 every 4).  With one step (4 VALU + 1 LDS)
             // between every two MFMAs each of the two waves of a SIMD paid that wait 16 times per slice; in bursts the
             // partner's vector burst runs under this wave's matrix burst.
-            float breg[32];
-            lap(cy_head);
+            f4 bq[8];                                  // the slice's 32 B operands: MFMA s takes bq[s >> 2][s & 3]
+            lap(cy_head, 0);
+            if (PBSO_HPRIO) set_pipe_prio();
+#ifdef PBSO_ABL_PIPE_REPEAT
+            // ablation (wrong results on purpose, scripts/debug/r06_ablate.sh): the pipeline of a buffer runs N times -- what one more
+            // pass costs is the pipeline's own pace, the rest of the kernel's time is what sits around it
+            int abl_reps = PBSO_ABL_PIPE_REPEAT;
+            asm volatile("" : "+s"(abl_reps));
+            for (int abl_rep = 0; abl_rep < abl_reps; ++abl_rep) {
+#endif
             wave_sync();                               // the previous buffer's staging reads are issued
-#pragma unroll
-            for (int n = 0; n < BN; ++n) coarse(0, n, n);
+            if constexpr (!DUMP && PBSO_VB_FORM == 1) vburst_pk(0);
+            else static_for<0, BN / 2>([&](auto hc) { coarse2(0, std::integral_constant<int, 2 * decltype(hc)::value>{}, 2 * decltype(hc)::value); });
             wave_sync();
 #pragma unroll
-            for (int s = 0; s < 32; ++s) breg[s] = bsrc[4 * s];
+            for (int i = 0; i < 8; ++i) bq[i] = bsrc[i];
+#ifdef PBSO_WAVE_TRACE
+            lap(cy_pipe, 7);
+#endif
             f4 acc0, acc1;
             static_for<0, U>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
@@ -611,25 +730,37 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 wave_sync();                           // this slice's operand reads are issued: the staging area is free
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (more) {
-#pragma unroll
-                    for (int n = 0; n < BN; ++n) coarse(rn, n, BN * ((u + 1) / R) + n);
+                    if constexpr (!DUMP && PBSO_VB_FORM == 1) vburst_pk(rn);
+                    else static_for<0, BN / 2>([&](auto hc) {
+                        constexpr int n = 2 * decltype(hc)::value;
+                        coarse2(rn, std::integral_constant<int, n>{}, BN * ((u + 1) / R) + n);
+                    });
                     wave_sync();
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<0, 32>([&](auto sc) {
                     constexpr int s = decltype(sc)::value;
-                    if constexpr (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s], breg[s], acc1, 0, 0, 0);
-                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s], breg[s], acc0, 0, 0, 0);
-                    // refill, two MFMAs behind (the MFMA reads its operands in its first pass)
-                    if constexpr (more && s >= 2) breg[s - 2] = bsrc[4 * (s - 2)];
+                    if constexpr (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg4[r][s >> 2][s & 3], bq[s >> 2][s & 3], acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg4[r][s >> 2][s & 3], bq[s >> 2][s & 3], acc0, 0, 0, 0);
+                    // refill: one ds_read_b128 behind every fourth MFMA, for the four operands consumed BEFORE these (the MFMA reads its
+                    // operands in its first pass).  A/B builds: PBSO_REFILL == 2 refills the four just consumed, 1 issues all eight
+                    // behind the burst's last MFMA (kernel 9.03 ms per 860 buffers against 8.83: scripts/debug/r06_ablate.sh)
+                    if constexpr (PBSO_REFILL == 0 && more && (s & 3) == 3 && s >= 7) bq[(s >> 2) - 1] = bsrc[(s >> 2) - 1];
+                    if constexpr (PBSO_REFILL == 2 && more && (s & 3) == 3) bq[s >> 2] = bsrc[s >> 2];
                     // last slice: nothing to refill -- half way through the burst the first operand registers are free and the
                     // next buffer's inputs land in them
-                    if constexpr (!more && s == 15) prefetch(next);
+                    if constexpr (!more && s == 15) prefetch(next, false);
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 if constexpr (more) {
-                    breg[30] = bsrc[4 * 30];
-                    breg[31] = bsrc[4 * 31];
+                    if constexpr (PBSO_REFILL == 0) bq[7] = bsrc[7];
+                    else if constexpr (PBSO_REFILL == 1) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) bq[i] = bsrc[i];
+                    }
+                } else {
+                    prefetch_gq();
+                    if (PBSO_HPRIO && p.rotate) __builtin_amdgcn_s_setprio(3);
                 }
                 if constexpr (r == R - 1) {
                     const f4 acc = acc0 + acc1;
@@ -638,6 +769,9 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                     combine_half(grp);
                 }
             });
+#ifdef PBSO_ABL_PIPE_REPEAT
+            }
+#endif
             } else {
                 // ---- split-bf16 projection.  The lane that owns a mode parks every block-start state twice: hi =
                 // the top 8 significant bits of x (rounded) and lo = the next 8 of x - hi, both bf16 bit patterns; the
@@ -782,7 +916,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 wave_sync();                                    // the previous buffer's staging reads are issued
                 if (!TAPS_VALU && lane == 0) taps[0] = gs;
             }
-            float breg[32];
+            f4 bq[8];
             if constexpr (TAPS_VALU) {
                 float pv[16];
 #pragma unroll
@@ -796,14 +930,14 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 static_for<0, R>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
                     if constexpr (r > 0) wave_sync();
-                    wdst[0] = f2{g_[r], g_[r]};
+                    park(0, f2{g_[r], g_[r]});
                     wave_sync();
 #pragma unroll
-                    for (int s2 = 0; s2 < 32; ++s2) breg[s2] = bsrc[4 * s2];
+                    for (int i = 0; i < 8; ++i) bq[i] = bsrc[i];
                     static_for<0, 32>([&](auto sc) {
                         constexpr int s2 = decltype(sc)::value;
-                        if constexpr (s2 & 1) ah1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s2], breg[s2], ah1, 0, 0, 0);
-                        else ah0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s2], breg[s2], ah0, 0, 0, 0);
+                        if constexpr (s2 & 1) ah1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg4[r][s2 >> 2][s2 & 3], bq[s2 >> 2][s2 & 3], ah1, 0, 0, 0);
+                        else ah0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg4[r][s2 >> 2][s2 & 3], bq[s2 >> 2][s2 & 3], ah0, 0, 0, 0);
                     });
                 });
                 const f4 ah = ah0 + ah1;                        // column 0 (lanes 0, 16, 32, 48): rows 4 (l >> 4) + v = tap index - 1
@@ -924,7 +1058,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                         }
                         static_for<0, BN>([&](auto nc) {
                             constexpr int n = decltype(nc)::value;
-                            wdst[n * (ST_ROW / 2)] = x2[r];
+                            park(n, x2[r]);
                             const float qa = fmaf(c1[r].x, x2[r].x, x2[r].x);
                             const float da = c1[r].y * x2[r].x;
                             const float qn_ = fmaf(c2[r].x, x2[r].y, qa);
@@ -937,7 +1071,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                         //     x_{n+1} = P x_n + g (F . T_n)        (32 independent FMAs with the profile values as operands + the
                         // coarse step) -- 36 vector instructions per 16 samples instead of 48 in a dependent chain.
                         for_each_block([&](const float (&tv)[BJ], int n) {
-                            wdst[n * (ST_ROW / 2)] = x2[r];
+                            park(n, x2[r]);
                             float uq0 = fq[r][0] * tv[0], uq1 = fq[r][1] * tv[1], ud0 = fd[r][0] * tv[0], ud1 = fd[r][1] * tv[1];
 #pragma unroll
                             for (int i = 2; i < BJ; i += 2) {
@@ -960,7 +1094,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                         if (__all(z_ok)) {
                             float qz = 0.f;
                             for_each_block([&](const float (&tv)[BJ], int n) {
-                                wdst[n * (ST_ROW / 2)] = f2{gr * z.x, gr * z.y};
+                                park(n, f2{gr * z.x, gr * z.y});
 #pragma unroll
                                 for (int k = 0; k < BJ; ++k) {
                                     const float in = fmaf(nca[r], z.y, tv[k]);
@@ -973,7 +1107,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                             if (QN) qn[r] = fmaf(gr * gr, qz, qn[r]);
                         } else {
                             for_each_block([&](const float (&tv)[BJ], int n) {
-                                wdst[n * (ST_ROW / 2)] = x2[r];
+                                park(n, x2[r]);
 #pragma unroll
                                 for (int k = 0; k < BJ; ++k) {
                                     const float gt = g_[r] * tv[k];
@@ -988,11 +1122,11 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                     lap(cy_step);
                     wave_sync();
 #pragma unroll
-                    for (int s2 = 0; s2 < 32; ++s2) breg[s2] = bsrc[4 * s2];
+                    for (int i = 0; i < 8; ++i) bq[i] = bsrc[i];
                     static_for<0, 32>([&](auto sc) {
                         constexpr int s2 = decltype(sc)::value;
-                        if constexpr (s2 & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s2], breg[s2], acc1, 0, 0, 0);
-                        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[r][s2], breg[s2], acc0, 0, 0, 0);
+                        if constexpr (s2 & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg4[r][s2 >> 2][s2 & 3], bq[s2 >> 2][s2 & 3], acc1, 0, 0, 0);
+                        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg4[r][s2 >> 2][s2 & 3], bq[s2 >> 2][s2 & 3], acc0, 0, 0, 0);
                     });
                 });
 #pragma unroll
@@ -1075,15 +1209,21 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
 
         // ---- the team's waves add their rings and store the buffer; one barrier per buffer (the ring
         //      alternates by buffer parity, so a wave can be one buffer ahead of the slowest reader)
+#ifdef PBSO_ABL_NO_COMBINE
+        if constexpr (false) {             // ablation: no barrier, no ring sums, no sample stores
+#else
         if constexpr (!HALF) {
-        lap(cy_pipe);
+#endif
+        lap(cy_pipe, 1);
         __syncthreads();
-        lap(cy_bar);
+        lap(cy_bar, 2);
         {
             // thread j adds the waves' ring entries 4j .. 4j+3 (samples 4j+1 .. 4j+4); thread 0 also sample 0
             const float *r0 = lds + ST_FLOATS + (b & 1) * RING;
             float *__restrict__ ao = aout + (size_t)b * B;
-            for (int j = tid; j < GROUP * NG / 4; j += blockDim.x) {
+            // (the thread index laundered: otherwise LICM keeps the ring address of thread j alive across the whole pipeline, and
+            //  the headline build, which has no register to spare, spills it)
+            for (int j = (int)lane_off(); j < GROUP * NG / 4; j += blockDim.x) {
                 f4 acc = *reinterpret_cast<const f4 *>(r0 + 4 * j);
                 for (int w = 1; w < W; ++w) acc += *reinterpret_cast<const f4 *>(r0 + w * WAVE_FLOATS + 4 * j);
                 AUDIO_STORE(&ao[4 * j + 1], acc.x);
@@ -1097,7 +1237,7 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                 AUDIO_STORE(&ao[0], acc);
             }
         }
-        lap(cy_comb);
+        lap(cy_comb, 3);
         }
     }
 
