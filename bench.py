@@ -195,7 +195,7 @@ def build_inputs(args, global_ids, total_buffers):
 
 def pmc_counts(form, objects, args):
     """instruction counts per wave and buffer of the block kernel from the PMC passes kept under profiles/ (same configuration only)"""
-    for name in ("r05_pmc_counts.json", "r04_pmc_counts.json", "r03_pmc_counts.json", "r02_pmc_counts.json"):
+    for name in ("r06_pmc_counts.json", "r05_pmc_counts.json", "r04_pmc_counts.json", "r03_pmc_counts.json", "r02_pmc_counts.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
             e = t["forms"][form]
@@ -211,7 +211,7 @@ def pmc_counts(form, objects, args):
 
 def measured_traffic(args, form, objects):
     """HBM bytes per launch from the PMC passes kept under profiles/ (same configuration only)."""
-    for name in ("r05_pmc_traffic_%s.json" % form, "r04_pmc_traffic_%s.json" % form, "r03_pmc_traffic_%s.json" % form, "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic_%s.json" % form, "r05_pmc_traffic_%s.json" % form, "r04_pmc_traffic_%s.json" % form, "r03_pmc_traffic_%s.json" % form, "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
             c = t["config"]

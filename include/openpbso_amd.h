@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PBSO_ABI_VERSION 5
+#define PBSO_ABI_VERSION 6
 #define PBSO_SAMPLE_RATE 44100          /* config.h:13 */
 #define PBSO_FRAMES_PER_BUFFER 513      /* config.h:14 */
 
@@ -138,7 +138,13 @@ typedef struct pbso_engine_desc {
                                * per step of 86 buffers).  2 and 3 fail at creation where the device lacks the interface.  4 (round 5): the gate
                                * for every launch as a wait of the SUBMITTING thread on a word of pinned host memory the previous bank's first
                                * workgroup writes (hipStreamWaitValue64 runs as a waiting kernel on this stack); costs the host one launch of
-                               * run-ahead */
+                               * run-ahead; fails at creation without pinned host memory.
+                               * Round 6: the DEVICE form of the gate is a kernel that spins on a memory word until another kernel
+                               * has started; where something serialises kernel dispatches -- a profiler collecting counters
+                               * (rocprofv3 --pmc: five of five passes ended at their time limit with the gate, none without),
+                               * AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING -- the waiting kernel can be dispatched first and never ends.  Under 0
+                               * (policy) the engine looks for such an environment at creation and then orders its launches by events only
+                               * (pbso_engine_info::start_gate says what it chose); 2 and 3 are the caller's explicit choice */
     int latency_path;         /* < 0: never prepare a launch on the bank's own stream (0: a step of at most four buffers submitted
                                * while the device is idle does -- nothing to overlap with, one stream hand-over less) */
     /* ---- ABI 5 */
@@ -270,9 +276,14 @@ int pbso_enqueue_force_batch(pbso_engine *e, int n, const int *object_ids, const
  * Returns n, or PBSO_ERR_INVALID (ids / vertex ids out of range, object order) / PBSO_ERR_STATE (a script is pending). */
 int pbso_enqueue_vertex_hits(pbso_engine *e, int n, const int *object_ids, const int *vids, const double *vn,
                              const int64_t *not_before);
-/* ModalSolver::enqueueArprmMessageNoFail (modal_solver.h:382-393); 1-slot queue */
+/* ModalSolver::enqueueArprmMessageNoFail (modal_solver.h:382-393); 1-slot queue: a message that finds the slot taken waits in
+ * the engine and enters when step() has taken the one before it (the reference's caller spins on try_enqueue meanwhile) */
 int pbso_enqueue_arprm(pbso_engine *e, int object_id, const double a[2], double sigma,
                        double mu, int64_t not_before);
+/* ABI 6.  1 while the object's AR-parameter slot holds a message that step() has not taken yet (or one is waiting for it): what
+ * ModalSolver::enqueueArprmMessage's try_enqueue would find full (modal_solver.h:378-381); 0 when a try_enqueue would succeed.  A
+ * caller that wants the reference's bounded spin (enqueueArprmMessageNoFail with maxIte >= 0) polls this between attempts. */
+int pbso_arprm_pending(pbso_engine *e, int object_id);
 /* ModalSolver::computeTransfer(pos) (modal_solver.h:286-300): FFAT lookup for
  * every mode on the device, result offered to the 1-slot transfer queue.
  * 1 = enqueued, 0 = no maps / queue still full.                               */
@@ -466,6 +477,11 @@ typedef struct pbso_engine_info {
     int last_time_chunk_shape;        /* the last time-chunked launch: modes per lane of its teams (0: none yet), ...              */
     int last_time_chunk_buffers;      /* ... buffers per chunk, ...                                                               */
     int last_time_chunk_teams;        /* ... and teams per chunk (its census has teams x chunks rows, chunk-major)                */
+    /* ---- ABI 6 */
+    int start_gate;                   /* the start gate of long launches (pbso_engine_desc::stream_sync): 0 none (asked for, or no interface),
+                                       * 1 a device-side wait (hipStreamWaitValue64), 2 the submitting thread waits on pinned host memory,
+                                       * -1 none because the environment serialises kernel dispatches (a waiting kernel would never end)   */
+    int64_t total_gate_timeouts;      /* host-side gate only: waits that gave up after 2 s (the launch then went ungated)                 */
 } pbso_engine_info;
 int pbso_get_info(pbso_engine *e, pbso_engine_info *out);
 /* diagnostics (engine created with env PBSO_CENSUS=1): for every object's

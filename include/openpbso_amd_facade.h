@@ -27,6 +27,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -289,7 +290,8 @@ public:
 
     // one 513-sample buffer on the GPU (modal_solver.h:181-276)
     void step() {
-        EngineLock lk_(_engine_mutex);
+        // (a unique_lock: released by hand in front of the pacing spin at the end, and then NOT taken again)
+        std::unique_lock<std::recursive_mutex> lk_(_engine_mutex);
         _finalize();
         // the samples reach the host with the kernel's own stores into pinned memory -- no copy call between the oscillator bank
         // and the SoundMessage (pageable fallback: step, then pbso_read_audio)
@@ -318,8 +320,7 @@ public:
             for (int i = 0; i < _N_modes; ++i) qn.data(i) = (T)_qnorm32[i];
         SoundMessage<T, BUF_SIZE> mess;
         for (int i = 0; i < BUF_SIZE; ++i) mess.data(i) = (T)samples[i];
-        _engine_mutex.unlock();          // the spin below must not block the GUI thread's enqueue calls
-        struct Relock { std::recursive_mutex &m; ~Relock() { m.lock(); } } relock_{_engine_mutex};
+        lk_.unlock();                    // the spin below must not block the GUI thread's enqueue calls
         (void)_queue_qnorm.try_enqueue(qn);                    // try_enqueue, may drop (:273)
         // enqueueSoundMessageNoFail (:275, :346-357): spin until the 3-slot queue has room --
         // this is the reference's real-time pacing
@@ -381,14 +382,27 @@ public:
     }
     // called from the PortAudio callback: wait-free (one acquire load, one copy, one release store)
     bool dequeueSoundMessage(SoundMessage<T, BUF_SIZE> &mess) { return _queue_sound.try_dequeue(mess); }
-    bool enqueueArprmMessageNoFail(const AutoregressiveForceParam<T> &mess, const int maxIte = -1) {
+    // _queue_arprm.try_enqueue (modal_solver.h:378-381): false while the 1-slot queue holds a message step() has not taken
+    bool enqueueArprmMessage(const AutoregressiveForceParam<T> &mess) {
         EngineLock lk_(_engine_mutex);
-        (void)maxIte;
         _finalize();
+        int full = pbso_arprm_pending(_engine, _obj);
+        _require(full);
+        if (full) return false;
         const double a[2] = {(double)mess.a.at(0), (double)mess.a.at(1)};
         int rc = pbso_enqueue_arprm(_engine, _obj, a, (double)mess.sigma, (double)mess.mu, 0);
         _require(rc);
         return rc == 1;
+    }
+    // modal_solver.h:382-393: try until accepted, at most maxIte times (maxIte < 0: for ever).  The engine's lock is held per
+    // attempt only, so the simulation thread's step() -- which is what empties the slot -- gets in between two of them.
+    bool enqueueArprmMessageNoFail(const AutoregressiveForceParam<T> &mess, const int maxIte = -1) {
+        int ite = 0;
+        while (maxIte < 0 || ite++ < maxIte) {
+            if (enqueueArprmMessage(mess)) return true;
+            std::this_thread::yield();
+        }
+        return false;
     }
 };
 #endif

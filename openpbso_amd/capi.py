@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBSO_LIB") or os.path.join(_HERE, "libopenpbso_amd.so")      # PBSO_LIB: A/B runs of two builds in one process tree
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_STATE, ERR_IO, ERR_MISSING_MAP, ERR_ASSERT, ERR_NOMEM = -1, -2, -3, -4, -5, -6, -7
 POINT_FORCE, GAUSSIAN_FORCE, AUTOREGRESSIVE_FORCE = 0, 1, 2
@@ -25,7 +25,7 @@ EXPORTS = [
     "pbso_set_use_transfer", "pbso_get_latest_transfer", "pbso_step", "pbso_step_into", "pbso_sync",
     "pbso_read_audio", "pbso_read_emitted", "pbso_read_qnorm", "pbso_read_state", "pbso_write_state",
     "pbso_audio_device_ptr", "pbso_pa_convert", "pbso_get_info",
-    "pbso_modes_read", "pbso_num_modes_audible", "pbso_material_read", "pbso_free", "pbso_read_census", "pbso_obj_read",
+    "pbso_modes_read", "pbso_num_modes_audible", "pbso_material_read", "pbso_free", "pbso_read_census", "pbso_obj_read", "pbso_arprm_pending",
     "pbso_mix_objects", "pbso_read_audio_rows", "pbso_compute_transfer_path",
     "pbso_step_to_host", "pbso_host_wait", "pbso_host_alloc", "pbso_host_free",
     # the device group (one engine per GPU, RCCL gather called from C++)
@@ -91,7 +91,7 @@ class EngineInfo(C.Structure):
                 ("total_timed_launches", C.c_int64), ("total_split_launches", C.c_int64),
                 ("total_time_chunk_launches", C.c_int64), ("total_dropped_hits", C.c_int64), ("total_one_stream_launches", C.c_int64),
                 ("total_dense_increment_launches", C.c_int64), ("total_segmented_scans", C.c_int64), ("last_time_chunk_shape", C.c_int), ("last_time_chunk_buffers", C.c_int),
-                ("last_time_chunk_teams", C.c_int)]
+                ("last_time_chunk_teams", C.c_int), ("start_gate", C.c_int), ("total_gate_timeouts", C.c_int64)]
 
 
 GroupDesc._fields_ = [("abi_version", C.c_int), ("devices", C.POINTER(C.c_int)), ("n_devices", C.c_int), ("world_size", C.c_int),
@@ -133,6 +133,7 @@ def lib():
     l.pbso_enqueue_force_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(ForceMsg), C.POINTER(C.c_int64),
                                            C.POINTER(C.c_ubyte)]
     l.pbso_enqueue_arprm.argtypes = [vp, C.c_int, dp, C.c_double, C.c_double, C.c_int64]
+    l.pbso_arprm_pending.argtypes = [vp, C.c_int]
     l.pbso_compute_transfer.argtypes = [vp, C.c_int, dp, C.c_int64]
     l.pbso_compute_transfer_batch.argtypes = [vp, C.c_int, dp, C.c_int, dp, C.c_int]
     l.pbso_object_n_maps.argtypes = [vp, C.c_int]

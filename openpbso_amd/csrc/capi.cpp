@@ -297,6 +297,13 @@ int pbso_enqueue_arprm(pbso_engine *e, int obj, const double a[2], double sigma,
     GUARD_END(e)
 }
 
+int pbso_arprm_pending(pbso_engine *e, int obj) {
+    NEED(e);
+    GUARD_BEGIN
+    return e->impl->arprm_pending(obj);
+    GUARD_END(e)
+}
+
 int pbso_compute_transfer(pbso_engine *e, int obj, const double pos[3], int64_t nb) {
     NEED(e);
     if (!pos) return PBSO_ERR_INVALID;

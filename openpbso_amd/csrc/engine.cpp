@@ -51,6 +51,24 @@ void free_retired_blocks() {
     (void)hipDeviceSynchronize();
     for (void *q : v) (void)hipFree(q);
 }
+// Does something in this process's environment let only ONE kernel run at a time?  Returns its name, or nullptr.
+//   rocprofv3 --pmc (rocprofiler-sdk counter collection serialises dispatches): ROCPROF_COUNTER_COLLECTION / ROCPROF_COUNTERS
+//   are set for the profiled process; the older rocprof sets ROCP_METRICS / ROCPROFILER_METRICS.  A kernel trace alone
+//   does not serialise (the default command runs under --kernel-trace --stats with the gate).
+//   AMD_SERIALIZE_KERNEL (HIP: wait before / after every kernel launch), HIP_LAUNCH_BLOCKING / CUDA_LAUNCH_BLOCKING.
+//   PBSO_START_GATE=0 says so by hand (a tool this list does not know); PBSO_START_GATE=1 overrides the list.
+static const char *serialising_environment() {
+    if (const char *v = std::getenv("PBSO_START_GATE")) return std::atoi(v) ? nullptr : "PBSO_START_GATE=0";
+    auto on = [](const char *name) {
+        const char *v = std::getenv(name);
+        return v && *v && std::strcmp(v, "0") != 0;
+    };
+    static const char *const names[] = {"ROCPROF_COUNTER_COLLECTION", "ROCPROF_COUNTERS", "ROCPROF_PMC", "ROCP_METRICS", "ROCPROFILER_METRICS",
+                                        "ROCPROFILER_PC_SAMPLING_BETA_ENABLED", "AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING", "CUDA_LAUNCH_BLOCKING"};
+    for (const char *n : names)
+        if (on(n)) return n;
+    return nullptr;
+}
 std::atomic<long long> g_alloc_events{0};       // buffer (re)allocations so far (PBSO_TIMELINE diagnostics)
 template <class T>
 hipError_t DevBuf<T>::ensure(size_t n, bool keep, hipStream_t s) {
@@ -317,8 +335,17 @@ int Engine::init() {
         HIPTRY(hipStreamCreateWithPriority(&prep_stream_, hipStreamNonBlocking, greatest));
         prep_priority_ = greatest;
     }
-    if (desc_.stream_sync != 1) {
-        // the HOST form of the start gate (policy since round 5, see step_chunk): a word of pinned host memory the bank's first
+    // A start gate that waits ON THE DEVICE is a kernel spinning on a memory word another kernel stores when it starts.  Anything that
+    // lets only one kernel run at a time can dispatch the waiting kernel first -- it then never ends (round 6: every rocprofv3 --pmc
+    // pass of the headline launch hung until its time limit with the gate and finished in 11 s without; profiles/NOTES.md).  Under the
+    // policy (stream_sync = 0) such an environment gets no gate; 2 / 3 stay the caller's explicit choice.
+    const char *serial_env = serialising_environment();
+    if (desc_.stream_sync == 0 && serial_env) {
+        gate_choice_ = -1;
+        if (std::getenv("PBSO_TIMELINE")) std::fprintf(stderr, "openpbso_amd: no start gate: %s serialises kernel dispatches\n", serial_env);
+    }
+    if (desc_.stream_sync != 1 && gate_choice_ != -1) {
+        // the HOST form of the start gate (stream_sync = 4, an option: see step_chunk): a word of pinned host memory the bank's first
         // workgroup writes and the submitting thread reads -- no waiting kernel on the device
         void *dptr = nullptr;
         if (hipHostMalloc((void **)&host_start_, sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess &&
@@ -340,8 +367,11 @@ int Engine::init() {
             if (desc_.stream_sync == 2) sync_values_ = signal_word(&sig_prep_);
         }
         (void)hipGetLastError();
-        if (desc_.stream_sync >= 2 && !(desc_.stream_sync == 2 ? sync_values_ : start_gate_))
+        if ((desc_.stream_sync == 2 || desc_.stream_sync == 3) && !(desc_.stream_sync == 2 ? sync_values_ : start_gate_))
             return fail(PBSO_ERR_HIP, "stream_sync = 2 / 3: the device has no hipStreamWaitValue64");
+        if (desc_.stream_sync == 4 && !host_start_)
+            return fail(PBSO_ERR_HIP, "stream_sync = 4: no pinned host memory for the gate's word");
+        gate_choice_ = desc_.stream_sync == 4 ? 2 : start_gate_ ? 1 : 0;
     }
     for (int i = 0; i < N_SETS; ++i) {
         // (waited for by the engine's own streams only, never by the host or another device: without the system-scope fence
@@ -520,7 +550,9 @@ int Engine::finalize() {
     int R = desc_.modes_per_lane;
     if (R != 0 && R != 1 && R != 2 && R != 3 && R != 4 && R != 8) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,3,4,8");
     const bool block = is_block();
-    if (block && R == 3) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,4,8 in the block form");
+    // (round 6: the block form's eight-modes-per-lane builds -- one wave per SIMD, 300 - 460 bytes of scratch per lane -- were never a
+    //  policy's choice and are gone)
+    if (block && (R == 3 || R == 8)) return fail(PBSO_ERR_INVALID, "modes_per_lane must be 0,1,2,4 in the block form");
 
     auto waves_of = [&](const Object &o, int r) { return std::max(1, (o.n_modes + 64 * r - 1) / (64 * r)); };
     auto total_waves = [&](int r) {
@@ -569,7 +601,7 @@ int Engine::finalize() {
         // wave shares its SIMD / CU with as few others as possible (measured: 8 x 4096 modes 425 -> 570 x
         // real time with 2-wave teams, 1 x 512 modes 778 -> 822 x with 1-wave teams): spread the waves
         // evenly over the 256 CUs.
-        const int team_max = block ? (R == 8 ? 4 : MAX_WAVES_PER_BLOCK_TEAM) : MAX_WAVES_PER_TEAM;
+        const int team_max = block ? MAX_WAVES_PER_BLOCK_TEAM : MAX_WAVES_PER_TEAM;
         int team_cap = (int)std::min<long long>(team_max, std::max<long long>(1, (total_waves(R) + n_cus_ - 1) / n_cus_));
         if (desc_.team_waves > 0) team_cap = std::min(team_max, desc_.team_waves);
         std::vector<std::vector<TeamDesc>> by_w(MAX_WAVES_PER_TEAM + 1);
@@ -1267,6 +1299,17 @@ int Engine::enqueue_arprm(int obj, const double a[2], double sigma, double mu, i
     return 1;
 }
 
+// what ModalSolver::enqueueArprmMessage's try_enqueue would find (modal_solver.h:378-381): the slot taken, or a message waiting for it
+int Engine::arprm_pending(int obj) {
+    if (!finalized_) return fail(PBSO_ERR_STATE, "arprm_pending before finalize");
+    if (!valid_obj(obj)) return fail(PBSO_ERR_INVALID, "object id");
+    const Object &o = objs_[obj];
+    if (o.arprm_full) return 1;
+    for (const TimedEvent &ev : o.pending)
+        if (ev.kind == TimedEvent::ARPRM) return 1;
+    return 0;
+}
+
 // ModalSolver::computeTransfer(pos), modal_solver.h:286-300
 int Engine::compute_transfer(int obj, const double pos[3], int64_t not_before) {
     if (!finalized_) return fail(PBSO_ERR_STATE, "compute_transfer before finalize");
@@ -1902,6 +1945,9 @@ bool Engine::choose_time_chunks(int nb, int n_dense_rows, int *set, int *cb) con
     // (engines whose bank steps dense buffers per sample -- the split-bf16 projection, forced_block < 0 -- keep their launches with
     //  many of them on the kernels that walk the buffers in order, as before round 5)
     if (tc_mode_ == 0 && !ftab_forced_ && (long long)n_dense_rows * 8 > N * nb) return false;
+    // (every dense row costs m_pad x 8 bytes of increments per plan set: a launch whose rows would take more than 1 GiB walks its
+    //  buffers in order instead -- 1024 x 512 sustained scraping in ten-second steps is 880 640 rows = 3.6 GB)
+    if ((long long)n_dense_rows * m_pad_ * 8 > (1LL << 30)) return false;
     const bool dense_majority = (long long)n_dense_rows * 2 > N * nb;
     // (a scene small enough for the pipeline kernel keeps its mostly-dense launches WITHOUT qnorm rows there: teams of five waves per
     //  64 modes walk the buffers in order and evaluate every increment once -- cut in time they are evaluated twice, for the scan and
@@ -2180,7 +2226,10 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         while (*w < last_bank_seq_) {
             std::this_thread::yield();
             // (fail-safe: a bank that never starts -- a device fault -- must not hang the caller; the launch then goes ungated)
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count() > 2.0) break;
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count() > 2.0) {
+                ++gate_timeouts_;                         // (pbso_engine_info::total_gate_timeouts)
+                break;
+            }
         }
         host_gate_used_ = true;
     } else if (gate_now && start_gate_) {
@@ -2272,8 +2321,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     LAUNCHTRY(launch_scatter_rows(d_stage, d_stage_slot, (int)stage_slot_.size(), d_slots_.p, m_pad_, sa));
     LAUNCHTRY(launch_modal_project(d_proj, (int)proj_.size(), d_shapes_.p, d_shape_off_.p, d_n_modes_.p, d_slots_.p, m_pad_, sa));
     // (a few events: one thread per (event, mode); listener paths -- many events per object -- by runs)
-    // (the run form puts the runs on grid.y: at most 65535 of them -- a larger launch takes the per-event form)
-    if (ffat_.size() >= 4 * ffat_runs_.size() && !ffat_runs_.empty() && ffat_runs_.size() <= 65535)
+    if (ffat_.size() >= 4 * ffat_runs_.size() && !ffat_runs_.empty())
         LAUNCHTRY(launch_ffat_lookup_runs(d_ffat, reinterpret_cast<const FfatRun *>(da + o_ffat_runs), (int)ffat_runs_.size(), d_geom_.p,
                                           d_geom_off_.p, d_n_modes_.p, d_psi_.p, d_xfer_.p, m_pad_, sa));
     else
@@ -2836,6 +2884,8 @@ int Engine::info(pbso_engine_info *out) {
     out->last_time_chunk_teams = last_tc_teams_;
     out->total_dropped_hits = dropped_hits_.load();
     out->total_one_stream_launches = tot_one_stream_launches_;
+    out->start_gate = gate_choice_;
+    out->total_gate_timeouts = gate_timeouts_;
     out->buffers_done = buffers_done_;
     out->last_step_host_plan_ms = last_plan_ms_;
     out->last_step_forced_rows = last_frows_;

@@ -181,6 +181,7 @@ public:
     int enqueue_force_batch(int n, const int *objs, const pbso_force_msg *msgs, const int64_t *stamps, unsigned char *accepted);
     int enqueue_vertex_hits(int n, const int *objs, const int *vids, const double *vn, const int64_t *stamps);
     int enqueue_arprm(int obj, const double a[2], double sigma, double mu, int64_t not_before);
+    int arprm_pending(int obj);
     int compute_transfer(int obj, const double pos[3], int64_t not_before);
     int compute_transfer_path(int n, const int *objs, const double *pos, const int64_t *stamps, unsigned char *accepted);
     int compute_transfer_batch(int obj, const double *pos, int n_pos, double *out, int out_cols);
@@ -254,6 +255,8 @@ private:
     unsigned long long *host_start_ = nullptr;          // the same word in pinned host memory: the host form of the gate (policy)
     unsigned long long *host_start_dev_ = nullptr;      // ... as the device sees it
     bool host_gate_used_ = false;
+    int gate_choice_ = 0;                                // pbso_engine_info::start_gate
+    long long gate_timeouts_ = 0;
     unsigned long long bank_seq_ = 0, last_bank_seq_ = 0;
     bool start_gate_ = false;
     // Plan sets: the host plans and uploads step k while the device still runs step k - N_SETS + 1.  Two sets are enough for

@@ -1270,13 +1270,12 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
 
 template <int R, int QNM, int PROJ, bool DUMP, bool FORCED = false, bool CHUNKED = false>
 static int launch_one(const IirParams &p, int n_teams, int W, hipStream_t stream) {
-    if constexpr (!CHUNKED && !DUMP && R != 8) {
+    if constexpr (!CHUNKED && !DUMP) {
         if (p.tc_cb > 0) return launch_one<R, QNM, PROJ, DUMP, FORCED, true>(p, n_teams, W, stream);
     }
     if (!CHUNKED && p.tc_cb > 0) return (int)hipErrorInvalidValue;       // (no chunked build of this shape: the engine never asks)
     const size_t lds = block_lds_bytes(W, R);
-    // R = 8 is the one-wave-per-SIMD build (512 registers: the 256 W-table operands go to AGPRs): teams of <= 4 waves
-    constexpr int MAXT = R == 8 ? 256 : 64 * MAX_WAVES_PER_BLOCK_TEAM;
+    constexpr int MAXT = 64 * MAX_WAVES_PER_BLOCK_TEAM;
     if (64 * W > MAXT) return (int)hipErrorInvalidValue;
     auto kern = iir_block_kernel<R, QNM, PROJ, DUMP, MAXT, FORCED, CHUNKED>;
     if (lds > 64 * 1024) {
@@ -1304,6 +1303,17 @@ static int launch_r(const IirParams &p, int n_teams, int W, bool qn, int proj, h
     return qn ? launch_one<R, 2, 0, false>(p, n_teams, W, s) : launch_one<R, 0, 0, false>(p, n_teams, W, s);
 }
 
+// The builds of one, two and four modes per lane are TWO translation units (the Makefile compiles this file twice, in parallel:
+// -DPBSO_BLOCK_PART=0 the four-modes-per-lane builds + everything else in this file, =1 the builds of one and two); without the
+// macro -- tests/test_kernel_asm_guards.py, the A/B variants of scripts/debug/r06_variant.sh with -DPBSO_ONLY_R4 -- one unit.
+int launch_block_r1(const IirParams &p, int n_teams, int W, bool qn, int proj, hipStream_t s);
+int launch_block_r2(const IirParams &p, int n_teams, int W, bool qn, int proj, hipStream_t s);
+#if !defined(PBSO_ONLY_R4) && (!defined(PBSO_BLOCK_PART) || PBSO_BLOCK_PART == 1)
+int launch_block_r1(const IirParams &p, int n_teams, int W, bool qn, int proj, hipStream_t s) { return launch_r<1>(p, n_teams, W, qn, proj, s); }
+int launch_block_r2(const IirParams &p, int n_teams, int W, bool qn, int proj, hipStream_t s) { return launch_r<2>(p, n_teams, W, qn, proj, s); }
+#endif
+
+#if !defined(PBSO_BLOCK_PART) || PBSO_BLOCK_PART == 0
 int launch_iir_block(const IirParams &p, int n_teams, int R, int W, int qnm, int proj, hipStream_t s) {
     if (n_teams <= 0) return 0;
     if (W < 1 || W > MAX_WAVES_PER_BLOCK_TEAM) return (int)hipErrorInvalidValue;
@@ -1311,9 +1321,8 @@ int launch_iir_block(const IirParams &p, int n_teams, int R, int W, int qnm, int
     const bool qn = qnm != 0;
     switch (R) {
 #ifndef PBSO_ONLY_R4          // (tests/test_kernel_asm_guards.py compiles the R = 4 builds alone: the headline shape's)
-    case 1: return launch_r<1>(p, n_teams, W, qn, proj, s);
-    case 2: return launch_r<2>(p, n_teams, W, qn, proj, s);
-    case 8: return launch_r<8>(p, n_teams, W, qn, proj, s);
+    case 1: return launch_block_r1(p, n_teams, W, qn, proj, s);
+    case 2: return launch_block_r2(p, n_teams, W, qn, proj, s);
 #endif
     case 4: return launch_r<4>(p, n_teams, W, qn, proj, s);
     }
@@ -1400,6 +1409,8 @@ int launch_listener_mix(const float *xdump, const float *xscale, const float *wt
                        n_modes, n_listeners, out_stride);
     return (int)hipGetLastError();
 }
+
+#endif      // PBSO_BLOCK_PART == 0
 
 }  // namespace iir_block
 }  // namespace pbso

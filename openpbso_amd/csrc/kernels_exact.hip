@@ -38,13 +38,29 @@ __device__ __forceinline__ double project_one(const ProjectEvent &ev, const doub
     return acc;
 }
 
+// Row-parallel kernels below: one workgroup per (row, tile of 256 columns), the workgroups FLAT on grid.x with the tiles of a row
+// adjacent -- rows are events, forced (object, buffer) pairs, transfer rows: a ten-second step of a large scene has more of them
+// than grid.y may count (65535).
+struct RowTile { unsigned row, tile; };
+__device__ __forceinline__ RowTile row_tile(int m_pad) {
+    const unsigned tiles = (unsigned)(m_pad + 255) / 256u;
+    return RowTile{blockIdx.x / tiles, blockIdx.x % tiles};
+}
+static inline bool flat_grid(int m_pad, long long n_rows, dim3 *grid) {
+    const long long wgs = (long long)((m_pad + 255) / 256) * n_rows;
+    if (wgs > 0x7fffffffLL) return false;
+    *grid = dim3((unsigned)wgs);
+    return true;
+}
+
 __global__ __launch_bounds__(256) void modal_project_kernel(
     const ProjectEvent *__restrict__ events, const double *__restrict__ shapes,
     const long long *__restrict__ shape_off, const int *__restrict__ n_modes,
     double *__restrict__ slots, int m_pad) {
     prep_prio();
-    const ProjectEvent ev = events[blockIdx.y];
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const RowTile rt = row_tile(m_pad);
+    const ProjectEvent ev = events[rt.row];
+    const int m = rt.tile * blockDim.x + threadIdx.x;
     if (m >= m_pad) return;
     double out = 0.0;
     if (m < n_modes[ev.obj]) out = project_one(ev, shapes + shape_off[ev.obj], m_pad, m);
@@ -55,7 +71,8 @@ int launch_modal_project(const ProjectEvent *events, int n_events, const double 
                          const long long *shape_off, const int *n_modes, double *slots,
                          int m_pad, hipStream_t stream) {
     if (n_events <= 0) return 0;
-    dim3 grid((m_pad + 255) / 256, n_events);
+    dim3 grid;
+    if (!flat_grid(m_pad, n_events, &grid)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(modal_project_kernel, grid, dim3(256), 0, stream, events, shapes, shape_off,
                        n_modes, slots, m_pad);
     return (int)hipGetLastError();
@@ -65,15 +82,17 @@ int launch_modal_project(const ProjectEvent *events, int n_events, const double 
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const double *__restrict__ src,
                                                            const int *__restrict__ dst_slot,
                                                            double *__restrict__ slots, int m_pad) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const RowTile rt = row_tile(m_pad);
+    const int m = rt.tile * blockDim.x + threadIdx.x;
     if (m >= m_pad) return;
-    slots[(size_t)dst_slot[blockIdx.y] * m_pad + m] = src[(size_t)blockIdx.y * m_pad + m];
+    slots[(size_t)dst_slot[rt.row] * m_pad + m] = src[(size_t)rt.row * m_pad + m];
 }
 
 int launch_scatter_rows(const double *src, const int *dst_slot, int n_rows, double *slots,
                         int m_pad, hipStream_t stream) {
     if (n_rows <= 0) return 0;
-    dim3 grid((m_pad + 255) / 256, n_rows);
+    dim3 grid;
+    if (!flat_grid(m_pad, n_rows, &grid)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(scatter_rows_kernel, grid, dim3(256), 0, stream, src, dst_slot, slots, m_pad);
     return (int)hipGetLastError();
 }
@@ -90,8 +109,9 @@ __global__ __launch_bounds__(256) void force_combine_kernel(
     const double *__restrict__ shapes, const long long *__restrict__ shape_off, const int *__restrict__ n_modes,
     int m_pad) {
     prep_prio();
-    const int row = blockIdx.y;
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const RowTile rt = row_tile(m_pad);
+    const int row = (int)rt.row;
+    const int m = rt.tile * blockDim.x + threadIdx.x;
     if (m >= m_pad) return;
     const int obj = row_obj[row];
     double S = 0.0;
@@ -112,7 +132,8 @@ int launch_force_combine(const int *row_ptr, const int *slot_idx, const int *row
                          const double *shapes, const long long *shape_off, const int *n_modes, int m_pad,
                          hipStream_t stream) {
     if (n_rows <= 0) return 0;
-    dim3 grid((m_pad + 255) / 256, n_rows);
+    dim3 grid;
+    if (!flat_grid(m_pad, n_rows, &grid)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(force_combine_kernel, grid, dim3(256), 0, stream, row_ptr, slot_idx, row_obj,
                        slots, c3, grows, direct, shapes, shape_off, n_modes, m_pad);
     return (int)hipGetLastError();
@@ -928,13 +949,14 @@ __device__ double ffat_get_map_val(const FfatGeom &g, const double *__restrict__
     return fabs(psi0 / kr);
 }
 
-// grid = (ceil(m_pad / 128), n_events)
+// grid = n_events x ceil(m_pad / 128) workgroups, flat on x (tiles of one event adjacent): grid.y counts to 65535 only
 __global__ __launch_bounds__(128) void ffat_lookup_kernel(
     const FfatEvent *__restrict__ events, const FfatGeom *__restrict__ geom,
     const long long *__restrict__ geom_off, const int *__restrict__ n_modes,
     const double *__restrict__ psi, double *__restrict__ rows, int m_pad) {
-    const FfatEvent ev = events[blockIdx.y];
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned tiles = (unsigned)(m_pad + 127) / 128u;
+    const FfatEvent ev = events[blockIdx.x / tiles];
+    const int m = (blockIdx.x % tiles) * blockDim.x + threadIdx.x;
     if (m >= m_pad) return;
     double out = 0.0;
     if (m < n_modes[ev.obj]) {
@@ -949,7 +971,9 @@ int launch_ffat_lookup(const FfatEvent *events, int n_events, const FfatGeom *ge
                        const long long *geom_off, const int *n_modes, const double *psi,
                        double *rows, int m_pad, hipStream_t stream) {
     if (n_events <= 0) return 0;
-    dim3 grid((m_pad + 127) / 128, n_events);
+    const long long wgs = (long long)((m_pad + 127) / 128) * n_events;
+    if (wgs > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    dim3 grid((unsigned)wgs);
     hipLaunchKernelGGL(ffat_lookup_kernel, grid, dim3(128), 0, stream, events, geom, geom_off,
                        n_modes, psi, rows, m_pad);
     return (int)hipGetLastError();
@@ -964,8 +988,8 @@ __global__ __launch_bounds__(128) void ffat_lookup_runs_kernel(
     const FfatEvent *__restrict__ events, const FfatRun *__restrict__ runs, const FfatGeom *__restrict__ geom,
     const long long *__restrict__ geom_off, const int *__restrict__ n_modes,
     const double *__restrict__ psi, double *__restrict__ rows, int m_pad) {
-    const FfatRun run = runs[blockIdx.y];
-    const int m = blockIdx.x;
+    const FfatRun run = runs[blockIdx.x / (unsigned)m_pad];      // (flat grid, the modes of one run adjacent: grid.y counts to 65535 only)
+    const int m = blockIdx.x % (unsigned)m_pad;
     const bool live = m < n_modes[run.obj];
     const FfatGeom &g = geom[geom_off[run.obj] + (live ? m : 0)];
     const bool on = live && g.valid;
@@ -980,8 +1004,8 @@ int launch_ffat_lookup_runs(const FfatEvent *events, const FfatRun *runs, int n_
                             const long long *geom_off, const int *n_modes, const double *psi,
                             double *rows, int m_pad, hipStream_t stream) {
     if (n_runs <= 0) return 0;
-    if (n_runs > 65535) return (int)hipErrorInvalidValue;     // (runs sit on grid.y; the engine sends larger launches through launch_ffat_lookup)
-    hipLaunchKernelGGL(ffat_lookup_runs_kernel, dim3(m_pad, n_runs), dim3(128), 0, stream, events, runs, geom, geom_off,
+    if ((long long)n_runs * m_pad > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(ffat_lookup_runs_kernel, dim3((unsigned)((long long)n_runs * m_pad)), dim3(128), 0, stream, events, runs, geom, geom_off,
                        n_modes, psi, rows, m_pad);
     return (int)hipGetLastError();
 }
@@ -1052,6 +1076,7 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const SplitObj *__restri
 int launch_sum_parts(const SplitObj *split, int n_split, const float *parts, float *audio, long long stride, long long n,
                      hipStream_t stream) {
     if (n_split <= 0 || n <= 0) return 0;
+    if (n_split > 65535) return (int)hipErrorInvalidValue;      // (objects stepped by several teams: each has more than 1024 modes)
     dim3 grid((unsigned)((n + 255) / 256), n_split);
     hipLaunchKernelGGL(sum_parts_kernel, grid, dim3(256), 0, stream, split, parts, audio, stride, n);
     return (int)hipGetLastError();
@@ -1061,15 +1086,17 @@ int launch_sum_parts(const SplitObj *split, int n_split, const float *parts, flo
 __global__ __launch_bounds__(256) void copy_rows_kernel(const int *__restrict__ src_row,
                                                         const int *__restrict__ dst_row,
                                                         double *rows, int m_pad) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const RowTile rt = row_tile(m_pad);
+    const int m = rt.tile * blockDim.x + threadIdx.x;
     if (m >= m_pad) return;
-    rows[(size_t)dst_row[blockIdx.y] * m_pad + m] = rows[(size_t)src_row[blockIdx.y] * m_pad + m];
+    rows[(size_t)dst_row[rt.row] * m_pad + m] = rows[(size_t)src_row[rt.row] * m_pad + m];
 }
 
 int launch_copy_rows(const int *src_row, const int *dst_row, int n, double *rows, int m_pad,
                      hipStream_t stream) {
     if (n <= 0) return 0;
-    dim3 grid((m_pad + 255) / 256, n);
+    dim3 grid;
+    if (!flat_grid(m_pad, n, &grid)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(copy_rows_kernel, grid, dim3(256), 0, stream, src_row, dst_row, rows, m_pad);
     return (int)hipGetLastError();
 }
@@ -1098,6 +1125,10 @@ int launch_sum_parts_copy_rows(const SplitObj *split, int n_split, const float *
                                const int *src_row, const int *dst_row, int n_copy, double *rows, int m_pad, hipStream_t stream) {
     if (n_split <= 0 || n <= 0) return launch_copy_rows(src_row, dst_row, n_copy, rows, m_pad, stream);
     if (n_copy <= 0) return launch_sum_parts(split, n_split, parts, audio, stride, n, stream);
+    if (n_split + (long long)n_copy > 65535) {        // (grid.y: two launches then; the copy's grid is flat)
+        const int e = launch_sum_parts(split, n_split, parts, audio, stride, n, stream);
+        return e ? e : launch_copy_rows(src_row, dst_row, n_copy, rows, m_pad, stream);
+    }
     dim3 grid((unsigned)std::max<long long>((n + 255) / 256, (m_pad + 255) / 256), n_split + n_copy);
     hipLaunchKernelGGL(sum_parts_copy_rows_kernel, grid, dim3(256), 0, stream, split, n_split, parts, audio, stride, n, src_row, dst_row,
                        rows, m_pad);

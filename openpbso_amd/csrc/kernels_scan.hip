@@ -470,7 +470,8 @@ __global__ __launch_bounds__(64 * SEG_MAX) void iir_scan_seg_kernel(PBSO_SCAN_AR
 // ---------------------------------------------------------------------------------------------------------
 // dense_increment_kernel: V[row][mode] = sum_{k=0..512} A^(512-k) u T_row[k], the state a unit force gain with the dense time
 // profile of row `row` (one (object, buffer) of the launch: ProfRow, kernels.h) leaves behind from rest -- for ALL dense rows of
-// a launch at once: grid (tiles of NW x 64 columns, groups of RB rows), one wave per (64 columns, group of rows).
+// a launch at once: grid (groups of RB rows, tiles of NW x 64 columns) -- the rows on x: a launch of a large all-dense scene has
+// more row groups than grid.y may count (65535) --, one wave per (64 columns, group of rows).
 //   per group of 16 blocks of 16 samples:  U[16 blocks][16 modes] = T[16 blocks x 16 taps] . F[16 taps x 16 modes]  per tile of
 //   16 modes and state component on v_mfma_f32_16x16x4_f32 (F = A^(15-i) u, the table of the forced block path; the A operand
 //   is the profile as the FIR of kernels_block.hip holds it), back to "lane = mode" through LDS, then
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(64 * INC_NW) void dense_increment_kernel(
     __shared__ __attribute__((aligned(16))) float lds_u[INC_NW][64 * U_ROW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int col0 = 64 * (blockIdx.x * INC_NW + wave);
+    const int col0 = 64 * (blockIdx.y * INC_NW + wave);
     if (col0 >= p.m_pad) return;                     // (no workgroup barrier in this kernel: a wave may leave)
     float *ua = lds_u[wave];
     auto wave_sync = [&]() {
@@ -505,8 +506,8 @@ __global__ __launch_bounds__(64 * INC_NW) void dense_increment_kernel(
     bool tile_dead = false;
     float fB[4][2][4];                               // B operand: F[tap 4 ks + (l >> 4)][mode 16 tl + (l & 15)], both components
     f2 c1 = f2{0.f, 0.f}, c2 = f2{0.f, 0.f};         // P = A^16 as (P11 - 1, P21), (P12, P22)
-    const int r_end = (int)(blockIdx.y + 1) * INC_RB < p.n_rows ? (int)(blockIdx.y + 1) * INC_RB : p.n_rows;
-    for (int row = blockIdx.y * INC_RB; row < r_end; ++row) {
+    const int r_end = (int)(blockIdx.x + 1) * INC_RB < p.n_rows ? (int)(blockIdx.x + 1) * INC_RB : p.n_rows;
+    for (int row = blockIdx.x * INC_RB; row < r_end; ++row) {
         const int obj = p_row_obj[row];
         f2 *__restrict__ vdst = reinterpret_cast<f2 *>(p_vinc) + (size_t)row * p.m_pad + col0;
         if (obj != cur_obj) {
@@ -584,7 +585,8 @@ int launch_dense_increments(const float *pc, const float *ftab, long long plane,
     if (n_rows <= 0) return 0;
     if (frames != 513 || m_pad % 64 || !ftab || !pc || !vinc) return (int)hipErrorInvalidValue;
     const iir_scan::IncDims dims = {n_rows, m_pad, b_pad, frames, plane};
-    const dim3 grid((m_pad / 64 + iir_scan::INC_NW - 1) / iir_scan::INC_NW, (n_rows + iir_scan::INC_RB - 1) / iir_scan::INC_RB);
+    const dim3 grid((n_rows + iir_scan::INC_RB - 1) / iir_scan::INC_RB, (m_pad / 64 + iir_scan::INC_NW - 1) / iir_scan::INC_NW);
+    if (grid.y > 65535u) return (int)hipErrorInvalidValue;        // (m_pad > 16 M columns)
     hipLaunchKernelGGL(iir_scan::dense_increment_kernel, grid, dim3(64 * iir_scan::INC_NW), 0, stream, pc, ftab, tprof, row_obj, n_modes,
                        vinc, dims);
     return (int)hipGetLastError();

@@ -341,6 +341,10 @@ class Engine:
         a = np.ascontiguousarray(a, dtype=np.float64)
         return bool(self._chk(self._l.pbso_enqueue_arprm(self._h, obj, _dp(a), sigma, mu, not_before)))
 
+    def arprm_pending(self, obj):
+        """pbso_arprm_pending: True while the object's AR-parameter slot is taken (a try_enqueue would fail, modal_solver.h:378-381)"""
+        return bool(self._chk(self._l.pbso_arprm_pending(self._h, obj)))
+
     def compute_transfer(self, obj, pos, not_before=0):
         p = np.ascontiguousarray(pos, dtype=np.float64)
         return bool(self._chk(self._l.pbso_compute_transfer(self._h, obj, _dp(p), not_before)))

@@ -3,6 +3,7 @@
 // (GetModalForceVertex :268-295 + enqueueForceMessage :610), the simulation
 // thread's step() loop (:527-536) and PaModalCallback (:192-212).  Writes the
 // mono float32 stream the callback would play to argv[1].
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -147,6 +148,44 @@ int main(int argc, char **argv) {
             threw = true;
         }
         std::printf("missing_ffat_dir: out_of_range=%d\n", (int)threw);
+    }
+    // two AR-parameter updates back to back from a second thread while the simulation thread steps (modal_solver.h:382-393): the
+    // second finds the 1-slot queue full and spins -- without holding the engine's lock between attempts -- until a step() of a
+    // sustained AutoregressiveForce contact (:226-236) has taken the first; with a bounded maxIte and nobody stepping it gives up
+    {
+        std::unique_ptr<ModalSolver<double>> s3(new ModalSolver<double>(n_modes));
+        s3->setIntegrator(integrator);
+        s3->setUseTransfer(false);
+        ForceMessage<double> f;
+        GetModalForceVertex(n_modes, modes, 2, vn, f, ForceType::AutoregressiveForce, 0.f);
+        f.sustainedForceStart = true;
+        const bool started = s3->enqueueForceMessage(f);
+        SoundMessage<double> sm;
+        s3->step();                                   // the contact is on
+        s3->dequeueSoundMessage(sm);
+        AutoregressiveForceParam<double> p1, p2;
+        p1.sigma = 0.002;
+        p2.sigma = 0.003;
+        const bool first = s3->enqueueArprmMessageNoFail(p1, 5);      // empty slot: accepted at once
+        const bool bounded = s3->enqueueArprmMessageNoFail(p2, 5);    // full slot, nobody steps: false after five tries
+        std::atomic<int> steps_started{0};
+        std::atomic<bool> done{false};
+        bool second = false;
+        int steps_at_accept = -1;
+        std::thread gui([&]() {
+            second = s3->enqueueArprmMessageNoFail(p2);               // maxIte = -1: spins until accepted
+            steps_at_accept = steps_started.load();
+            done = true;
+        });
+        int guard = 0;
+        while (!done && guard++ < 2000) {
+            ++steps_started;
+            s3->step();
+            s3->dequeueSoundMessage(sm);
+        }
+        gui.join();
+        std::printf("arprm: started=%d first=%d bounded=%d second=%d after_a_step=%d\n", (int)started, (int)first, (int)bounded, (int)second,
+                    (int)(steps_at_accept >= 1));
     }
     pbso_facade::VecX<double> qn = solver->getQBufferNorm();
     const TransMessage<double> &tr = solver->getLatestTransfer();

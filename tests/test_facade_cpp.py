@@ -47,6 +47,9 @@ def test_facade_audio_matches_oracle(tmp_path):
     assert "transfer[0]=1e+07" in r.stdout            # setUseTransfer(false) -> unit transfer
     assert "clear: enqueued=1 sound_after_clear=0" in r.stdout       # "Clear force": accepted, that step emits no buffer
     assert "missing_ffat_dir: out_of_range=1" in r.stdout            # empty map -> at(0) throws, as in the reference
+    # enqueueArprmMessageNoFail (modal_solver.h:382-393): bounded tries on a full slot fail, the unbounded call of a second thread
+    # gets in once a step() has taken the message before it
+    assert "arprm: started=1 first=1 bounded=0 second=1 after_a_step=1" in r.stdout, r.stdout
     got = np.fromfile(out, dtype=np.float32).astype(np.float64)
     n_modes, n_verts, nb = 96, 8, 6
     raw = np.fromfile(out + ".model", dtype=np.float64)

@@ -35,7 +35,7 @@ def _scene(n_obj=6, n_modes=300, seed=5):
     return objs, evs
 
 
-@pytest.mark.parametrize("form,mpl", [(capi.FORM_BLOCK_BF16, 0), (capi.FORM_BLOCK_BF16, 4), (capi.FORM_BLOCK, 2), (capi.FORM_BLOCK, 8),
+@pytest.mark.parametrize("form,mpl", [(capi.FORM_BLOCK_BF16, 0), (capi.FORM_BLOCK_BF16, 4), (capi.FORM_BLOCK, 2), (capi.FORM_BLOCK, 4),
                                       (capi.FORM_VELOCITY, 0), (capi.FORM_VELOCITY, 3), (capi.FORM_DIRECT, 1)])
 def test_vertex_hits_through_the_bank_match_the_oracle(form, mpl):
     objs, evs = _scene()

@@ -77,12 +77,11 @@ def test_config2_512_modes_poisson_train(mpl, rotate, monkeypatch):
     print(f"C2 R={mpl} rotate={rotate} max/peak={mx:.2e} relL2={l2:.2e}")
 
 
-@pytest.mark.parametrize("form", [capi.FORM_BLOCK, capi.FORM_VELOCITY])
-@pytest.mark.parametrize("mpl", [4, 8])
+@pytest.mark.parametrize("form,mpl", [(capi.FORM_BLOCK, 4), (capi.FORM_VELOCITY, 4), (capi.FORM_VELOCITY, 8)])
 def test_config5_shape_large_objects(mpl, form, monkeypatch):
     """configs[4] object size: 4096 modes per object -> teams of 16 / 8 waves
-    (the 1024-thread build of the per-sample kernel; the block form caps a team at 8 waves, 4 with
-    eight modes per lane, and cuts the object into several teams), Gaussian + point forces."""
+    (the 1024-thread build of the per-sample kernel; the block form caps a team at 8 waves and cuts the object into
+    several teams; eight modes per lane are the per-sample kernel's only -- round 6), Gaussian + point forces."""
     n_modes, nb = 4096, 10
     objs, evs = [], []
     rng = np.random.default_rng(55)
@@ -97,7 +96,7 @@ def test_config5_shape_large_objects(mpl, form, monkeypatch):
     got = run_engine(objs, evs, nb, modes_per_lane=mpl, form=form)
     _check(got, want)
     waves = 4096 // (64 * mpl)
-    cap = 16 if form == capi.FORM_VELOCITY else (4 if mpl == 8 else 8)
+    cap = 16 if form == capi.FORM_VELOCITY else 8
     assert got["info"]["waves_per_object"] == min(waves, cap) and got["info"]["n_teams"] == 2 * max(1, waves // cap)
     monkeypatch.delenv("PBSO_TEAM_WAVES")            # a nearly empty chip: one wave per CU
     got = run_engine(objs, evs, nb, modes_per_lane=mpl, form=form)
@@ -406,7 +405,7 @@ def test_objects_split_over_several_teams():
     want = run_oracle(objs, evs, nb)
     ref = None
     for mpl, split in ((0, None), (1, [3, 4]), (3, None), (4, None), (8, [1, 6])):
-        kw = dict(form=capi.FORM_VELOCITY) if mpl == 3 else {}      # three modes per lane: per-sample kernel only
+        kw = dict(form=capi.FORM_VELOCITY) if mpl in (3, 8) else {}      # three / eight modes per lane: per-sample kernel only
         got = run_engine(objs, evs, nb, modes_per_lane=mpl, split=split, **kw)
         assert got["info"]["n_teams"] > 3 or mpl == 8
         _check(got, want)
@@ -609,6 +608,10 @@ def test_degenerate_objects_and_arguments():
             eng.finalize()                                   # no objects
     with pytest.raises(PbsoError):
         Engine(modes_per_lane=5)
+    with pytest.raises(PbsoError):
+        e = Engine(modes_per_lane=8, form=capi.FORM_BLOCK)      # (round 6: the block form's eight-modes-per-lane builds spilled at one wave per SIMD)
+        e.add_object(synth.eigenvalues(64, 1), synth.RHO, synth.ALPHA, synth.BETA)
+        e.finalize()
 
 
 def test_long_steps_cut_into_launches(monkeypatch):

@@ -68,7 +68,7 @@ def test_block_kernel_generated_code(block_asm):
     """K1b, the kernel behind the headline: the f32 build <R=4, qnorm, f32 projection> and the split-bf16 build keep
     0 bytes of scratch and <= 256 VGPRs (two waves per SIMD), the matrix work per buffer is the count the roofline prices
     (8 slices x 32 = 256 v_mfma_f32_16x16x4_f32; 8 x 12 = 96 v_mfma_f32_16x16x32_bf16), the LDS-DMA of a direct hit sets M0 right
-    before every global_load_lds_dword and nothing else touches M0, and the coarse step stays on full-rate instructions."""
+    before every global_load_lds_dword and nothing else touches M0."""
     asm, kernels = block_asm
     # 8 builds that walk the buffers in order + their 6 time-chunked twins (K5; the builds that keep block states for a listener
     # mix have none)
@@ -98,10 +98,23 @@ def test_block_kernel_generated_code(block_asm):
         assert dma and len(m0) == len(dma)
         assert all("s_mov_b32 m0" in lines[i] for i in m0)
         assert all(i - 1 in m0 for i in dma)                       # M0 (the LDS address) is written right before its load
-        # no half-rate packed arithmetic or bf16 conversion anywhere near the recurrence (profiles/r02_valu_issue.txt): the only packed
-        # ops are the few v_pk_add_f32 that add accumulator pairs
-        assert not re.search(r"\bv_pk_(fma|mul)_f32\b", body) and "v_cvt_pk_bf16" not in body
+        # no bf16 conversion instruction anywhere near the recurrence (profiles/r02_valu_issue.txt); the only other packed ops are the
+        # few v_pk_add_f32 that add accumulator pairs
+        assert not re.search(r"\bv_pk_mul_f32\b", body) and "v_cvt_pk_bf16" not in body
         assert len(re.findall(r"\bv_pk_add_f32\b", body)) <= 16
+    # Round 6, the f32 projection's pipeline (builds without DUMP): the vector burst is ONE asm statement -- sixteen coarse steps of two
+    # v_pk_fma_f32 on the (Q, D) register pair, 8 slices x 32 per buffer body, the block-start states parked by 8 x 8 ds_write2_b64
+    # between the steps -- and the matrix burst refills its B operands by ds_read_b128 (8 per slice, 7 slices + the first fill; the
+    # forced builds fill three more times per group).  The few ds_read_b32 left are the landing area of a direct hit and the taps.
+    # With the steps as separate asm statements the compiler put an s_nop behind each: 269 per body (round 5), now a few dozen.
+    for key, body in kernels.items():
+        f32_pipeline = key[2] == 0 and key[3] == 0
+        assert len(re.findall(r"\bv_pk_fma_f32\b", body)) == (256 if f32_pipeline else 0), key
+        if key[2] == 0:
+            assert len(re.findall(r"\bds_write2_b64\b", body)) == 64, key
+            assert len(re.findall(r"\bds_read_b128\b", body)) >= 64 and len(re.findall(r"\bds_read_b32\b", body)) <= 24, key
+        if f32_pipeline:
+            assert len(re.findall(r"\bs_nop\b", body)) <= 130, key
     # descriptors come through scalar loads (one s_load_dwordx8 per BufDesc, or x4 + x2 for the words the build uses), never
     # through per-lane vector loads
     assert re.search(r"s_load_dwordx[48]", f32) and re.search(r"s_load_dwordx[48]", bf16)
