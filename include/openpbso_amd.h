@@ -153,6 +153,13 @@ typedef struct pbso_engine_desc {
                                * maps composed in LDS -- for launches of 2 .. 8 chunks of more than one buffer whose whole scan is a few hundred
                                * waves: it shortens a lone scan, not a throughput-bound one), 1 always the serial scan, 2 the segmented one
                                * wherever the launch has 2 .. 8 chunks */
+    /* ---- ABI 6 */
+    int fuse_short_launches;  /* < 0: never.  0 (policy): a launch in which every AutoregressiveForce adds its samples once -- any launch of
+                               * one buffer: the real-time step -- evaluates variates, zero-state uses and profile rows in ONE kernel instead
+                               * of three, and in a launch of one buffer the combine kernel takes the rows of explicit data and the
+                               * projections that outlive the buffer itself instead of a scatter and a projection launch in front of it:
+                               * a sustained-contact buffer is three kernels (profiles, combine, oscillator bank) instead of seven.  The same
+                               * values in the same order: bit-identical to the separate launches */
 } pbso_engine_desc;
 
 enum pbso_bank_kernel {

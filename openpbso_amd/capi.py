@@ -52,7 +52,7 @@ class EngineDesc(C.Structure):
                 ("profile_margin_pct", C.c_int), ("profile_priority", C.c_int), ("team_waves", C.c_int),
                 ("pipe_consumers", C.c_int), ("pipe_max_teams", C.c_longlong), ("chunk_buffers", C.c_int),
                 ("plan_threads", C.c_int), ("plan_pin", C.c_int), ("timing_every", C.c_int), ("warm_copies", C.c_int),
-                ("stream_sync", C.c_int), ("latency_path", C.c_int), ("time_chunk_shape", C.c_int), ("scan_kernel", C.c_int)]
+                ("stream_sync", C.c_int), ("latency_path", C.c_int), ("time_chunk_shape", C.c_int), ("scan_kernel", C.c_int), ("fuse_short_launches", C.c_int)]
 BANK_AUTO, BANK_BLOCK, BANK_PIPE = 0, 1, 2
 
 

@@ -14,6 +14,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 
 #include <pthread.h>
 #include <sched.h>
@@ -299,6 +300,7 @@ int Engine::init() {
     if (desc_.profile_priority < 0 || desc_.profile_priority > 4) return fail(PBSO_ERR_INVALID, "profile_priority");
     if (desc_.stream_sync < 0 || desc_.stream_sync > 4) return fail(PBSO_ERR_INVALID, "stream_sync");
     latency_path_ = desc_.latency_path >= 0;
+    fuse_short_ = desc_.fuse_short_launches >= 0;
     if (desc_.qnorm_mode < PBSO_QNORM_OFF || desc_.qnorm_mode > PBSO_QNORM_CLOSED)
         return fail(PBSO_ERR_INVALID, "qnorm_mode");
     {
@@ -1290,6 +1292,7 @@ static void push_timed(std::deque<TimedEvent> &q, const TimedEvent &ev) {
 int Engine::enqueue_arprm(int obj, const double a[2], double sigma, double mu, int64_t not_before) {
     if (!finalized_) return fail(PBSO_ERR_STATE, "enqueue_arprm before finalize");
     if (!valid_obj(obj)) return fail(PBSO_ERR_INVALID, "object id");
+    path_to_pending(objs_[obj], INT64_MAX);              // (a parameter message that waits for its slot holds the events behind it back)
     TimedEvent ev;
     ev.kind = TimedEvent::ARPRM;
     ev.not_before = not_before;
@@ -1315,6 +1318,7 @@ int Engine::compute_transfer(int obj, const double pos[3], int64_t not_before) {
     if (!finalized_) return fail(PBSO_ERR_STATE, "compute_transfer before finalize");
     if (!valid_obj(obj)) return fail(PBSO_ERR_INVALID, "object id");
     Object &o = objs_[obj];
+    path_to_pending(o, INT64_MAX);                                // (a path given earlier: its positions are in front of this one)
     if (!o.have_maps) return 0;                                   // :290-291
     if (!o.maps_cover_modes)                                      // (the maps are fixed at finalize: checked once, there)
         return fail(PBSO_ERR_MISSING_MAP, "FFAT map for a modeId in 0..N_modes-1 is missing (std::map::at throws)");
@@ -1332,20 +1336,98 @@ int Engine::compute_transfer(int obj, const double pos[3], int64_t not_before) {
 // after frame (tools/real_time_modal_sound.cpp:844, 1172), pre-scheduled as the throughput harness has it
 int Engine::compute_transfer_path(int n, const int *objs, const double *pos, const int64_t *stamps, unsigned char *accepted) {
     if (n < 0 || (n > 0 && (!objs || !pos || !stamps))) return fail(PBSO_ERR_INVALID, "compute_transfer_path arguments");
+    if (!finalized_) return fail(PBSO_ERR_STATE, "compute_transfer before finalize");
+    // Runs of ONE object with ascending stamps -- the shape a camera path and the throughput harness have -- are kept as an array
+    // with a cursor (Object::path) for the planner; anything else goes call by call.
     int taken = 0;
-    for (int i = 0; i < n; ++i) {
-        const int rc = compute_transfer(objs[i], pos + 3 * (size_t)i, stamps[i]);
-        if (rc < 0) return rc;
-        if (accepted) accepted[i] = rc ? 1 : 0;
-        taken += rc ? 1 : 0;
+    const int N = (int)objs_.size();
+    for (int i = 0; i < n;) {
+        const int o = objs[i];
+        int j = i + 1;
+        while (j < n && objs[j] == o && stamps[j] > stamps[j - 1]) ++j;
+        bool run = o >= 0 && o < N && j - i >= 4;
+        if (run) {
+            Object &ob = objs_[o];
+            // every call of the run must be one pbso_compute_transfer accepts and appends: maps there, behind what the object's path
+            // already holds, and the first not an immediate call that finds the 1-slot queue taken
+            run = ob.have_maps && ob.maps_cover_modes && (!ob.path_left() || stamps[i] > ob.path.back().stamp) &&
+                  !(stamps[i] <= buffers_done_ && ob.pending.empty() && !ob.path_left() && ob.trans_full);
+            if (run) {
+                if (!ob.path_left()) { ob.path.clear(); ob.path_head = 0; }
+                for (int e = i; e < j; ++e) ob.path.push_back(Object::PathEv{stamps[e], {pos[3 * (size_t)e], pos[3 * (size_t)e + 1], pos[3 * (size_t)e + 2]}});
+                if (accepted) std::memset(accepted + i, 1, (size_t)(j - i));
+                taken += j - i;
+            }
+        }
+        if (!run) {
+            for (int e = i; e < j; ++e) {
+                const int rc = compute_transfer(objs[e], pos + 3 * (size_t)e, stamps[e]);
+                if (rc < 0) return rc;
+                if (accepted) accepted[e] = rc ? 1 : 0;
+                taken += rc ? 1 : 0;
+            }
+        }
+        i = j;
     }
     return taken;
+}
+
+// the positions of the object's path stamped below `before` enter its pending list as pbso_compute_transfer puts them
+void Engine::path_to_pending(Object &o, int64_t before) {
+    while (o.path_left() && o.path[o.path_head].stamp < before) {
+        const Object::PathEv &pe = o.path[o.path_head++];
+        TimedEvent ev;
+        ev.kind = TimedEvent::TRANSFER;
+        ev.not_before = pe.stamp;
+        ev.v[0] = pe.pos[0]; ev.v[1] = pe.pos[1]; ev.v[2] = pe.pos[2]; ev.v[3] = 0;
+        ev.flag = 0;
+        push_timed(o.pending, ev);
+    }
+    if (!o.path_left()) { o.path.clear(); o.path_head = 0; }
+}
+
+// Planner, before an object's buffers are planned: the positions of its path that fall into this launch.  For an object with
+// nothing else going on -- no live force, no message or stamped call due, the transfer in use, the 1-slot queue free -- a position
+// stamped s is what plan_object makes of it: try_enqueue into _queue_trans at the first buffer t >= s (modal_solver.h:286-300),
+// dequeued by the same step (:242-256) -- one lookup event and that buffer's transfer row; a second position that falls into the
+// same buffer finds the queue full and is dropped.  Otherwise they go through the pending list.
+int Engine::consume_path(PlanCtx &c, int oi, int nb) {
+    Object &o = objs_[oi];
+    if (!o.path_left()) return PBSO_OK;
+    const int64_t horizon = buffers_done_ + nb;
+    if (o.path[o.path_head].stamp >= horizon) return PBSO_OK;
+    const bool quiet = o.pending.empty() && (o.force_q.empty() || o.force_q.front().not_before >= horizon) && o.active.empty() &&
+                       !o.sustained && o.use_transfer && !o.trans_full && !o.arprm_full;
+    if (!quiet) {
+        path_to_pending(o, horizon);
+        return PBSO_OK;
+    }
+    int last_b = -1;
+    for (; o.path_left(); ++o.path_head) {
+        const Object::PathEv &pe = o.path[o.path_head];
+        const int64_t rel = pe.stamp - buffers_done_;
+        if (rel >= nb) break;
+        const int b = rel > 0 ? (int)rel : 0;
+        if (b == last_b) continue;                       // the queue still holds the position before it: try_enqueue fails, the move is lost
+        FfatEvent fe;
+        fe.obj = oi;
+        fe.row = c.xfer_base + c.n_xfer++;
+        fe.pos[0] = pe.pos[0]; fe.pos[1] = pe.pos[1]; fe.pos[2] = pe.pos[2];
+        c.ffat.push_back(fe);
+        o.trans_row = fe.row;
+        o.latest_row = fe.row;
+        plan_desc_[(size_t)oi * nb + b].trow = fe.row;
+        last_b = b;
+    }
+    if (!o.path_left()) { o.path.clear(); o.path_head = 0; }
+    return PBSO_OK;
 }
 
 // ModalSolver::setUseTransfer, modal_solver.h:148-152
 int Engine::set_use_transfer(int obj, int use, int64_t not_before) {
     if (!finalized_) return fail(PBSO_ERR_STATE, "set_use_transfer before finalize");
     if (!valid_obj(obj)) return fail(PBSO_ERR_INVALID, "object id");
+    path_to_pending(objs_[obj], INT64_MAX);
     TimedEvent ev;
     ev.kind = TimedEvent::USE_TRANSFER;
     ev.not_before = not_before;
@@ -1693,6 +1775,7 @@ int Engine::plan_object_span(PlanCtx &c, int oi, int nb) {
     Object &o = objs_[oi];
     {
         int rc = consume_script(c, oi, nb);
+        if (rc == PBSO_OK) rc = consume_path(c, oi, nb);
         if (rc != PBSO_OK) return rc;
     }
     int b = 0;
@@ -1755,7 +1838,7 @@ int Engine::plan(int nb) {
         h_xfer_init[i] = o.latest_row;
         if (!o.force_q.empty() || !o.active.empty() || !o.pending.empty() || o.trans_full ||
             o.sustained || (!o.use_transfer && o.latest_row != XFER_UNIT) ||
-            (script_.n > 0 && hit_off_[(size_t)i + 1] > hit_off_[i]))
+            (script_.n > 0 && hit_off_[(size_t)i + 1] > hit_off_[i]) || (o.path_left() && o.path[o.path_head].stamp < buffers_done_ + nb))
             busy_.push_back(i);
     }
     // contiguous shares of the busy objects, one planning context (host thread) each
@@ -1767,11 +1850,14 @@ int Engine::plan(int nb) {
     std::vector<size_t> need(T, 0);
     size_t need_all = 0;
     for (int t = 0; t < T; ++t) {
-        for (int k = lo[t]; k < lo[t + 1]; ++k)
+        for (int k = lo[t]; k < lo[t + 1]; ++k) {
             for (const TimedEvent &ev : objs_[busy_[k]].pending) {
                 if (ev.not_before >= buffers_done_ + nb) break;      // sorted by stamp (push_timed): the rest is later
                 if (ev.kind == TimedEvent::TRANSFER) ++need[t];
             }
+            // (the object's path: at most one position fires per buffer)
+            need[t] += std::min<size_t>(objs_[busy_[k]].path.size() - objs_[busy_[k]].path_head, (size_t)nb);
+        }
         need_all += need[t];
     }
     if ((int)need_all > xfer_cap_) {
@@ -2144,6 +2230,33 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         for (int i = 0; i < n_cl; ++i) { cp[i] = copy_latest[2 * i]; cp[n_cl + n_cq + i] = copy_latest[2 * i + 1]; }
         for (int i = 0; i < n_cq; ++i) { cp[n_cl + i] = copy_queued[2 * i]; cp[n_cl + n_cq + n_cl + i] = copy_queued[2 * i + 1]; }
     }
+    // A launch of ONE buffer (the real-time step): the rows of explicit data and the projections whose vectors outlive the buffer are
+    // taken by the combine kernel itself -- every slot filled now is read by exactly one row of this launch -- instead of a scatter and
+    // a projection launch in front of it (kernels_exact.hip: force_combine_kernel).  Any slot that is NOT read exactly once (a force
+    // whose profile is all zero in this buffer leaves its row out) keeps the separate launches.
+    bool fuse_combine = fuse_short_ && nb == 1 && n_frows > 0 && (!stage_slot_.empty() || !proj_.empty());
+    if (fuse_combine) {
+        const int n_ev = (int)(proj_direct_.size() + proj_.size());
+        std::unordered_map<int, std::pair<int, int>> code;      // slot -> (entry, references)
+        for (size_t e = 0; e < proj_.size(); ++e) code[proj_[e].slot] = {-((int)(proj_direct_.size() + e) + 1), 0};
+        for (size_t r = 0; r < stage_slot_.size(); ++r) code[stage_slot_[r]] = {-(n_ev + (int)r + 1), 0};
+        fuse_combine = code.size() == proj_.size() + stage_slot_.size();      // (a slot filled twice in one launch: never, but not fused)
+        for (int si : slot_idx_) {
+            if (si < 0) continue;
+            auto it = code.find(si);
+            if (it != code.end()) ++it->second.second;
+        }
+        for (const auto &kv : code) fuse_combine = fuse_combine && kv.second.second == 1;
+        if (fuse_combine) {
+            for (int &si : slot_idx_) {
+                if (si < 0) continue;
+                auto it = code.find(si);
+                if (it != code.end()) si = it->second.first;
+            }
+            proj_direct_.insert(proj_direct_.end(), proj_.begin(), proj_.end());
+            proj_.clear();
+        }
+    }
     size_t off = ps.front_bytes;
     auto place = [&](size_t bytes) { const size_t o = off; off += arena_align(bytes); return o; };
     const size_t o_row_ptr = place(row_ptr_.size() * sizeof(int)), o_slot_idx = place(slot_idx_.size() * sizeof(int));
@@ -2314,11 +2427,13 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         LAUNCHTRY(launch_force_rows(d_prow, (int)prof_rows_.size(), d_pent, reinterpret_cast<const ArUse *>(da + o_aruse), (int)ar_uses_.size(),
                                     reinterpret_cast<const ArStream *>(da + o_arstream), reinterpret_cast<const int *>(da + o_arseg),
                                     (int)seg_stream_.size(), ar_max_segs_, d_arstate_.p, d_ar_snaps_.p, d_ar_vnorm_.p, d_ar_vstate_.p,
-                                    d_ar_segcount_.p, d_ar_cbuf_.p, d_ar_recs_.p, d_ar_fins_.p, ps.d_tprof.p, B_, b_pad_, b_pad_, sp));
+                                    d_ar_segcount_.p, d_ar_cbuf_.p, d_ar_recs_.p, d_ar_fins_.p, ps.d_tprof.p, B_, b_pad_, b_pad_,
+                                    /* every AR force adds its samples once (a launch of one buffer): one launch instead of three */
+                                    fuse_short_ && !ar_uses_.empty() && ar_uses_.size() == ar_streams_.size(), sp));
     else if (device_profiles_)
         LAUNCHTRY(launch_force_profiles(d_chain, n_chains, d_prow, d_pent, d_arstate_.p, ps.d_tprof.p, B_, b_pad_, ar_serial_ ? 1 : 0, k2_prio_, sp));
     if (evq.has_k2) HIPTRY(hipEventRecord(evq.f1, sp));
-    LAUNCHTRY(launch_scatter_rows(d_stage, d_stage_slot, (int)stage_slot_.size(), d_slots_.p, m_pad_, sa));
+    if (!fuse_combine) LAUNCHTRY(launch_scatter_rows(d_stage, d_stage_slot, (int)stage_slot_.size(), d_slots_.p, m_pad_, sa));
     LAUNCHTRY(launch_modal_project(d_proj, (int)proj_.size(), d_shapes_.p, d_shape_off_.p, d_n_modes_.p, d_slots_.p, m_pad_, sa));
     // (a few events: one thread per (event, mode); listener paths -- many events per object -- by runs)
     if (ffat_.size() >= 4 * ffat_runs_.size() && !ffat_runs_.empty())
@@ -2330,7 +2445,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     //  move in as the bank's retire, so most of it is done when the last one leaves -- queued behind the bank in
     //  the bank's own stream it would start only then: 0.785 instead of 0.735 ms per step at 1024 x 512)
     LAUNCHTRY(launch_force_combine(d_row_ptr, d_slot_idx, d_row_obj, n_frows, d_slots_.p, d_c3_.p, grows.p, d_projd, d_shapes_.p,
-                                   d_shape_off_.p, d_n_modes_.p, m_pad_, sa));
+                                   d_shape_off_.p, d_n_modes_.p, m_pad_, (int)proj_direct_.size(), d_stage, d_stage_slot, sa));
     if (split_prep) HIPTRY(hipEventRecord(ev_aux_join_[cur_set_], sa));
     if (split_prep && !tc_launch) HIPTRY(hipStreamWaitEvent(sp, ev_aux_join_[cur_set_], 0));
     if (tc_launch) {

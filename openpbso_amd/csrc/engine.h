@@ -142,6 +142,13 @@ struct Object {
     bool use_transfer = true;                            // _useTransfer
     int latest_row = XFER_UNIT;                          // where _latest_transfer lives (XFER_UNIT or own row)
     std::deque<TimedEvent> pending;                      // stamped arprm / transfer / use-transfer calls
+    // Round 6: a listener PATH given in one pbso_compute_transfer_path call (this object's positions, stamps ascending) stays an
+    // array with a cursor; the planner turns the positions of an otherwise quiet object straight into lookup events and transfer
+    // rows (Engine::consume_path), and any call that orders itself against pending events moves the rest into `pending` first
+    struct PathEv { int64_t stamp; double pos[3]; };
+    std::vector<PathEv> path;
+    size_t path_head = 0;
+    bool path_left() const { return path_head < path.size(); }
 };
 
 // Everything one planning pass over a contiguous range of objects produces.  The planner runs one
@@ -227,6 +234,9 @@ private:
     int script_to_queue(int oi, int h0, int h1, const char **why);     // hits h0 .. h1 - 1 of object oi enter its queue, in order
     int flush_script();                                                 // all of it (another enqueue call came before the step)
     int consume_script(PlanCtx &c, int oi, int nb);                     // planner: the object's hits of this launch
+    // the listener's twin of the hit script (Object::path)
+    void path_to_pending(Object &o, int64_t before);     // positions stamped below `before` enter the pending list, in order
+    int consume_path(PlanCtx &c, int oi, int nb);
     static int cfail(PlanCtx &c, int code, const char *msg) { c.err = msg; return code; }
 
     pbso_engine_desc desc_;
@@ -422,6 +432,7 @@ private:
     double timeline_h0_ = 0;
     int k2_margin_pct_ = 100;                            // PBSO_K2_MARGIN_PCT: scales the candidate range (tests: < 100 forces the shortfall path)
     bool k2_rows_launch_ = false;                        // this launch takes the row-parallel form
+    bool fuse_short_ = true;                             // pbso_engine_desc::fuse_short_launches
     std::vector<ArStream> ar_streams_;
     std::vector<ArUse> ar_uses_;
     std::vector<int> seg_stream_, ar_stream_of_state_, ar_last_use_, ar_epoch_, ar_param_;

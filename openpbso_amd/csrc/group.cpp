@@ -20,9 +20,12 @@ namespace {
 // ---- the part of RCCL's C API this file calls (rccl/rccl.h; the values are NCCL's ABI)
 typedef struct ncclComm *ncclComm_t;
 typedef struct { char internal[PBSO_GROUP_ID_BYTES]; } ncclUniqueId;
-typedef enum { ncclSuccess = 0 } ncclResult_t;
-typedef enum { ncclFloat = 7 } ncclDataType_t;
-typedef enum { ncclSum = 0 } ncclRedOp_t;
+// (fixed underlying type: the library returns codes this file does not name -- values outside a plain enum's range would be
+//  undefined behaviour)
+enum ncclResult_t : int { ncclSuccess = 0 };
+enum ncclDataType_t : int { ncclFloat = 7 };
+enum ncclRedOp_t : int { ncclSum = 0 };
+static_assert(sizeof(ncclUniqueId) == 128, "NCCL_UNIQUE_ID_BYTES");
 
 struct Rccl {
     void *lib = nullptr;
@@ -38,6 +41,8 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    int version = 0;
     std::string err;
     bool load() {
         if (lib) return ok;                              // (a library that lacks a symbol stays unusable: no second try through null pointers)
@@ -54,7 +59,12 @@ struct Rccl {
         sym(GetUniqueId, "ncclGetUniqueId"); sym(CommInitRank, "ncclCommInitRank"); sym(CommInitAll, "ncclCommInitAll");
         sym(CommDestroy, "ncclCommDestroy"); sym(AllGather, "ncclAllGather"); sym(AllReduce, "ncclAllReduce");
         sym(Send, "ncclSend"); sym(Recv, "ncclRecv"); sym(GroupStart, "ncclGroupStart"); sym(GroupEnd, "ncclGroupEnd");
-        sym(GetErrorString, "ncclGetErrorString");
+        sym(GetErrorString, "ncclGetErrorString"); sym(GetVersion, "ncclGetVersion");
+        // the declarations above are NCCL 2's ABI (ncclFloat = 7, a 128-byte id, ncclSum = 0: unchanged since 2.0): refuse anything else
+        if (all && (GetVersion(&version) != ncclSuccess || version < 2000)) {
+            all = false;
+            err = "librccl reports version " + std::to_string(version) + ": not the NCCL 2 ABI this file declares";
+        }
         ok = all;
         return ok;
     }

@@ -197,11 +197,12 @@ int launch_modal_project(const ProjectEvent *events, int n_events, const double 
                          int m_pad, hipStream_t stream);
 int launch_scatter_rows(const double *src, const int *dst_slot, int n_rows, double *slots,
                         int m_pad, hipStream_t stream);
-// slot_idx >= 0: a row of the slot pool; < 0: event -(idx + 1) of `direct`, projected on the fly
+// slot_idx >= 0: a row of the slot pool; < 0: event -(idx + 1) of `direct`, projected on the fly (and left in the pool when the
+// event names a slot); an index past n_events: row (index - n_events) of the staged explicit data, copied to stage_slot[row] as well
 int launch_force_combine(const int *row_ptr, const int *slot_idx, const int *row_obj, int n_rows,
-                         const double *slots, const double *c3, float *grows, const ProjectEvent *direct,
+                         double *slots, const double *c3, float *grows, const ProjectEvent *direct,
                          const double *shapes, const long long *shape_off, const int *n_modes, int m_pad,
-                         hipStream_t stream);
+                         int n_events, const double *stage, const int *stage_slot, hipStream_t stream);
 
 // ---- K2: force time profiles on the device (forces.h:81-137)
 struct ArState {         // AutoregressiveForce members that evolve (forces.h:62-72), one per live AR force
@@ -253,7 +254,7 @@ struct ArFin { uint32_t x; int32_t saved_available; double saved; };      // per
 int launch_force_rows(const ProfRow *rows, int n_rows, const ProfEntry *entries, const ArUse *uses, int n_uses,
                       const ArStream *streams, const int *seg_stream, int n_segs, int max_segs_per_stream, ArState *states,
                       ArState *snaps, double *vnorm, uint32_t *vstate, int *seg_count, double *cbuf, ArRec *recs, ArFin *fins,
-                      float *tprof, int frames, int b_pad, int c_pitch, hipStream_t stream);
+                      float *tprof, int frames, int b_pad, int c_pitch, bool fused, hipStream_t stream);      // fused: every stream has ONE use -> one launch
 
 struct FfatGeom {        // FFAT_Map<double,3> runtime fields, one per (object, mode)
     double k;

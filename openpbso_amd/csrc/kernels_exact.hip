@@ -102,12 +102,16 @@ int launch_scatter_rows(const double *src, const int *dst_slot, int n_rows, doub
 // (setZero then += , modal_solver.h:209,218), then g = (float)(c3 * S).
 // A negative slot index -(e + 1) stands for projection event e evaluated here (the hit of a PointForce lives
 // for one buffer: writing its row to the pool only to read it back once costs a kernel and 170 MB of traffic).
+// Round 6 (launches of ONE buffer: every slot filled now is read by exactly one row): the entries -(e + 1) with e >= n_events stand for
+// row e - n_events of the staged explicit data, and an event with slot >= 0 is a projection whose vector outlives the buffer -- the
+// row takes the value AND leaves it in the slot pool, which is what scatter_rows_kernel / modal_project_kernel did in launches of
+// their own in front of this one (two hand-overs of ~7 us in the real-time step).  Same values, same order of additions.
 __global__ __launch_bounds__(256) void force_combine_kernel(
     const int *__restrict__ row_ptr, const int *__restrict__ slot_idx,
     const int *__restrict__ row_obj, const double *__restrict__ slots,
     const double *__restrict__ c3, float *__restrict__ grows, const ProjectEvent *__restrict__ direct,
     const double *__restrict__ shapes, const long long *__restrict__ shape_off, const int *__restrict__ n_modes,
-    int m_pad) {
+    int m_pad, int n_events, const double *__restrict__ stage, const int *__restrict__ stage_slot, double *slots_w) {
     prep_prio();
     const RowTile rt = row_tile(m_pad);
     const int row = (int)rt.row;
@@ -119,23 +123,30 @@ __global__ __launch_bounds__(256) void force_combine_kernel(
         const int si = slot_idx[j];
         if (si >= 0) {
             S += slots[(size_t)si * m_pad + m];
-        } else {
+        } else if (-si - 1 < n_events) {
             const ProjectEvent ev = direct[-si - 1];
-            S += m < n_modes[obj] ? project_one(ev, shapes + shape_off[obj], m_pad, m) : 0.0;
+            const double v = m < n_modes[obj] ? project_one(ev, shapes + shape_off[obj], m_pad, m) : 0.0;
+            if (ev.slot >= 0) slots_w[(size_t)ev.slot * m_pad + m] = v;
+            S += v;
+        } else {
+            const int r = -si - 1 - n_events;
+            const double v = stage[(size_t)r * m_pad + m];
+            slots_w[(size_t)stage_slot[r] * m_pad + m] = v;
+            S += v;
         }
     }
     grows[(size_t)row * m_pad + m] = (float)(c3[(size_t)obj * m_pad + m] * S);
 }
 
 int launch_force_combine(const int *row_ptr, const int *slot_idx, const int *row_obj, int n_rows,
-                         const double *slots, const double *c3, float *grows, const ProjectEvent *direct,
+                         double *slots, const double *c3, float *grows, const ProjectEvent *direct,
                          const double *shapes, const long long *shape_off, const int *n_modes, int m_pad,
-                         hipStream_t stream) {
+                         int n_events, const double *stage, const int *stage_slot, hipStream_t stream) {
     if (n_rows <= 0) return 0;
     dim3 grid;
     if (!flat_grid(m_pad, n_rows, &grid)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(force_combine_kernel, grid, dim3(256), 0, stream, row_ptr, slot_idx, row_obj,
-                       slots, c3, grows, direct, shapes, shape_off, n_modes, m_pad);
+                       static_cast<const double *>(slots), c3, grows, direct, shapes, shape_off, n_modes, m_pad, n_events, stage, stage_slot, slots);
     return (int)hipGetLastError();
 }
 
@@ -572,13 +583,12 @@ __device__ __forceinline__ void ar_defaults(ArState &s) {          // forces.h:7
     s.a[0] = 0.783; s.a[1] = 0.116; s.sigma = 0.00148; s.mu = 0.142;
 }
 
-__global__ __launch_bounds__(K2_THREADS) void ar_variates_kernel(
-    const int *__restrict__ seg_stream, const ArStream *__restrict__ streams, const ArState *__restrict__ states,
+// (bodies as device functions: the three kernels of the row-parallel form call them with their block index, and the fused kernel of
+//  single-use launches -- force_rows_fused_kernel, round 6 -- calls them one after the other from the workgroup of a row)
+__device__ __forceinline__ void ar_variates_body(
+    int seg, int si, uint32_t (*cnt)[K2_THREADS / 64], const ArStream *__restrict__ streams, const ArState *__restrict__ states,
     ArState *__restrict__ snaps, double *__restrict__ vnorm, uint32_t *__restrict__ vstate, int *__restrict__ seg_count) {
-    prep_prio();
-    __shared__ uint32_t cnt[2][K2_THREADS / 64];
-    const int seg = blockIdx.x, lane = threadIdx.x;
-    const int si = seg_stream[seg];
+    const int lane = threadIdx.x;
     const ArStream S = streams[si];
     const int k = seg - S.seg_base;
     if (k == 0 && lane == 0) {                     // the force as this launch finds it (read by the two kernels that follow)
@@ -605,6 +615,14 @@ __global__ __launch_bounds__(K2_THREADS) void ar_variates_kernel(
         xb = mulmod31(xb, q);
     }
     if (lane == 0) seg_count[seg] = acc;
+}
+
+__global__ __launch_bounds__(K2_THREADS) void ar_variates_kernel(
+    const int *__restrict__ seg_stream, const ArStream *__restrict__ streams, const ArState *__restrict__ states,
+    ArState *__restrict__ snaps, double *__restrict__ vnorm, uint32_t *__restrict__ vstate, int *__restrict__ seg_count) {
+    prep_prio();
+    __shared__ uint32_t cnt[2][K2_THREADS / 64];
+    ar_variates_body((int)blockIdx.x, seg_stream[blockIdx.x], cnt, streams, states, snaps, vnorm, vstate, seg_count);
 }
 
 // x_k = a0 x_{k-1} + a1 x_{k-2} + c_k over nrm[0 .. frames) in place, history (h1, h2) = (x_{-1}, x_{-2}): ONE wave, the scan
@@ -668,19 +686,16 @@ __device__ __forceinline__ void ar_params(const ArUse &U, const ProfEntry *__res
 
 // one workgroup per AR use: c_k = sigma n_k into cbuf, the state the use reaches from rest and M = A^frames into recs;
 // the last use of a stream also says where the engine stands after the launch (fins)
-__global__ __launch_bounds__(K2_THREADS) void ar_zero_state_kernel(
+__device__ __forceinline__ void ar_zero_state_body(
+    int use, double *k2_lds, uint32_t (*cnt)[K2_THREADS / 64], int &carry,
     const ArUse *__restrict__ uses, const ArStream *__restrict__ streams, const ProfEntry *__restrict__ entries,
     const ArState *__restrict__ snaps, const double *__restrict__ vnorm, const uint32_t *__restrict__ vstate,
     const int *__restrict__ seg_count, double *__restrict__ cbuf, ArRec *__restrict__ recs, ArFin *__restrict__ fins,
     int frames, int c_pitch) {
-    prep_prio();
-    extern __shared__ __attribute__((aligned(16))) double k2_lds[];
-    __shared__ uint32_t cnt[2][K2_THREADS / 64];
-    __shared__ int carry;
     double *nrm = k2_lds;
     int *pre = reinterpret_cast<int *>(k2_lds + frames);        // [n_seg + 1] accepted pairs before segment i
     const int lane = threadIdx.x, wv = lane >> 6, l64 = lane & 63;
-    const ArUse U = uses[blockIdx.x];
+    const ArUse U = uses[use];
     const ArStream S = streams[U.stream];
     const ArState snap = snaps[U.stream];
     double a0, a1, sigma, mu;
@@ -795,18 +810,29 @@ __global__ __launch_bounds__(K2_THREADS) void ar_zero_state_kernel(
     }
 }
 
+__global__ __launch_bounds__(K2_THREADS) void ar_zero_state_kernel(
+    const ArUse *__restrict__ uses, const ArStream *__restrict__ streams, const ProfEntry *__restrict__ entries,
+    const ArState *__restrict__ snaps, const double *__restrict__ vnorm, const uint32_t *__restrict__ vstate,
+    const int *__restrict__ seg_count, double *__restrict__ cbuf, ArRec *__restrict__ recs, ArFin *__restrict__ fins,
+    int frames, int c_pitch) {
+    prep_prio();
+    extern __shared__ __attribute__((aligned(16))) double k2_lds[];
+    __shared__ uint32_t cnt[2][K2_THREADS / 64];
+    __shared__ int carry;
+    ar_zero_state_body((int)blockIdx.x, k2_lds, cnt, carry, uses, streams, entries, snaps, vnorm, vstate, seg_count, cbuf, recs, fins, frames, c_pitch);
+}
+
 // one workgroup per profile row: Force::Add of every live force of the (object, buffer) in list order (forces.h:81-128)
-__global__ __launch_bounds__(K2_THREADS) void force_rows_kernel(
+__device__ __forceinline__ void force_rows_body(
+    int row_index, double *k2_lds,
     const ProfRow *__restrict__ rows, const ProfEntry *__restrict__ entries, const ArUse *__restrict__ uses,
     const ArStream *__restrict__ streams, const ArState *__restrict__ snaps, const ArRec *__restrict__ recs,
     const ArFin *__restrict__ fins, const double *__restrict__ cbuf, ArState *__restrict__ states, float *__restrict__ tprof,
     int frames, int b_pad, int c_pitch) {
-    prep_prio();
-    extern __shared__ __attribute__((aligned(16))) double k2_lds[];
     double *nrm = k2_lds;
     double *acc = k2_lds + frames;
     const int lane = threadIdx.x, wv = lane >> 6, l64 = lane & 63;
-    const ProfRow row = rows[blockIdx.x];
+    const ProfRow row = rows[row_index];
     float *out = tprof + (size_t)row.prow * b_pad;
     for (int i = lane; i < frames; i += K2_THREADS) acc[i] = 0.0;                  // setZero, modal_solver.h:206
     __syncthreads();
@@ -867,11 +893,61 @@ __global__ __launch_bounds__(K2_THREADS) void force_rows_kernel(
     for (int i = lane; i < b_pad; i += K2_THREADS) out[i] = i < frames ? (float)acc[i] : 0.f;
 }
 
+__global__ __launch_bounds__(K2_THREADS) void force_rows_kernel(
+    const ProfRow *__restrict__ rows, const ProfEntry *__restrict__ entries, const ArUse *__restrict__ uses,
+    const ArStream *__restrict__ streams, const ArState *__restrict__ snaps, const ArRec *__restrict__ recs,
+    const ArFin *__restrict__ fins, const double *__restrict__ cbuf, ArState *__restrict__ states, float *__restrict__ tprof,
+    int frames, int b_pad, int c_pitch) {
+    prep_prio();
+    extern __shared__ __attribute__((aligned(16))) double k2_lds[];
+    force_rows_body((int)blockIdx.x, k2_lds, rows, entries, uses, streams, snaps, recs, fins, cbuf, states, tprof, frames, b_pad, c_pitch);
+}
+
+// Round 6: the three kernels above as ONE launch, for launches in which every AutoregressiveForce adds its samples ONCE (one use per
+// stream: every launch of one buffer -- the real-time facade's step, tools/real_time_modal_sound.cpp:527-536 with a sustained contact
+// on, :1127-1160).  Nothing then crosses from one profile row to another: the workgroup of a row evaluates the candidate segments of
+// each of its AR forces, their zero-state uses, and then the row, through the same global scratch arrays and with the same bodies --
+// bit-identical profiles, two launch hand-overs less (~7 us each in a chain of dependent launches, profiles/r04_stream_sync.txt).
+__global__ __launch_bounds__(K2_THREADS) void force_rows_fused_kernel(
+    const ProfRow *__restrict__ rows, const ProfEntry *__restrict__ entries, const ArUse *__restrict__ uses,
+    const ArStream *__restrict__ streams, ArState *__restrict__ states, ArState *__restrict__ snaps, double *__restrict__ vnorm,
+    uint32_t *__restrict__ vstate, int *__restrict__ seg_count, double *__restrict__ cbuf, ArRec *__restrict__ recs,
+    ArFin *__restrict__ fins, float *__restrict__ tprof, int frames, int b_pad, int c_pitch) {
+    prep_prio();
+    extern __shared__ __attribute__((aligned(16))) double k2_lds[];
+    __shared__ uint32_t cnt[2][K2_THREADS / 64];
+    __shared__ int carry;
+    const ProfRow row = rows[blockIdx.x];
+    for (int ei = row.entry_begin; ei < row.entry_end; ++ei) {
+        const ProfEntry e = entries[ei];
+        if (e.kind < 2) continue;                                          // (Point / Gaussian: nothing to prepare)
+        const int use = e.count;
+        const int si = uses[use].stream;
+        const ArStream S = streams[si];
+        for (int k = 0; k < S.n_seg; ++k) {
+            ar_variates_body(S.seg_base + k, si, cnt, streams, states, snaps, vnorm, vstate, seg_count);
+            __syncthreads();                                               // (cnt is reused by the next segment)
+        }
+        __threadfence();                                                   // snaps, variates and counts: written by some threads, read by all
+        __syncthreads();
+        ar_zero_state_body(use, k2_lds, cnt, carry, uses, streams, entries, snaps, vnorm, vstate, seg_count, cbuf, recs, fins, frames, c_pitch);
+        __threadfence();
+        __syncthreads();
+    }
+    force_rows_body((int)blockIdx.x, k2_lds, rows, entries, uses, streams, snaps, recs, fins, cbuf, states, tprof, frames, b_pad, c_pitch);
+}
+
 int launch_force_rows(const ProfRow *rows, int n_rows, const ProfEntry *entries, const ArUse *uses, int n_uses,
                       const ArStream *streams, const int *seg_stream, int n_segs, int max_segs_per_stream, ArState *states,
                       ArState *snaps, double *vnorm, uint32_t *vstate, int *seg_count, double *cbuf, ArRec *recs, ArFin *fins,
-                      float *tprof, int frames, int b_pad, int c_pitch, hipStream_t stream) {
+                      float *tprof, int frames, int b_pad, int c_pitch, bool fused, hipStream_t stream) {
     if (n_rows <= 0) return 0;
+    if (fused && n_uses > 0) {
+        const size_t lds = std::max(sizeof(double) * (size_t)frames + sizeof(int) * ((size_t)max_segs_per_stream + 2), sizeof(double) * 2 * (size_t)frames);
+        hipLaunchKernelGGL(force_rows_fused_kernel, dim3(n_rows), dim3(K2_THREADS), lds, stream, rows, entries, uses, streams, states, snaps,
+                           vnorm, vstate, seg_count, cbuf, recs, fins, tprof, frames, b_pad, c_pitch);
+        return (int)hipGetLastError();
+    }
     if (n_segs > 0)
         hipLaunchKernelGGL(ar_variates_kernel, dim3(n_segs), dim3(K2_THREADS), 0, stream, seg_stream, streams, states, snaps, vnorm,
                            vstate, seg_count);

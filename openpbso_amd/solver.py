@@ -133,7 +133,7 @@ def _select_from_env():
 SELECT_FIELDS = ("bank_kernel", "time_chunks", "direct_hits", "forced_block", "dense_launches", "device_profiles",
                  "profile_kernel", "profile_margin_pct", "profile_priority", "team_waves", "pipe_consumers",
                  "pipe_max_teams", "chunk_buffers", "plan_threads", "plan_pin", "timing_every", "warm_copies", "stream_sync", "latency_path",
-                 "time_chunk_shape", "scan_kernel")
+                 "time_chunk_shape", "scan_kernel", "fuse_short_launches")
 
 
 def fill_engine_desc(d, device, form, qnorm, modes_per_lane, stream, frames_per_buffer, select):
@@ -335,6 +335,23 @@ class Engine:
         # (only a script the engine TOOK is held here: a refused call -- a script already pending, bad ids -- leaves the
         #  arrays of the pending one, which the engine still points at, alive)
         self._borrowed = (o, v, n, t)
+        return rc
+
+    @staticmethod
+    def prepare_vertex_hits(objs, vids, vns, not_before):
+        """the arguments of enqueue_vertex_hits converted once (a caller that replays pre-built scripts step after step: the
+        conversions cost more than the call for a small step); hand the result to enqueue_prepared_vertex_hits"""
+        o = np.ascontiguousarray(objs, dtype=np.int32)
+        v = np.ascontiguousarray(vids, dtype=np.int32)
+        n = np.ascontiguousarray(vns, dtype=np.float64).reshape(-1, 3)
+        t = np.ascontiguousarray(not_before, dtype=np.int64)
+        assert o.size == v.size == t.size == n.shape[0]
+        return (o.size, o.ctypes.data_as(C.POINTER(C.c_int)), v.ctypes.data_as(C.POINTER(C.c_int)), _dp(n),
+                t.ctypes.data_as(C.POINTER(C.c_int64)), (o, v, n, t))
+
+    def enqueue_prepared_vertex_hits(self, prepared):
+        rc = self._chk(self._l.pbso_enqueue_vertex_hits(self._h, *prepared[:5]))
+        self._borrowed = prepared[5]
         return rc
 
     def enqueue_arprm(self, obj, a, sigma, mu, not_before=0):

@@ -1131,6 +1131,55 @@ def test_row_parallel_profiles_equal_the_chain_kernel(margin, monkeypatch):
     assert (np.abs(whole["audio"] - chain["audio"]) <= 2e-7 * peak).all()
 
 
+def test_one_buffer_steps_fused_launches_are_bit_identical():
+    """round 6 (pbso_engine_desc::fuse_short_launches): a launch of ONE buffer -- the real-time facade's step -- evaluates the AR
+    forces' variates, zero-state uses and profile rows in one kernel, and its combine kernel takes the explicit data rows and the
+    projections that outlive the buffer itself: three kernels per sustained-contact buffer instead of seven.  Same values in the same
+    order: audio, qnorm rows and state equal the separate launches BIT FOR BIT, step by step -- sustained scraping fed by explicit
+    data, by face hits and by vertex hits, AR parameter updates, a second plain AR force and a Gaussian overlapping (two forces in one
+    row), a force whose profile row is skipped, plain impulses -- and both match the oracle"""
+    n_modes, nb = 96, 26
+    objs = [ObjSpec(synth.eigenvalues(n_modes, 800 + i), shapes=synth.mode_shapes(n_modes, 800 + i)) for i in range(4)]
+    rng = np.random.default_rng(800)
+    vns = synth.unit_normals(nb, 8)
+    evs = []
+    for i in range(4):
+        evs.append(dict(t=0, obj=i, kind="use_transfer", use=False))
+    # object 0: sustained contact, explicit data every buffer (the facade: GetModalForceVertex on the host)
+    evs.append(force_ev(0, 0, data=rng.standard_normal(n_modes) * 1e-3, force_type=2, start=True))
+    for b in range(1, nb - 4):
+        evs.append(force_ev(b, 0, data=rng.standard_normal(n_modes) * 1e-3, force_type=2))
+    evs.append(dict(t=6, obj=0, kind="arprm", a=[0.5, 0.3], sigma=0.004, mu=0.2))
+    evs.append(force_ev(nb - 4, 0, force_type=2, end=True))
+    # object 1: sustained contact from a dummy start message (data = 0: its row is left out), then face hits projected on the device
+    evs.append(force_ev(0, 1, force_type=2, start=True))
+    for b in range(2, nb - 2):
+        bary = rng.random(3)
+        evs.append(force_ev(b, 1, vids=rng.integers(0, synth.N_VERTS, 3), coords=bary / bary.sum(), vn=vns[b], force_type=2))
+    evs.append(dict(t=9, obj=1, kind="arprm", a=[0.9, -0.2], sigma=0.001, mu=0.1))
+    # object 2: a Gaussian and a plain AR force alive together, then vertex hits (impulses)
+    evs.append(force_ev(3, 2, data=rng.standard_normal(n_modes) * 1e-3, force_type=1, width=1500.0))
+    evs.append(force_ev(4, 2, vid=5, vn=vns[4], force_type=2))
+    evs.append(force_ev(5, 2, vid=7, vn=vns[5], force_type=1, width=900.0))
+    for b in (9, 10, 15):
+        evs.append(force_ev(b, 2, vid=int(rng.integers(0, synth.N_VERTS)), vn=vns[b]))
+    # object 3: impulses only, one clearAllForces
+    for b in (0, 2, 3, 11):
+        evs.append(force_ev(b, 3, data=rng.standard_normal(n_modes) * 1e-3))
+    evs.append(force_ev(12, 3, clear=True))
+    split = [1] * nb
+    fused = run_engine(objs, evs, nb, split=split)
+    apart = run_engine(objs, evs, nb, split=split, fuse_short_launches=-1)
+    assert np.array_equal(fused["audio"], apart["audio"]) and np.array_equal(fused["emitted"], apart["emitted"])
+    for key in apart["qnorm"]:
+        assert np.array_equal(fused["qnorm"][key], apart["qnorm"][key]), key
+    for i in range(4):
+        for a, b in zip(fused["state"][i], apart["state"][i]):
+            assert np.array_equal(a, b), i
+    want = run_oracle(objs, evs, nb)
+    _check(fused, want)
+
+
 @pytest.mark.parametrize("mpl", [1, 2, 4])
 @pytest.mark.parametrize("qnorm", [capi.QNORM_ALL, capi.QNORM_OFF])
 def test_block_kernel_forced_path_every_buffer_kind(qnorm, mpl, monkeypatch):
@@ -1219,3 +1268,63 @@ def test_listener_path_call_equals_call_by_call():
     assert np.array_equal(a_audio, b_audio) and np.abs(a_audio[:2]).max() > 0
     for x, y in zip(a_latest, b_latest):
         assert np.array_equal(x, y)
+
+
+def test_listener_path_kept_as_an_array_over_several_steps():
+    """round 6: a path given object by object with ascending stamps stays an array with a cursor (Engine::consume_path) -- over
+    several steps, beside a script of vertex hits on the same objects (both become descriptor edits of a quiet object), with a
+    setUseTransfer / a single computeTransfer / an AR-parameter call arriving in between (each moves the rest of that object's path
+    into the pending list first), overdue positions (the first fires, the others find the queue full) -- against the same calls
+    one by one: audio, latest transfer rows, bit for bit"""
+    from openpbso_amd import Engine
+    n_obj, n_modes, steps = 5, 96, [6, 5, 7]
+    total = sum(steps)
+    lams = [synth.eigenvalues(n_modes, 60 + i) for i in range(n_obj)]
+    shapes = [synth.mode_shapes(n_modes, 60 + i) for i in range(n_obj)]
+    maps = [synth.ffat_maps(lams[i], 60 + i, dim=4, cell_size=0.01) for i in range(n_obj)]
+    rng = np.random.default_rng(8)
+    dirs = rng.standard_normal((n_obj, total, 3))
+    pos = 0.5 * dirs / np.linalg.norm(dirs, axis=2, keepdims=True)
+    hit_b = {i: sorted(rng.choice(total, 5, replace=False).tolist()) for i in range(n_obj)}
+    vns = synth.unit_normals(total, 4)
+
+    def run(batch):
+        with Engine() as eng:
+            for i in range(n_obj):
+                eng.add_object(lams[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
+                eng.set_ffat_maps(i, maps[i])
+            eng.finalize()
+            for i in range(n_obj):
+                # object 3: its path starts two buffers late with three positions stamped 0 (overdue at the first step that sees them)
+                st = np.arange(total, dtype=np.int64) if i != 3 else np.concatenate([[0, 0, 0], np.arange(3, total)]).astype(np.int64)
+                if i == 3:
+                    eng.step(2)
+                if batch:
+                    assert eng.compute_transfer_path(np.full(total, i, dtype=np.int32), pos[i], st).all() or i == 3
+                else:
+                    for p_, t_ in zip(pos[i], st):
+                        eng.compute_transfer(i, p_, int(t_))
+            done = 2
+            audio, latest = [], []
+            for k, nb in enumerate(steps):
+                fo = np.concatenate([np.full(len([b for b in hit_b[i] if done <= b < done + nb]), i, dtype=np.int32) for i in range(n_obj)])
+                ft = np.concatenate([np.array([b for b in hit_b[i] if done <= b < done + nb], dtype=np.int64) for i in range(n_obj)])
+                if fo.size:
+                    eng.enqueue_vertex_hits(fo, (ft % synth.N_VERTS).astype(np.int32), vns[ft], ft)
+                if k == 1:
+                    eng.set_use_transfer(1, False, done + 2)             # object 1: its path's rest goes through the pending list
+                    eng.compute_transfer(2, pos[2][0], done + 1)         # object 2: a single call in front of the path's later positions
+                    eng.enqueue_arprm(4, [0.7, 0.1], 0.002, 0.1, done)   # object 4: a parameter message (no AR force: it waits)
+                eng.step(nb)
+                audio.append(eng.audio().copy())
+                latest.append([eng.latest_transfer(i).copy() for i in range(n_obj)])
+                done += nb
+            return audio, latest
+
+    a_audio, a_latest = run(True)
+    b_audio, b_latest = run(False)
+    for k in range(len(steps)):
+        assert np.array_equal(a_audio[k], b_audio[k]), k
+        for x, y in zip(a_latest[k], b_latest[k]):
+            assert np.array_equal(x, y), k
+    assert np.abs(a_audio[-1]).max() > 0

@@ -193,6 +193,36 @@ def test_one_rank_group_runs_every_rccl_call_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_one_rank_gathers_at_the_headline_size():
+    """the gathers at the size the headline line steps -- 1024 objects x 860 buffers x 513 floats = 1.8 GB per
+    target -- on a one-rank communicator (PBSO_GROUP_RCCL_ALWAYS): the in-place ncclAllGather of the whole target, and the
+    gather-to-root whose ncclSend / ncclRecv pair to itself goes in pieces of 256 MB (one piece of 1.8 GB came back wrong on RCCL
+    2.26.6, group.cpp: P2P_MAX).  pbso_group_read_result against pbso_read_audio of the rank's engine, bit for bit.  (What a
+    one-GPU box can show: the calls, their sizes and the events around them; nothing crosses a link.)"""
+    from openpbso_amd import ForceMessage
+    from openpbso_amd.group import Group
+    n_obj, M, nb = 1024, 512, 860
+    rng = np.random.default_rng(3)
+    with Group([0], transport=capi.GROUP_RCCL_ALWAYS) as grp:
+        grp.plan([M] * n_obj)
+        for i in range(n_obj):
+            grp.add_object(i, synth.eigenvalues(M, 3000 + i), synth.RHO, synth.ALPHA, synth.BETA)
+        grp.finalize()
+        eng = grp.engine(0)
+        for i in range(n_obj):
+            eng.set_use_transfer(i, False)
+            for t in (0, 400, 859):
+                assert grp.enqueue_force(i, ForceMessage(data=rng.standard_normal(M) * 1e-3), t)
+        grp.step(nb)
+        want = eng.audio().copy()
+        assert want.shape == (n_obj, nb * 513) and np.isfinite(want).all() and np.abs(want[-1, -513:]).max() > 0
+        grp.gather(capi.GATHER_ALL)
+        assert np.array_equal(grp.result(0), want)
+        grp.gather(capi.GATHER_ROOT)
+        assert np.array_equal(grp.result(0), want)              # (the rows that came back through eight ncclRecv pieces)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world,modes", [(2, [4096, 64, 64, 64]), (3, [300] * 7), (8, [512] * 19 + [64] * 5), (3, [128, 128]), (4, [64] * 4)])
 def test_loopback_ranks_on_one_device_equal_the_single_engine(world, modes):
     """PBSO_GROUP_LOOPBACK: the job's ranks as engines of ONE process on ONE device, the collectives as device copies -- everything
