@@ -2061,6 +2061,10 @@ bool Engine::choose_time_chunks(int nb, int n_dense_rows, int *set, int *cb) con
         // more than their 1.07 / 1.5 / 2 rounds) -- and the shorter the workgroups, the cheaper that tail: such scenes are cut in
         // time too (1.22 / 1.66 / 2.21 ms).  A scene that fills the chip exactly (1024 x 512: one round) is not.
         const bool over_full = waves > capacity;
+        // (round 6, ADVICE r05: a mostly-dense scene that fills the chip anyway gains nothing from the cut -- its increments are
+        //  evaluated twice, for the scan and in the bank: 1024 x 512 sustained scraping 7.90 ms per second of audio cut in time against
+        //  7.37 for the walk, profiles/r06_bench_c4scr_*.json -- so the cut is for dense scenes that leave wave slots free)
+        if (dense_majority && waves >= capacity) return false;
         if (over_full && !dense_majority) {
             // measured, in rounds of the exactly-full chip (scripts/debug/r04_tcrounds.py): the walk of 1100 / 1536 / 2048 / 3000
             // objects x 512 modes takes 1.57 / 1.90 / 2.54 / 3.07 -- whole rounds + a last, partly filled one that runs faster the
