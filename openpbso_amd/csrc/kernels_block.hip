@@ -738,6 +738,9 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                     wave_sync();
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef PBSO_MB_PRIO
+                __builtin_amdgcn_s_setprio(PBSO_MB_PRIO);          // (A/B: the matrix burst above / below the partner's vector instructions)
+#endif
                 static_for<0, 32>([&](auto sc) {
                     constexpr int s = decltype(sc)::value;
                     if constexpr (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg4[r][s >> 2][s & 3], bq[s >> 2][s & 3], acc1, 0, 0, 0);
@@ -747,13 +750,23 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
                     // behind the burst's last MFMA (kernel 9.03 ms per 860 buffers against 8.83: scripts/debug/r06_ablate.sh)
                     if constexpr (PBSO_REFILL == 0 && more && (s & 3) == 3 && s >= 7) bq[(s >> 2) - 1] = bsrc[(s >> 2) - 1];
                     if constexpr (PBSO_REFILL == 2 && more && (s & 3) == 3) bq[s >> 2] = bsrc[s >> 2];
+                    if constexpr (PBSO_REFILL == 3 && more && (s & 7) == 7 && s >= 15) {      // (two reads behind every eighth MFMA)
+                        bq[(s >> 2) - 3] = bsrc[(s >> 2) - 3];
+                        bq[(s >> 2) - 2] = bsrc[(s >> 2) - 2];
+                    }
                     // last slice: nothing to refill -- half way through the burst the first operand registers are free and the
                     // next buffer's inputs land in them
                     if constexpr (!more && s == 15) prefetch(next, false);
+#ifndef PBSO_NO_MB_SCHED_BARRIER
                     __builtin_amdgcn_sched_barrier(0);
+#endif
                 });
+#ifdef PBSO_MB_PRIO
+                __builtin_amdgcn_s_setprio(PBSO_MB_PRIO_VB);
+#endif
                 if constexpr (more) {
                     if constexpr (PBSO_REFILL == 0) bq[7] = bsrc[7];
+                    else if constexpr (PBSO_REFILL == 3) { bq[6] = bsrc[6]; bq[7] = bsrc[7]; }
                     else if constexpr (PBSO_REFILL == 1) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) bq[i] = bsrc[i];
