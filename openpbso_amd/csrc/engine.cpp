@@ -2545,6 +2545,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     if (tc_launch) {
         TcSet &ts = tc_[tc_set];
         kp.tc_cb = tc_cb;
+        if (const char *v = std::getenv("PBSO_TC_LDS_PAD")) kp.lds_pad = std::atoi(v);      // (diagnostics: scripts/debug/r06_c5_occupancy.sh)
         kp.tc_xs = d_xs_[cur_set_].p;
         kp.tc_xtrow = d_xtrow_[cur_set_].p;
         kp.census_stride = ts.n_teams;

@@ -113,6 +113,7 @@ struct IirParams {
     // time-chunked launch of the block form (kernels_scan.hip): tc_cb > 0 buffers per chunk, grid (team, chunk); the states at
     // the chunks' first buffers [n_obj][n_chunks][m_pad] pairs (q, d), unscaled, and the transfer rows in force there
     int tc_cb = 0;
+    int lds_pad = 0;             // diagnostics (PBSO_TC_LDS_PAD): extra dynamic LDS per workgroup of a time-chunked block launch -- fewer teams per CU
     const float *tc_xs = nullptr;
     const int *tc_xtrow = nullptr;
     int census_stride = 0;       // census rows per chunk (= the launch's teams, all size classes)

@@ -30,10 +30,15 @@
 // in block buffers (the per-sample state never exists here), per-sample accumulation in literal ones.
 //
 // Layout.  Team / column mapping as K1: workgroup = W waves, lane owns R modes, slice r at column
-// col0 + r * 64 W + tid.  MFMA k-step = two adjacent columns (pair): lane l holds
-//   A[j = l & 15][k = l >> 4]   = W-table entry: k = 2 * (mode of the pair) + (0: a_{j+1}, 1: b_{j+1})
-//   B[k = l >> 4][n = l & 15]   = state component k of block n, read back from the LDS staging area
+// col0 + r * 64 W + tid.  An MFMA contracts four (mode, component) values; lane l holds
+//   A[j = l & 15][k = l >> 4]   = W-table entry (a_{j+1} or b_{j+1} of one mode)
+//   B[k = l >> 4][n = l & 15]   = one state component of block n, read back from the LDS staging area
 //   D[i = 4 (l >> 4) + v][n]    = output sample 16 n + i of the group, v = 0..3
+// Which four: in the W table as the host lays it out (and in the split-bf16 projection, kernels_pipe.hip, the listener mix) an MFMA
+// takes a PAIR of adjacent columns, k = 2 * (mode of the pair) + component.  The f32 pipeline of this file (round 6) takes ONE
+// component of four modes a quarter of the wave apart -- MFMA 4 i + jj of a slice: component jj & 1 of the modes 16 k + 2 i + (jj >> 1)
+// -- so that a lane's 32 B operands of a slice are 128 contiguous bytes of the staging image (ST_PAIR below) and come in with eight
+// ds_read_b128; the W table is read through that permutation once per launch.
 #include <type_traits>
 
 #include "kernels.h"
@@ -220,7 +225,11 @@ __global__ __launch_bounds__(MAXT) void iir_block_kernel(
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
+#ifdef PBSO_ABL_W_COALESCED        // (ablation, wrong results: what the permuted read of the table costs a time-chunked launch's preamble)
+                for (int jj = 0; jj < 4; ++jj) wreg4[r][i][jj] = wsrc[(4 * i + jj) * 64 + lane];
+#else
                 for (int jj = 0; jj < 4; ++jj) wreg4[r][i][jj] = wsrc[(8 * (lane >> 4) + i) * 64 + 16 * jj + (lane & 15)];
+#endif
         } else {
             const unsigned *__restrict__ wu = reinterpret_cast<const unsigned *>(wsrc);
 #pragma unroll
@@ -1287,7 +1296,7 @@ static int launch_one(const IirParams &p, int n_teams, int W, hipStream_t stream
         if (p.tc_cb > 0) return launch_one<R, QNM, PROJ, DUMP, FORCED, true>(p, n_teams, W, stream);
     }
     if (!CHUNKED && p.tc_cb > 0) return (int)hipErrorInvalidValue;       // (no chunked build of this shape: the engine never asks)
-    const size_t lds = block_lds_bytes(W, R);
+    const size_t lds = block_lds_bytes(W, R) + (CHUNKED ? (size_t)p.lds_pad : 0);
     constexpr int MAXT = 64 * MAX_WAVES_PER_BLOCK_TEAM;
     if (64 * W > MAXT) return (int)hipErrorInvalidValue;
     auto kern = iir_block_kernel<R, QNM, PROJ, DUMP, MAXT, FORCED, CHUNKED>;
