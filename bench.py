@@ -110,6 +110,11 @@ def parse(argv=None):
                     help="getQBufferNorm rows: on (the block form evaluates them in closed form), closed form, or off")
     ap.add_argument("--no-qnorm", action="store_true", help="same as --qnorm off")
     ap.add_argument("--modes-per-lane", type=int, default=0)
+    ap.add_argument("--submit-thread", type=int, default=-1, choices=[-1, 0, 1],
+                    help="1: the engine's second submitting thread (pbso_engine_desc::submit_thread): pbso_step records its stream calls and "
+                         "returns, a worker makes them while the caller plans the next launch (legs without the device group only).  "
+                         "-1 (default): on for steps of fewer than 256 buffers -- where planning + submitting a launch is comparable to the "
+                         "launch itself --, off for the long steps of the headline (nothing to gain: 8.91 against 8.90 ms)")
     ap.add_argument("--scenario", choices=["impulses", "scraping", "listener"], default="impulses",
                     help="impulses: Poisson PointForce hits (headline, configs[1]/[3]); scraping: sustained "
                          "AutoregressiveForce with one face hit per buffer (configs[4]); listener: impulses + FFAT maps "
@@ -143,6 +148,12 @@ def parse(argv=None):
     if args.plan_threads <= 0:
         args.plan_threads = 1 if args.buffers <= 128 else 4
     return args
+
+
+def submit_thread_of(args):
+    """--submit-thread for a leg of args.buffers buffers per step (-1: on for short steps)"""
+    st = int(getattr(args, "submit_thread", -1))
+    return st if st >= 0 else (1 if args.buffers < 256 else 0)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -463,7 +474,7 @@ def measure(args, ctx, global_ids, want_parity):
         eng = grp.engine(rank)
     else:
         eng = Engine(device=ctx["dev_index"], form=form_c, qnorm=qnorm_c, modes_per_lane=args.modes_per_lane, stream=stream,
-                     chunk_buffers=max(128, args.buffers))
+                     chunk_buffers=max(128, args.buffers), submit_thread=submit_thread_of(args))
         for i, gid in enumerate(global_ids):
             eng.add_object(lam[i], synth.RHO, synth.ALPHA, synth.BETA, mode_shapes=shapes[i])
     if args.scenario == "listener":
@@ -575,6 +586,8 @@ def measure(args, ctx, global_ids, want_parity):
 
     gather_mode = capi.GATHER_MIX if do_mix else (capi.GATHER_ROOT if do_root else capi.GATHER_ALL)
 
+    deferred = (not use_group) and submit_thread_of(args) > 0
+
     def one_step(k, capture=False):
         if use_group:
             n_calls[0] += 1
@@ -591,6 +604,8 @@ def measure(args, ctx, global_ids, want_parity):
             pending[slot] = None
         eng.step(nb, into=audios[slot].data_ptr())
         feed(k + 1)                                    # the next step's messages, while the device runs this one
+        if deferred and (capture or do_mix or do_root or do_gather):
+            eng.flush()                                # (torch work behind the step on the engine's stream: its launches first)
         if capture:
             captured[0] = audios[slot].index_select(0, rows_t)
         if do_mix:
@@ -619,6 +634,8 @@ def measure(args, ctx, global_ids, want_parity):
     def drain():
         if use_group:
             grp.sync()
+        elif deferred:
+            eng.flush()                                # (the synchronize that follows must see every launch in its stream)
         for i, w in enumerate(pending):
             if w is not None:
                 w.wait()
@@ -749,6 +766,7 @@ def measure(args, ctx, global_ids, want_parity):
             "pass": bool((mx <= TOL_MAX).all() and (l2 <= TOL_L2).all()),
         }
     res["_cpu_inputs"] = (lam, shapes, scripts)
+    res["device_group"] = bool(use_group)
     res["collective_by"] = ("pbso_group (C ABI: RCCL called from C++" + ("; ONE rank: the collectives are issued on a one-rank communicator, "
                             "nothing crosses a link)" if world == 1 else ")")) if use_group else (
         ("torch.distributed" + (" (pbso_group not used: %s)" % group_note if group_note else "")) if do_gather else None)
@@ -1047,6 +1065,7 @@ def main():
                 "recurrence_form": args.form, "gather": m["gather"], "group_ranks": rccl_ranks, "rccl_ranks": rccl_ranks if backend == "nccl" else None,
                 "backend": backend if use_dist else None,
                 "collective_by": m.get("collective_by"),
+                "submit_thread": 0 if m.get("device_group") else submit_thread_of(args),
                 "host_planner_threads": int(os.environ["PBSO_PLAN_THREADS"]), "host_cores": host_cores(), "parallelism": f"object-sharded x{world}",
                 "launched_by": "bench.py" if os.environ.get("PBSO_BENCH_SPAWNED") else ("torch.distributed.run" if use_dist else "single process"),
             },

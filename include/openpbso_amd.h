@@ -133,8 +133,9 @@ typedef struct pbso_engine_desc {
                                * hipStreamWaitValue64 -- a START GATE in front of the preparation kernels of launches of >= 256 buffers:
                                * they wait for a value the previous launch's bank kernel stores when it starts, so the preparation
                                * never runs two launches ahead (a long scan that does trails its bank and collides with the next
-                               * bank's start).  1 events only.  2 the hand-over to the bank through a value in signal memory too (half
-                               * the latency of an event, 1 % per step on small scenes).  3 the gate for every launch (costs 0.5 - 1.5 %
+                               * bank's start); since round 6 also the hand-over of launches of fewer than 256 buffers to the bank's stream
+                               * through a value in signal memory instead of an event (half the latency: 1.5 - 6 % per step of 86 buffers).
+                               * 1 events only.  2 the hand-over through a value for every launch.  3 the gate for every launch (costs 0.5 - 1.5 %
                                * per step of 86 buffers).  2 and 3 fail at creation where the device lacks the interface.  4 (round 5): the gate
                                * for every launch as a wait of the SUBMITTING thread on a word of pinned host memory the previous bank's first
                                * workgroup writes (hipStreamWaitValue64 runs as a waiting kernel on this stack); costs the host one launch of
@@ -160,6 +161,14 @@ typedef struct pbso_engine_desc {
                                * projections that outlive the buffer itself instead of a scatter and a projection launch in front of it:
                                * a sustained-contact buffer is three kernels (profiles, combine, oscillator bank) instead of seven.  The same
                                * values in the same order: bit-identical to the separate launches */
+    int submit_thread;        /* > 0: a second host thread makes the HIP calls of a launch (uploads, kernel launches, event records) while
+                               * pbso_step returns and the caller's thread plans the next one -- for scenes whose step is set by the HOST
+                               * (64 x 256 with a listener move per buffer: 0.045 ms of planning + 0.043 ms of calls against a 0.057 ms
+                               * bank).  What changes for the caller: when pbso_step returns, its launches are not necessarily in their
+                               * streams yet.  Every entry point that reads results or uses the engine's streams waits for that thread first;
+                               * a caller that puts work of its OWN on the engine's stream behind a step calls pbso_flush in between; an
+                               * error of a recorded call surfaces at the next entry point that waits.  0 (default): every call is made by
+                               * pbso_step itself.  Not with stream_sync = 4; engines of a device group never use it */
 } pbso_engine_desc;
 
 enum pbso_bank_kernel {
@@ -328,6 +337,9 @@ int pbso_get_latest_transfer(pbso_engine *e, int object_id, double *out);
 int pbso_step(pbso_engine *e, int n_buffers);
 /* same, audio written to a caller-owned device buffer [n_objects][n_buffers*B] fp32 */
 int pbso_step_into(pbso_engine *e, int n_buffers, void *d_audio);
+/* ABI 6, engines with submit_thread > 0: returns when every launch of the pbso_step calls so far is in its stream (NOT when the device is
+ * done: that is pbso_sync) -- from then on work of the caller on the engine's stream is ordered behind them.  A no-op otherwise. */
+int pbso_flush(pbso_engine *e);
 /* ... and delivered to the HOST, where the reference's consumer lives (the PortAudio callback takes SoundMessages from a host
  * queue, modal_solver.h:79-82, 346-363; tools/real_time_modal_sound.cpp:192-212): host_out[n_objects][n_buffers * B] fp32.
  * host_out from pbso_host_alloc (or any pinned, device-mapped host memory): the oscillator bank writes its samples straight
@@ -489,6 +501,8 @@ typedef struct pbso_engine_info {
                                        * 1 a device-side wait (hipStreamWaitValue64), 2 the submitting thread waits on pinned host memory,
                                        * -1 none because the environment serialises kernel dispatches (a waiting kernel would never end)   */
     int64_t total_gate_timeouts;      /* host-side gate only: waits that gave up after 2 s (the launch then went ungated)                 */
+    int64_t total_ffat_shared_events; /* listener events located once per EVENT (objects whose modes share one map geometry, round 6) ...   */
+    int64_t total_ffat_general_events;/* ... and those evaluated per (event, mode)                                                          */
 } pbso_engine_info;
 int pbso_get_info(pbso_engine *e, pbso_engine_info *out);
 /* diagnostics (engine created with env PBSO_CENSUS=1): for every object's

@@ -25,7 +25,7 @@ EXPORTS = [
     "pbso_set_use_transfer", "pbso_get_latest_transfer", "pbso_step", "pbso_step_into", "pbso_sync",
     "pbso_read_audio", "pbso_read_emitted", "pbso_read_qnorm", "pbso_read_state", "pbso_write_state",
     "pbso_audio_device_ptr", "pbso_pa_convert", "pbso_get_info",
-    "pbso_modes_read", "pbso_num_modes_audible", "pbso_material_read", "pbso_free", "pbso_read_census", "pbso_obj_read", "pbso_arprm_pending",
+    "pbso_modes_read", "pbso_num_modes_audible", "pbso_material_read", "pbso_free", "pbso_read_census", "pbso_obj_read", "pbso_arprm_pending", "pbso_flush",
     "pbso_mix_objects", "pbso_read_audio_rows", "pbso_compute_transfer_path",
     "pbso_step_to_host", "pbso_host_wait", "pbso_host_alloc", "pbso_host_free",
     # the device group (one engine per GPU, RCCL gather called from C++)
@@ -52,7 +52,7 @@ class EngineDesc(C.Structure):
                 ("profile_margin_pct", C.c_int), ("profile_priority", C.c_int), ("team_waves", C.c_int),
                 ("pipe_consumers", C.c_int), ("pipe_max_teams", C.c_longlong), ("chunk_buffers", C.c_int),
                 ("plan_threads", C.c_int), ("plan_pin", C.c_int), ("timing_every", C.c_int), ("warm_copies", C.c_int),
-                ("stream_sync", C.c_int), ("latency_path", C.c_int), ("time_chunk_shape", C.c_int), ("scan_kernel", C.c_int), ("fuse_short_launches", C.c_int)]
+                ("stream_sync", C.c_int), ("latency_path", C.c_int), ("time_chunk_shape", C.c_int), ("scan_kernel", C.c_int), ("fuse_short_launches", C.c_int), ("submit_thread", C.c_int)]
 BANK_AUTO, BANK_BLOCK, BANK_PIPE = 0, 1, 2
 
 
@@ -91,7 +91,8 @@ class EngineInfo(C.Structure):
                 ("total_timed_launches", C.c_int64), ("total_split_launches", C.c_int64),
                 ("total_time_chunk_launches", C.c_int64), ("total_dropped_hits", C.c_int64), ("total_one_stream_launches", C.c_int64),
                 ("total_dense_increment_launches", C.c_int64), ("total_segmented_scans", C.c_int64), ("last_time_chunk_shape", C.c_int), ("last_time_chunk_buffers", C.c_int),
-                ("last_time_chunk_teams", C.c_int), ("start_gate", C.c_int), ("total_gate_timeouts", C.c_int64)]
+                ("last_time_chunk_teams", C.c_int), ("start_gate", C.c_int), ("total_gate_timeouts", C.c_int64),
+                ("total_ffat_shared_events", C.c_int64), ("total_ffat_general_events", C.c_int64)]
 
 
 GroupDesc._fields_ = [("abi_version", C.c_int), ("devices", C.POINTER(C.c_int)), ("n_devices", C.c_int), ("world_size", C.c_int),
@@ -134,6 +135,7 @@ def lib():
                                            C.POINTER(C.c_ubyte)]
     l.pbso_enqueue_arprm.argtypes = [vp, C.c_int, dp, C.c_double, C.c_double, C.c_int64]
     l.pbso_arprm_pending.argtypes = [vp, C.c_int]
+    l.pbso_flush.argtypes = [vp]
     l.pbso_compute_transfer.argtypes = [vp, C.c_int, dp, C.c_int64]
     l.pbso_compute_transfer_batch.argtypes = [vp, C.c_int, dp, C.c_int, dp, C.c_int]
     l.pbso_object_n_maps.argtypes = [vp, C.c_int]

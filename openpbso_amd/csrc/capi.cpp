@@ -315,6 +315,7 @@ int pbso_compute_transfer(pbso_engine *e, int obj, const double pos[3], int64_t 
 int pbso_listeners_enable(pbso_engine *e, int obj) {
     NEED(e);
     GUARD_BEGIN
+    { int drc_ = e->impl->drain_submit(); if (drc_ != PBSO_OK) return drc_; }
     return e->impl->listeners_enable(obj);
     GUARD_END(e)
 }
@@ -322,6 +323,7 @@ int pbso_listeners_enable(pbso_engine *e, int obj) {
 int pbso_mix_listeners(pbso_engine *e, int obj, const double *pos, int n_listeners, float *out, size_t n_out) {
     NEED(e);
     GUARD_BEGIN
+    { int drc_ = e->impl->drain_submit(); if (drc_ != PBSO_OK) return drc_; }
     return e->impl->mix_listeners(obj, pos, n_listeners, out, n_out);
     GUARD_END(e)
 }
@@ -336,6 +338,7 @@ int pbso_object_n_maps(pbso_engine *e, int obj) {
 int pbso_compute_transfer_batch(pbso_engine *e, int obj, const double *pos, int n_pos, double *out, int out_cols) {
     NEED(e);
     GUARD_BEGIN
+    { int drc_ = e->impl->drain_submit(); if (drc_ != PBSO_OK) return drc_; }
     return e->impl->compute_transfer_batch(obj, pos, n_pos, out, out_cols);
     GUARD_END(e)
 }
@@ -351,6 +354,7 @@ int pbso_get_latest_transfer(pbso_engine *e, int obj, double *out) {
     NEED(e);
     if (!out) return PBSO_ERR_INVALID;
     GUARD_BEGIN
+    { int drc_ = e->impl->drain_submit(); if (drc_ != PBSO_OK) return drc_; }
     return e->impl->get_latest_transfer(obj, out);
     GUARD_END(e)
 }
@@ -359,6 +363,13 @@ int pbso_step(pbso_engine *e, int n_buffers) {
     NEED(e);
     GUARD_BEGIN
     return e->impl->step(n_buffers, nullptr);
+    GUARD_END(e)
+}
+
+int pbso_flush(pbso_engine *e) {
+    NEED(e);
+    GUARD_BEGIN
+    return e->impl->drain_submit();
     GUARD_END(e)
 }
 
@@ -373,6 +384,7 @@ int pbso_step_into(pbso_engine *e, int n_buffers, void *d_audio) {
 int pbso_read_audio_rows(pbso_engine *e, const int *object_ids, int n_rows, float *host_out) {
     NEED(e);
     GUARD_BEGIN
+    { int drc_ = e->impl->drain_submit(); if (drc_ != PBSO_OK) return drc_; }
     return e->impl->read_audio_rows(object_ids, n_rows, host_out);
     GUARD_END(e)
 }
@@ -388,6 +400,7 @@ int pbso_compute_transfer_path(pbso_engine *e, int n, const int *object_ids, con
 int pbso_mix_objects(pbso_engine *e, void *d_out) {
     NEED(e);
     GUARD_BEGIN
+    { int drc_ = e->impl->drain_submit(); if (drc_ != PBSO_OK) return drc_; }
     return e->impl->mix_objects(d_out);
     GUARD_END(e)
 }
@@ -395,6 +408,7 @@ int pbso_mix_objects(pbso_engine *e, void *d_out) {
 int pbso_step_to_host(pbso_engine *e, int n_buffers, float *host_out, size_t n_floats) {
     NEED(e);
     GUARD_BEGIN
+    { int drc_ = e->impl->drain_submit(); if (drc_ != PBSO_OK) return drc_; }
     return e->impl->step_to_host(n_buffers, host_out, n_floats);
     GUARD_END(e)
 }
@@ -402,6 +416,7 @@ int pbso_step_to_host(pbso_engine *e, int n_buffers, float *host_out, size_t n_f
 int pbso_host_wait(pbso_engine *e) {
     NEED(e);
     GUARD_BEGIN
+    { int drc_ = e->impl->drain_submit(); if (drc_ != PBSO_OK) return drc_; }
     return e->impl->host_wait();
     GUARD_END(e)
 }
@@ -427,6 +442,7 @@ int pbso_read_audio(pbso_engine *e, float *out, size_t n) {
     NEED(e);
     if (!out) return PBSO_ERR_INVALID;
     GUARD_BEGIN
+    { int drc_ = e->impl->drain_submit(); if (drc_ != PBSO_OK) return drc_; }
     return e->impl->read_audio(out, n);
     GUARD_END(e)
 }
@@ -443,6 +459,7 @@ int pbso_read_qnorm(pbso_engine *e, int obj, int buffer, float *out, int n) {
     NEED(e);
     if (!out) return PBSO_ERR_INVALID;
     GUARD_BEGIN
+    { int drc_ = e->impl->drain_submit(); if (drc_ != PBSO_OK) return drc_; }
     return e->impl->read_qnorm(obj, buffer, out, n);
     GUARD_END(e)
 }
@@ -451,6 +468,7 @@ int pbso_read_state(pbso_engine *e, int obj, double *q1, double *q2, int n) {
     NEED(e);
     if (!q1 || !q2) return PBSO_ERR_INVALID;
     GUARD_BEGIN
+    { int drc_ = e->impl->drain_submit(); if (drc_ != PBSO_OK) return drc_; }
     return e->impl->read_state(obj, q1, q2, n);
     GUARD_END(e)
 }
@@ -459,6 +477,7 @@ int pbso_write_state(pbso_engine *e, int obj, const double *q1, const double *q2
     NEED(e);
     if (!q1 || !q2) return PBSO_ERR_INVALID;
     GUARD_BEGIN
+    { int drc_ = e->impl->drain_submit(); if (drc_ != PBSO_OK) return drc_; }
     return e->impl->write_state(obj, q1, q2, n);
     GUARD_END(e)
 }
@@ -481,6 +500,7 @@ int pbso_read_census(pbso_engine *e, unsigned long long *out, size_t n) {
     NEED(e);
     if (!out) return PBSO_ERR_INVALID;
     GUARD_BEGIN
+    { int drc_ = e->impl->drain_submit(); if (drc_ != PBSO_OK) return drc_; }
     return e->impl->read_census(out, n);
     GUARD_END(e)
 }
@@ -489,6 +509,7 @@ int pbso_get_info(pbso_engine *e, pbso_engine_info *out) {
     NEED(e);
     if (!out) return PBSO_ERR_INVALID;
     GUARD_BEGIN
+    { int drc_ = e->impl->drain_submit(); if (drc_ != PBSO_OK) return drc_; }
     return e->impl->info(out);
     GUARD_END(e)
 }

@@ -3,6 +3,7 @@
 // kernels in kernels_iir.hip / kernels_exact.hip.
 #include "engine.h"
 #include "plan_pool.h"
+#include "submit_queue.h"
 
 #include <algorithm>
 #include <chrono>
@@ -206,6 +207,8 @@ Engine::~Engine() {
                      (long long)tot_steps_, hprof_[0] / tot_steps_, hprof_[1] / tot_steps_, hprof_[2] / tot_steps_, hprof_[3] / tot_steps_,
                      hprof_[4] / tot_steps_, hprof_[6] / tot_steps_, hprof_[7] / tot_steps_, hprof_[8] / tot_steps_, hprof_[5] / tot_steps_);
     delete pool_;
+    delete submit_;                                    // (the worker makes what it still holds, then ends)
+    submit_ = nullptr;
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (aux_stream_) (void)hipStreamSynchronize(aux_stream_);
     if (timeline_have_base_) {                         // (the reference launch's quad was kept out of the free list)
@@ -216,7 +219,7 @@ Engine::~Engine() {
     free_retired_blocks();
     d_ca_.release(); d_cb_.release(); d_sq_.release(); d_sd_.release(); d_ss_.release(); d_c3_.release(); d_gq_.release();
     d_shapes_.release(); d_shape_off_.release(); d_g32_.release(); d_g32_off_.release(); d_n_modes_.release(); d_geom_.release();
-    d_geom_off_.release(); d_psi_.release(); d_slots_.release(); d_xfer_.release();
+    d_geom_off_.release(); d_psi_.release(); d_psi_t_.release(); d_ffat_k_.release(); d_ffat_valid_.release(); d_ffat_shared_.release(); d_slots_.release(); d_xfer_.release();
     d_pc_.release(); d_wtab_.release(); d_ftab_.release(); d_dump_row_.release(); d_xdump_.release(); d_xscale_.release(); d_wtab32_.release();
     d_ar_snaps_.release(); d_ar_vnorm_.release(); d_ar_cbuf_.release(); d_ar_vstate_.release(); d_ar_segcount_.release();
     d_ar_recs_.release(); d_ar_fins_.release();
@@ -271,6 +274,28 @@ int Engine::hip_fail(hipError_t e, const char *what) {
         int _e = (expr);                                               \
         if (_e != 0) return hip_fail((hipError_t)_e, #expr);           \
     } while (0)
+// Engine::step_chunk's stream calls: made at once, or -- with the second submitting thread (submit_queue.h) -- recorded with their
+// arguments evaluated HERE and made by the worker.  `defer` and `ops` are step_chunk's locals.
+#define QHIP(fn, ...)                                                                      \
+    do {                                                                                   \
+        if (defer) ops.push_back(make_submit_op(#fn, fn, __VA_ARGS__));                    \
+        else HIPTRY(fn(__VA_ARGS__));                                                      \
+    } while (0)
+#define QLAUNCH(fn, ...)                                                                   \
+    do {                                                                                   \
+        if (defer) ops.push_back(make_submit_op(#fn, fn, __VA_ARGS__));                    \
+        else LAUNCHTRY(fn(__VA_ARGS__));                                                   \
+    } while (0)
+// a device buffer that has to GROW while recorded calls are still waiting: its keep-copy and the retirement of the old block are
+// immediate calls and must come behind them in their streams -- wait for the worker first (rare: the first steps of an engine)
+#define GROWTRY(buf, n, keep, s)                                                           \
+    do {                                                                                   \
+        if (defer && (size_t)(n) > (buf).cap) {                                            \
+            int _d = drain_submit();                                                       \
+            if (_d != PBSO_OK) return _d;                                                  \
+        }                                                                                  \
+        HIPTRY((buf).ensure((n), (keep), (s)));                                            \
+    } while (0)
 
 int Engine::init() {
     if (desc_.abi_version != PBSO_ABI_VERSION) return fail(PBSO_ERR_INVALID, "abi_version mismatch");
@@ -301,6 +326,8 @@ int Engine::init() {
     if (desc_.stream_sync < 0 || desc_.stream_sync > 4) return fail(PBSO_ERR_INVALID, "stream_sync");
     latency_path_ = desc_.latency_path >= 0;
     fuse_short_ = desc_.fuse_short_launches >= 0;
+    if (desc_.submit_thread > 0 && desc_.stream_sync == 4)
+        return fail(PBSO_ERR_INVALID, "submit_thread with stream_sync = 4: the host-side gate would make the caller wait for the worker's launches");
     if (desc_.qnorm_mode < PBSO_QNORM_OFF || desc_.qnorm_mode > PBSO_QNORM_CLOSED)
         return fail(PBSO_ERR_INVALID, "qnorm_mode");
     {
@@ -366,7 +393,7 @@ int Engine::init() {
         };
         if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, desc_.device) == hipSuccess && can) {
             start_gate_ = signal_word(&sig_start_);
-            if (desc_.stream_sync == 2) sync_values_ = signal_word(&sig_prep_);
+            if (desc_.stream_sync == 2 || desc_.stream_sync == 0) sync_values_ = signal_word(&sig_prep_);      // (0: for short launches, step_chunk)
         }
         (void)hipGetLastError();
         if ((desc_.stream_sync == 2 || desc_.stream_sync == 3) && !(desc_.stream_sync == 2 ? sync_values_ : start_gate_))
@@ -1001,6 +1028,68 @@ int Engine::finalize() {
             HIPTRY(d_psi_.ensure(psi.size()));
             HIPTRY(hipMemcpy(d_psi_.p, psi.data(), psi.size() * sizeof(double), hipMemcpyHostToDevice));
         }
+        // Objects whose valid modes all carry ONE geometry (a map file's header: box, centre, cell size, face layout) -- every scene
+        // we know of: the maps of an object are made over the same box -- get their maps a second time, transposed, and their listener
+        // events the kernel that locates a position once per event (kernels_exact.hip, ffat_lookup_shared_kernel).  Compared field by
+        // field, bit for bit; a single differing mode keeps the object on the general kernels.  PBSO_FFAT_SHARED=0: never.
+        {
+            const char *env = std::getenv("PBSO_FFAT_SHARED");
+            const bool want = !(env && std::atoi(env) == 0);
+            std::vector<FfatShared> shared(N);
+            std::memset(shared.data(), 0, shared.size() * sizeof(FfatShared));
+            std::vector<double> mode_k(geom.size(), 0.0), psi_t;
+            std::vector<int> mode_valid(geom.size(), 0);
+            ffat_shared_h_.assign(N, 0);
+            n_ffat_shared_ = 0;
+            auto same_geometry = [](const FfatGeom &a, const FfatGeom &b) {
+                return a.n_psi == b.n_psi && !std::memcmp(&a.cell_size, &b.cell_size, sizeof(double)) &&
+                       !std::memcmp(a.center3, b.center3, sizeof(a.center3)) && !std::memcmp(a.low_corners, b.low_corners, sizeof(a.low_corners)) &&
+                       !std::memcmp(a.center, b.center, sizeof(a.center)) && !std::memcmp(a.bbox_low, b.bbox_low, sizeof(a.bbox_low)) &&
+                       !std::memcmp(a.bbox_top, b.bbox_top, sizeof(a.bbox_top)) && !std::memcmp(a.n_elements, b.n_elements, sizeof(a.n_elements)) &&
+                       !std::memcmp(a.strides, b.strides, sizeof(a.strides));
+            };
+            for (int i = 0; i < N && want; ++i) {
+                const Object &o = objs_[i];
+                const FfatGeom *g = geom.data() + goff[i];
+                const int ng = (int)((i + 1 < N ? goff[i + 1] : (long long)geom.size()) - goff[i]);
+                const int nm = std::min(o.n_modes, ng);
+                int first = -1, n_valid = 0;
+                bool same = true;
+                for (int m = 0; m < nm && same; ++m) {
+                    if (!g[m].valid) continue;
+                    if (first < 0) first = m;
+                    else same = same_geometry(g[first], g[m]);
+                    n_valid += 1;
+                }
+                if (!same || first < 0 || n_valid < 2) continue;          // (one map: nothing to share)
+                const int pitch = (nm + 15) / 16 * 16;
+                const size_t n_psi = (size_t)g[first].n_psi;
+                shared[i].psit_off = (long long)psi_t.size();
+                shared[i].pitch = pitch;
+                shared[i].first_valid = first;
+                psi_t.resize(psi_t.size() + n_psi * pitch, 0.0);
+                double *dst = psi_t.data() + shared[i].psit_off;
+                for (size_t c0 = 0; c0 < n_psi; c0 += 512)          // (blocks of cells: the strided writes of one block stay in cache)
+                    for (int m = 0; m < nm; ++m) {
+                        if (!g[m].valid) continue;
+                        const double *src = psi.data() + g[m].psi_off;
+                        for (size_t c = c0; c < std::min(n_psi, c0 + 512); ++c) dst[c * pitch + m] = src[c];
+                    }
+                ffat_shared_h_[i] = 1;
+                n_ffat_shared_ += 1;
+            }
+            for (size_t j = 0; j < geom.size(); ++j) { mode_k[j] = geom[j].k; mode_valid[j] = geom[j].valid; }
+            if (n_ffat_shared_ > 0) {
+                HIPTRY(d_ffat_shared_.ensure(N));
+                HIPTRY(hipMemcpy(d_ffat_shared_.p, shared.data(), N * sizeof(FfatShared), hipMemcpyHostToDevice));
+                HIPTRY(d_ffat_k_.ensure(mode_k.size()));
+                HIPTRY(hipMemcpy(d_ffat_k_.p, mode_k.data(), mode_k.size() * sizeof(double), hipMemcpyHostToDevice));
+                HIPTRY(d_ffat_valid_.ensure(mode_valid.size()));
+                HIPTRY(hipMemcpy(d_ffat_valid_.p, mode_valid.data(), mode_valid.size() * sizeof(int), hipMemcpyHostToDevice));
+                HIPTRY(d_psi_t_.ensure(psi_t.size()));
+                HIPTRY(hipMemcpy(d_psi_t_.p, psi_t.data(), psi_t.size() * sizeof(double), hipMemcpyHostToDevice));
+            }
+        }
     }
     HIPTRY(hipMemcpy(d_n_modes_.p, nmodes.data(), N * sizeof(int), hipMemcpyHostToDevice));
     HIPTRY(d_board_.ensure(4096));
@@ -1009,6 +1098,7 @@ int Engine::finalize() {
     HIPTRY(d_xfer_.ensure((size_t)2 * N * m_pad_));
     HIPTRY(hipMemset(d_xfer_.p, 0, (size_t)2 * N * m_pad_ * sizeof(double)));
     (void)warm_copy_engines();
+    if (desc_.submit_thread > 0) submit_ = new SubmitQueue(desc_.device);
     finalized_ = true;
     return PBSO_OK;
 }
@@ -2095,19 +2185,21 @@ int Engine::step(int nb, void *d_audio_user) {
     if (failed_) return fail(PBSO_ERR_STATE, "an earlier step failed half-way (" + failed_why_ + "): queues and force lists are no "
                                              "longer consistent, create a new engine");
     const int N = (int)objs_.size();
+    const bool defer = submit_ != nullptr;             // (GROWTRY: a buffer that grows waits for the recorded calls first)
     float *audio = (float *)d_audio_user;
     // outputs of the whole step (growth drains the device first, see DevBuf::ensure)
     if (!audio) {
-        HIPTRY(d_audio_.ensure((size_t)N * nb * B_, false, stream_));
+        GROWTRY(d_audio_, (size_t)N * nb * B_, false, stream_);
         audio = d_audio_.p;
     }
-    if (desc_.qnorm_mode != PBSO_QNORM_OFF || n_dump_ > 0) HIPTRY(d_qnorm_.ensure((size_t)N * nb * m_pad_, false, stream_));
+    if (desc_.qnorm_mode != PBSO_QNORM_OFF || n_dump_ > 0) GROWTRY(d_qnorm_, (size_t)N * nb * m_pad_, false, stream_);
     if (n_dump_ > 0) {
         // block-start states of the objects a multi-listener mix was asked for (pbso_listeners_enable)
-        HIPTRY(d_xdump_.ensure((size_t)n_dump_ * nb * 32 * m_pad_ * 2, false, stream_));
-        HIPTRY(d_xscale_.ensure((size_t)n_dump_ * nb * m_pad_, false, stream_));
+        GROWTRY(d_xdump_, (size_t)n_dump_ * nb * 32 * m_pad_ * 2, false, stream_);
+        GROWTRY(d_xscale_, (size_t)n_dump_ * nb * m_pad_, false, stream_);
         if (dump_rows_dirty_) {
-            HIPTRY(d_dump_row_.ensure(N, false, stream_));
+            if (defer) { int drc = drain_submit(); if (drc != PBSO_OK) return drc; }
+            GROWTRY(d_dump_row_, N, false, stream_);
             HIPTRY(hipMemcpyAsync(d_dump_row_.p, dump_row_.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, stream_));
             HIPTRY(hipStreamSynchronize(stream_));           // (dump_row_ is pageable host memory)
             dump_rows_dirty_ = false;
@@ -2119,7 +2211,7 @@ int Engine::step(int nb, void *d_audio_user) {
         // (a step's launches may run on different kernels: room for either kind's partial rows)
         int rows = std::max(use_split() ? n_ts_part_rows_ : 0, n_part_rows_);
         if (tc_ok_) for (const TcSet &ts : tc_) rows = std::max(rows, ts.n_part_rows);
-        if (rows) HIPTRY(d_audio_parts_.ensure((size_t)rows * nb * B_, false, stream_));
+        if (rows) GROWTRY(d_audio_parts_, (size_t)rows * nb * B_, false, stream_);
     }
     emitted_.assign((size_t)N * nb, 1);
     const int64_t step_id = tot_steps_;
@@ -2148,7 +2240,16 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     plan_b0_ = b0;
     plan_nb_total_ = nb_total;
     const auto tw0 = std::chrono::steady_clock::now();
-    HIPTRY(hipEventSynchronize(ev_set_[cur_set_]));      // this set's previous uploads are done
+    // the second submitting thread: this launch's stream calls are recorded (QHIP / QLAUNCH) and handed over at the end
+    const bool defer = submit_ != nullptr;
+    std::vector<SubmitOp> ops;
+    if (defer) {
+        ops.reserve(48);
+        submit_->wait(set_batch_[cur_set_]);             // the launch that last used this plan set has been MADE (its events recorded) ...
+        std::string why;
+        if (submit_->error(&why)) return fail(PBSO_ERR_HIP, "a launch of an earlier step failed on the submitting thread: " + why);
+    }
+    HIPTRY(hipEventSynchronize(ev_set_[cur_set_]));      // ... and this set's previous uploads are done
 
     const auto t0 = std::chrono::steady_clock::now();
     hprof_[0] += std::chrono::duration<double, std::milli>(t0 - tw0).count();
@@ -2181,17 +2282,21 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     // nothing to run beside -- its preparation goes on the bank's own stream, and the 11 us an event takes to hand a launch
     // from one stream to the other (profiles/r04_stream_sync.txt) are saved.  Ordering only: same kernels, same arguments.
     bool one_stream = false;
-    if (latency_path_ && nb == nb_total && nb <= 4) {
+    if (latency_path_ && nb == nb_total && nb <= 4 && !defer) {      // (the query below needs the previous launch's events recorded)
         one_stream = last_set_ < 0 || hipEventQuery(ev_k1_done_[last_set_]) == hipSuccess;      // (the previous bank, hence its preparation)
         (void)hipGetLastError();
     }
+    // K5: a launch without (many) dense-profile buffers on a chip the scene cannot fill runs the block kernel as (team, chunk of
+    // buffers) workgroups behind a scan of the buffer-start states (kernels_scan.hip)
+    int tc_set = -1, tc_cb = 0;
+    const bool tc_launch = is_block() && !split_always_ && choose_time_chunks(nb, n_prows_, &tc_set, &tc_cb);
     hipStream_t sk = stream_, sp = one_stream ? sk : prep_stream_;
     // (the preparation stream takes over again behind a launch that went without it: behind that launch's bank)
-    if (!one_stream && last_one_stream_ && last_set_ >= 0) HIPTRY(hipStreamWaitEvent(sp, ev_k1_done_[last_set_], 0));
+    if (!one_stream && last_one_stream_ && last_set_ >= 0) QHIP(hipStreamWaitEvent, sp, ev_k1_done_[last_set_], 0);
     DevBuf<float> &grows = d_grows_[cur_set_];
     // device arenas (growth drains the device first, see DevBuf::ensure)
-    HIPTRY(d_slots_.ensure(std::max<size_t>(1, n_slots_.load()) * m_pad_, true, sp));
-    HIPTRY(grows.ensure(std::max<size_t>(1, (size_t)n_frows) * m_pad_, false, sp));
+    GROWTRY(d_slots_, std::max<size_t>(1, n_slots_.load()) * m_pad_, true, sp);
+    GROWTRY(grows, std::max<size_t>(1, (size_t)n_frows) * m_pad_, false, sp);
     const bool qn = desc_.qnorm_mode != PBSO_QNORM_OFF;
 
     {
@@ -2220,8 +2325,8 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     //      launches ago) has finished.  (The upload stays on this stream: on one of its own the next launch's scan starts as soon
     //      as this launch's has finished -- beside the START of a bank, whose workgroups then wait for the slots it holds:
     //      512 x 512 x 86 0.51 -> 0.59 ms per step, scripts/debug/r04_sync.sh.)
-    HIPTRY(hipStreamWaitEvent(sp, ev_k1_done_[cur_set_], 0));
-    if (timed) HIPTRY(hipEventRecord(evq.p0, sp));
+    QHIP(hipStreamWaitEvent, sp, ev_k1_done_[cur_set_], 0);
+    if (timed) QHIP(hipEventRecord, evq.p0, sp);
     evq.h_prep = host_ms();
     // ---- ONE upload: everything the planner produced sits behind the descriptors in the set's pinned arena.
     // (Twelve separate copies cost the host 0.1 ms of API calls per step, and the small ones went through
@@ -2275,8 +2380,17 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     const size_t o_stage = place(stage_.size() * sizeof(double)), o_stage_slot = place(stage_slot_.size() * sizeof(int));
     const size_t o_proj = place(proj_.size() * sizeof(ProjectEvent)), o_projd = place(proj_direct_.size() * sizeof(ProjectEvent));
     // the listener events as runs of one object each (the planner lists them object by object): one geometry read per (run, mode)
+    // (events of objects whose modes share one map geometry first: they go to the kernel that locates a position once per event)
+    int n_ffat_sh = 0;
+    if (n_ffat_shared_ > 0 && !ffat_.empty()) {
+        auto mid = std::stable_partition(ffat_.begin(), ffat_.end(), [&](const FfatEvent &e) { return ffat_shared_h_[e.obj] != 0; });
+        n_ffat_sh = (int)(mid - ffat_.begin());
+    }
+    const int n_ffat_gen = (int)ffat_.size() - n_ffat_sh;
+    tot_ffat_shared_events_ += n_ffat_sh;
+    tot_ffat_general_events_ += n_ffat_gen;
     ffat_runs_.clear();
-    for (size_t i = 0; i < ffat_.size(); ++i) {
+    for (size_t i = (size_t)n_ffat_sh; i < ffat_.size(); ++i) {
         if (ffat_runs_.empty() || ffat_runs_.back().obj != ffat_[i].obj) ffat_runs_.push_back(FfatRun{ffat_[i].obj, (int)i, 0, 0});
         ffat_runs_.back().count += 1;
     }
@@ -2301,16 +2415,16 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         if (k2_rows_launch_) {
             const size_t ns = std::max<size_t>(1, ar_streams_.size()), nu = std::max<size_t>(1, ar_uses_.size());
             const size_t ng = std::max<size_t>(1, seg_stream_.size());
-            HIPTRY(d_ar_snaps_.ensure(ns, false, sp));
-            HIPTRY(d_ar_fins_.ensure(ns, false, sp));
-            HIPTRY(d_ar_recs_.ensure(nu, false, sp));
-            HIPTRY(d_ar_cbuf_.ensure(nu * (size_t)b_pad_, false, sp));
-            HIPTRY(d_ar_vnorm_.ensure(ng * 2 * K2_SEG, false, sp));
-            HIPTRY(d_ar_vstate_.ensure(ng * K2_SEG, false, sp));
-            HIPTRY(d_ar_segcount_.ensure(ng, false, sp));
+            GROWTRY(d_ar_snaps_, ns, false, sp);
+            GROWTRY(d_ar_fins_, ns, false, sp);
+            GROWTRY(d_ar_recs_, nu, false, sp);
+            GROWTRY(d_ar_cbuf_, nu * (size_t)b_pad_, false, sp);
+            GROWTRY(d_ar_vnorm_, ng * 2 * K2_SEG, false, sp);
+            GROWTRY(d_ar_vstate_, ng * K2_SEG, false, sp);
+            GROWTRY(d_ar_segcount_, ng, false, sp);
         }
-        HIPTRY(ps.d_tprof.ensure(std::max<size_t>(1, (size_t)n_prows_) * b_pad_, false, sp));
-        HIPTRY(d_arstate_.ensure(std::max<size_t>(1, n_ar_states_.load()), true, sp));
+        GROWTRY(ps.d_tprof, std::max<size_t>(1, (size_t)n_prows_) * b_pad_, false, sp);
+        GROWTRY(d_arstate_, std::max<size_t>(1, n_ar_states_.load()), true, sp);
     } else {
         put(o_tprof, tprof_.data(), tprof_.size() * sizeof(float));
     }
@@ -2321,9 +2435,9 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     put(o_ffat, ffat_.data(), ffat_.size() * sizeof(FfatEvent));
     put(o_ffat_runs, ffat_runs_.data(), ffat_runs_.size() * sizeof(FfatRun));
     put(o_copy, cp.data(), cp.size() * sizeof(int));
-    HIPTRY(ps.d_arena.ensure(off, false, sp));
-    HIPTRY(hipMemcpyAsync(ps.d_arena.p, ha, off, hipMemcpyHostToDevice, sp));
-    HIPTRY(hipEventRecord(ev_set_[cur_set_], sp));          // this set's pinned arena is reusable
+    GROWTRY(ps.d_arena, off, false, sp);
+    QHIP(hipMemcpyAsync, ps.d_arena.p, ha, off, hipMemcpyHostToDevice, sp);
+    QHIP(hipEventRecord, ev_set_[cur_set_], sp);          // this set's pinned arena is reusable
     // the start gate: this launch's preparation kernels behind the START of the previous launch's bank (engine.h).  By policy
     // for LONG launches only: there the gate's few microseconds are nothing, and what it prevents is expensive -- a scan of 860
     // buffers that the preparation stream runs TWO launches ahead trails the bank it was squeezed beside by 0.2 ms, holds LDS
@@ -2350,7 +2464,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         }
         host_gate_used_ = true;
     } else if (gate_now && start_gate_) {
-        HIPTRY(hipStreamWaitValue64(sp, sig_start_, last_bank_seq_, hipStreamWaitValueGte, ~0ull));
+        QHIP(hipStreamWaitValue64, sp, sig_start_, last_bank_seq_, hipStreamWaitValueGte, ~0ull);
     }
     evq.h_copy = host_ms();
     const auto tsub1 = std::chrono::steady_clock::now();
@@ -2390,7 +2504,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     if (census_) {
         size_t rows = (size_t)std::max(n_teams_, use_split() ? n_ts_teams_ : 0);
         if (tc_ok_) for (const TcSet &ts : tc_) rows = std::max(rows, (size_t)ts.n_teams * nb);
-        HIPTRY(d_census_.ensure(rows * CENSUS_WORDS, false, sk));
+        GROWTRY(d_census_, rows * CENSUS_WORDS, false, sk);
         kp.census = d_census_.p;
     }
     kp.nb = nb; kp.n_tiles = n_tiles_; kp.m_pad = m_pad_; kp.b_pad = b_pad_;
@@ -2406,10 +2520,6 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     kp.frames = B_;
     kp.ftab = ftab_forced_ ? d_ftab_.p : nullptr;
     kp.forced_block = (forced_block_ && n_prows_ > 0) ? 1 : 0;      // (the build with the forced block path only when a buffer needs it)
-    // K5: a launch without (many) dense-profile buffers on a chip the scene cannot fill runs the block kernel as (team, chunk of
-    // buffers) workgroups behind a scan of the buffer-start states (kernels_scan.hip)
-    int tc_set = -1, tc_cb = 0;
-    const bool tc_launch = is_block() && !split_always_ && choose_time_chunks(nb, n_prows_, &tc_set, &tc_cb);
     // K2 -> time-profile rows ; K3 / scatter -> data slots ; K4 -> transfer rows ; combine -> g rows
     // Round 5: a launch with many dense-profile rows FORKS its preparation.  The force profiles (variates -> zero-state chains ->
     // rows) and the dense increments that need them are one dependent chain, projection -> combine another, and nothing connects
@@ -2423,53 +2533,56 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     hipStream_t sa = split_prep ? aux_stream_ : sp;
     if (split_prep) {
         tot_prep_splits_ += 1;
-        HIPTRY(hipEventRecord(ev_aux_fork_[cur_set_], sp));         // (behind the upload and, for gated launches, the start gate)
-        HIPTRY(hipStreamWaitEvent(sa, ev_aux_fork_[cur_set_], 0));
+        QHIP(hipEventRecord, ev_aux_fork_[cur_set_], sp);         // (behind the upload and, for gated launches, the start gate)
+        QHIP(hipStreamWaitEvent, sa, ev_aux_fork_[cur_set_], 0);
     }
-    if (device_profiles_ && timed && n_chains > 0) { HIPTRY(hipEventRecord(evq.f0, sp)); evq.has_k2 = true; }
+    if (device_profiles_ && timed && n_chains > 0) { QHIP(hipEventRecord, evq.f0, sp); evq.has_k2 = true; }
     if (device_profiles_ && k2_rows_launch_)
-        LAUNCHTRY(launch_force_rows(d_prow, (int)prof_rows_.size(), d_pent, reinterpret_cast<const ArUse *>(da + o_aruse), (int)ar_uses_.size(),
+        QLAUNCH(launch_force_rows, d_prow, (int)prof_rows_.size(), d_pent, reinterpret_cast<const ArUse *>(da + o_aruse), (int)ar_uses_.size(),
                                     reinterpret_cast<const ArStream *>(da + o_arstream), reinterpret_cast<const int *>(da + o_arseg),
                                     (int)seg_stream_.size(), ar_max_segs_, d_arstate_.p, d_ar_snaps_.p, d_ar_vnorm_.p, d_ar_vstate_.p,
                                     d_ar_segcount_.p, d_ar_cbuf_.p, d_ar_recs_.p, d_ar_fins_.p, ps.d_tprof.p, B_, b_pad_, b_pad_,
                                     /* every AR force adds its samples once (a launch of one buffer): one launch instead of three */
-                                    fuse_short_ && !ar_uses_.empty() && ar_uses_.size() == ar_streams_.size(), sp));
+                                    fuse_short_ && !ar_uses_.empty() && ar_uses_.size() == ar_streams_.size(), sp);
     else if (device_profiles_)
-        LAUNCHTRY(launch_force_profiles(d_chain, n_chains, d_prow, d_pent, d_arstate_.p, ps.d_tprof.p, B_, b_pad_, ar_serial_ ? 1 : 0, k2_prio_, sp));
-    if (evq.has_k2) HIPTRY(hipEventRecord(evq.f1, sp));
-    if (!fuse_combine) LAUNCHTRY(launch_scatter_rows(d_stage, d_stage_slot, (int)stage_slot_.size(), d_slots_.p, m_pad_, sa));
-    LAUNCHTRY(launch_modal_project(d_proj, (int)proj_.size(), d_shapes_.p, d_shape_off_.p, d_n_modes_.p, d_slots_.p, m_pad_, sa));
+        QLAUNCH(launch_force_profiles, d_chain, n_chains, d_prow, d_pent, d_arstate_.p, ps.d_tprof.p, B_, b_pad_, ar_serial_ ? 1 : 0, k2_prio_, sp);
+    if (evq.has_k2) QHIP(hipEventRecord, evq.f1, sp);
+    if (!fuse_combine) QLAUNCH(launch_scatter_rows, d_stage, d_stage_slot, (int)stage_slot_.size(), d_slots_.p, m_pad_, sa);
+    QLAUNCH(launch_modal_project, d_proj, (int)proj_.size(), d_shapes_.p, d_shape_off_.p, d_n_modes_.p, d_slots_.p, m_pad_, sa);
     // (a few events: one thread per (event, mode); listener paths -- many events per object -- by runs)
-    if (ffat_.size() >= 4 * ffat_runs_.size() && !ffat_runs_.empty())
-        LAUNCHTRY(launch_ffat_lookup_runs(d_ffat, reinterpret_cast<const FfatRun *>(da + o_ffat_runs), (int)ffat_runs_.size(), d_geom_.p,
-                                          d_geom_off_.p, d_n_modes_.p, d_psi_.p, d_xfer_.p, m_pad_, sa));
+    if (n_ffat_sh > 0)
+        QLAUNCH(launch_ffat_lookup_shared, d_ffat, n_ffat_sh, d_ffat_shared_.p, d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_ffat_k_.p,
+                                            d_ffat_valid_.p, d_psi_t_.p, d_xfer_.p, m_pad_, sa);
+    if ((size_t)n_ffat_gen >= 4 * ffat_runs_.size() && !ffat_runs_.empty())
+        QLAUNCH(launch_ffat_lookup_runs, d_ffat, reinterpret_cast<const FfatRun *>(da + o_ffat_runs), (int)ffat_runs_.size(), d_geom_.p,
+                                          d_geom_off_.p, d_n_modes_.p, d_psi_.p, d_xfer_.p, m_pad_, sa);
     else
-        LAUNCHTRY(launch_ffat_lookup(d_ffat, (int)ffat_.size(), d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p, d_xfer_.p, m_pad_, sa));
+        QLAUNCH(launch_ffat_lookup, d_ffat + n_ffat_sh, n_ffat_gen, d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p, d_xfer_.p, m_pad_, sa);
     // (the combine stays on the preparation stream even when the bank fills the register file: its workgroups
     //  move in as the bank's retire, so most of it is done when the last one leaves -- queued behind the bank in
     //  the bank's own stream it would start only then: 0.785 instead of 0.735 ms per step at 1024 x 512)
-    LAUNCHTRY(launch_force_combine(d_row_ptr, d_slot_idx, d_row_obj, n_frows, d_slots_.p, d_c3_.p, grows.p, d_projd, d_shapes_.p,
-                                   d_shape_off_.p, d_n_modes_.p, m_pad_, (int)proj_direct_.size(), d_stage, d_stage_slot, sa));
-    if (split_prep) HIPTRY(hipEventRecord(ev_aux_join_[cur_set_], sa));
-    if (split_prep && !tc_launch) HIPTRY(hipStreamWaitEvent(sp, ev_aux_join_[cur_set_], 0));
+    QLAUNCH(launch_force_combine, d_row_ptr, d_slot_idx, d_row_obj, n_frows, d_slots_.p, d_c3_.p, grows.p, d_projd, d_shapes_.p,
+                                   d_shape_off_.p, d_n_modes_.p, m_pad_, (int)proj_direct_.size(), d_stage, d_stage_slot, sa);
+    if (split_prep) QHIP(hipEventRecord, ev_aux_join_[cur_set_], sa);
+    if (split_prep && !tc_launch) QHIP(hipStreamWaitEvent, sp, ev_aux_join_[cur_set_], 0);
     if (tc_launch) {
         // The scan hands the state from launch to launch by itself (the chunked bank launches never write it), so it runs HERE, on
         // the preparation stream, beside the previous launch's oscillator bank -- behind a launch of another kind it waits for
         // that launch's bank, which wrote the state it starts from.
         const int n_chunks = (nb + tc_cb - 1) / tc_cb;
-        HIPTRY(d_xs_[cur_set_].ensure((size_t)N * n_chunks * m_pad_ * 2, false, sp));
-        HIPTRY(d_xtrow_[cur_set_].ensure((size_t)N * n_chunks, false, sp));
+        GROWTRY(d_xs_[cur_set_], (size_t)N * n_chunks * m_pad_ * 2, false, sp);
+        GROWTRY(d_xtrow_[cur_set_], (size_t)N * n_chunks, false, sp);
         // dense-profile buffers (Gaussian / AR, forces.h:92-128): what each leaves in the state per unit gain, all of them at once
         const float *vinc = nullptr;
         if (n_prows_ > 0) {
-            HIPTRY(d_vinc_[cur_set_].ensure((size_t)n_prows_ * m_pad_ * 2, false, sp));
-            LAUNCHTRY(launch_dense_increments(d_pc_.p, d_ftab_.p, (long long)N * m_pad_, d_tprof, reinterpret_cast<const int *>(da + o_prow_obj),
-                                              d_n_modes_.p, n_prows_, m_pad_, b_pad_, B_, d_vinc_[cur_set_].p, sp));
+            GROWTRY(d_vinc_[cur_set_], (size_t)n_prows_ * m_pad_ * 2, false, sp);
+            QLAUNCH(launch_dense_increments, d_pc_.p, d_ftab_.p, (long long)N * m_pad_, d_tprof, reinterpret_cast<const int *>(da + o_prow_obj),
+                                              d_n_modes_.p, n_prows_, m_pad_, b_pad_, B_, d_vinc_[cur_set_].p, sp);
             vinc = d_vinc_[cur_set_].p;
             tot_tc_dense_launches_ += 1;
         }
-        if (!last_launch_tc_ && last_set_ >= 0) HIPTRY(hipStreamWaitEvent(sp, ev_k1_done_[last_set_], 0));
-        if (split_prep) HIPTRY(hipStreamWaitEvent(sp, ev_aux_join_[cur_set_], 0));      // (the increments above did not need the gains; the scan does)
+        if (!last_launch_tc_ && last_set_ >= 0) QHIP(hipStreamWaitEvent, sp, ev_k1_done_[last_set_], 0);
+        if (split_prep) QHIP(hipStreamWaitEvent, sp, ev_aux_join_[cur_set_], 0);      // (the increments above did not need the gains; the scan does)
         // Cut along the time axis itself -- one wave per chunk (kernels_scan.hip, SEG) -- in two cases.  (a) The whole scan is a
         // handful of waves: it halves the latency of a scan that has the device to itself (1 x 512 x 86: 11.3 -> 5.7 us).  (b) LONG
         // chunks of a scene whose serial scan is at most two waves per SIMD: that scan can only start as the previous bank's
@@ -2489,20 +2602,23 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
                          (desc_.scan_kernel == 2 || (tc_cb > 1 && scan_waves * n_chunks <= 2LL * n_cus_) ||
                           (tc_cb >= 32 && scan_waves <= 8LL * n_cus_) || (tc_cb > 1 && vinc && scan_waves <= 2LL * n_cus_));
         if (seg) tot_seg_scans_ += 1;
-        LAUNCHTRY(launch_iir_scan(kp, N, d_scan_.p, tc_cb, n_chunks, d_xs_[cur_set_].p, d_xtrow_[cur_set_].p, direct_hits_, vinc, seg, sp));
+        QLAUNCH(launch_iir_scan, kp, N, d_scan_.p, tc_cb, n_chunks, d_xs_[cur_set_].p, d_xtrow_[cur_set_].p, direct_hits_, vinc, seg, sp);
     }
     // ---- compute stream: the bank after its preparation (and, stream order, after the previous bank)
     if (one_stream) {
         tot_one_stream_launches_ += 1;
-    } else if (sync_values_) {
-        LAUNCHTRY(launch_signal_value(sig_prep_, ++prep_seq_, sp));
-        HIPTRY(hipStreamWaitValue64(sk, sig_prep_, prep_seq_, hipStreamWaitValueGte, ~0ull));
+    } else if (sync_values_ && (desc_.stream_sync == 2 || nb < 256)) {
+        // (round 6: by policy for launches of fewer than 256 buffers -- a step of 86 buffers: 64 x 256 with a listener move per buffer
+        //  0.0765 -> 0.0717 ms, 16 / 128 / 256 / 512 x 512 impulses 4 / 2.7 / 1.7 / 1.5 % per step, 64 x 512 and 1 x 512 unchanged,
+        //  profiles/r06_value_handover.txt; long launches keep the event: nothing to gain there, and their numbers stand as measured)
+        QLAUNCH(launch_signal_value, sig_prep_, ++prep_seq_, sp);
+        QHIP(hipStreamWaitValue64, sk, sig_prep_, prep_seq_, hipStreamWaitValueGte, ~0ull);
     } else {
-        HIPTRY(hipEventRecord(ev_prep_done_[cur_set_], sp));
-        HIPTRY(hipStreamWaitEvent(sk, ev_prep_done_[cur_set_], 0));
+        QHIP(hipEventRecord, ev_prep_done_[cur_set_], sp);
+        QHIP(hipStreamWaitEvent, sk, ev_prep_done_[cur_set_], 0);
     }
     const auto tsub2 = std::chrono::steady_clock::now();
-    if (timed) HIPTRY(hipEventRecord(evq.k0, sk));
+    if (timed) QHIP(hipEventRecord, evq.k0, sk);
     evq.h_bank = host_ms();
     kp.audio_parts = d_audio_parts_.p ? d_audio_parts_.p + (size_t)b0 * B_ : nullptr;
     // Side by side only while everything is resident at once (largest teams first, on the engine's
@@ -2557,7 +2673,7 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         kp.rotate_prio = (rotate_prio_ && ts.waves * (long long)((nb + tc_cb - 1) / tc_cb) <= 8LL * n_cus_) ? 1 : 0;
         for (const SizeClass &c : ts.classes) {
             kp.teams = ts.d_teams.p + c.first;
-            LAUNCHTRY(iir_block::launch_iir_block(kp, c.count, ts.R, c.W, desc_.qnorm_mode, form_ == PBSO_FORM_BLOCK_BF16 ? 1 : 0, sk));
+            QLAUNCH(iir_block::launch_iir_block, kp, c.count, ts.R, c.W, desc_.qnorm_mode, form_ == PBSO_FORM_BLOCK_BF16 ? 1 : 0, sk);
         }
     }
     if (split_launch) {
@@ -2573,11 +2689,11 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
             // ahead of the producer, which is left with the 32 coarse steps (kernels_pipe.hip, iir_pipe5_kernel)
             if (dense_majority && ftab_forced_ && desc_.qnorm_mode == PBSO_QNORM_OFF) nc = 4;
             if (desc_.pipe_consumers > 0) nc = desc_.pipe_consumers;
-            LAUNCHTRY(iir_pipe::launch_iir_pipe(kp, n_ts_teams_, nc, desc_.qnorm_mode, sk));
+            QLAUNCH(iir_pipe::launch_iir_pipe, kp, n_ts_teams_, nc, desc_.qnorm_mode, sk);
         }
     }
     const bool fork = !tc_launch && !split_launch && classes_.size() > 1 && ev_fork_ && total_team_waves_ <= 16LL * n_cus_;
-    if (fork) HIPTRY(hipEventRecord(ev_fork_, sk));
+    if (fork) QHIP(hipEventRecord, ev_fork_, sk);
     for (size_t ci = 0; ci < (tc_launch || split_launch ? 0 : classes_.size()); ++ci) {
         const SizeClass &c = classes_[ci];
         hipStream_t s = sk;
@@ -2585,32 +2701,36 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
             const int j = (int)((ci - 1) % N_CLASS_STREAMS);
             s = class_stream_[j];
             if (!used[j]) {
-                HIPTRY(hipStreamWaitEvent(s, ev_fork_, 0));
+                QHIP(hipStreamWaitEvent, s, ev_fork_, 0);
                 used[j] = true;
             }
         }
         kp.teams = d_teams_.p + c.first;
         if (is_block() && !dense_heavy)
-            LAUNCHTRY(iir_block::launch_iir_block(kp, c.count, R_, c.W, desc_.qnorm_mode, form_ == PBSO_FORM_BLOCK_BF16 ? 1 : 0, s));
+            QLAUNCH(iir_block::launch_iir_block, kp, c.count, R_, c.W, desc_.qnorm_mode, form_ == PBSO_FORM_BLOCK_BF16 ? 1 : 0, s);
         else
-            LAUNCHTRY(iir_scalar::launch_iir_bank(kp, c.count, R_, c.W, form_ == PBSO_FORM_DIRECT ? 1 : 0, desc_.qnorm_mode, s));
+            QLAUNCH(iir_scalar::launch_iir_bank, kp, c.count, R_, c.W, form_ == PBSO_FORM_DIRECT ? 1 : 0, desc_.qnorm_mode, s);
     }
     for (int j = 0; j < N_CLASS_STREAMS; ++j) {
         if (!used[j]) continue;
-        HIPTRY(hipEventRecord(ev_join_[j], class_stream_[j]));
-        HIPTRY(hipStreamWaitEvent(sk, ev_join_[j], 0));
+        QHIP(hipEventRecord, ev_join_[j], class_stream_[j]);
+        QHIP(hipStreamWaitEvent, sk, ev_join_[j], 0);
     }
     // objects stepped by several teams: the teams' partial sums of this launch's buffers, added in team order
     // ... and _latest_transfer = trans (modal_solver.h:251) in the same launch; then re-park a still-queued transfer
-    LAUNCHTRY(launch_sum_parts_copy_rows(tc_launch ? tc_[tc_set].d_split.p : split_launch ? d_ts_split_.p : d_split_.p,
+    QLAUNCH(launch_sum_parts_copy_rows, tc_launch ? tc_[tc_set].d_split.p : split_launch ? d_ts_split_.p : d_split_.p,
                                          tc_launch ? tc_[tc_set].n_split : split_launch ? n_ts_split_ : n_split_, kp.audio_parts,
                                          audio + (size_t)b0 * B_, (long long)nb_total * B_, (long long)nb * B_, d_copy, d_copy + (n_cl + n_cq), n_cl,
-                                         d_xfer_.p, m_pad_, sk));
-    if (timed) HIPTRY(hipEventRecord(evq.k1, sk));
-    LAUNCHTRY(launch_copy_rows(d_copy + n_cl, d_copy + (n_cl + n_cq) + n_cl, n_cq, d_xfer_.p, m_pad_, sk));
-    if (timed) HIPTRY(hipEventRecord(evq.p1, sk));
+                                         d_xfer_.p, m_pad_, sk);
+    if (timed) QHIP(hipEventRecord, evq.k1, sk);
+    QLAUNCH(launch_copy_rows, d_copy + n_cl, d_copy + (n_cl + n_cq) + n_cl, n_cq, d_xfer_.p, m_pad_, sk);
+    if (timed) QHIP(hipEventRecord, evq.p1, sk);
     evq.h_done = host_ms();
-    HIPTRY(hipEventRecord(ev_k1_done_[cur_set_], sk));
+    QHIP(hipEventRecord, ev_k1_done_[cur_set_], sk);
+    if (defer) {
+        evq.batch = submit_->pushed() + 1;
+        set_batch_[cur_set_] = submit_->push(std::move(ops));     // (from here on the worker makes the calls; the caller goes on to plan)
+    }
     if (timed) ev_pending_.push_back(evq);
     else ev_free_.push_back(evq);
     buffers_done_ += nb;
@@ -2627,7 +2747,24 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     return PBSO_OK;
 }
 
+// the second submitting thread has made every recorded call (NOT a device synchronisation); a call that failed there surfaces here
+int Engine::drain_submit() {
+    if (!submit_) return PBSO_OK;
+    submit_->drain();
+    std::string why;
+    if (submit_->error(&why)) {
+        failed_ = true;
+        failed_why_ = why;
+        return fail(PBSO_ERR_HIP, "a launch failed on the submitting thread: " + why);
+    }
+    return PBSO_OK;
+}
+
 int Engine::sync() {
+    {
+        int drc = drain_submit();
+        if (drc != PBSO_OK) return drc;
+    }
     HIPTRY(hipSetDevice(desc_.device));      // the caller's thread may have another device current
     if (aux_stream_) HIPTRY(hipStreamSynchronize(aux_stream_));
     if (prep_stream_) HIPTRY(hipStreamSynchronize(prep_stream_));
@@ -2888,6 +3025,7 @@ int Engine::step_to_host(int nb, float *host_out, size_t n) {
         if (hipPointerGetAttributes(&attr, host_out) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer) {
             int rc = step(nb, attr.devicePointer);
             if (rc != PBSO_OK) return rc;
+            if ((rc = drain_submit()) != PBSO_OK) return rc;          // (the event below goes behind the step's launches)
             HIPTRY(hipEventRecord(ev_host_copy_[slot], stream_));      // "delivered" = the bank (and what follows it) has finished
             host_last_ = slot;
             host_slot_ ^= 1;
@@ -2899,6 +3037,7 @@ int Engine::step_to_host(int nb, float *host_out, size_t n) {
     HIPTRY(hipStreamWaitEvent(stream_, ev_host_copy_[slot], 0));          // the copy that last read this buffer is done
     int rc = step(nb, d_audio_host_[slot].p);
     if (rc != PBSO_OK) return rc;
+    if ((rc = drain_submit()) != PBSO_OK) return rc;
     HIPTRY(hipEventRecord(ev_host_bank_[slot], stream_));
     HIPTRY(hipStreamWaitEvent(copy_stream_, ev_host_bank_[slot], 0));
     HIPTRY(hipMemcpyAsync(host_out, d_audio_host_[slot].p, total * sizeof(float), hipMemcpyDeviceToHost, copy_stream_));
@@ -3006,6 +3145,8 @@ int Engine::info(pbso_engine_info *out) {
     out->total_one_stream_launches = tot_one_stream_launches_;
     out->start_gate = gate_choice_;
     out->total_gate_timeouts = gate_timeouts_;
+    out->total_ffat_shared_events = tot_ffat_shared_events_;
+    out->total_ffat_general_events = tot_ffat_general_events_;
     out->buffers_done = buffers_done_;
     out->last_step_host_plan_ms = last_plan_ms_;
     out->last_step_forced_rows = last_frows_;
@@ -3034,6 +3175,7 @@ int Engine::harvest_timing(bool blocking) {
     size_t done = 0;
     for (; done < ev_pending_.size(); ++done) {
         EvQuad &q = ev_pending_[done];
+        if (submit_ && q.batch > submit_->done()) break;      // (its events are not recorded yet: an unrecorded event reads as complete)
         if (!blocking && hipEventQuery(q.p1) != hipSuccess) break;
         float ms = 0, ms2 = 0;
         HIPTRY(hipEventElapsedTime(&ms, q.k0, q.k1));

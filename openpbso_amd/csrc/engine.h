@@ -21,6 +21,7 @@
 #include "kernels.h"
 
 namespace pbso {
+class SubmitQueue;       // submit_queue.h
 
 // ---- growable device / pinned-host buffers ---------------------------------
 template <class T>
@@ -203,6 +204,7 @@ public:
     int host_wait();
     int step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_id);   // one launch of at most chunk_buffers_ buffers
     int sync();
+    int drain_submit();                                  // the submitting thread has made every recorded call (not a device sync)
     int read_audio(float *out, size_t n);
     int read_audio_rows(const int *rows, int n_rows, float *out);
     int read_emitted(unsigned char *out, size_t n);
@@ -287,7 +289,7 @@ private:
     hipEvent_t ev_fork_ = nullptr, ev_join_[N_CLASS_STREAMS] = {nullptr, nullptr, nullptr};
     int xfer_cap_ = 0;                                   // scratch transfer rows per plan set
     hipEvent_t ev_set_[N_SETS] = {};
-    struct EvQuad { hipEvent_t k0, k1, p0, p1, f0, f1; int64_t step_id; bool has_k2; double h_enter, h_prep, h_copy, h_bank, h_done; };      // bank, pipeline, force-profile kernel
+    struct EvQuad { hipEvent_t k0, k1, p0, p1, f0, f1; int64_t step_id; bool has_k2; double h_enter, h_prep, h_copy, h_bank, h_done; unsigned long long batch = 0; };      // bank, pipeline, force-profile kernel
     std::vector<EvQuad> ev_free_, ev_pending_;           // one quad per step, harvested in info()
     int harvest_timing(bool blocking);
     double tot_kernel_ms_ = 0, tot_device_ms_ = 0, tot_plan_ms_ = 0, last_kernel_ms_ = 0, last_device_ms_ = 0;
@@ -374,6 +376,13 @@ private:
     DevBuf<FfatGeom> d_geom_;
     DevBuf<long long> d_geom_off_;
     DevBuf<double> d_psi_;
+    // objects whose modes share one FFAT map geometry (finalize): the maps once more, transposed (kernels.h, FfatShared)
+    DevBuf<double> d_psi_t_, d_ffat_k_;
+    DevBuf<int> d_ffat_valid_;
+    DevBuf<FfatShared> d_ffat_shared_;
+    std::vector<unsigned char> ffat_shared_h_;           // per object: its listener events go to ffat_lookup_shared_kernel
+    int n_ffat_shared_ = 0;
+    int64_t tot_ffat_shared_events_ = 0, tot_ffat_general_events_ = 0;
     DevBuf<double> d_slots_;                             // [n_slots][m_pad] ForceMessage::data rows
     DevBuf<double> d_xfer_;                              // [n_obj + scratch][m_pad]
     DevBuf<float> d_audio_, d_qnorm_;
@@ -433,6 +442,9 @@ private:
     int k2_margin_pct_ = 100;                            // PBSO_K2_MARGIN_PCT: scales the candidate range (tests: < 100 forces the shortfall path)
     bool k2_rows_launch_ = false;                        // this launch takes the row-parallel form
     bool fuse_short_ = true;                             // pbso_engine_desc::fuse_short_launches
+    // the second submitting thread (submit_queue.h; pbso_engine_desc::submit_thread): created by finalize, nullptr = every call at once
+    SubmitQueue *submit_ = nullptr;
+    unsigned long long set_batch_[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // per plan set: the batch of the launch that last used it
     std::vector<ArStream> ar_streams_;
     std::vector<ArUse> ar_uses_;
     std::vector<int> seg_stream_, ar_stream_of_state_, ar_last_use_, ar_epoch_, ar_param_;

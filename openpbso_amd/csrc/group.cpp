@@ -230,6 +230,7 @@ int pbso_group_create(const pbso_group_desc *d, pbso_group **out) {
         }
         g->edesc = d->engine;
         g->edesc.abi_version = PBSO_ABI_VERSION;
+        g->edesc.submit_thread = 0;          // (the group puts its collectives on the ranks' streams right behind a step: no deferred launches)
         g->frames = d->engine.frames_per_buffer > 0 ? d->engine.frames_per_buffer : PBSO_FRAMES_PER_BUFFER;
         int ndev = 0;
         GHIP(g, hipGetDeviceCount(&ndev));

@@ -277,6 +277,15 @@ struct FfatEvent {
     double pos[3];
 };
 struct FfatRun { int obj, first, count, pad; };          // consecutive events of one object in the launch's list
+// an object whose modes share one map geometry (kernels_exact.hip, ffat_lookup_shared_kernel): its maps transposed, psi_t[cell][mode]
+struct FfatShared {
+    long long psit_off;  // offset into the transposed pool (doubles)
+    int pitch;           // doubles per cell row (>= n_modes, a multiple of 16); 0: the object's modes do not share a geometry
+    int first_valid;     // a mode whose FfatGeom stands for all of them
+};
+int launch_ffat_lookup_shared(const FfatEvent *events, int n_events, const FfatShared *shared, const FfatGeom *geom, const long long *geom_off,
+                              const int *n_modes, const double *mode_k, const int *mode_valid, const double *psi_t, double *rows, int m_pad,
+                              hipStream_t stream);
 int launch_ffat_lookup_runs(const FfatEvent *events, const FfatRun *runs, int n_runs, const FfatGeom *geom,
                             const long long *geom_off, const int *n_modes, const double *psi,
                             double *rows, int m_pad, hipStream_t stream);

@@ -966,8 +966,16 @@ int launch_force_rows(const ProfRow *rows, int n_rows, const ProfEntry *entries,
 __device__ __forceinline__ double dmin_(double x, double y) { return (y < x) ? y : x; }  // std::min
 __device__ __forceinline__ double dmax_(double x, double y) { return (x < y) ? y : x; }  // std::max
 
-__device__ double ffat_get_map_val(const FfatGeom &g, const double *__restrict__ psi,
-                                   const double p[3]) {
+// Where a position falls in a map (Intersect + the cell corners and weights of Interpolate) and its distance from the map's
+// centre: everything of GetMapVal that does not touch Psi or k.  Split out in round 6 so that the kernel of objects whose modes
+// share one geometry (ffat_lookup_shared_kernel) evaluates it once per event; the same expressions in the same order either way
+// (this file is built with -ffp-contract=off: no expression is contracted differently after the split).
+struct FfatLoc {
+    int i00, i10, i01, i11;          // indices into the mode's Psi: (x, y), (xp, y), (x, yp), (xp, yp)
+    double c0, c1, c2, c3;           // the bilinear weights, in GetMapVal's order
+    double r;                        // |p - center|
+};
+__device__ __forceinline__ FfatLoc ffat_locate(const FfatGeom &g, const double p[3]) {
     // Intersect, ffat_solver.h:681-686
     double d[3], t_enter[3], surf[3];
 #pragma unroll
@@ -1010,19 +1018,28 @@ __device__ double ffat_get_map_val(const FfatGeom &g, const double *__restrict__
     else { y = Ny - 1; yp = Ny - 1; ty = 0; }
     tx = dmin_(dmax_(tx, 0.0), 1.0);
     ty = dmin_(dmax_(ty, 0.0), 1.0);
-    const double c0 = (1.0 - tx) * (1.0 - ty), c1 = tx * (1.0 - ty), c2 = (1.0 - tx) * ty, c3 = tx * ty;
+    FfatLoc L;
+    L.c0 = (1.0 - tx) * (1.0 - ty); L.c1 = tx * (1.0 - ty); L.c2 = (1.0 - tx) * ty; L.c3 = tx * ty;
     const int base = g.strides[face];
-    // GetMapVal :1198-1204 with GetDataQuadStride :141-144
-    double psi0 = 0.0;
-    psi0 += c0 * psi[base + x * Ny + y];
-    psi0 += c1 * psi[base + xp * Ny + y];
-    psi0 += c2 * psi[base + x * Ny + yp];
-    psi0 += c3 * psi[base + xp * Ny + yp];
+    L.i00 = base + x * Ny + y; L.i10 = base + xp * Ny + y; L.i01 = base + x * Ny + yp; L.i11 = base + xp * Ny + yp;
     // Reconstruct :899-906; (p - _center).norm() = sqrt(x^2 + (y^2 + z^2)) (Eigen's unrolled redux)
     const double dx = p[0] - g.center3[0], dy = p[1] - g.center3[1], dz = p[2] - g.center3[2];
-    const double r = sqrt(dx * dx + (dy * dy + dz * dz));
-    const double kr = g.k * r;
+    L.r = sqrt(dx * dx + (dy * dy + dz * dz));
+    return L;
+}
+// GetMapVal :1198-1204 with GetDataQuadStride :141-144 on the four corners' values, then Reconstruct's 1 / (k r)
+__device__ __forceinline__ double ffat_combine(const FfatLoc &L, double p00, double p10, double p01, double p11, double k) {
+    double psi0 = 0.0;
+    psi0 += L.c0 * p00;
+    psi0 += L.c1 * p10;
+    psi0 += L.c2 * p01;
+    psi0 += L.c3 * p11;
+    const double kr = k * L.r;
     return fabs(psi0 / kr);
+}
+__device__ double ffat_get_map_val(const FfatGeom &g, const double *__restrict__ psi, const double p[3]) {
+    const FfatLoc L = ffat_locate(g, p);
+    return ffat_combine(L, psi[L.i00], psi[L.i10], psi[L.i01], psi[L.i11], g.k);
 }
 
 // grid = n_events x ceil(m_pad / 128) workgroups, flat on x (tiles of one event adjacent): grid.y counts to 65535 only
@@ -1083,6 +1100,76 @@ int launch_ffat_lookup_runs(const FfatEvent *events, const FfatRun *runs, int n_
     if ((long long)n_runs * m_pad > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(ffat_lookup_runs_kernel, dim3((unsigned)((long long)n_runs * m_pad)), dim3(128), 0, stream, events, runs, geom, geom_off,
                        n_modes, psi, rows, m_pad);
+    return (int)hipGetLastError();
+}
+
+// K4 for objects whose modes all carry the SAME map geometry (bounding box, centre, cell size, face layout: what a map file's
+// header holds; only k and Psi differ from mode to mode -- the engine checks it field by field at finalize, Engine::finalize).
+// Round 6.  Then where a listener position falls on the cube, its four cells and their weights, is one evaluation per EVENT instead of
+// one per (event, mode) -- eight of GetMapVal's nine fp64 divisions and its square root -- and with the object's maps also held
+// TRANSPOSED, psi_t[cell][mode], the four corner reads of a wave are four runs of consecutive doubles and so is its write: lane =
+// mode.  64 x 256 x 86 with a listener move per buffer (BASELINE configs[2]): the per-(run, mode) kernel above gathers from 201 MB of
+// maps and scatters 1.4 M eight-byte writes, 35 us -- a third of that step's device time, in the window between two oscillator
+// banks where nothing else can run (the bank holds every register); this one moves 10 KB per event, 55 MB.
+// One workgroup per (group of FFAT_SH_EVENTS events, tile of 256 modes): the first lanes locate one event each -- together, in the
+// time of one -- and leave cells, weights and distance in LDS; then every lane, a mode, walks the group's events (sixteen corner
+// reads in flight).  With a workgroup per event each of its four waves located the position again: 19 us for the 5504 events of that
+// step, most of it the divisions.  Events of other objects are left to the kernels above (skipped here).
+// Same arithmetic (ffat_locate + ffat_combine), bit-exact with the oracle.
+constexpr int FFAT_SH_EVENTS = 4;
+__global__ __launch_bounds__(256) void ffat_lookup_shared_kernel(
+    const FfatEvent *__restrict__ events, int n_events, const FfatShared *__restrict__ shared, const FfatGeom *__restrict__ geom,
+    const long long *__restrict__ geom_off, const int *__restrict__ n_modes, const double *__restrict__ mode_k,
+    const int *__restrict__ mode_valid, const double *__restrict__ psi_t, double *__restrict__ rows, int m_pad) {
+    __shared__ FfatLoc loc[FFAT_SH_EVENTS];
+    __shared__ int ev_obj[FFAT_SH_EVENTS], ev_row[FFAT_SH_EVENTS];
+    const unsigned tiles = (unsigned)(m_pad + 255) / 256u;
+    const int e0 = (int)(blockIdx.x / tiles) * FFAT_SH_EVENTS;
+    if (threadIdx.x < FFAT_SH_EVENTS) {
+        const int e = e0 + (int)threadIdx.x;
+        int obj = -1, row = 0;
+        if (e < n_events) {
+            const FfatEvent ev = events[e];
+            const FfatShared sh = shared[ev.obj];
+            if (sh.pitch != 0) {
+                obj = ev.obj;
+                row = ev.row;
+                loc[threadIdx.x] = ffat_locate(geom[geom_off[ev.obj] + sh.first_valid], ev.pos);
+            }
+        }
+        ev_obj[threadIdx.x] = obj;
+        ev_row[threadIdx.x] = row;
+    }
+    __syncthreads();
+    const int m = (int)(blockIdx.x % tiles) * 256 + (int)threadIdx.x;
+    if (m >= m_pad) return;
+#pragma unroll
+    for (int j = 0; j < FFAT_SH_EVENTS; ++j) {
+        const int obj = ev_obj[j];
+        if (obj < 0) continue;                      // (workgroup-uniform)
+        const FfatShared sh = shared[obj];
+        const long long go = geom_off[obj];
+        double out = 0.0;
+        if (m < n_modes[obj] && mode_valid[go + m]) {
+            const FfatLoc L = loc[j];
+            const double *__restrict__ pt = psi_t + sh.psit_off + m;
+            const size_t pitch = (size_t)sh.pitch;
+            // computeTransfer wraps GetMapVal in another std::abs (modal_solver.h:295)
+            out = fabs(ffat_combine(L, pt[(size_t)L.i00 * pitch], pt[(size_t)L.i10 * pitch], pt[(size_t)L.i01 * pitch], pt[(size_t)L.i11 * pitch],
+                                    mode_k[go + m]));
+        }
+        rows[(size_t)ev_row[j] * m_pad + m] = out;
+    }
+}
+
+int launch_ffat_lookup_shared(const FfatEvent *events, int n_events, const FfatShared *shared, const FfatGeom *geom, const long long *geom_off,
+                              const int *n_modes, const double *mode_k, const int *mode_valid, const double *psi_t, double *rows, int m_pad,
+                              hipStream_t stream) {
+    if (n_events <= 0) return 0;
+    const long long wgs = (long long)((m_pad + 255) / 256) * ((n_events + FFAT_SH_EVENTS - 1) / FFAT_SH_EVENTS);
+    if (wgs > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(ffat_lookup_shared_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, events, n_events, shared, geom, geom_off, n_modes,
+                       mode_k, mode_valid, psi_t, rows, m_pad);
     return (int)hipGetLastError();
 }
 

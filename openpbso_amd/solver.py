@@ -133,7 +133,7 @@ def _select_from_env():
 SELECT_FIELDS = ("bank_kernel", "time_chunks", "direct_hits", "forced_block", "dense_launches", "device_profiles",
                  "profile_kernel", "profile_margin_pct", "profile_priority", "team_waves", "pipe_consumers",
                  "pipe_max_teams", "chunk_buffers", "plan_threads", "plan_pin", "timing_every", "warm_copies", "stream_sync", "latency_path",
-                 "time_chunk_shape", "scan_kernel", "fuse_short_launches")
+                 "time_chunk_shape", "scan_kernel", "fuse_short_launches", "submit_thread")
 
 
 def fill_engine_desc(d, device, form, qnorm, modes_per_lane, stream, frames_per_buffer, select):
@@ -424,6 +424,10 @@ class Engine:
 
     def sync(self):
         self._chk(self._l.pbso_sync(self._h))
+
+    def flush(self):
+        """pbso_flush: with submit_thread, until the recorded launches of the steps so far are in their streams (not a device sync)"""
+        self._chk(self._l.pbso_flush(self._h))
 
     def host_buffer(self, n_buffers):
         """a pinned numpy array [n_objects][n_buffers * 513] float32 for step_to_host (freed with the engine)"""
