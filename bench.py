@@ -113,8 +113,9 @@ def parse(argv=None):
     ap.add_argument("--submit-thread", type=int, default=-1, choices=[-1, 0, 1],
                     help="1: the engine's second submitting thread (pbso_engine_desc::submit_thread): pbso_step records its stream calls and "
                          "returns, a worker makes them while the caller plans the next launch (legs without the device group only).  "
-                         "-1 (default): on for steps of fewer than 256 buffers -- where planning + submitting a launch is comparable to the "
-                         "launch itself --, off for the long steps of the headline (nothing to gain: 8.91 against 8.90 ms)")
+                         "-1 (default): on for steps of fewer than 256 buffers over at least 4096 (object, buffer) pairs -- where planning + "
+                         "submitting a launch is comparable to the launch itself --, off for the long steps of the headline (nothing to gain: "
+                         "8.91 against 8.90 ms) and for scenes of a few objects (nothing to plan)")
     ap.add_argument("--scenario", choices=["impulses", "scraping", "listener"], default="impulses",
                     help="impulses: Poisson PointForce hits (headline, configs[1]/[3]); scraping: sustained "
                          "AutoregressiveForce with one face hit per buffer (configs[4]); listener: impulses + FFAT maps "
@@ -153,7 +154,9 @@ def parse(argv=None):
 def submit_thread_of(args):
     """--submit-thread for a leg of args.buffers buffers per step (-1: on for short steps)"""
     st = int(getattr(args, "submit_thread", -1))
-    return st if st >= 0 else (1 if args.buffers < 256 else 0)
+    # (on where a step's planning is comparable to its launch -- thousands of (object, buffer) descriptors for a short launch; a scene of
+    #  a few objects plans in a microsecond and only pays the hand-over to the worker: 1 x 512 x 86 0.030 -> 0.04 - 0.055 ms per step)
+    return st if st >= 0 else (1 if (args.buffers < 256 and args.objects * args.buffers >= 4096) else 0)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -702,6 +705,7 @@ def measure(args, ctx, global_ids, want_parity):
         "kernel_ms": (info1["total_kernel_ms"] - info0["total_kernel_ms"]) / max(1, info1["total_timed_launches"] - info0["total_timed_launches"]),
         "device_ms": (info1["total_device_ms"] - info0["total_device_ms"]) / max(1, info1["total_timed_launches"] - info0["total_timed_launches"]),
         "plan_ms": (info1["total_host_plan_ms"] - info0["total_host_plan_ms"]) / args.steps,
+        "submit_ms": (info1["total_host_submit_ms"] - info0["total_host_submit_ms"]) / args.steps,
         "enqueue_ms": enqueue_s[0] / args.steps * 1e3, "info": info1, "form_run": info1.get("recurrence_form"),
     }
     if res["kernel_samples"] <= 0:
@@ -1037,7 +1041,7 @@ def main():
             "rows on (closed form x0' G x0 in force-free block buffers, per-sample sums in dense-profile buffers)" if block_run else
             ("rows on (closed form)" if args.qnorm == "closed" else "rows on (per-sample sums)"))
         coll_txt = ("RCCL" if backend == "nccl" else backend + " (host transport standing in for RCCL)")
-        host_ms = m["plan_ms"] + m["enqueue_ms"]
+        host_ms = m["plan_ms"] + m["enqueue_ms"] + m["submit_ms"]
         out = {
             "metric": "audio samples/s & real-time x at N_obj x N_modes",
             "value": hn["value"], "unit": "audio samples/s", "realtime_x": hn["realtime_x"],
@@ -1071,8 +1075,12 @@ def main():
             },
             "roofline": roof,
             "timing": {"device_pipeline_ms": m["device_ms"], "host_plan_ms": m["plan_ms"], "host_enqueue_ms": m["enqueue_ms"],
-                       "host_ms": host_ms, "host_bound": bool(host_ms > 0.8 * m["kernel_ms"]),
-                       "note": "host_ms = planning + feeding per step (overlapped with the device); host_bound: host_ms > 0.8 x kernel_ms"},
+                       "host_submit_ms": m["submit_ms"], "host_ms": host_ms, "host_bound": bool(host_ms > 0.8 * hn["ms_per_step"]),
+                       "host_ms_over_kernel_ms": host_ms / m["kernel_ms"] if m["kernel_ms"] > 0 else None,
+                       "note": "host_ms = the CALLING thread's work per step: feeding the messages + planning + packing / uploading / launching "
+                               "(with submit_thread: recording the calls; a worker makes them); it overlaps the device.  host_bound: host_ms > "
+                               "0.8 x ms_per_step -- the step is as long as the caller's own work.  (Rounds 1-5 compared planning + feeding "
+                               "with the bank kernel's time and left the submit calls out.)"},
         }
         if "d2h_ms" in m:
             step_s = nb * B / SAMPLE_RATE

@@ -501,6 +501,8 @@ typedef struct pbso_engine_info {
                                        * 1 a device-side wait (hipStreamWaitValue64), 2 the submitting thread waits on pinned host memory,
                                        * -1 none because the environment serialises kernel dispatches (a waiting kernel would never end)   */
     int64_t total_gate_timeouts;      /* host-side gate only: waits that gave up after 2 s (the launch then went ungated)                 */
+    double total_host_submit_ms;      /* the caller's thread in pbso_step behind the planner: packing the plan, the upload and launch calls -- or, with
+                                       * submit_thread, recording them (the wait for a free plan set is not in it)                        */
     int64_t total_ffat_shared_events; /* listener events located once per EVENT (objects whose modes share one map geometry, round 6) ...   */
     int64_t total_ffat_general_events;/* ... and those evaluated per (event, mode)                                                          */
 } pbso_engine_info;

@@ -92,7 +92,7 @@ class EngineInfo(C.Structure):
                 ("total_time_chunk_launches", C.c_int64), ("total_dropped_hits", C.c_int64), ("total_one_stream_launches", C.c_int64),
                 ("total_dense_increment_launches", C.c_int64), ("total_segmented_scans", C.c_int64), ("last_time_chunk_shape", C.c_int), ("last_time_chunk_buffers", C.c_int),
                 ("last_time_chunk_teams", C.c_int), ("start_gate", C.c_int), ("total_gate_timeouts", C.c_int64),
-                ("total_ffat_shared_events", C.c_int64), ("total_ffat_general_events", C.c_int64)]
+                ("total_host_submit_ms", C.c_double), ("total_ffat_shared_events", C.c_int64), ("total_ffat_general_events", C.c_int64)]
 
 
 GroupDesc._fields_ = [("abi_version", C.c_int), ("devices", C.POINTER(C.c_int)), ("n_devices", C.c_int), ("world_size", C.c_int),

@@ -3145,6 +3145,7 @@ int Engine::info(pbso_engine_info *out) {
     out->total_one_stream_launches = tot_one_stream_launches_;
     out->start_gate = gate_choice_;
     out->total_gate_timeouts = gate_timeouts_;
+    out->total_host_submit_ms = hprof_[4];
     out->total_ffat_shared_events = tot_ffat_shared_events_;
     out->total_ffat_general_events = tot_ffat_general_events_;
     out->buffers_done = buffers_done_;
