@@ -6,7 +6,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out/p6; export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/p6
 WHAT="${1:-tests bench stats pmc}"
-if [[ $WHAT == *tests* ]]; then timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt; fi
+if [[ $WHAT == *tests* ]]; then timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -4 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt; fi
 if [[ $WHAT == *bench* ]]; then
   t0=$(date +%s); python bench.py > $O/bench_default.json 2> $O/bench_default.err; t1=$(date +%s); echo "python bench.py: $((t1 - t0)) s wall" | tee $O/default_command_wall_seconds.txt
   python bench.py --steps 20 --warmup 5 > $O/bench_driver_flags_steps20_warmup5.json 2> /dev/null

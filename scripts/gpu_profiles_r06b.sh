@@ -9,16 +9,16 @@ b() { name=$1; shift; timeout 900 python bench.py "$@" > $O/bench_$name.json 2> 
 b form_block_bf16 --no-cpu-baseline --form block_bf16 --no-strong-share
 b qnorm_off --no-cpu-baseline --qnorm off --no-second-form --no-strong-share
 b host_delivery --host-delivery --no-cpu-baseline --no-second-form --no-strong-share
-b c2_1x512 --no-cpu-baseline --objects 1 --modes 512 --buffers 86 --steps 40 --warmup 2
-b c3_64x256_listener --no-cpu-baseline --objects 64 --modes 256 --scenario listener --buffers 86 --steps 40 --warmup 2
-b c5_8x4096_scraping --no-cpu-baseline --objects 8 --modes 4096 --scenario scraping --buffers 86 --steps 40 --warmup 2
-b c5_8x4096_scraping_qnorm_off --no-cpu-baseline --objects 8 --modes 4096 --scenario scraping --qnorm off --buffers 86 --steps 40 --warmup 2
+b c2_1x512 --no-cpu-baseline --objects 1 --modes 512 --buffers 86 --steps 200 --warmup 5
+b c3_64x256_listener --no-cpu-baseline --objects 64 --modes 256 --scenario listener --buffers 86 --steps 200 --warmup 5
+b c5_8x4096_scraping --no-cpu-baseline --objects 8 --modes 4096 --scenario scraping --buffers 86 --steps 200 --warmup 5
+b c5_8x4096_scraping_qnorm_off --no-cpu-baseline --objects 8 --modes 4096 --scenario scraping --qnorm off --buffers 86 --steps 200 --warmup 5
 b c2_1x512_10s_steps --no-cpu-baseline --objects 1 --modes 512
 b c3_64x256_listener_10s_steps --no-cpu-baseline --objects 64 --modes 256 --scenario listener
 b c5_8x4096_scraping_10s_steps --no-cpu-baseline --objects 8 --modes 4096 --scenario scraping
 b c5_8x4096_scraping_qnorm_off_10s_steps --no-cpu-baseline --objects 8 --modes 4096 --scenario scraping --qnorm off
 for o in 512 256 128; do
-b share_${o}x512 --no-cpu-baseline --no-second-form --objects $o --buffers 86 --steps 40 --warmup 3
+b share_${o}x512 --no-cpu-baseline --no-second-form --objects $o --buffers 86 --steps 200 --warmup 5
 done
 # (1024 x 512 sustained scraping, one-second steps -- mostly dense, chip-filling: the policy's path against the walk)
 b c4scr_1024x512_scraping --no-cpu-baseline --no-second-form --no-strong-share --no-one-second-leg --scenario scraping --buffers 86 --steps 10 --warmup 2
