@@ -16,11 +16,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CHILD = r"""
-import json, sys
+import json, os, sys
 import numpy as np
 sys.path.insert(0, %r)
 from openpbso_amd import Engine, ForceMessage, capi, synth
-n_obj, M, nb = 128, 256, 300
+n_obj, M, nb = 128, 256, int(os.environ.get("PBSO_TEST_NB", "300"))
 rng = np.random.default_rng(1)
 with Engine(qnorm=capi.QNORM_OFF, form=capi.FORM_BLOCK, chunk_buffers=nb) as eng:
     for i in range(n_obj):
@@ -29,7 +29,7 @@ with Engine(qnorm=capi.QNORM_OFF, form=capi.FORM_BLOCK, chunk_buffers=nb) as eng
     for i in range(n_obj):
         eng.set_use_transfer(i, False)
         eng.enqueue_force(i, ForceMessage(data=rng.standard_normal(M) * 1e-3))
-    for _ in range(4):
+    for _ in range(int(os.environ.get("PBSO_TEST_STEPS", "4"))):
         eng.step(nb)
     a = eng.audio()
     info = eng.info()
@@ -61,3 +61,16 @@ def test_gated_steps_complete_under_serialising_settings():
     # one hardware queue for all streams: packets in submission order, the bank that releases a wait is always in front of it
     one = _run({"GPU_MAX_HW_QUEUES": "1"})
     assert one["finite"] and one["checksum"] == base["checksum"]
+
+
+def test_short_steps_handed_over_by_value_complete_under_serialising_settings():
+    """round 6: launches of fewer than 256 buffers hand over to the bank's stream through a value in signal memory by policy -- again a
+    kernel that waits on the device, so the same rule: events only where kernels are serialised; the same samples either way"""
+    short = {"PBSO_TEST_NB": "40", "PBSO_TEST_STEPS": "12"}
+    base = _run(short)
+    assert base["finite"] and base["peak"] > 0 and base["tc"] == 12
+    for extra in ({"AMD_SERIALIZE_KERNEL": "3"}, {"PBSO_START_GATE": "0"}, {"GPU_MAX_HW_QUEUES": "1"}, {"HIP_LAUNCH_BLOCKING": "1"}):
+        got = _run(dict(short, **extra))
+        assert got["finite"] and got["checksum"] == base["checksum"] and got["peak"] == base["peak"], extra
+        if "GPU_MAX_HW_QUEUES" not in extra:
+            assert got["start_gate"] == -1, extra
