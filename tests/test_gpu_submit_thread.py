@@ -142,3 +142,15 @@ def test_flush_orders_the_callers_own_stream_work():
 def test_group_engines_and_the_host_gate_refuse_or_ignore_the_thread():
     with pytest.raises(Exception, match="stream_sync = 4"):
         Engine(submit_thread=1, stream_sync=4)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scripts_with_the_submitting_thread_match_the_oracle(seed, monkeypatch):
+    """the fuzz suite's scripts (tests/test_gpu_fuzz.py: arbitrary interleavings of forces, hits, listener moves, clears, AR updates) on
+    engines with the thread, on-device hit projection, launches cut at random lengths, the kernels the fuzz suite rotates through"""
+    from tests.test_gpu_fuzz import _run_seed
+    rng = np.random.default_rng(55000 + seed)
+    monkeypatch.setenv("PBSO_CHUNK_BUFFERS", str(int(rng.choice([1, 2, 5, 128]))))
+    kw = dict(submit_thread=1, time_chunks=int(rng.choice([0, -1, 1, 3])), qnorm=int(rng.choice([capi.QNORM_ALL, capi.QNORM_CLOSED])),
+              form=int(rng.choice([capi.FORM_BLOCK, capi.FORM_BLOCK_BF16, capi.FORM_VELOCITY])))
+    _run_seed(seed + 200000, [5, 64, 200, 1100], kw, projected_hits=True)
