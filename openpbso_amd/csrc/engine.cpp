@@ -1952,7 +1952,12 @@ int Engine::plan(int nb) {
     }
     if ((int)need_all > xfer_cap_) {
         const int ncap = std::max<int>((int)need_all, 2 * xfer_cap_ + 16);
-        // rows [2N + s*cap, ...) change meaning with cap: nothing may be in flight (ensure() drains)
+        // rows [2N + s*cap, ...) change meaning with cap: nothing may be in flight (ensure() drains) -- nor still waiting in the
+        // submitting thread's queue: its recorded launches hold the old block's address, and the keep-copy must come behind them
+        {
+            int drc = drain_submit();
+            if (drc != PBSO_OK) return drc;
+        }
         HIPTRY(d_xfer_.ensure((size_t)(2 * N + N_SETS * ncap) * m_pad_, true, stream_));
         HIPTRY(hipDeviceSynchronize());
         xfer_cap_ = ncap;

@@ -154,3 +154,56 @@ def test_random_scripts_with_the_submitting_thread_match_the_oracle(seed, monkey
     kw = dict(submit_thread=1, time_chunks=int(rng.choice([0, -1, 1, 3])), qnorm=int(rng.choice([capi.QNORM_ALL, capi.QNORM_CLOSED])),
               form=int(rng.choice([capi.FORM_BLOCK, capi.FORM_BLOCK_BF16, capi.FORM_VELOCITY])))
     _run_seed(seed + 200000, [5, 64, 200, 1100], kw, projected_hits=True)
+
+
+def test_transfer_rows_grow_while_the_worker_lags():
+    """the planner grows the pool of transfer rows (and re-cuts its per-set scratch areas) when a step fires more listener events than any
+    before it; with the thread that must wait for the recorded launches of the steps before -- they hold the old block's address and
+    the keep-copy has to come behind them.  Steps of 1, 2, 4 ... 64 buffers with a listener move per object and buffer, issued back to back"""
+    objs = _scene(6, 96, 4400)
+    n_modes = 96
+    # (a first step of 64 buffers without listener events sizes every per-step buffer: a buffer that grows waits for the worker by
+    #  itself, GROWTRY, and would hide what this test is after)
+    steps = [64, 1, 2, 4, 8, 16, 32, 64, 3, 64]
+    total = sum(steps)
+    pos = [synth.listener_path(total - 64, radius=0.3 + 0.03 * i) for i in range(len(objs))]
+
+    def run(thread):
+        with Engine(submit_thread=thread) as eng:
+            for lam, shapes, maps in objs:
+                oid = eng.add_object(lam, synth.RHO, synth.ALPHA, synth.BETA, n_modes, shapes)
+                eng.set_ffat_maps(oid, maps)
+            eng.finalize()
+            N = len(objs)
+            out = [torch.zeros((N, nb * B), dtype=torch.float32, device="cuda") for nb in steps]
+            torch.cuda.synchronize()
+            rng = np.random.default_rng(9)
+            for o in range(N):
+                assert eng.enqueue_force(o, ForceMessage(data=rng.standard_normal(n_modes) * 1e-3), 0)
+            # (the whole script up front, stamped: nothing between two steps but the next step's plan -- the worker is still making
+            #  the calls of step k when the planner of step k + 1 finds its rows too few)
+            done = 0
+            for k, nb in enumerate(steps):
+                for o in range(N):
+                    if k % 2:
+                        assert eng.enqueue_force(o, ForceMessage(vid=int(rng.integers(0, synth.N_VERTS)), vn=np.array([0.6, 0.0, 0.8])), done)
+                done += nb
+            for o in range(N):
+                # (a position every third buffer: most launches START with the row the launch before them left in force)
+                # (single stamped calls: they wait in the object's pending list, and a plan counts the ones due in ITS buffers -- a path
+                #  array is counted whole by the first plan that sees it)
+                for j, t in enumerate(range(65, total, 3)):
+                    eng.compute_transfer(o, pos[o][j], t)
+            ptrs = [t.data_ptr() for t in out]
+            for k, nb in enumerate(steps):
+                eng.step(nb, into=ptrs[k])
+            eng.sync()
+            return [t.cpu().numpy() for t in out], [eng.latest_transfer(o).copy() for o in range(N)]
+
+    a_audio, a_latest = run(1)
+    b_audio, b_latest = run(0)
+    for k in range(len(steps)):
+        assert np.array_equal(a_audio[k], b_audio[k]), k
+    for x, y in zip(a_latest, b_latest):
+        assert np.array_equal(x, y)
+    assert np.abs(a_audio[-1]).max() > 0
