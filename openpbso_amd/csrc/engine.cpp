@@ -2956,7 +2956,11 @@ int Engine::mix_listeners(int obj, const double *pos, int n_listeners, float *ou
         e = dev.ensure(n_listeners, false, stream_);
         if (e == hipSuccess) e = hipMemcpyAsync(dev.p, evs.data(), n_listeners * sizeof(FfatEvent), hipMemcpyHostToDevice, stream_);
         if (e == hipSuccess) {
-            int le = launch_ffat_lookup(dev.p, n_listeners, d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p, rows.p, m_pad_, stream_);
+            // (the object's modes share one map geometry: every listener located once, lane = mode -- kernels_exact.hip, round 6)
+            int le = (!ffat_shared_h_.empty() && ffat_shared_h_[obj])
+                         ? launch_ffat_lookup_shared(dev.p, n_listeners, d_ffat_shared_.p, d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_ffat_k_.p,
+                                                     d_ffat_valid_.p, d_psi_t_.p, rows.p, m_pad_, stream_)
+                         : launch_ffat_lookup(dev.p, n_listeners, d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_psi_.p, rows.p, m_pad_, stream_);
             if (le) e = (hipError_t)le;
         }
         if (e == hipSuccess) e = hipStreamSynchronize(stream_);
