@@ -3106,9 +3106,25 @@ int Engine::compute_transfer_batch(int obj, const double *pos, int n_pos, double
     if (e == hipSuccess) e = hipMemcpyAsync(dpos.p, pos, (size_t)3 * n_pos * sizeof(double), hipMemcpyHostToDevice, stream_);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ev_k[i], hipEventDisableTiming);
     const FfatGeom *g0 = d_geom_.p + geom_off_h_[obj];
+    // (round 6) an object whose modes share one map geometry: the positions as lookup events of the shared-geometry kernel -- located
+    // once per position, lane = mode, the maps read cell-major (kernels_exact.hip) -- instead of one workgroup per (mode, 1024 positions)
+    const bool shared = !ffat_shared_h_.empty() && ffat_shared_h_[obj] && e == hipSuccess;
+    DevBuf<FfatEvent> dev_ev;
+    if (shared) {
+        std::vector<FfatEvent> evs((size_t)n_pos);
+        for (int p = 0; p < n_pos; ++p) {
+            evs[p].obj = obj;
+            evs[p].row = (p % CH) + ((p / CH) & 1) * CH;          // (its row in the two-chunk row buffer)
+            for (int j = 0; j < 3; ++j) evs[p].pos[j] = pos[3 * (size_t)p + j];
+        }
+        e = dev_ev.ensure((size_t)n_pos, false, stream_);
+        if (e == hipSuccess) e = hipMemcpy(dev_ev.p, evs.data(), (size_t)n_pos * sizeof(FfatEvent), hipMemcpyHostToDevice);
+    }
     auto launch_chunk = [&](int c) -> hipError_t {
         const int p0 = c * CH, n = std::min(CH, n_pos - p0);
-        int le = launch_ffat_batch(dpos.p + 3 * (size_t)p0, n, g0, nmap, d_psi_.p, rows.p + (size_t)(c & 1) * CH * m_pad_, m_pad_, stream_);
+        int le = shared ? launch_ffat_lookup_shared(dev_ev.p + p0, n, d_ffat_shared_.p, d_geom_.p, d_geom_off_.p, d_n_modes_.p, d_ffat_k_.p,
+                                                    d_ffat_valid_.p, d_psi_t_.p, rows.p, m_pad_, stream_)
+                        : launch_ffat_batch(dpos.p + 3 * (size_t)p0, n, g0, nmap, d_psi_.p, rows.p + (size_t)(c & 1) * CH * m_pad_, m_pad_, stream_);
         if (le) return (hipError_t)le;
         return hipEventRecord(ev_k[c & 1], stream_);
     };
@@ -3128,6 +3144,7 @@ int Engine::compute_transfer_batch(int obj, const double *pos, int n_pos, double
         if (ev) (void)hipEventDestroy(ev);
     rows.release();
     dpos.release();
+    dev_ev.release();
     return rc == PBSO_OK ? 1 : rc;
 }
 
