@@ -444,9 +444,12 @@ def test_transfer_queue_and_use_transfer_toggle():
         assert np.array_equal(got["latest"][0], want["latest"][0])
 
 
-def test_ffat_lookup_bit_exact_batch():
+@pytest.mark.parametrize("shared", ["1", "0"])
+def test_ffat_lookup_bit_exact_batch(shared, monkeypatch):
     """computeTransfer(pos, T*) batched: fp64 kernel vs oracle, bit for bit,
-    including listeners whose ray leaves through a face edge (clamped bilinear)."""
+    including listeners whose ray leaves through a face edge (clamped bilinear) -- through the shared-geometry lookup
+    (round 6: the object's maps share one header) and through the per-(mode, 1024 positions) kernel (PBSO_FFAT_SHARED=0)."""
+    monkeypatch.setenv("PBSO_FFAT_SHARED", shared)
     from oracle import oracle_py as orc
     from openpbso_amd import Engine
     n_modes = 48
@@ -857,10 +860,13 @@ def test_multi_listener_mix_matches_independent_solvers(form, monkeypatch):
             assert np.abs(mix[l] - single).max() <= 1e-4 * np.abs(want).max()
 
 
-def test_compute_transfer_batch_chunks_large_maps_and_reused_output():
+@pytest.mark.parametrize("shared", ["1", "0"])
+def test_compute_transfer_batch_chunks_large_maps_and_reused_output(shared, monkeypatch):
     """the batched lookup stages a mode's map in LDS (56 KB window): a map too large for it is read in place, a call with
     more positions than one chunk (16 384) is cut, and a caller-owned output array is filled in place -- all three against
-    the per-listener path (K4's per-event kernel, the one a step uses), bit for bit"""
+    the per-listener path (K4's per-event kernel, the one a step uses), bit for bit; with the shared-geometry lookup (round 6) the cut
+    and the two-chunk row buffer are the same, the kernel another"""
+    monkeypatch.setenv("PBSO_FFAT_SHARED", shared)
     from openpbso_amd import Engine
     n_modes = 6
     lam = synth.eigenvalues(n_modes, 35)
