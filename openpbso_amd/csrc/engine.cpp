@@ -2542,7 +2542,18 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
         QHIP(hipStreamWaitEvent, sa, ev_aux_fork_[cur_set_], 0);
     }
     if (device_profiles_ && timed && n_chains > 0) { QHIP(hipEventRecord, evq.f0, sp); evq.has_k2 = true; }
-    if (device_profiles_ && k2_rows_launch_)
+    // (round 6, second half) a one-buffer launch whose profile rows go through the fused kernel and whose combine takes its rows itself:
+    // both in ONE launch -- they touch different arrays (kernels_exact.hip, force_rows_combine_kernel)
+    const bool rows_and_combine = device_profiles_ && k2_rows_launch_ && fuse_combine && sa == sp && !prof_rows_.empty() && n_frows > 0 &&
+                                  fuse_short_ && !ar_uses_.empty() && ar_uses_.size() == ar_streams_.size();
+    if (rows_and_combine)
+        QLAUNCH(launch_force_rows_combine, d_prow, (int)prof_rows_.size(), d_pent, reinterpret_cast<const ArUse *>(da + o_aruse),
+                                            reinterpret_cast<const ArStream *>(da + o_arstream), ar_max_segs_, d_arstate_.p, d_ar_snaps_.p,
+                                            d_ar_vnorm_.p, d_ar_vstate_.p, d_ar_segcount_.p, d_ar_cbuf_.p, d_ar_recs_.p, d_ar_fins_.p,
+                                            ps.d_tprof.p, B_, b_pad_, b_pad_, d_row_ptr, d_slot_idx, d_row_obj, n_frows, d_slots_.p, d_c3_.p,
+                                            grows.p, d_projd, d_shapes_.p, d_shape_off_.p, d_n_modes_.p, m_pad_, (int)proj_direct_.size(),
+                                            d_stage, d_stage_slot, sp);
+    else if (device_profiles_ && k2_rows_launch_)
         QLAUNCH(launch_force_rows, d_prow, (int)prof_rows_.size(), d_pent, reinterpret_cast<const ArUse *>(da + o_aruse), (int)ar_uses_.size(),
                                     reinterpret_cast<const ArStream *>(da + o_arstream), reinterpret_cast<const int *>(da + o_arseg),
                                     (int)seg_stream_.size(), ar_max_segs_, d_arstate_.p, d_ar_snaps_.p, d_ar_vnorm_.p, d_ar_vstate_.p,
@@ -2566,8 +2577,9 @@ int Engine::step_chunk(int nb, int b0, int nb_total, float *audio, int64_t step_
     // (the combine stays on the preparation stream even when the bank fills the register file: its workgroups
     //  move in as the bank's retire, so most of it is done when the last one leaves -- queued behind the bank in
     //  the bank's own stream it would start only then: 0.785 instead of 0.735 ms per step at 1024 x 512)
-    QLAUNCH(launch_force_combine, d_row_ptr, d_slot_idx, d_row_obj, n_frows, d_slots_.p, d_c3_.p, grows.p, d_projd, d_shapes_.p,
-                                   d_shape_off_.p, d_n_modes_.p, m_pad_, (int)proj_direct_.size(), d_stage, d_stage_slot, sa);
+    if (!rows_and_combine)
+        QLAUNCH(launch_force_combine, d_row_ptr, d_slot_idx, d_row_obj, n_frows, d_slots_.p, d_c3_.p, grows.p, d_projd, d_shapes_.p,
+                                       d_shape_off_.p, d_n_modes_.p, m_pad_, (int)proj_direct_.size(), d_stage, d_stage_slot, sa);
     if (split_prep) QHIP(hipEventRecord, ev_aux_join_[cur_set_], sa);
     if (split_prep && !tc_launch) QHIP(hipStreamWaitEvent, sp, ev_aux_join_[cur_set_], 0);
     if (tc_launch) {

@@ -256,6 +256,13 @@ int launch_force_rows(const ProfRow *rows, int n_rows, const ProfEntry *entries,
                       const ArStream *streams, const int *seg_stream, int n_segs, int max_segs_per_stream, ArState *states,
                       ArState *snaps, double *vnorm, uint32_t *vstate, int *seg_count, double *cbuf, ArRec *recs, ArFin *fins,
                       float *tprof, int frames, int b_pad, int c_pitch, bool fused, hipStream_t stream);      // fused: every stream has ONE use -> one launch
+// ... and, for a one-buffer launch, the fused profile rows AND the combine rows (launch_force_combine's arguments) in one launch
+int launch_force_rows_combine(const ProfRow *rows, int n_rows, const ProfEntry *entries, const ArUse *uses, const ArStream *streams,
+                              int max_segs_per_stream, ArState *states, ArState *snaps, double *vnorm, uint32_t *vstate, int *seg_count,
+                              double *cbuf, ArRec *recs, ArFin *fins, float *tprof, int frames, int b_pad, int c_pitch,
+                              const int *row_ptr, const int *slot_idx, const int *row_obj, int n_frows, double *slots, const double *c3,
+                              float *grows, const struct ProjectEvent *direct, const double *shapes, const long long *shape_off, const int *n_modes,
+                              int m_pad, int n_events, const double *stage, const int *stage_slot, hipStream_t stream);
 
 struct FfatGeom {        // FFAT_Map<double,3> runtime fields, one per (object, mode)
     double k;

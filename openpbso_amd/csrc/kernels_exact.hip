@@ -12,6 +12,7 @@
 //                      Intersect (:676-712), Interpolate (:736-803),
 //                      GetDataQuadStride (:141-144), Reconstruct (:899-906)
 //   copy_rows          _latest_transfer = trans (modal_solver.h:251)
+#include <cstring>
 #include "kernels.h"
 
 namespace pbso {
@@ -42,10 +43,11 @@ __device__ __forceinline__ double project_one(const ProjectEvent &ev, const doub
 // adjacent -- rows are events, forced (object, buffer) pairs, transfer rows: a ten-second step of a large scene has more of them
 // than grid.y may count (65535).
 struct RowTile { unsigned row, tile; };
-__device__ __forceinline__ RowTile row_tile(int m_pad) {
+__device__ __forceinline__ RowTile row_tile_of(unsigned block, int m_pad) {
     const unsigned tiles = (unsigned)(m_pad + 255) / 256u;
-    return RowTile{blockIdx.x / tiles, blockIdx.x % tiles};
+    return RowTile{block / tiles, block % tiles};
 }
+__device__ __forceinline__ RowTile row_tile(int m_pad) { return row_tile_of(blockIdx.x, m_pad); }
 static inline bool flat_grid(int m_pad, long long n_rows, dim3 *grid) {
     const long long wgs = (long long)((m_pad + 255) / 256) * n_rows;
     if (wgs > 0x7fffffffLL) return false;
@@ -106,14 +108,15 @@ int launch_scatter_rows(const double *src, const int *dst_slot, int n_rows, doub
 // row e - n_events of the staged explicit data, and an event with slot >= 0 is a projection whose vector outlives the buffer -- the
 // row takes the value AND leaves it in the slot pool, which is what scatter_rows_kernel / modal_project_kernel did in launches of
 // their own in front of this one (two hand-overs of ~7 us in the real-time step).  Same values, same order of additions.
-__global__ __launch_bounds__(256) void force_combine_kernel(
-    const int *__restrict__ row_ptr, const int *__restrict__ slot_idx,
+// (the body as a device function: the kernel below calls it with its block index, and the one launch of a real-time buffer under
+//  sustained contact -- force_rows_combine_kernel, behind K2 -- with the index of a block behind the profile rows')
+__device__ __forceinline__ void force_combine_body(
+    unsigned block, const int *__restrict__ row_ptr, const int *__restrict__ slot_idx,
     const int *__restrict__ row_obj, const double *__restrict__ slots,
     const double *__restrict__ c3, float *__restrict__ grows, const ProjectEvent *__restrict__ direct,
     const double *__restrict__ shapes, const long long *__restrict__ shape_off, const int *__restrict__ n_modes,
     int m_pad, int n_events, const double *__restrict__ stage, const int *__restrict__ stage_slot, double *slots_w) {
-    prep_prio();
-    const RowTile rt = row_tile(m_pad);
+    const RowTile rt = row_tile_of(block, m_pad);
     const int row = (int)rt.row;
     const int m = rt.tile * blockDim.x + threadIdx.x;
     if (m >= m_pad) return;
@@ -136,6 +139,16 @@ __global__ __launch_bounds__(256) void force_combine_kernel(
         }
     }
     grows[(size_t)row * m_pad + m] = (float)(c3[(size_t)obj * m_pad + m] * S);
+}
+__global__ __launch_bounds__(256) void force_combine_kernel(
+    const int *__restrict__ row_ptr, const int *__restrict__ slot_idx,
+    const int *__restrict__ row_obj, const double *__restrict__ slots,
+    const double *__restrict__ c3, float *__restrict__ grows, const ProjectEvent *__restrict__ direct,
+    const double *__restrict__ shapes, const long long *__restrict__ shape_off, const int *__restrict__ n_modes,
+    int m_pad, int n_events, const double *__restrict__ stage, const int *__restrict__ stage_slot, double *slots_w) {
+    prep_prio();
+    force_combine_body(blockIdx.x, row_ptr, slot_idx, row_obj, slots, c3, grows, direct, shapes, shape_off, n_modes, m_pad, n_events, stage,
+                       stage_slot, slots_w);
 }
 
 int launch_force_combine(const int *row_ptr, const int *slot_idx, const int *row_obj, int n_rows,
@@ -908,15 +921,12 @@ __global__ __launch_bounds__(K2_THREADS) void force_rows_kernel(
 // on, :1127-1160).  Nothing then crosses from one profile row to another: the workgroup of a row evaluates the candidate segments of
 // each of its AR forces, their zero-state uses, and then the row, through the same global scratch arrays and with the same bodies --
 // bit-identical profiles, two launch hand-overs less (~7 us each in a chain of dependent launches, profiles/r04_stream_sync.txt).
-__global__ __launch_bounds__(K2_THREADS) void force_rows_fused_kernel(
+__device__ __forceinline__ void force_rows_fused_body(
+    double *k2_lds, uint32_t (*cnt)[K2_THREADS / 64], int &carry,
     const ProfRow *__restrict__ rows, const ProfEntry *__restrict__ entries, const ArUse *__restrict__ uses,
     const ArStream *__restrict__ streams, ArState *__restrict__ states, ArState *__restrict__ snaps, double *__restrict__ vnorm,
     uint32_t *__restrict__ vstate, int *__restrict__ seg_count, double *__restrict__ cbuf, ArRec *__restrict__ recs,
     ArFin *__restrict__ fins, float *__restrict__ tprof, int frames, int b_pad, int c_pitch) {
-    prep_prio();
-    extern __shared__ __attribute__((aligned(16))) double k2_lds[];
-    __shared__ uint32_t cnt[2][K2_THREADS / 64];
-    __shared__ int carry;
     const ProfRow row = rows[blockIdx.x];
     for (int ei = row.entry_begin; ei < row.entry_end; ++ei) {
         const ProfEntry e = entries[ei];
@@ -935,6 +945,71 @@ __global__ __launch_bounds__(K2_THREADS) void force_rows_fused_kernel(
         __syncthreads();
     }
     force_rows_body((int)blockIdx.x, k2_lds, rows, entries, uses, streams, snaps, recs, fins, cbuf, states, tprof, frames, b_pad, c_pitch);
+}
+__global__ __launch_bounds__(K2_THREADS) void force_rows_fused_kernel(
+    const ProfRow *__restrict__ rows, const ProfEntry *__restrict__ entries, const ArUse *__restrict__ uses,
+    const ArStream *__restrict__ streams, ArState *__restrict__ states, ArState *__restrict__ snaps, double *__restrict__ vnorm,
+    uint32_t *__restrict__ vstate, int *__restrict__ seg_count, double *__restrict__ cbuf, ArRec *__restrict__ recs,
+    ArFin *__restrict__ fins, float *__restrict__ tprof, int frames, int b_pad, int c_pitch) {
+    prep_prio();
+    extern __shared__ __attribute__((aligned(16))) double k2_lds[];
+    __shared__ uint32_t cnt[2][K2_THREADS / 64];
+    __shared__ int carry;
+    force_rows_fused_body(k2_lds, cnt, carry, rows, entries, uses, streams, states, snaps, vnorm, vstate, seg_count, cbuf, recs, fins, tprof, frames,
+                          b_pad, c_pitch);
+}
+
+// The profile rows of a one-buffer launch and its combine rows in ONE launch (round 6, second half): the two touch different arrays --
+// time profiles and AR state here, spatial gains and the slot pool there -- so the workgroups [0, n_rows) take a profile row each
+// (force_rows_fused_body) and the workgroups behind them a tile of a combine row (force_combine_body).  The real-time step under a
+// sustained contact was upload -> profiles 14 us -> combine 3.4 us -> bank: the combine now runs beside the profiles, and one launch
+// hand-over (~4 us) is gone.  Same bodies, same values.
+struct CombineArgs {
+    const int *row_ptr, *slot_idx, *row_obj;
+    double *slots;
+    const double *c3;
+    float *grows;
+    const ProjectEvent *direct;
+    const double *shapes;
+    const long long *shape_off;
+    const int *n_modes;
+    int m_pad, n_events;
+    const double *stage;
+    const int *stage_slot;
+};
+__global__ __launch_bounds__(K2_THREADS) void force_rows_combine_kernel(
+    int n_rows, const ProfRow *__restrict__ rows, const ProfEntry *__restrict__ entries, const ArUse *__restrict__ uses,
+    const ArStream *__restrict__ streams, ArState *__restrict__ states, ArState *__restrict__ snaps, double *__restrict__ vnorm,
+    uint32_t *__restrict__ vstate, int *__restrict__ seg_count, double *__restrict__ cbuf, ArRec *__restrict__ recs,
+    ArFin *__restrict__ fins, float *__restrict__ tprof, int frames, int b_pad, int c_pitch, CombineArgs c) {
+    prep_prio();
+    extern __shared__ __attribute__((aligned(16))) double k2_lds[];
+    __shared__ uint32_t cnt[2][K2_THREADS / 64];
+    __shared__ int carry;
+    if ((int)blockIdx.x < n_rows) {
+        force_rows_fused_body(k2_lds, cnt, carry, rows, entries, uses, streams, states, snaps, vnorm, vstate, seg_count, cbuf, recs, fins, tprof,
+                              frames, b_pad, c_pitch);
+    } else {
+        force_combine_body(blockIdx.x - (unsigned)n_rows, c.row_ptr, c.slot_idx, c.row_obj, c.slots, c.c3, c.grows, c.direct, c.shapes,
+                           c.shape_off, c.n_modes, c.m_pad, c.n_events, c.stage, c.stage_slot, c.slots);
+    }
+}
+static_assert(K2_THREADS == 256, "the combine body's tiles are 256 modes wide");
+
+int launch_force_rows_combine(const ProfRow *rows, int n_rows, const ProfEntry *entries, const ArUse *uses, const ArStream *streams,
+                              int max_segs_per_stream, ArState *states, ArState *snaps, double *vnorm, uint32_t *vstate, int *seg_count,
+                              double *cbuf, ArRec *recs, ArFin *fins, float *tprof, int frames, int b_pad, int c_pitch,
+                              const int *row_ptr, const int *slot_idx, const int *row_obj, int n_frows, double *slots, const double *c3,
+                              float *grows, const ProjectEvent *direct, const double *shapes, const long long *shape_off, const int *n_modes,
+                              int m_pad, int n_events, const double *stage, const int *stage_slot, hipStream_t stream) {
+    if (n_rows <= 0 || n_frows <= 0) return (int)hipErrorInvalidValue;
+    const long long wgs = (long long)n_rows + (long long)((m_pad + 255) / 256) * n_frows;
+    if (wgs > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    const size_t lds = std::max(sizeof(double) * (size_t)frames + sizeof(int) * ((size_t)max_segs_per_stream + 2), sizeof(double) * 2 * (size_t)frames);
+    CombineArgs c{row_ptr, slot_idx, row_obj, slots, c3, grows, direct, shapes, shape_off, n_modes, m_pad, n_events, stage, stage_slot};
+    hipLaunchKernelGGL(force_rows_combine_kernel, dim3((unsigned)wgs), dim3(K2_THREADS), lds, stream, n_rows, rows, entries, uses, streams, states,
+                       snaps, vnorm, vstate, seg_count, cbuf, recs, fins, tprof, frames, b_pad, c_pitch, c);
+    return (int)hipGetLastError();
 }
 
 int launch_force_rows(const ProfRow *rows, int n_rows, const ProfEntry *entries, const ArUse *uses, int n_uses,
